@@ -1,0 +1,116 @@
+"""ctypes binding of libdlrm_hip.so (C ABI declared in include/dlrm_hip.h).
+
+The library is built in-tree (dlrm_amd/csrc/Makefile -> dlrm_amd/libdlrm_hip.so) so that it travels
+with the repository snapshot to a GPU box.  There is NO fallback: if the shared object is missing
+and cannot be built, or a call returns non-zero, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdlrm_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+UPD_ATOMIC, UPD_DETERMINISTIC = 0, 1
+
+_lock = threading.Lock()
+_lib = None
+
+_vp, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+_pp = C.POINTER(C.c_void_p)
+_pi64 = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); must list every symbol of include/dlrm_hip.h
+SIGNATURES = {
+    "dlrm_hip_abi_version": (_i32, []),
+    "dlrm_hip_build_info": (C.c_char_p, []),
+    "dlrm_hip_device_info": (_i32, [_i32, C.POINTER(_i32), C.POINTER(_i32), _pi64, C.c_char_p, _i32]),
+    "dlrm_emb_fwd": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64, _vp]),
+    "dlrm_emb_bwd_sgd": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64,
+                                _f32, _i32, _vp]),
+    "dlrm_emb_adagrad_workspace_bytes": (_i64, [_i32, _pi64, _pi64]),
+    "dlrm_emb_bwd_rowwise_adagrad": (_i32, [_i32, _i64, _i32, _pp, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32,
+                                            _vp, _i64, _f32, _f32, _vp, _i64, _vp]),
+    "dlrm_interact_fwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _vp]),
+    "dlrm_interact_bwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _pp, _pi64, _vp]),
+    "dlrm_linear_fwd": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
+    "dlrm_linear_bwd_data": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64,
+                                    _vp, _vp]),
+    "dlrm_linear_bwd_weight": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp]),
+    "dlrm_act_bwd": (_i32, [_i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
+    "dlrm_loss_workspace_bytes": (_i64, [_i64]),
+    "dlrm_bce_loss": (_i32, [_i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
+    "dlrm_mse_loss": (_i32, [_i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
+    "dlrm_sgd_dense": (_i32, [_i64, _vp, _vp, _f32, _vp]),
+    "dlrm_a2a_unpack": (_i32, [_i32, _i64, _i32, C.POINTER(_i32), _vp, _vp, _i64, _vp]),
+}
+
+_ERR = {-1: "DLRM_E_ARG (null pointer / bad size)", -2: "DLRM_E_ALIGN", -3: "DLRM_E_RANGE (compiled limit exceeded)",
+        -4: "DLRM_E_MODE (unknown mode / not implemented)"}
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile libdlrm_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=False, capture_output=not verbose)
+    r = subprocess.run(["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libdlrm_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+def _sources_newer_than_lib() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    for f in os.listdir(CSRC):
+        if f.endswith((".hip", ".h")) and os.path.getmtime(os.path.join(CSRC, f)) > t:
+            return True
+    return False
+
+
+def load():
+    """Return the loaded library (building it first when sources are newer and hipcc exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if _sources_newer_than_lib():
+            if os.path.exists("/opt/rocm/bin/hipcc"):
+                build()
+            elif not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    "libdlrm_hip.so is missing and hipcc is not available; the HIP extension is required "
+                    "(there is no fallback path). Run `python -c 'import __graft_entry__ as g; g.build()'`.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        if rc < 0:
+            raise RuntimeError(f"{what} failed: {_ERR.get(rc, rc)}")
+        raise RuntimeError(f"{what} failed: hipError_t {rc}")
+
+
+def ptr_array(ptrs):
+    n = len(ptrs)
+    return (C.c_void_p * n)(*[C.c_void_p(int(p)) if p else None for p in ptrs])
+
+
+def i64_array(vals):
+    return (C.c_int64 * len(vals))(*[int(v) for v in vals])

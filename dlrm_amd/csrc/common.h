@@ -1,0 +1,44 @@
+// common.h — shared device/host helpers for libdlrm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dlrm_hip.h"
+
+#define DLRM_WAVE 64
+
+// kernel launch wrapper: returns the hipError_t of the launch as a positive int
+#define DLRM_LAUNCH_CHECK()                      \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+#define DLRM_REQUIRE(cond, code, msg)                                        \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            fprintf(stderr, "libdlrm_hip: %s: %s\n", __func__, msg);         \
+            return (code);                                                   \
+        }                                                                    \
+    } while (0)
+
+static inline bool dlrm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+__device__ __forceinline__ float dlrm_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Tables are passed to the embedding kernels BY VALUE in the kernarg segment (no H2D copy of a
+// pointer table, HIP-graph friendly).  32 tables x 6 x 8 B = 1.5 KiB.
+#define DLRM_MAX_TABLES_PER_LAUNCH 32
+struct EmbArgs {
+    float*      w[DLRM_MAX_TABLES_PER_LAUNCH];
+    const void* idx[DLRM_MAX_TABLES_PER_LAUNCH];
+    const void* off[DLRM_MAX_TABLES_PER_LAUNCH];
+    const float* psw[DLRM_MAX_TABLES_PER_LAUNCH];
+    long long   nnz[DLRM_MAX_TABLES_PER_LAUNCH];
+    long long   rows[DLRM_MAX_TABLES_PER_LAUNCH];
+    int         slot[DLRM_MAX_TABLES_PER_LAUNCH];  // feature slot (column block) of the table in out/dout
+};

@@ -1,0 +1,492 @@
+// emb.hip — batched multi-table EmbeddingBag(sum) forward and fused backward+SGD for gfx950.
+//
+// Reference call sites replaced (see include/dlrm_hip.h):
+//   forward : DLRM_Net.apply_emb loop over nn.EmbeddingBag            dlrm_s_pytorch.py:407-462
+//   backward: EmbeddingBagBackward -> sparse COO grad -> SGD.step     dlrm_s_pytorch.py:1613,1620
+//
+// Design (HBM-bound integer/byte work, no MFMA):
+//   * one launch covers every table: blockIdx.y = table, table pointers live in the kernarg
+//     segment (EmbArgs by value), so there is no pointer-table H2D copy and the launch is
+//     hipGraph-capturable.
+//   * a "group" of LPB lanes owns one bag; lane c of the group owns columns [4c, 4c+4) of the
+//     row (one 16-byte global_load_dwordx4 per row), so a D=128 row is one fully coalesced
+//     512-byte read by half a wavefront and rows are accumulated IN INDEX ORDER per column —
+//     bit-identical to the torch CPU kernel (no cross-lane reduction over rows).
+//   * each group works on U bags at once: the U first-row loads are issued back to back
+//     (U independent 512 B reads in flight per half-wave) before any dependent add, which is
+//     what keeps HBM busy for one-hot (Criteo) inputs where every bag has exactly one row.
+//   * bags with more rows continue with a 4-deep load pipeline per bag.
+#include "common.h"
+
+namespace {
+
+template <int VEC> struct Vec;
+template <> struct Vec<4> { using T = float4; };
+template <> struct Vec<1> { using T = float; };
+
+__device__ __forceinline__ void v_zero(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void v_zero(float& a) { a = 0.f; }
+// acc = fma(w, v, acc) per component.  With w == 1.0f this is exactly acc + v (single rounding),
+// so the unweighted path reproduces the reference's plain in-order sum bit for bit.
+__device__ __forceinline__ void v_fma(float4& a, float w, const float4& v) {
+    a.x = __builtin_fmaf(w, v.x, a.x); a.y = __builtin_fmaf(w, v.y, a.y);
+    a.z = __builtin_fmaf(w, v.z, a.z); a.w = __builtin_fmaf(w, v.w, a.w);
+}
+__device__ __forceinline__ void v_fma(float& a, float w, const float& v) { a = __builtin_fmaf(w, v, a); }
+__device__ __forceinline__ float4 v_scale(float s, const float4& v) {
+    return make_float4(s * v.x, s * v.y, s * v.z, s * v.w);
+}
+__device__ __forceinline__ float v_scale(float s, const float& v) { return s * v; }
+
+__device__ __forceinline__ void v_atomic_add(float* p, const float4& v) {
+    // -munsafe-fp-atomics: each of these is one global_atomic_add_f32 (no return, no CAS loop)
+    atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+__device__ __forceinline__ void v_atomic_add(float* p, const float& v) { atomicAdd(p, v); }
+
+// -------------------------------------------------------------------------------------------
+// forward
+// -------------------------------------------------------------------------------------------
+template <int VEC, int LPB, int NCH, typename IT, int U>
+__global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs a, long long B, int D,
+                                                      float* __restrict__ out, long long out_ld) {
+    using VT = typename Vec<VEC>::T;
+    const int t = blockIdx.y;
+    const float* __restrict__ W = a.w[t];
+    const IT* __restrict__ idx = (const IT*)a.idx[t];
+    const IT* __restrict__ off = (const IT*)a.off[t];
+    const float* __restrict__ psw = a.psw[t];
+    const long long nnz = a.nnz[t];
+
+    constexpr int GPB = 256 / LPB;  // groups (bags in flight) per workgroup
+    const int g = threadIdx.x / LPB;
+    const int lig = threadIdx.x % LPB;
+    const long long b0 = ((long long)blockIdx.x * GPB + g) * U;
+    if (b0 >= B) return;
+
+    long long s[U], e[U];
+    {
+        long long o[U + 1];
+#pragma unroll
+        for (int u = 0; u <= U; ++u) {
+            const long long b = b0 + u;
+            o[u] = (b < B) ? (long long)off[b] : nnz;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { s[u] = o[u]; e[u] = (b0 + u < B) ? o[u + 1] : o[u]; }
+    }
+
+    VT acc[U][NCH];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) v_zero(acc[u][c]);
+
+    // ---- phase 1: first row of every bag, all loads in flight together --------------------
+    long long r0[U];
+    float w0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        r0[u] = 0; w0[u] = 1.f;
+        if (s[u] < e[u]) {
+            r0[u] = (long long)idx[s[u]];
+            if (psw) w0[u] = psw[s[u]];
+        }
+    }
+    VT v0[U][NCH];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = (c * LPB + lig) * VEC;
+            v_zero(v0[u][c]);
+            if (s[u] < e[u] && col < D) v0[u][c] = *(const VT*)(W + r0[u] * D + col);
+        }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (s[u] < e[u]) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) v_fma(acc[u][c], w0[u], v0[u][c]);
+        }
+
+    // ---- phase 2: remaining rows of multi-hot bags, 4 row loads in flight per bag ----------
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        long long i = s[u] + 1;
+        const long long end = e[u];
+        for (; i + 4 <= end; i += 4) {
+            long long r[4]; float w[4]; VT v[4][NCH];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { r[k] = (long long)idx[i + k]; w[k] = psw ? psw[i + k] : 1.f; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int col = (c * LPB + lig) * VEC;
+                    v_zero(v[k][c]);
+                    if (col < D) v[k][c] = *(const VT*)(W + r[k] * D + col);
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) v_fma(acc[u][c], w[k], v[k][c]);
+        }
+        for (; i < end; ++i) {
+            const long long r = (long long)idx[i];
+            const float w = psw ? psw[i] : 1.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = (c * LPB + lig) * VEC;
+                if (col < D) { VT v = *(const VT*)(W + r * D + col); v_fma(acc[u][c], w, v); }
+            }
+        }
+    }
+
+    // ---- store: bag b of table t goes to out[b, (slot_base+t)*D : +D] ------------------------
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long long b = b0 + u;
+        if (b < B) {
+            float* o = out + b * out_ld + (long long)a.slot[t] * D;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = (c * LPB + lig) * VEC;
+                if (col < D) *(VT*)(o + col) = acc[u][c];
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// backward + SGD, atomic mode, general tables:  W[idx,:] += (-lr * psw) * dout[b,:]
+// -------------------------------------------------------------------------------------------
+template <int VEC, int LPB, int NCH, typename IT, int U>
+__global__ __launch_bounds__(256) void emb_bwd_sgd_atomic_kernel(EmbArgs a, long long B, int D,
+                                                                 const float* __restrict__ dout,
+                                                                 long long dout_ld, float neg_lr) {
+    using VT = typename Vec<VEC>::T;
+    const int t = blockIdx.y;
+    float* __restrict__ W = a.w[t];
+    const IT* __restrict__ idx = (const IT*)a.idx[t];
+    const IT* __restrict__ off = (const IT*)a.off[t];
+    const float* __restrict__ psw = a.psw[t];
+    const long long nnz = a.nnz[t];
+
+    constexpr int GPB = 256 / LPB;
+    const int g = threadIdx.x / LPB;
+    const int lig = threadIdx.x % LPB;
+    const long long b0 = ((long long)blockIdx.x * GPB + g) * U;
+    if (b0 >= B) return;
+
+    long long s[U], e[U];
+    {
+        long long o[U + 1];
+#pragma unroll
+        for (int u = 0; u <= U; ++u) {
+            const long long b = b0 + u;
+            o[u] = (b < B) ? (long long)off[b] : nnz;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { s[u] = o[u]; e[u] = (b0 + u < B) ? o[u + 1] : o[u]; }
+    }
+    // gradient rows (coalesced 16 B per lane) and first indices, all in flight together
+    VT gr[U][NCH];
+    long long r0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const long long b = b0 + u;
+        r0[u] = (s[u] < e[u]) ? (long long)idx[s[u]] : 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = (c * LPB + lig) * VEC;
+            v_zero(gr[u][c]);
+            if (b < B && col < D)
+                gr[u][c] = v_scale(neg_lr, *(const VT*)(dout + b * dout_ld + (long long)a.slot[t] * D + col));
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        for (long long i = s[u]; i < e[u]; ++i) {
+            const long long r = (i == s[u]) ? r0[u] : (long long)idx[i];
+            const float w = psw ? psw[i] : 1.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int col = (c * LPB + lig) * VEC;
+                if (col < D) v_atomic_add(W + r * D + col, psw ? v_scale(w, gr[u][c]) : gr[u][c]);
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// backward + SGD, atomic mode, TINY tables (rows*D*4 <= LDS budget): every workgroup first sums
+// its slice of the batch into an LDS image of the whole table gradient (LDS atomics), then
+// flushes the non-zero entries with one global atomic each.  Criteo has tables with 3..100 rows
+// that are hit ~B/rows times per step; without this the same few cache lines take tens of
+// thousands of serialized global atomics.
+// -------------------------------------------------------------------------------------------
+template <typename IT>
+__global__ __launch_bounds__(256) void emb_bwd_sgd_lds_kernel(EmbArgs a, long long B, int D,
+                                                              const float* __restrict__ dout,
+                                                              long long dout_ld, float neg_lr,
+                                                              int bags_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float lds_acc[];
+    const int t = blockIdx.y;
+    float* __restrict__ W = a.w[t];
+    const IT* __restrict__ idx = (const IT*)a.idx[t];
+    const IT* __restrict__ off = (const IT*)a.off[t];
+    const float* __restrict__ psw = a.psw[t];
+    const long long nnz = a.nnz[t];
+    const int n_elem = (int)(a.rows[t] * D);
+
+    for (int e = threadIdx.x; e < n_elem; e += 256) lds_acc[e] = 0.f;
+    __syncthreads();
+
+    const long long b_begin = (long long)blockIdx.x * bags_per_block;
+    const long long b_end = (b_begin + bags_per_block < B) ? b_begin + bags_per_block : B;
+    // thread -> (bag, column): consecutive threads take consecutive columns of one bag so the
+    // dout reads are coalesced and the LDS atomics of a wave land on distinct banks.
+    const long long n_work = (b_end - b_begin) * D;
+    for (long long x = threadIdx.x; x < n_work; x += 256) {
+        const long long bl = x / D;
+        const int d = (int)(x - bl * D);
+        const long long b = b_begin + bl;
+        const float gneg = neg_lr * dout[b * dout_ld + (long long)a.slot[t] * D + d];
+        const long long s = (long long)off[b];
+        const long long e = (b + 1 < B) ? (long long)off[b + 1] : nnz;
+        for (long long i = s; i < e; ++i) {
+            const long long r = (long long)idx[i];
+            atomicAdd(&lds_acc[r * D + d], psw ? psw[i] * gneg : gneg);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_elem; e += 256) {
+        const float v = lds_acc[e];
+        if (v != 0.f) atomicAdd(W + e, v);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// backward + SGD, deterministic mode: owner-computes.  Group G of NG owns the rows with
+// row % NG == G, scans every lookup of its table in input order and applies
+//     W[r,:] = fma(-lr, psw_i * dout[bag(i),:], W[r,:])
+// sequentially — the exact operation order of `p.add_(sparse_grad, alpha=-lr)` on the
+// uncoalesced COO gradient, hence bit-identical to the reference.  O(NG * nnz) index reads:
+// a validation mode, not the production path.
+// -------------------------------------------------------------------------------------------
+template <typename IT>
+__global__ __launch_bounds__(256) void emb_bwd_sgd_det_kernel(EmbArgs a, long long B, int D,
+                                                              const float* __restrict__ dout,
+                                                              long long dout_ld, float neg_lr) {
+    const int t = blockIdx.y;
+    float* __restrict__ W = a.w[t];
+    const IT* __restrict__ idx = (const IT*)a.idx[t];
+    const IT* __restrict__ off = (const IT*)a.off[t];
+    const float* __restrict__ psw = a.psw[t];
+    const long long nnz = a.nnz[t];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long NG = (long long)gridDim.x * 4;
+    const long long G = (long long)blockIdx.x * 4 + wave;  // one owner group = one wavefront
+    for (long long b = 0; b < B; ++b) {
+        const long long s = (long long)off[b];
+        const long long e = (b + 1 < B) ? (long long)off[b + 1] : nnz;
+        for (long long i = s; i < e; ++i) {
+            const long long r = (long long)idx[i];
+            if (r % NG != G) continue;  // wave-uniform
+            const float w = psw ? psw[i] : 1.f;
+            for (int d = lane; d < D; d += 64) {
+                float gval = dout[b * dout_ld + (long long)a.slot[t] * D + d];
+                if (psw) gval = gval * w;  // the COO value the reference materialises
+                float* p = W + r * D + d;
+                *p = __builtin_fmaf(neg_lr, gval, *p);
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// host-side dispatch
+// -------------------------------------------------------------------------------------------
+struct Shape { int vec, lpb, nch; };
+
+static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+static bool pick_shape(int D, bool vec_ok, Shape* s) {
+    if (vec_ok && D % 4 == 0) {
+        const int d4 = D / 4;
+        int lpb = pow2ceil(d4); if (lpb < 4) lpb = 4; if (lpb > 64) lpb = 64;
+        const int nch = (d4 + lpb - 1) / lpb;
+        if (nch > 4) return false;
+        *s = {4, lpb, nch == 3 ? 4 : nch};
+        return true;
+    }
+    int lpb = pow2ceil(D); if (lpb < 4) lpb = 4; if (lpb > 64) lpb = 64;
+    const int nch = (D + lpb - 1) / lpb;
+    if (nch > 4) return false;
+    *s = {1, lpb, nch == 3 ? 4 : nch};
+    return true;
+}
+
+constexpr int kU = 4;  // bags per group
+
+#define EMB_DISPATCH_SHAPE(KERNEL, IT, ...)                                                        \
+    do {                                                                                           \
+        const int key = sh.vec * 10000 + sh.lpb * 10 + sh.nch;                                     \
+        switch (key) {                                                                             \
+            case 4 * 10000 + 4 * 10 + 1:  hipLaunchKernelGGL((KERNEL<4, 4, 1, IT, kU>), grid, block, 0, st, __VA_ARGS__); break;  \
+            case 4 * 10000 + 8 * 10 + 1:  hipLaunchKernelGGL((KERNEL<4, 8, 1, IT, kU>), grid, block, 0, st, __VA_ARGS__); break;  \
+            case 4 * 10000 + 16 * 10 + 1: hipLaunchKernelGGL((KERNEL<4, 16, 1, IT, kU>), grid, block, 0, st, __VA_ARGS__); break; \
+            case 4 * 10000 + 32 * 10 + 1: hipLaunchKernelGGL((KERNEL<4, 32, 1, IT, kU>), grid, block, 0, st, __VA_ARGS__); break; \
+            case 4 * 10000 + 64 * 10 + 1: hipLaunchKernelGGL((KERNEL<4, 64, 1, IT, kU>), grid, block, 0, st, __VA_ARGS__); break; \
+            case 4 * 10000 + 64 * 10 + 2: hipLaunchKernelGGL((KERNEL<4, 64, 2, IT, kU>), grid, block, 0, st, __VA_ARGS__); break; \
+            case 4 * 10000 + 64 * 10 + 4: hipLaunchKernelGGL((KERNEL<4, 64, 4, IT, kU>), grid, block, 0, st, __VA_ARGS__); break; \
+            case 1 * 10000 + 4 * 10 + 1:  hipLaunchKernelGGL((KERNEL<1, 4, 1, IT, kU>), grid, block, 0, st, __VA_ARGS__); break;  \
+            case 1 * 10000 + 8 * 10 + 1:  hipLaunchKernelGGL((KERNEL<1, 8, 1, IT, kU>), grid, block, 0, st, __VA_ARGS__); break;  \
+            case 1 * 10000 + 16 * 10 + 1: hipLaunchKernelGGL((KERNEL<1, 16, 1, IT, kU>), grid, block, 0, st, __VA_ARGS__); break; \
+            case 1 * 10000 + 32 * 10 + 1: hipLaunchKernelGGL((KERNEL<1, 32, 1, IT, kU>), grid, block, 0, st, __VA_ARGS__); break; \
+            case 1 * 10000 + 64 * 10 + 1: hipLaunchKernelGGL((KERNEL<1, 64, 1, IT, kU>), grid, block, 0, st, __VA_ARGS__); break; \
+            case 1 * 10000 + 64 * 10 + 2: hipLaunchKernelGGL((KERNEL<1, 64, 2, IT, kU>), grid, block, 0, st, __VA_ARGS__); break; \
+            case 1 * 10000 + 64 * 10 + 4: hipLaunchKernelGGL((KERNEL<1, 64, 4, IT, kU>), grid, block, 0, st, __VA_ARGS__); break; \
+            default: return DLRM_E_RANGE;                                                          \
+        }                                                                                          \
+    } while (0)
+
+static int check_common(int T, int64_t B, int D, const void* const* weight_host, const int64_t* rows_host,
+                        const void* const* indices_host, const void* const* offsets_host,
+                        const int64_t* nnz_host, int idx_bits) {
+    if (T <= 0 || B <= 0 || D <= 0) return DLRM_E_ARG;
+    if (!weight_host || !rows_host || !indices_host || !offsets_host || !nnz_host) return DLRM_E_ARG;
+    if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
+    for (int t = 0; t < T; ++t) {
+        if (!weight_host[t] || !offsets_host[t]) return DLRM_E_ARG;
+        if (nnz_host[t] < 0 || rows_host[t] <= 0) return DLRM_E_ARG;
+        if (nnz_host[t] > 0 && !indices_host[t]) return DLRM_E_ARG;
+    }
+    return 0;
+}
+
+static void fill_args(EmbArgs& a, const int* ids, int n, void* const* weight_host, const int64_t* rows_host,
+                      const void* const* indices_host, const void* const* offsets_host,
+                      const int64_t* nnz_host, const void* const* psw_host) {
+    for (int k = 0; k < DLRM_MAX_TABLES_PER_LAUNCH; ++k) {
+        const int t = ids[k < n ? k : 0];
+        a.w[k] = (float*)weight_host[t];
+        a.idx[k] = indices_host[t];
+        a.off[k] = offsets_host[t];
+        a.psw[k] = psw_host ? (const float*)psw_host[t] : nullptr;
+        a.nnz[k] = nnz_host[t];
+        a.rows[k] = rows_host[t];
+        a.slot[k] = t;
+    }
+}
+
+}  // namespace
+
+extern "C" int dlrm_emb_fwd(int T, int64_t B, int D, const void* const* weight_host,
+                            const int64_t* rows_host, const void* const* indices_host,
+                            const void* const* offsets_host, const int64_t* nnz_host,
+                            const void* const* psw_host, int idx_bits, float* out, int64_t out_ld,
+                            void* stream) {
+    int rc = check_common(T, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host, idx_bits);
+    if (rc) return rc;
+    if (!out || out_ld < (int64_t)T * D) return DLRM_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+
+    bool vec_ok = dlrm_aligned16(out) && (out_ld % 4 == 0);
+    for (int t = 0; t < T; ++t) vec_ok = vec_ok && dlrm_aligned16(weight_host[t]);
+    Shape sh;
+    if (!pick_shape(D, vec_ok, &sh)) {
+        fprintf(stderr, "libdlrm_hip: dlrm_emb_fwd: embedding dim %d not supported (max 1024, or 256 unaligned)\n", D);
+        return DLRM_E_RANGE;
+    }
+    const int bags_per_block = (256 / sh.lpb) * kU;
+    for (int t0 = 0; t0 < T; t0 += DLRM_MAX_TABLES_PER_LAUNCH) {
+        const int n = (T - t0 < DLRM_MAX_TABLES_PER_LAUNCH) ? T - t0 : DLRM_MAX_TABLES_PER_LAUNCH;
+        int ids[DLRM_MAX_TABLES_PER_LAUNCH];
+        for (int k = 0; k < n; ++k) ids[k] = t0 + k;
+        EmbArgs a;
+        fill_args(a, ids, n, (void* const*)weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host);
+        dim3 grid((unsigned)((B + bags_per_block - 1) / bags_per_block), (unsigned)n, 1), block(256, 1, 1);
+        if (idx_bits == 64) EMB_DISPATCH_SHAPE(emb_fwd_kernel, long long, a, (long long)B, D, out, (long long)out_ld);
+        else                EMB_DISPATCH_SHAPE(emb_fwd_kernel, int, a, (long long)B, D, out, (long long)out_ld);
+        DLRM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int dlrm_emb_bwd_sgd(int T, int64_t B, int D, void* const* weight_host,
+                                const int64_t* rows_host, const void* const* indices_host,
+                                const void* const* offsets_host, const int64_t* nnz_host,
+                                const void* const* psw_host, int idx_bits, const float* dout,
+                                int64_t dout_ld, float lr, int mode, void* stream) {
+    int rc = check_common(T, B, D, (const void* const*)weight_host, rows_host, indices_host, offsets_host,
+                          nnz_host, idx_bits);
+    if (rc) return rc;
+    if (!dout || dout_ld < (int64_t)T * D) return DLRM_E_ARG;
+    if (mode != DLRM_UPD_ATOMIC && mode != DLRM_UPD_DETERMINISTIC) return DLRM_E_MODE;
+    hipStream_t st = (hipStream_t)stream;
+    const float neg_lr = -lr;
+    dim3 block(256, 1, 1);
+
+    if (mode == DLRM_UPD_DETERMINISTIC) {
+        for (int t0 = 0; t0 < T; t0 += DLRM_MAX_TABLES_PER_LAUNCH) {
+            const int n = (T - t0 < DLRM_MAX_TABLES_PER_LAUNCH) ? T - t0 : DLRM_MAX_TABLES_PER_LAUNCH;
+            int ids[DLRM_MAX_TABLES_PER_LAUNCH];
+            for (int k = 0; k < n; ++k) ids[k] = t0 + k;
+            EmbArgs a;
+            fill_args(a, ids, n, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host);
+            dim3 grid(64, (unsigned)n, 1);
+            if (idx_bits == 64)
+                hipLaunchKernelGGL(emb_bwd_sgd_det_kernel<long long>, grid, block, 0, st, a, (long long)B, D, dout, (long long)dout_ld, neg_lr);
+            else
+                hipLaunchKernelGGL(emb_bwd_sgd_det_kernel<int>, grid, block, 0, st, a, (long long)B, D, dout, (long long)dout_ld, neg_lr);
+            DLRM_LAUNCH_CHECK();
+        }
+        return 0;
+    }
+
+    // atomic mode: tables whose whole gradient image fits the LDS budget ("tiny") go through the
+    // LDS pre-reduction kernel, everything else through direct global atomics; each class is
+    // launched once per 32 tables (EmbArgs.slot keeps the original table -> dout column mapping).
+    constexpr int64_t kLdsBudget = 64 * 1024;  // bytes of LDS gradient image per workgroup
+    bool vec_ok = dlrm_aligned16(dout) && (dout_ld % 4 == 0);
+    for (int t = 0; t < T; ++t) vec_ok = vec_ok && dlrm_aligned16(weight_host[t]);
+    Shape sh;
+    if (!pick_shape(D, vec_ok, &sh)) return DLRM_E_RANGE;
+    const int bags_per_block = (256 / sh.lpb) * kU;
+
+    for (int cls = 0; cls < 2; ++cls) {       // 0 = general, 1 = tiny
+        int t = 0;
+        while (t < T) {
+            int ids[DLRM_MAX_TABLES_PER_LAUNCH];
+            int n = 0;
+            int64_t max_rows = 0;
+            for (; t < T && n < DLRM_MAX_TABLES_PER_LAUNCH; ++t) {
+                const bool tiny = rows_host[t] * (int64_t)D * 4 <= kLdsBudget;
+                if ((int)tiny != cls || nnz_host[t] == 0) continue;
+                ids[n++] = t;
+                if (rows_host[t] > max_rows) max_rows = rows_host[t];
+            }
+            if (n == 0) break;
+            EmbArgs a;
+            fill_args(a, ids, n, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host);
+            if (cls == 1) {
+                const size_t lds = (size_t)(max_rows * D * 4);
+                // enough bags per workgroup to amortise the flush, enough workgroups to fill the chip
+                int bpb = 1024;
+                while (bpb > 64 && (B + bpb - 1) / bpb * n < 512) bpb >>= 1;
+                dim3 grid((unsigned)((B + bpb - 1) / bpb), (unsigned)n, 1);
+                if (idx_bits == 64)
+                    hipLaunchKernelGGL(emb_bwd_sgd_lds_kernel<long long>, grid, block, lds, st, a, (long long)B, D, dout, (long long)dout_ld, neg_lr, bpb);
+                else
+                    hipLaunchKernelGGL(emb_bwd_sgd_lds_kernel<int>, grid, block, lds, st, a, (long long)B, D, dout, (long long)dout_ld, neg_lr, bpb);
+            } else {
+                dim3 grid((unsigned)((B + bags_per_block - 1) / bags_per_block), (unsigned)n, 1);
+                if (idx_bits == 64) EMB_DISPATCH_SHAPE(emb_bwd_sgd_atomic_kernel, long long, a, (long long)B, D, dout, (long long)dout_ld, neg_lr);
+                else                EMB_DISPATCH_SHAPE(emb_bwd_sgd_atomic_kernel, int, a, (long long)B, D, dout, (long long)dout_ld, neg_lr);
+            }
+            DLRM_LAUNCH_CHECK();
+        }
+    }
+    return 0;
+}

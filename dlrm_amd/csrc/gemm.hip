@@ -1,0 +1,345 @@
+// gemm.hip — fp32 MFMA GEMM with fused MLP epilogues for gfx950 (the bottom/top MLP towers).
+//
+// Reference call sites replaced: nn.Linear + nn.ReLU / nn.Sigmoid inside the nn.Sequential built
+// by DLRM_Net.create_mlp and run by apply_mlp (dlrm_s_pytorch.py:208-246, 399-405), plus their
+// autograd (AddmmBackward / ReluBackward / SigmoidBackward) in E.backward() (:1613).
+//
+// One kernel template, C[M,N] = sum_k A(m,k)·B(n,k), instantiated for the three operand layouts the
+// three MLP GEMMs need, so that every operand tile is a straight row copy global -> LDS:
+//   forward  Y  = X·W^T   : A = X  (k contiguous)      B = W (k contiguous)
+//   dgrad    dX = dY·W    : A = dY (k contiguous)      B = W (k = row index: "k strided")
+//   wgrad    dW = dY^T·X  : A = dY (k = row, strided)  B = X (k = row, strided), split over k = batch
+//
+// Tile 128x128x32, 256 threads = 4 waves in a 2x2 grid, each wave 64x64 = 2x2 tiles of
+// v_mfma_f32_32x32x2_f32 (exact fp32, 64 accumulator registers).  The k order inside a tile is
+// permuted so that the 4 k-values a lane feeds to 4 consecutive MFMAs are contiguous: a
+// k-contiguous operand fragment is ONE ds_read_b128 (rows padded to 36 floats: conflict-free),
+// a k-strided fragment is 4 conflict-free ds_read_b32.  Global -> register -> LDS staging is
+// double buffered with one barrier per k-tile; the next tile's global loads are issued before the
+// MFMAs of the current one.  Workgroup ids are remapped so that the n-tiles sharing an A row panel
+// run on the same XCD (private L2).
+//
+// Fused epilogues: +bias and ReLU/sigmoid (forward); activation-derivative mask of the previous
+// layer and bias-gradient column sums (dgrad); atomic accumulation of k-splits (wgrad).
+#include "common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LD_KC = BK + 4;    // k-contiguous operand tile: [128][36] floats
+constexpr int LD_KS = 128 + 4;   // k-strided operand tile  : [32][132] floats
+constexpr int TILE_F = 128 * LD_KC;          // 4608 floats (== 32 * 144 > 32 * 132, shared size)
+static_assert(TILE_F >= BK * LD_KS, "tile buffer too small");
+
+struct GemmArgs {
+    long long M, N, K;             // GEMM extents (M x N output, K reduction)
+    const float* A; long long lda;
+    const float* B; long long ldb;
+    float* C; long long ldc;
+    int vecA, vecB;                // 16-byte vector loads legal for the operand
+    long long kchunk;              // reduction length per blockIdx.z slice (multiple of BK)
+    const float* bias;             // [N] added before activation            (nullable)
+    int act;                       // DLRM_ACT_* applied to the result
+    const float* mask; long long ldmask; int mask_act;   // result *= act'(mask[m,n])   (nullable)
+    float* colsum;                 // [N] += column sums of the result        (nullable)
+    int atomic_out;                // 1: atomicAdd into C instead of store
+    int tiles_m, tiles_n;
+};
+
+template <bool KC>
+__device__ __forceinline__ void load_tile(float4 (&r)[4], const float* __restrict__ P, long long ld, int vec,
+                                          long long row0, long long rows_max, long long k0, long long k_end,
+                                          int tid) {
+    // KC : tile = 128 rows (row0..) x 32 k;  thread -> row (tid>>3)+32i, k-quad tid&7
+    // !KC: tile = 32 k-rows (k0..) x 128 columns (row0..); thread -> k-row (tid>>5)+8i, col-quad tid&31
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        long long gr, gc, gr_max, gc_max;
+        if (KC) { gr = row0 + (tid >> 3) + 32 * i; gc = k0 + (tid & 7) * 4; gr_max = rows_max; gc_max = k_end; }
+        else    { gr = k0 + (tid >> 5) + 8 * i;    gc = row0 + (tid & 31) * 4; gr_max = k_end; gc_max = rows_max; }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gr < gr_max) {
+            const float* p = P + gr * ld + gc;
+            if (vec) {
+                if (gc < gc_max) v = *(const float4*)p;     // extents are multiples of 4 on this path
+            } else {
+                if (gc + 0 < gc_max) v.x = p[0];
+                if (gc + 1 < gc_max) v.y = p[1];
+                if (gc + 2 < gc_max) v.z = p[2];
+                if (gc + 3 < gc_max) v.w = p[3];
+            }
+        }
+        r[i] = v;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, const float4 (&r)[4], int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* p = KC ? s + ((tid >> 3) + 32 * i) * LD_KC + (tid & 7) * 4
+                      : s + ((tid >> 5) + 8 * i) * LD_KS + (tid & 31) * 4;
+        *(float4*)__builtin_assume_aligned(p, 16) = r[i];
+    }
+}
+
+// fragment for the 32-row sub-tile starting at `sub` (0..127), k-group kk (8 k-values):
+// lane l supplies row sub + (l&31) and k-values kk*8 + 4*(l>>5) + {0,1,2,3}
+template <bool KC>
+__device__ __forceinline__ float4 load_frag(const float* __restrict__ s, int sub, int kk, int lane) {
+    if (KC) {
+        return *(const float4*)__builtin_assume_aligned(s + (sub + (lane & 31)) * LD_KC + kk * 8 + 4 * (lane >> 5), 16);
+    } else {
+        const float* p = s + (kk * 8 + 4 * (lane >> 5)) * LD_KS + sub + (lane & 31);
+        return make_float4(p[0], p[LD_KS], p[2 * LD_KS], p[3 * LD_KS]);
+    }
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == DLRM_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DLRM_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+// derivative of the activation expressed through its OUTPUT y (what the forward pass saved)
+__device__ __forceinline__ float act_grad(float g, float y, int act) {
+    if (act == DLRM_ACT_RELU) return y > 0.f ? g : 0.f;
+    if (act == DLRM_ACT_SIGMOID) return g * ((1.f - y) * y);
+    return g;
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][A tile | B tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware remap: hardware places workgroup b on XCD b%8; give each XCD a contiguous range of
+    // logical tile ids so the tiles_n workgroups that share one A row panel hit the same L2.
+    const int nwg = g.tiles_m * g.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, local = id >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int tile_m = id / g.tiles_n, tile_n = id - tile_m * g.tiles_n;
+    const long long m0 = (long long)tile_m * BM, n0 = (long long)tile_n * BN;
+    const long long k_begin = (long long)blockIdx.z * g.kchunk;
+    const long long k_end = (k_begin + g.kchunk < g.K) ? k_begin + g.kchunk : g.K;
+    const int nk = (int)((k_end - k_begin + BK - 1) / BK);
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    if (nk > 0) {
+        load_tile<A_KC>(ra, g.A, g.lda, g.vecA, m0, g.M, k_begin, k_end, tid);
+        load_tile<B_KC>(rb, g.B, g.ldb, g.vecB, n0, g.N, k_begin, k_end, tid);
+        store_tile<A_KC>(lds, ra, tid);
+        store_tile<B_KC>(lds + TILE_F, rb, tid);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* sA = lds + (kt & 1) * 2 * TILE_F;
+        const float* sB = sA + TILE_F;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const long long k0 = k_begin + (long long)(kt + 1) * BK;
+            load_tile<A_KC>(ra, g.A, g.lda, g.vecA, m0, g.M, k0, k_end, tid);
+            load_tile<B_KC>(rb, g.B, g.ldb, g.vecB, n0, g.N, k0, k_end, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 fa[2], fb[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fa[t] = load_frag<A_KC>(sA, wm * 64 + t * 32, kk, lane);
+                fb[t] = load_frag<B_KC>(sB, wn * 64 + t * 32, kk, lane);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].x, fb[tn].x, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].y, fb[tn].y, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].z, fb[tn].z, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].w, fb[tn].w, acc[tm][tn], 0, 0, 0);
+                }
+        }
+        if (more) {
+            float* dA = lds + ((kt + 1) & 1) * 2 * TILE_F;
+            store_tile<A_KC>(dA, ra, tid);
+            store_tile<B_KC>(dA + TILE_F, rb, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col_l = lane & 31, rofs = 4 * (lane >> 5);
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+        const long long n = n0 + wn * 64 + tn * 32 + col_l;
+        const bool n_ok = n < g.N;
+        const float bv = (g.bias && n_ok) ? g.bias[n] : 0.f;
+        float cs = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + rofs;
+                if (n_ok && m < g.M) {
+                    float v = acc[tm][tn][r] + bv;
+                    v = act_apply(v, g.act);
+                    if (g.mask) v = act_grad(v, g.mask[m * g.ldmask + n], g.mask_act);
+                    cs += v;
+                    float* c = g.C + m * g.ldc + n;
+                    if (g.atomic_out) atomicAdd(c, v); else *c = v;
+                }
+            }
+        }
+        if (g.colsum) {
+            cs += __shfl_xor(cs, 32, 64);
+            if (lane < 32 && n_ok) atomicAdd(g.colsum + n, cs);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dZ = dY ⊙ act'(Y), dbias += colsum(dZ)   (tower outputs whose dY does not come from a dgrad GEMM)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void act_bwd_kernel(long long M, int N, const float* __restrict__ dY, long long lddy,
+                                                      const float* __restrict__ Y, long long ldy, int act,
+                                                      float* __restrict__ dZ, long long lddz, float* __restrict__ dbias,
+                                                      int tx, int rows_per_block) {
+    __shared__ float red[256];
+    const int ty_n = 256 / tx;
+    const int cx = threadIdx.x % tx, ry = threadIdx.x / tx;
+    const long long n = (long long)blockIdx.y * tx + cx;
+    const long long m_begin = (long long)blockIdx.x * rows_per_block;
+    const long long m_end = (m_begin + rows_per_block < M) ? m_begin + rows_per_block : M;
+    float cs = 0.f;
+    if (n < N) {
+        for (long long m = m_begin + ry; m < m_end; m += ty_n) {
+            const float v = act_grad(dY[m * lddy + n], Y[m * ldy + n], act);
+            dZ[m * lddz + n] = v;
+            cs += v;
+        }
+    }
+    if (dbias) {
+        red[threadIdx.x] = cs;
+        __syncthreads();
+        for (int s = ty_n >> 1; s > 0; s >>= 1) {
+            if (ry < s) red[threadIdx.x] += red[threadIdx.x + s * tx];
+            __syncthreads();
+        }
+        if (ry == 0 && n < N) atomicAdd(dbias + n, red[cx]);
+    }
+}
+
+static int pow2ceil_i(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+template <bool A_KC, bool B_KC>
+static int launch_gemm(GemmArgs& g, int splits, hipStream_t st) {
+    g.tiles_m = (int)((g.M + BM - 1) / BM);
+    g.tiles_n = (int)((g.N + BN - 1) / BN);
+    const size_t lds = 2 * 2 * TILE_F * sizeof(float);   // 73,728 B: two workgroups per CU
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<A_KC, B_KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), block(256);
+    hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC>), grid, block, lds, st, g);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+static int vec_ok_kc(const float* p, long long ld, long long kext) { return dlrm_aligned16(p) && ld % 4 == 0 && kext % 4 == 0; }
+static int vec_ok_ks(const float* p, long long ld, long long cext) { return dlrm_aligned16(p) && ld % 4 == 0 && cext % 4 == 0; }
+
+}  // namespace
+
+extern "C" int dlrm_linear_fwd(int64_t M, int N, int K, const float* X, int64_t ldx, const float* W,
+                               int64_t ldw, const float* bias, int act, float* Y, int64_t ldy,
+                               void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !X || !W || !Y) return DLRM_E_ARG;
+    if (ldx < K || ldw < K || ldy < N) return DLRM_E_ARG;
+    if (act < DLRM_ACT_NONE || act > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
+    GemmArgs g = {};
+    g.M = M; g.N = N; g.K = K;
+    g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
+    g.vecA = vec_ok_kc(X, ldx, K); g.vecB = vec_ok_kc(W, ldw, K);
+    g.kchunk = ((K + BK - 1) / BK) * BK;
+    g.bias = bias; g.act = act;
+    return launch_gemm<true, true>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, int64_t lddy,
+                                    const float* W, int64_t ldw, const float* Xact, int64_t ldxa,
+                                    int xact_kind, float* dX, int64_t lddx, float* dbias_prev,
+                                    void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !dY || !W || !dX) return DLRM_E_ARG;
+    if (lddy < N || ldw < K || lddx < K) return DLRM_E_ARG;
+    if (xact_kind < DLRM_ACT_NONE || xact_kind > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
+    if (xact_kind != DLRM_ACT_NONE && (!Xact || ldxa < K)) return DLRM_E_ARG;
+    GemmArgs g = {};
+    g.M = M; g.N = K; g.K = N;                       // output [M, K_layer], reduce over N_layer
+    g.A = dY; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = lddx;
+    g.vecA = vec_ok_kc(dY, lddy, N); g.vecB = vec_ok_ks(W, ldw, K);
+    g.kchunk = ((N + BK - 1) / BK) * BK;
+    g.act = DLRM_ACT_NONE;
+    if (xact_kind != DLRM_ACT_NONE) { g.mask = Xact; g.ldmask = ldxa; g.mask_act = xact_kind; }
+    g.colsum = dbias_prev;
+    return launch_gemm<true, false>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, int64_t lddy,
+                                      const float* X, int64_t ldx, float* dW, int64_t lddw,
+                                      int accumulate, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !dY || !X || !dW) return DLRM_E_ARG;
+    if (lddy < N || ldx < K || lddw < K) return DLRM_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g = {};
+    g.M = N; g.N = K; g.K = M;                       // output [N_layer, K_layer], reduce over the batch
+    g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx; g.C = dW; g.ldc = lddw;
+    g.vecA = vec_ok_ks(dY, lddy, N); g.vecB = vec_ok_ks(X, ldx, K);
+    g.act = DLRM_ACT_NONE;
+    // split the batch reduction so that >= ~4 workgroups per CU exist; slices of >= 512 rows
+    const int tiles = (int)(((N + BM - 1) / BM) * ((K + BN - 1) / BN));
+    int splits = (1024 + tiles - 1) / tiles;
+    const int64_t max_splits = (M + 511) / 512;
+    if (splits > max_splits) splits = (int)max_splits;
+    if (splits < 1) splits = 1;
+    int64_t kchunk = (M + splits - 1) / splits;
+    kchunk = ((kchunk + BK - 1) / BK) * BK;
+    splits = (int)((M + kchunk - 1) / kchunk);
+    g.kchunk = kchunk;
+    g.atomic_out = (splits > 1 || accumulate) ? 1 : 0;
+    if (g.atomic_out && !accumulate) {
+        hipError_t e = hipMemset2DAsync(dW, (size_t)lddw * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)N, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return launch_gemm<false, false>(g, splits, st);
+}
+
+extern "C" int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, const float* Y,
+                            int64_t ldy, int act, float* dZ, int64_t lddz, float* dbias, void* stream) {
+    if (M <= 0 || N <= 0 || !dY || !Y || !dZ) return DLRM_E_ARG;
+    if (lddy < N || ldy < N || lddz < N) return DLRM_E_ARG;
+    if (act < DLRM_ACT_NONE || act > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
+    int tx = pow2ceil_i(N); if (tx > 64) tx = 64;
+    const int ty_n = 256 / tx;
+    int rows_per_block = ty_n * 16;
+    dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (unsigned)((N + tx - 1) / tx), 1);
+    hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (long long)M, N, dY,
+                       (long long)lddy, Y, (long long)ldy, act, dZ, (long long)lddz, dbias, tx, rows_per_block);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}

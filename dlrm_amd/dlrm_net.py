@@ -1,0 +1,351 @@
+"""DLRM_Net for MI355X: the module surface of the reference's `DLRM_Net`
+(dlrm_s_pytorch.py:207-612), every device operation a hand-written HIP kernel.
+
+Drop-in contract:
+  * constructor signature, `forward(dense_x, lS_o, lS_i)`, the public helpers `create_mlp`,
+    `create_emb`, `apply_mlp`, `apply_emb`, `interact_features`, and the attributes
+    `emb_l / v_W_l / bot_l / top_l / loss_fn / loss_ws / ndevices / loss_threshold /
+    weighted_pooling / quantize_emb`;
+  * `state_dict()` keys and shapes: `emb_l.{k}.weight`, `bot_l.{2i}.weight|bias`, `top_l.{2i}...`;
+  * parameter initialisation consumes the numpy RNG in the reference's order (tables, bottom tower,
+    top tower; weight then bias), so equal seeds give equal initial parameters;
+  * `ext_dist.my_size > 1` selects the table-sharded / batch-split distributed forward;
+  * configuration errors terminate through `sys.exit("ERROR: ...")` like the reference.
+What differs by design: embedding parameters never receive a `.grad`; their sparse update is fused
+into one kernel that runs when the optimizer steps (see `EmbeddingUpdateHook`), so the COO gradient
+of the reference (nnz x D floats per table) is never written to HBM.
+"""
+from __future__ import annotations
+
+import sys
+import weakref
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ext_dist, ops
+from .functional import (BCELossFunction, EmbeddingBagsFunction, InteractFunction, MLPFunction,
+                         MSELossFunction, OutSlot)
+from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, BagBatch
+
+
+_EMB_INIT_DEVICE = None
+
+
+def set_embedding_init(device=None) -> None:
+    """None (default): tables are drawn from numpy's global RNG exactly like the reference
+    (dlrm_s_pytorch.py:280-284).  A torch device: tables are allocated and drawn U(-sqrt(1/n), sqrt(1/n))
+    directly in that device's memory (needed for the 96 GB Criteo-Terabyte tables)."""
+    global _EMB_INIT_DEVICE
+    _EMB_INIT_DEVICE = device
+
+
+class FusedMLP(nn.Sequential):
+    """nn.Sequential of Linear / ReLU / Sigmoid children (same child names -> same state_dict keys as
+    the reference tower) whose forward runs the whole tower through the fused GEMM kernels.
+    Being an nn.Module it can be wrapped by DistributedDataParallel exactly like the reference's."""
+
+    def _layers(self):
+        mods = list(self.children())
+        params, acts = [], []
+        i = 0
+        while i < len(mods):
+            lin = mods[i]
+            if not isinstance(lin, nn.Linear):
+                raise RuntimeError("FusedMLP expects Linear layers each followed by ReLU or Sigmoid")
+            act = ACT_NONE
+            if i + 1 < len(mods) and isinstance(mods[i + 1], (nn.ReLU, nn.Sigmoid)):
+                act = ACT_RELU if isinstance(mods[i + 1], nn.ReLU) else ACT_SIGMOID
+                i += 1
+            params += [lin.weight, lin.bias]
+            acts.append(act)
+            i += 1
+        return params, tuple(acts)
+
+    def forward(self, x, out_slot: Optional[OutSlot] = None):
+        params, acts = self._layers()
+        return MLPFunction.apply(x, acts, out_slot, *params)
+
+
+class FusedBCELoss(nn.Module):
+    """BCELoss(reduction="mean") computed by the fused loss kernel."""
+
+    def forward(self, p, target):
+        return BCELossFunction.apply(p, target, None)
+
+
+class FusedMSELoss(nn.Module):
+    def forward(self, p, target):
+        return MSELossFunction.apply(p, target)
+
+
+class EmbeddingUpdateHook:
+    """Applies the fused sparse embedding update when an optimizer steps.
+
+    `run()` in the reference builds `torch.optim.SGD(dlrm.parameters())` and calls
+    zero_grad / backward / step (dlrm_s_pytorch.py:1343-1369, 1611-1621).  Embedding parameters keep
+    `.grad is None` (SGD skips them); backward parks (weights, bags, d_out) here and a global
+    optimizer step pre-hook launches `dlrm_emb_bwd_sgd` with the learning rate the optimizer holds at
+    that moment — the same point in the step, with the same lr, as the reference's sparse update."""
+
+    _models: "weakref.WeakSet" = weakref.WeakSet()
+    _handle = None
+
+    @classmethod
+    def register(cls, model: "DLRM_Net") -> None:
+        cls._models.add(model)
+        if cls._handle is None:
+            from torch.optim.optimizer import register_optimizer_step_pre_hook
+            cls._handle = register_optimizer_step_pre_hook(cls._pre_step)
+
+    @staticmethod
+    def _pre_step(optimizer, args, kwargs):
+        for model in list(EmbeddingUpdateHook._models):
+            if model._pending_emb:
+                model.apply_pending_embedding_updates(optimizer)
+
+
+class DLRM_Net(nn.Module):
+    # ---------------------------------------------------------------- parameter construction
+    def create_mlp(self, ln, sigmoid_layer):
+        """Tower with ln[i] -> ln[i+1] Linear layers; Sigmoid after layer `sigmoid_layer`, ReLU after
+        the others.  W ~ N(0, sqrt(2/(m+n))), b ~ N(0, sqrt(1/m)) drawn from numpy's global RNG
+        (dlrm_s_pytorch.py:208-246)."""
+        mods = []
+        for i in range(ln.size - 1):
+            fan_in, fan_out = int(ln[i]), int(ln[i + 1])
+            lin = nn.Linear(fan_in, fan_out, bias=True)
+            w = np.random.normal(0.0, np.sqrt(2 / (fan_out + fan_in)), size=(fan_out, fan_in)).astype(np.float32)
+            b = np.random.normal(0.0, np.sqrt(1 / fan_out), size=fan_out).astype(np.float32)
+            lin.weight.data = torch.tensor(w, requires_grad=True)
+            lin.bias.data = torch.tensor(b, requires_grad=True)
+            mods.append(lin)
+            mods.append(nn.Sigmoid() if i == sigmoid_layer else nn.ReLU())
+        return FusedMLP(*mods)
+
+    def create_emb(self, m, ln, weighted_pooling=None):
+        """One EmbeddingBag(sum) parameter holder per LOCAL table, W ~ U(-sqrt(1/n), sqrt(1/n)) from
+        numpy's global RNG (dlrm_s_pytorch.py:248-294).  The holders own the parameters (state_dict
+        parity); lookups go through the batched HIP kernel, not through the holders' forward."""
+        tables = nn.ModuleList()
+        pool_w = []
+        for i in range(ln.size):
+            if ext_dist.my_size > 1 and i not in self.local_emb_indices:
+                continue
+            n = int(ln[i])
+            if getattr(self, "qr_flag", False) and n > self.qr_threshold:
+                sys.exit("ERROR: QR embeddings are not supported by the MI355X DLRM_Net")
+            if getattr(self, "md_flag", False) and n > self.md_threshold:
+                sys.exit("ERROR: mixed-dimension embeddings are not supported by the MI355X DLRM_Net")
+            bound = np.sqrt(1 / n)
+            if _EMB_INIT_DEVICE is None:
+                w = torch.tensor(np.random.uniform(low=-bound, high=bound, size=(n, m)).astype(np.float32))
+            else:
+                # benchmark-scale tables (tens of GB) cannot go through a float64 numpy temporary on the
+                # host: same distribution, drawn on the device (see set_embedding_init)
+                w = torch.empty((n, m), dtype=torch.float32, device=_EMB_INIT_DEVICE).uniform_(-bound, bound)
+            holder = nn.EmbeddingBag(n, m, mode="sum", sparse=True, _weight=w)
+            pool_w.append(None if weighted_pooling is None else torch.ones(n, dtype=torch.float32))
+            tables.append(holder)
+        return tables, pool_w
+
+    def __init__(self, m_spa=None, ln_emb=None, ln_bot=None, ln_top=None, arch_interaction_op=None,
+                 arch_interaction_itself=False, sigmoid_bot=-1, sigmoid_top=-1, sync_dense_params=True,
+                 loss_threshold=0.0, ndevices=-1, qr_flag=False, qr_operation="mult", qr_collisions=0,
+                 qr_threshold=200, md_flag=False, md_threshold=200, weighted_pooling=None,
+                 loss_function="bce"):
+        super().__init__()
+        self._pending_emb: list = []
+        self.emb_update_mode = ops.UPD_ATOMIC
+        if m_spa is None or ln_emb is None or ln_bot is None or ln_top is None or arch_interaction_op is None:
+            return  # empty shell, like the reference's guard (dlrm_s_pytorch.py:320-326)
+
+        self.ndevices = ndevices
+        self.output_d = 0
+        self.parallel_model_batch_size = -1
+        self.parallel_model_is_not_prepared = True
+        self.arch_interaction_op = arch_interaction_op
+        self.arch_interaction_itself = arch_interaction_itself
+        self.sync_dense_params = sync_dense_params
+        self.loss_threshold = loss_threshold
+        self.loss_function = loss_function
+        self.weighted_pooling = ("learned" if weighted_pooling is not None and weighted_pooling != "fixed"
+                                 else weighted_pooling)
+        self.qr_flag = qr_flag
+        if qr_flag:
+            self.qr_collisions, self.qr_operation, self.qr_threshold = qr_collisions, qr_operation, qr_threshold
+        self.md_flag = md_flag
+        if md_flag:
+            self.md_threshold = md_threshold
+        self.m_spa = m_spa
+
+        if ext_dist.my_size > 1:
+            n_emb = len(ln_emb)
+            if n_emb < ext_dist.my_size:
+                sys.exit("only (%d) sparse features for (%d) devices, table partitions will fail"
+                         % (n_emb, ext_dist.my_size))
+            self.n_global_emb = n_emb
+            self.n_local_emb, self.n_emb_per_rank = ext_dist.get_split_lengths(n_emb)
+            self.local_emb_slice = ext_dist.get_my_slice(n_emb)
+            self.local_emb_indices = list(range(n_emb))[self.local_emb_slice]
+
+        if ndevices > 1:
+            sys.exit("ERROR: single-process multi-GPU (ndevices=%d) is not supported; launch one process per "
+                     "GPU (torchrun) to use table-sharded embeddings over RCCL" % ndevices)
+        self.emb_l, pool_w = self.create_emb(m_spa, ln_emb, weighted_pooling)
+        if self.weighted_pooling == "learned":
+            sys.exit("ERROR: learned weighted pooling is not supported by the MI355X DLRM_Net yet")
+        self.v_W_l = pool_w
+        self.bot_l = self.create_mlp(ln_bot, sigmoid_bot)
+        self.top_l = self.create_mlp(ln_top, sigmoid_top)
+
+        self.quantize_emb = False
+        self.emb_l_q = []
+        self.quantize_bits = 32
+
+        if loss_function == "mse":
+            self.loss_fn = FusedMSELoss()
+        elif loss_function == "bce":
+            self.loss_fn = FusedBCELoss()
+        elif loss_function == "wbce":
+            import __main__ as _m  # the reference reads the CLI global `args.loss_weights` (:391)
+            lw = getattr(getattr(_m, "args", None), "loss_weights", "1.0-1.0")
+            self.loss_ws = torch.tensor(np.fromstring(lw, dtype=float, sep="-"))
+            self.loss_fn = torch.nn.BCELoss(reduction="none")
+        else:
+            sys.exit("ERROR: --loss-function=" + str(loss_function) + " is not supported")
+        EmbeddingUpdateHook.register(self)
+
+    # ---------------------------------------------------------------- operators
+    def apply_mlp(self, x, layers, out_slot: Optional[OutSlot] = None):
+        if out_slot is not None:
+            return layers(x, out_slot=out_slot)
+        return layers(x)
+
+    def _bags(self, lS_o, lS_i, v_W_l) -> BagBatch:
+        psw = None
+        if v_W_l is not None and any(w is not None for w in v_W_l):
+            psw = [None if w is None else w.to(lS_i[k].device).gather(0, lS_i[k].long()) for k, w in enumerate(v_W_l)]
+        return BagBatch(lS_o, lS_i, psw)
+
+    def _emb_weights(self, emb_l) -> List[torch.Tensor]:
+        return [e.weight for e in emb_l]
+
+    def _emb_packed(self, lS_o, lS_i, emb_l, v_W_l, out_slot: Optional[OutSlot] = None):
+        """[B, T*D] pooled embeddings of all given tables, one kernel launch."""
+        bags = self._bags(lS_o, lS_i, v_W_l)
+        return EmbeddingBagsFunction.apply(self._stash_embedding_grad, bags, out_slot, *self._emb_weights(emb_l))
+
+    def apply_emb(self, lS_o, lS_i, emb_l, v_W_l):
+        """Reference-shaped result: a list with one [B, D] tensor per table (dlrm_s_pytorch.py:407-462)."""
+        if self.quantize_emb:
+            sys.exit("ERROR: quantized embeddings are a CPU-only inference option of the reference")
+        packed = self._emb_packed(lS_o, lS_i, emb_l, v_W_l)
+        D = emb_l[0].weight.size(1)
+        return list(packed.split(D, dim=1))
+
+    def interact_features(self, x, ly):
+        if self.arch_interaction_op == "dot":
+            D = x.size(1)
+            return InteractFunction.apply(D, bool(self.arch_interaction_itself), x, *ly)
+        if self.arch_interaction_op == "cat":
+            return torch.cat([x] + list(ly), dim=1)
+        sys.exit("ERROR: --arch-interaction-op=" + str(self.arch_interaction_op) + " is not supported")
+
+    def quantize_embedding(self, bits):
+        sys.exit("ERROR: quantized embeddings are a CPU-only inference option of the reference")
+
+    # ---------------------------------------------------------------- fused sparse update
+    def _stash_embedding_grad(self, weights, bags, dout):
+        self._pending_emb.append((weights, bags, dout))
+
+    def apply_pending_embedding_updates(self, optimizer=None, lr: Optional[float] = None) -> None:
+        """Launch the fused backward+update for every stashed embedding gradient."""
+        pending, self._pending_emb = self._pending_emb, []
+        for weights, bags, dout in pending:
+            if lr is not None:
+                ops.emb_bwd_sgd(weights, bags, dout, lr, self.emb_update_mode)
+                continue
+            lrs = _embedding_lrs(optimizer, weights)
+            if lrs is None:
+                self._pending_emb.append((weights, bags, dout))   # another optimizer owns these tables
+                continue
+            if len(set(lrs)) == 1:
+                ops.emb_bwd_sgd(weights, bags, dout, lrs[0], self.emb_update_mode)
+            else:
+                sys.exit("ERROR: embedding tables in param groups with different learning rates are not supported")
+
+    # ---------------------------------------------------------------- forward paths
+    def forward(self, dense_x, lS_o, lS_i):
+        if ext_dist.my_size > 1:
+            return self.distributed_forward(dense_x, lS_o, lS_i)
+        return self.sequential_forward(dense_x, lS_o, lS_i)
+
+    def _clamp(self, p):
+        if 0.0 < self.loss_threshold < 1.0:
+            return torch.clamp(p, min=self.loss_threshold, max=(1.0 - self.loss_threshold))
+        return p
+
+    def sequential_forward(self, dense_x, lS_o, lS_i):
+        """bottom MLP -> embeddings -> interaction -> top MLP (dlrm_s_pytorch.py:587-612), with the
+        bottom tower and the embedding kernel writing directly into the [B, (1+T)*D] feature buffer."""
+        if self.arch_interaction_op != "dot":
+            x = self.apply_mlp(dense_x, self.bot_l)
+            ly = self.apply_emb(lS_o, lS_i, self.emb_l, self.v_W_l)
+            return self._clamp(self.apply_mlp(self.interact_features(x, ly), self.top_l))
+        B = dense_x.size(0)
+        T = len(self.emb_l)
+        D = self.emb_l[0].weight.size(1)
+        feat = torch.empty((B, (1 + T) * D), dtype=torch.float32, device=dense_x.device)
+        x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :D]))
+        if x.size(1) != D:
+            sys.exit("ERROR: bottom MLP output (%d) and embedding dimension (%d) differ" % (x.size(1), D))
+        E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l, out_slot=OutSlot(feat[:, D:]))
+        z = InteractFunction.apply(D, bool(self.arch_interaction_itself), x, E)
+        return self._clamp(self.apply_mlp(z, self.top_l))
+
+    def distributed_forward(self, dense_x, lS_o, lS_i):
+        """Table-wise sharded embeddings + batch-split MLPs (dlrm_s_pytorch.py:528-585): every rank pools
+        the WHOLE batch for its tables, one all-to-all turns table-split into batch-split, the bottom
+        MLP runs while the exchange is in flight."""
+        batch_size = dense_x.size(0)
+        if batch_size < ext_dist.my_size:
+            sys.exit("ERROR: batch_size (%d) must be larger than number of ranks (%d)" % (batch_size, ext_dist.my_size))
+        if batch_size % ext_dist.my_size != 0:
+            sys.exit("ERROR: batch_size %d can not split across %d ranks evenly" % (batch_size, ext_dist.my_size))
+        dense_x = dense_x[ext_dist.get_my_slice(batch_size)]
+        lS_o = lS_o[self.local_emb_slice]
+        lS_i = lS_i[self.local_emb_slice]
+        if len(self.emb_l) != len(lS_o) or len(self.emb_l) != len(lS_i):
+            sys.exit("ERROR: corrupted model input detected in distributed_forward call")
+        D = self.emb_l[0].weight.size(1)
+        E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l)           # [B, T_loc*D] == packed send buffer
+        req = ext_dist.alltoall([E], self.n_emb_per_rank, emb_dim=D)
+        x = self.apply_mlp(dense_x, self.bot_l)                             # overlaps the exchange
+        ly = list(req.wait())                                               # N x [B/N, T_s*D], read in place
+        z = self.interact_features(x, ly)
+        return self._clamp(self.apply_mlp(z, self.top_l))
+
+
+def _embedding_lrs(optimizer, weights) -> Optional[List[float]]:
+    """Learning rate of the param group holding each embedding table, or None if the optimizer does not
+    own them.  Only plain SGD is accepted for the fused update."""
+    if optimizer is None:
+        return None
+    owner = {}
+    for group in optimizer.param_groups:
+        for p in group["params"]:
+            owner[id(p)] = group
+    groups = [owner.get(id(w)) for w in weights]
+    if all(g is None for g in groups):
+        return None
+    if any(g is None for g in groups):
+        sys.exit("ERROR: optimizer holds only some of the embedding tables")
+    if not isinstance(optimizer, torch.optim.SGD):
+        sys.exit("ERROR: the fused embedding update implements torch.optim.SGD; got %s" % type(optimizer).__name__)
+    for g in groups:
+        if g.get("momentum", 0) != 0 or g.get("weight_decay", 0) != 0 or g.get("nesterov", False) or g.get("maximize", False):
+            sys.exit("ERROR: fused sparse SGD supports momentum=0, weight_decay=0 only (as sparse gradients do)")
+    return [float(g["lr"]) for g in groups]

@@ -1,0 +1,276 @@
+"""Distributed helper with the public surface of the reference's `extend_distributed.py`
+(init_distributed, get_my_slice, get_split_lengths, alltoall -> request.wait(), all_gather, barrier,
+print_all, DDP, my_rank/my_size/my_local_rank/my_local_size), re-implemented for one process per
+MI355X with torch.distributed on RCCL ("nccl" backend on ROCm) or gloo on CPU hosts.
+
+Semantics kept from the reference (extend_distributed.py:47-62, 389-486, 541-576):
+  * contiguous block partition of n items over the ranks, the first n % size ranks get one extra;
+  * the pooled-embedding exchange: every rank holds [B, T_loc*D] (its tables, whole batch) and ends
+    with one [B/N, T_s*D] block per source rank s (all tables, its batch slice); backward is the
+    mirror exchange;
+  * the exchange is asynchronous between alltoall() and .wait() so the bottom MLP overlaps it.
+What differs: one all_to_all_single per direction on RCCL (7 concurrent xGMI point-to-point
+transfers per GPU) is the only implementation (no scatter/gather emulations); send and receive
+buffers are the kernels' own output/input buffers (no cat / split / contiguous copies on the GPU
+path): the embedding kernel writes the packed send buffer, interaction reads the receive buffer in
+place, interaction backward writes the packed reverse send buffer.
+"""
+from __future__ import annotations
+
+import builtins
+import os
+import sys
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+from torch.nn.parallel import DistributedDataParallel as DDP  # noqa: F401  (re-export, as the reference does)
+
+my_rank = -1
+my_size = -1
+my_local_rank = -1
+my_local_size = -1
+alltoall_supported = False
+a2a_impl = os.environ.get("DLRM_ALLTOALL_IMPL", "")  # parsed for CLI parity; only "alltoall" exists here
+
+_orig_print = builtins.print
+
+
+def _env_int(names: Sequence[str], default: int = -1) -> int:
+    for n in names:
+        v = os.environ.get(n)
+        if v is not None and v != "":
+            try:
+                iv = int(v)
+            except ValueError:
+                continue
+            if iv >= 0:
+                return iv
+    return default
+
+
+def get_my_slice(n: int) -> slice:
+    """Contiguous share of range(n) owned by this rank (extend_distributed.py:47-51)."""
+    base, extra = divmod(n, my_size)
+    lo = my_rank * base + min(my_rank, extra)
+    hi = lo + base + (1 if my_rank < extra else 0)
+    return slice(lo, hi, 1)
+
+
+def get_split_lengths(n: int) -> Tuple[int, Optional[List[int]]]:
+    """(my share, per-rank shares or None when the split is even) (extend_distributed.py:54-62)."""
+    base, extra = divmod(n, my_size)
+    if extra == 0:
+        return base, None
+    shares = [base + 1 if r < extra else base for r in range(my_size)]
+    return shares[my_rank], shares
+
+
+def _rank0_print(*args, **kwargs):
+    force = kwargs.pop("print_all", False)
+    if my_rank <= 0 or force:
+        _orig_print(*args, **kwargs)
+
+
+def print_all(*args, **kwargs):
+    _orig_print(*args, **kwargs)
+
+
+def init_distributed(rank: int = -1, local_rank: int = -1, size: int = -1, use_gpu: bool = False, backend: str = ""):
+    """Discover rank/size from torchrun or MPI-style environment variables and create the process group."""
+    global my_rank, my_size, my_local_rank, my_local_size, alltoall_supported
+    env_size = _env_int(["WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "MV2_COMM_WORLD_SIZE"])
+    env_rank = _env_int(["RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "MV2_COMM_WORLD_RANK"])
+    env_lrank = _env_int(["LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "MV2_COMM_WORLD_LOCAL_RANK"])
+    env_lsize = _env_int(["LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "MV2_COMM_WORLD_LOCAL_SIZE"])
+    if size < 0:
+        size = env_size
+    if rank < 0:
+        rank = env_rank
+    if local_rank < 0:
+        local_rank = env_lrank
+    if size > 1 and rank >= 0:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ["RANK"] = str(rank)
+        os.environ["WORLD_SIZE"] = str(size)
+        if not backend:
+            backend = "nccl" if use_gpu else "gloo"   # "nccl" is RCCL on ROCm
+        if local_rank < 0:
+            local_rank = rank % max(env_lsize, torch.cuda.device_count() if use_gpu else 1, 1)
+        if use_gpu:
+            if torch.cuda.device_count() <= local_rank:
+                sys.exit("ERROR: local rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+            torch.cuda.set_device(local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group(backend, rank=rank, world_size=size)
+        my_rank, my_size = dist.get_rank(), dist.get_world_size()
+        my_local_rank = local_rank
+        my_local_size = env_lsize if env_lsize > 0 else my_size
+        # capability probe (the reference does the same 4-element exchange, extend_distributed.py:165-173)
+        probe = torch.zeros(my_size, dtype=torch.float32, device="cuda" if use_gpu else "cpu")
+        try:
+            dist.all_to_all_single(probe.clone(), probe)
+            alltoall_supported = True
+        except RuntimeError as exc:  # pragma: no cover - backend specific
+            alltoall_supported = False
+            sys.exit("ERROR: backend %s does not support all_to_all_single: %s" % (backend, exc))
+        builtins.print = _rank0_print
+    else:
+        my_rank, my_size, my_local_rank, my_local_size = 0, 1, 0, 1
+    _orig_print("Running on %d ranks using %s backend" % (my_size, backend or "none")) if my_rank <= 0 else None
+
+
+def barrier():
+    if my_size > 1:
+        dist.barrier()
+
+
+# ------------------------------------------------------------------------------------------------
+# pooled-embedding all-to-all
+# ------------------------------------------------------------------------------------------------
+class _Exchange:
+    """Bookkeeping of one exchange: all sizes are in ELEMENTS of the flat fp32 buffers."""
+
+    def __init__(self, batch: int, emb_dim: int, local_tables: int, tables_per_rank: Optional[List[int]]):
+        self.batch = batch
+        self.emb_dim = emb_dim
+        self.local_tables = local_tables
+        self.local_batch, batch_shares = get_split_lengths(batch)
+        self.batch_shares = batch_shares or [self.local_batch] * my_size
+        self.tables_per_rank = tables_per_rank or [local_tables] * my_size
+        self.total_tables = sum(self.tables_per_rank)
+        # forward: send rows of my tables to the rank owning each batch slice ...
+        self.send_counts = [m * local_tables * emb_dim for m in self.batch_shares]
+        # ... receive my batch slice of every rank's tables
+        self.recv_counts = [self.local_batch * t * emb_dim for t in self.tables_per_rank]
+        self.work = None
+        self.buffer = None
+
+
+class _A2AStart(Function):
+    @staticmethod
+    def forward(ctx, ex: _Exchange, *blocks):
+        # blocks: [B, k*D] pieces of this rank's pooled embeddings, concatenated column-wise.
+        if len(blocks) == 1 and blocks[0].is_contiguous():
+            send = blocks[0].view(-1)          # the embedding kernel already wrote the packed layout
+        else:
+            send = torch.cat([b.reshape(ex.batch, -1) for b in blocks], dim=1).view(-1)
+        recv = send.new_empty(sum(ex.recv_counts))
+        ex.work = dist.all_to_all_single(recv, send, ex.recv_counts, ex.send_counts, async_op=True)
+        ex.buffer = recv
+        ex.send_keepalive = send
+        ctx.ex = ex
+        ctx.widths = [b.size(1) for b in blocks]
+        return recv
+
+    @staticmethod
+    def backward(ctx, _unused):
+        ex = ctx.ex
+        ex.work.wait()                          # reverse exchange launched by _A2AWait.backward
+        ex.work = None
+        g = ex.buffer.view(ex.batch, -1)        # [B, T_loc*D]
+        ex.buffer = None
+        if len(ctx.widths) == 1:
+            return (None, g)
+        return (None, *[p.contiguous() for p in g.split(ctx.widths, dim=1)])
+
+
+class _A2AWait(Function):
+    @staticmethod
+    def forward(ctx, ex: _Exchange, recv):
+        ex.work.wait()
+        ex.work = None
+        ex.send_keepalive = None
+        ctx.ex = ex
+        outs, o = [], 0
+        for t, n in zip(ex.tables_per_rank, ex.recv_counts):
+            outs.append(recv[o:o + n].view(ex.local_batch, t * ex.emb_dim))
+            o += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ex = ctx.ex
+        # interaction backward hands back adjacent chunks of ONE flat buffer; use it in place
+        g0 = grads[0]
+        packed = None
+        if all(g.is_contiguous() for g in grads):
+            adjacent, p = True, g0.data_ptr()
+            for g in grads:
+                adjacent = adjacent and g.data_ptr() == p and g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr()
+                p += g.numel() * 4
+            if adjacent:
+                packed = torch.as_strided(g0, (sum(ex.recv_counts),), (1,))
+        if packed is None:
+            packed = torch.cat([g.contiguous().view(-1) for g in grads])
+        back = packed.new_empty(ex.batch * ex.local_tables * ex.emb_dim)
+        ex.work = dist.all_to_all_single(back, packed, ex.send_counts, ex.recv_counts, async_op=True)
+        ex.buffer = back
+        ex.send_keepalive = packed
+        return (None, packed)   # shape-only gradient for the flat receive buffer; data travels via `ex`
+
+
+class Request:
+    """Handle returned by alltoall(); wait() yields one [B/N, T_s*D] tensor per source rank."""
+
+    def __init__(self, ex: _Exchange, recv: torch.Tensor):
+        self._ex, self._recv = ex, recv
+
+    def wait(self):
+        outs = _A2AWait.apply(self._ex, self._recv)
+        self._ex = self._recv = None
+        return outs
+
+
+def alltoall(inputs: Sequence[torch.Tensor], per_rank_table_splits: Optional[List[int]],
+             emb_dim: Optional[int] = None) -> Request:
+    """Start the exchange of pooled embeddings.
+
+    Reference form (extend_distributed.py:541-576): `inputs` = one [B, D] tensor per local table.
+    Zero-copy form: a single packed [B, T_loc*D] block plus `emb_dim=D` (what the embedding kernel
+    writes), which is sent without any cat/copy."""
+    if my_size <= 1:
+        raise RuntimeError("alltoall called without an initialised multi-rank process group")
+    batch = inputs[0].size(0)
+    width = sum(t.size(1) for t in inputs)
+    if emb_dim is None:
+        emb_dim = inputs[0].size(1)
+    if width % emb_dim != 0:
+        raise RuntimeError("alltoall: input width is not a multiple of the embedding dimension")
+    ex = _Exchange(batch, emb_dim, width // emb_dim, per_rank_table_splits)
+    recv = _A2AStart.apply(ex, *inputs)
+    return Request(ex, recv)
+
+
+class _AllGather(Function):
+    @staticmethod
+    def forward(ctx, x, lengths, dim):
+        ctx.dim, ctx.start, ctx.len = dim, sum(lengths[:my_rank]), lengths[my_rank]
+        x = x.contiguous()
+        if dim == 0:
+            shape = list(x.shape)
+            shape[0] = sum(lengths)
+            out = x.new_empty(shape)
+            dist.all_gather(list(out.split(lengths, dim=0)), x)
+            return out
+        pieces = []
+        for n in lengths:
+            shape = list(x.shape)
+            shape[dim] = n
+            pieces.append(x.new_empty(shape))
+        dist.all_gather(pieces, x)
+        return torch.cat(pieces, dim=dim)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.narrow(ctx.dim, ctx.start, ctx.len), None, None
+
+
+def all_gather(x: torch.Tensor, lengths: Optional[List[int]], dim: int = 0) -> torch.Tensor:
+    if not lengths:
+        lengths = [x.size(dim)] * my_size
+    elif not isinstance(lengths, (list, tuple)):
+        lengths = [lengths] * my_size
+    return _AllGather.apply(x, list(lengths), dim)

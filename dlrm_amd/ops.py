@@ -1,0 +1,345 @@
+"""Tensor-level wrappers around the C ABI (no autograd here; see functional.py).
+
+Every function enqueues HIP kernels on torch's current stream for the tensors' device and returns
+immediately.  Tensors must be fp32 CUDA(HIP) tensors whose last dimension is contiguous; leading
+dimensions are passed as explicit strides so strided views (e.g. a slot of the [B, F, D] interaction
+buffer) are used in place.  Anything else raises — there is no CPU/eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, UPD_ATOMIC, UPD_DETERMINISTIC  # noqa: F401
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32, ndim: Optional[int] = None) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"dlrm_amd: `{name}` must be a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"dlrm_amd: `{name}` must be {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"dlrm_amd: `{name}` must be {ndim}-D, got shape {tuple(t.shape)}")
+    if t.dim() >= 1 and t.numel() > 0 and t.stride(-1) != 1:
+        raise RuntimeError(f"dlrm_amd: `{name}` must be contiguous in its last dimension")
+
+
+def _ld(t: torch.Tensor) -> int:
+    """leading dimension (elements) of a 2-D row-major view"""
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+# ------------------------------------------------------------------------------------------------
+# embedding bags
+# ------------------------------------------------------------------------------------------------
+class BagBatch:
+    """Host-side descriptor of one batch of bags for T tables (device pointers + sizes).
+
+    Mirrors what `apply_emb` receives (dlrm_s_pytorch.py:407): lS_o[k] = bag starts of table k,
+    lS_i[k] = flat indices of table k; both either lists of 1-D tensors or stacked 2-D tensors."""
+
+    def __init__(self, lS_o, lS_i, per_sample_weights: Optional[Sequence[Optional[torch.Tensor]]] = None):
+        T = len(lS_i)
+        if len(lS_o) != T:
+            raise RuntimeError("dlrm_amd: offsets / indices table counts differ")
+        self.T = T
+        self.keep = []  # keep tensors alive while kernels may still read them
+        idx_ptrs, off_ptrs, nnz = [], [], []
+        dt = None
+        B = None
+        for k in range(T):
+            i_k, o_k = lS_i[k], lS_o[k]
+            if i_k.dtype not in (torch.int64, torch.int32) or o_k.dtype != i_k.dtype:
+                raise RuntimeError("dlrm_amd: indices/offsets must both be int64 or both int32")
+            if dt is None:
+                dt = i_k.dtype
+            elif dt != i_k.dtype:
+                raise RuntimeError("dlrm_amd: all tables must use the same index dtype")
+            if not i_k.is_cuda or not o_k.is_cuda:
+                raise RuntimeError("dlrm_amd: indices/offsets must be GPU tensors")
+            if not i_k.is_contiguous():
+                i_k = i_k.contiguous()
+            if not o_k.is_contiguous():
+                o_k = o_k.contiguous()
+            if B is None:
+                B = o_k.numel()
+            elif B != o_k.numel():
+                raise RuntimeError("dlrm_amd: every table must have the same number of bags")
+            self.keep += [i_k, o_k]
+            idx_ptrs.append(i_k.data_ptr() if i_k.numel() else 0)
+            off_ptrs.append(o_k.data_ptr())
+            nnz.append(i_k.numel())
+        self.B = int(B)
+        self.idx_bits = 64 if dt == torch.int64 else 32
+        self.nnz = nnz
+        self._idx = _lib.ptr_array(idx_ptrs)
+        self._off = _lib.ptr_array(off_ptrs)
+        self._nnz = _lib.i64_array(nnz)
+        self._psw = None
+        if per_sample_weights is not None and any(w is not None for w in per_sample_weights):
+            ptrs = []
+            for k, w in enumerate(per_sample_weights):
+                if w is None:
+                    ptrs.append(0)
+                else:
+                    _req(w, "per_sample_weights")
+                    if w.numel() != nnz[k]:
+                        raise RuntimeError("dlrm_amd: per_sample_weights size mismatch")
+                    w = w.contiguous()
+                    self.keep.append(w)
+                    ptrs.append(w.data_ptr())
+            self._psw = _lib.ptr_array(ptrs)
+
+
+def _weights_desc(weights: Sequence[torch.Tensor]):
+    D = None
+    for w in weights:
+        _req(w, "embedding weight", ndim=2)
+        if not w.is_contiguous():
+            raise RuntimeError("dlrm_amd: embedding tables must be contiguous [rows, D]")
+        if D is None:
+            D = w.size(1)
+        elif D != w.size(1):
+            raise RuntimeError("dlrm_amd: all embedding tables must share one embedding dimension")
+    return int(D), _lib.ptr_array([w.data_ptr() for w in weights]), _lib.i64_array([w.size(0) for w in weights])
+
+
+def emb_fwd(weights: Sequence[torch.Tensor], bags: BagBatch, out: torch.Tensor) -> torch.Tensor:
+    """out[b, t*D:(t+1)*D] = sum-pooled bag (t, b).  `out` is a [B, >= T*D] view (row stride free)."""
+    lib = _lib.load()
+    D, wp, rows = _weights_desc(weights)
+    _req(out, "out", ndim=2)
+    if out.size(0) != bags.B or out.size(1) < bags.T * D or len(weights) != bags.T:
+        raise RuntimeError("dlrm_amd: emb_fwd shape mismatch")
+    rc = lib.dlrm_emb_fwd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
+                          bags.idx_bits, C.c_void_p(out.data_ptr()), _ld(out), _stream())
+    _lib.check(rc, "dlrm_emb_fwd")
+    return out
+
+
+def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Tensor, lr: float,
+                mode: int = UPD_ATOMIC) -> None:
+    """Fused EmbeddingBag backward + sparse SGD: W_t[idx] -= lr * dout[bag, t*D:(t+1)*D] (in place)."""
+    lib = _lib.load()
+    D, wp, rows = _weights_desc(weights)
+    _req(dout, "dout", ndim=2)
+    if dout.size(0) != bags.B or dout.size(1) < bags.T * D or len(weights) != bags.T:
+        raise RuntimeError("dlrm_amd: emb_bwd_sgd shape mismatch")
+    rc = lib.dlrm_emb_bwd_sgd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
+                              bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout), float(lr), int(mode),
+                              _stream())
+    _lib.check(rc, "dlrm_emb_bwd_sgd")
+
+
+def emb_bwd_rowwise_adagrad(weights: Sequence[torch.Tensor], states: Sequence[torch.Tensor], bags: BagBatch,
+                            dout: torch.Tensor, lr: float, eps: float,
+                            workspace: Optional[torch.Tensor] = None) -> None:
+    lib = _lib.load()
+    D, wp, rows = _weights_desc(weights)
+    _req(dout, "dout", ndim=2)
+    for s_, w in zip(states, weights):
+        _req(s_, "adagrad state", ndim=1)
+        if s_.numel() != w.size(0):
+            raise RuntimeError("dlrm_amd: row-wise adagrad state must be [rows]")
+    sp = _lib.ptr_array([s_.data_ptr() for s_ in states])
+    need = lib.dlrm_emb_adagrad_workspace_bytes(bags.T, bags._nnz, rows)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dout.device)
+    rc = lib.dlrm_emb_bwd_rowwise_adagrad(bags.T, bags.B, D, wp, sp, rows, bags._idx, bags._off, bags._nnz,
+                                          bags._psw, bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout),
+                                          float(lr), float(eps), C.c_void_p(workspace.data_ptr()),
+                                          workspace.numel() * workspace.element_size(), _stream())
+    _lib.check(rc, "dlrm_emb_bwd_rowwise_adagrad")
+
+
+# ------------------------------------------------------------------------------------------------
+# interaction
+# ------------------------------------------------------------------------------------------------
+def _feature_table(tensors: Sequence[torch.Tensor], D: int):
+    """Each [B, k*D] tensor contributes k features: (ptr + j*D*4, row stride)."""
+    ptrs, lds = [], []
+    B = tensors[0].size(0)
+    for t in tensors:
+        _req(t, "feature block", ndim=2)
+        if t.size(0) != B or t.size(1) % D != 0:
+            raise RuntimeError("dlrm_amd: feature blocks must be [B, k*D]")
+        for j in range(t.size(1) // D):
+            ptrs.append(t.data_ptr() + 4 * j * D)
+            lds.append(_ld(t))
+    return B, ptrs, lds
+
+
+def interact_out_width(F: int, D: int, self_interaction: bool) -> int:
+    return D + (F * (F + 1) // 2 if self_interaction else F * (F - 1) // 2)
+
+
+def interact_fwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool, R: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    B, ptrs, lds = _feature_table(blocks, D)
+    _req(R, "R", ndim=2)
+    F = len(ptrs)
+    if R.size(0) != B or R.size(1) < interact_out_width(F, D, self_interaction):
+        raise RuntimeError("dlrm_amd: interact_fwd output shape mismatch")
+    rc = lib.dlrm_interact_fwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(bool(self_interaction)),
+                               C.c_void_p(R.data_ptr()), _ld(R), _stream())
+    _lib.check(rc, "dlrm_interact_fwd")
+    return R
+
+
+def interact_bwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool, dR: torch.Tensor,
+                 dblocks: Sequence[torch.Tensor]) -> None:
+    lib = _lib.load()
+    B, ptrs, lds = _feature_table(blocks, D)
+    B2, dptrs, dlds = _feature_table(dblocks, D)
+    _req(dR, "dR", ndim=2)
+    if B != B2 or len(ptrs) != len(dptrs) or dR.size(0) != B:
+        raise RuntimeError("dlrm_amd: interact_bwd shape mismatch")
+    F = len(ptrs)
+    rc = lib.dlrm_interact_bwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(bool(self_interaction)),
+                               C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
+                               _stream())
+    _lib.check(rc, "dlrm_interact_bwd")
+
+
+# ------------------------------------------------------------------------------------------------
+# MLP layers
+# ------------------------------------------------------------------------------------------------
+def linear_fwd(X: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], act: int, Y: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _req(X, "X", ndim=2); _req(W, "W", ndim=2); _req(Y, "Y", ndim=2)
+    M, K = X.shape
+    N = W.size(0)
+    if W.size(1) != K or Y.size(0) != M or Y.size(1) != N:
+        raise RuntimeError(f"dlrm_amd: linear_fwd shape mismatch X{tuple(X.shape)} W{tuple(W.shape)} Y{tuple(Y.shape)}")
+    if bias is not None:
+        _req(bias, "bias", ndim=1)
+    rc = lib.dlrm_linear_fwd(M, N, K, C.c_void_p(X.data_ptr()), _ld(X), C.c_void_p(W.data_ptr()), _ld(W),
+                             C.c_void_p(bias.data_ptr()) if bias is not None else None, int(act),
+                             C.c_void_p(Y.data_ptr()), _ld(Y), _stream())
+    _lib.check(rc, "dlrm_linear_fwd")
+    return Y
+
+
+def linear_bwd_data(dY: torch.Tensor, W: torch.Tensor, Xact: Optional[torch.Tensor], xact_kind: int,
+                    dX: torch.Tensor, dbias_prev: Optional[torch.Tensor]) -> torch.Tensor:
+    lib = _lib.load()
+    _req(dY, "dY", ndim=2); _req(W, "W", ndim=2); _req(dX, "dX", ndim=2)
+    M, N = dY.shape
+    K = W.size(1)
+    if W.size(0) != N or dX.size(0) != M or dX.size(1) != K:
+        raise RuntimeError("dlrm_amd: linear_bwd_data shape mismatch")
+    if Xact is not None:
+        _req(Xact, "Xact", ndim=2)
+    rc = lib.dlrm_linear_bwd_data(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(W.data_ptr()), _ld(W),
+                                  C.c_void_p(Xact.data_ptr()) if Xact is not None else None,
+                                  _ld(Xact) if Xact is not None else 0, int(xact_kind if Xact is not None else ACT_NONE),
+                                  C.c_void_p(dX.data_ptr()), _ld(dX),
+                                  C.c_void_p(dbias_prev.data_ptr()) if dbias_prev is not None else None, _stream())
+    _lib.check(rc, "dlrm_linear_bwd_data")
+    return dX
+
+
+def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    _req(dY, "dY", ndim=2); _req(X, "X", ndim=2); _req(dW, "dW", ndim=2)
+    M, N = dY.shape
+    K = X.size(1)
+    if X.size(0) != M or dW.size(0) != N or dW.size(1) != K:
+        raise RuntimeError("dlrm_amd: linear_bwd_weight shape mismatch")
+    rc = lib.dlrm_linear_bwd_weight(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(X.data_ptr()), _ld(X),
+                                    C.c_void_p(dW.data_ptr()), _ld(dW), int(bool(accumulate)), _stream())
+    _lib.check(rc, "dlrm_linear_bwd_weight")
+    return dW
+
+
+def act_bwd(dY: torch.Tensor, Y: torch.Tensor, act: int, dZ: torch.Tensor, dbias: Optional[torch.Tensor]) -> torch.Tensor:
+    lib = _lib.load()
+    _req(dY, "dY", ndim=2); _req(Y, "Y", ndim=2); _req(dZ, "dZ", ndim=2)
+    M, N = dY.shape
+    rc = lib.dlrm_act_bwd(M, N, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(Y.data_ptr()), _ld(Y), int(act),
+                          C.c_void_p(dZ.data_ptr()), _ld(dZ),
+                          C.c_void_p(dbias.data_ptr()) if dbias is not None else None, _stream())
+    _lib.check(rc, "dlrm_act_bwd")
+    return dZ
+
+
+# ------------------------------------------------------------------------------------------------
+# loss, dense SGD
+# ------------------------------------------------------------------------------------------------
+def _loss_ws(B: int, device) -> torch.Tensor:
+    n = _lib.load().dlrm_loss_workspace_bytes(B)
+    return torch.empty(max(int(n) // 4, 1), dtype=torch.float32, device=device)
+
+
+def bce_loss(p: torch.Tensor, target: torch.Tensor, weights: Optional[torch.Tensor], grad_scale: float,
+             want_grad: bool):
+    """returns (loss[1], dp or None); p/target are [B] or [B,1] contiguous."""
+    lib = _lib.load()
+    _req(p, "p"); _req(target, "target")
+    if not p.is_contiguous() or not target.is_contiguous() or p.numel() != target.numel():
+        raise RuntimeError("dlrm_amd: bce_loss needs contiguous p/target of equal size")
+    B = p.numel()
+    loss = torch.empty(1, dtype=torch.float32, device=p.device)
+    dp = torch.empty_like(p) if want_grad else None
+    ws = _loss_ws(B, p.device)
+    if weights is not None:
+        _req(weights, "weights")
+        weights = weights.contiguous()
+    rc = lib.dlrm_bce_loss(B, C.c_void_p(p.data_ptr()), C.c_void_p(target.data_ptr()),
+                           C.c_void_p(weights.data_ptr()) if weights is not None else None, float(grad_scale),
+                           C.c_void_p(loss.data_ptr()), C.c_void_p(dp.data_ptr()) if dp is not None else None,
+                           C.c_void_p(ws.data_ptr()), _stream())
+    _lib.check(rc, "dlrm_bce_loss")
+    return loss, dp
+
+
+def mse_loss(p: torch.Tensor, target: torch.Tensor, grad_scale: float, want_grad: bool):
+    lib = _lib.load()
+    _req(p, "p"); _req(target, "target")
+    if not p.is_contiguous() or not target.is_contiguous() or p.numel() != target.numel():
+        raise RuntimeError("dlrm_amd: mse_loss needs contiguous p/target of equal size")
+    B = p.numel()
+    loss = torch.empty(1, dtype=torch.float32, device=p.device)
+    dp = torch.empty_like(p) if want_grad else None
+    ws = _loss_ws(B, p.device)
+    rc = lib.dlrm_mse_loss(B, C.c_void_p(p.data_ptr()), C.c_void_p(target.data_ptr()), float(grad_scale),
+                           C.c_void_p(loss.data_ptr()), C.c_void_p(dp.data_ptr()) if dp is not None else None,
+                           C.c_void_p(ws.data_ptr()), _stream())
+    _lib.check(rc, "dlrm_mse_loss")
+    return loss, dp
+
+
+def sgd_dense(w: torch.Tensor, g: torch.Tensor, lr: float) -> None:
+    lib = _lib.load()
+    _req(w, "w"); _req(g, "g")
+    if not w.is_contiguous() or not g.is_contiguous() or w.numel() != g.numel():
+        raise RuntimeError("dlrm_amd: sgd_dense needs contiguous tensors of equal size")
+    rc = lib.dlrm_sgd_dense(w.numel(), C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), float(lr), _stream())
+    _lib.check(rc, "dlrm_sgd_dense")
+
+
+def a2a_unpack(recv: torch.Tensor, tables_per_rank: List[int], b_local: int, D: int, out: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _req(recv, "recv"); _req(out, "out", ndim=2)
+    arr = (C.c_int * len(tables_per_rank))(*tables_per_rank)
+    rc = lib.dlrm_a2a_unpack(len(tables_per_rank), b_local, D, arr, C.c_void_p(recv.data_ptr()),
+                             C.c_void_p(out.data_ptr()), _ld(out), _stream())
+    _lib.check(rc, "dlrm_a2a_unpack")
+    return out
+
+
+def device_info(device: int = 0) -> dict:
+    lib = _lib.load()
+    cu, lds, hbm = C.c_int(), C.c_int(), C.c_int64()
+    name = C.create_string_buffer(256)
+    rc = lib.dlrm_hip_device_info(device, C.byref(cu), C.byref(lds), C.byref(hbm), name, 256)
+    _lib.check(rc, "dlrm_hip_device_info")
+    return {"name": name.value.decode(), "cu_count": cu.value, "lds_bytes": lds.value, "hbm_bytes": hbm.value,
+            "build": lib.dlrm_hip_build_info().decode(), "abi": lib.dlrm_hip_abi_version()}

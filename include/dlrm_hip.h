@@ -1,0 +1,180 @@
+/*
+ * dlrm_hip.h — C ABI of libdlrm_hip.so: the MI355X (gfx950 / CDNA4) implementation of the
+ * DLRM forward/backward hot path.
+ *
+ * The reference (facebookresearch/dlrm) has no FFI of its own: its hot path is a chain of
+ * PyTorch operator calls inside `DLRM_Net` (dlrm_s_pytorch.py:207-612).  Each entry point
+ * below replaces one of those operator call sites; the citation names the call site.
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions (every function):
+ *   - extern "C", returns int: 0 = ok, <0 = argument error (DLRM_E_*), >0 = hipError_t.
+ *   - all matrices are fp32 row-major with an explicit leading dimension in ELEMENTS.
+ *   - `*_dev` / plain `float*` arguments are DEVICE pointers borrowed for the call.
+ *   - `*_host` arguments are HOST arrays (of device pointers or sizes) read during the call.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Nothing allocates, nothing
+ *     synchronises; work is enqueued on `stream` and the call returns.
+ */
+#ifndef DLRM_HIP_H
+#define DLRM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLRM_E_ARG     (-1)  /* null pointer / non-positive size                    */
+#define DLRM_E_ALIGN   (-2)  /* pointer or leading dimension violates alignment     */
+#define DLRM_E_RANGE   (-3)  /* size exceeds a compiled limit (see message on stderr)*/
+#define DLRM_E_MODE    (-4)  /* unknown mode / activation / index width             */
+
+/* activation codes (dlrm_s_pytorch.py:238-241: ReLU everywhere, Sigmoid at sigmoid_layer) */
+#define DLRM_ACT_NONE    0
+#define DLRM_ACT_RELU    1
+#define DLRM_ACT_SIGMOID 2
+
+/* embedding-update modes */
+#define DLRM_UPD_ATOMIC        0  /* fast: LDS pre-reduction for tiny tables + HW fp32 atomics */
+#define DLRM_UPD_DETERMINISTIC 1  /* exact: per-row in-input-order FMA chain (bit-exact vs torch sparse SGD) */
+
+/* library / device introspection ------------------------------------------------------- */
+int         dlrm_hip_abi_version(void);          /* bumps when a signature changes */
+const char* dlrm_hip_build_info(void);           /* "gfx950 <date> <compiler>"     */
+int         dlrm_hip_device_info(int device, int* cu_count, int* lds_bytes,
+                                 int64_t* hbm_bytes, char* name, int name_len);
+
+/* ---------------------------------------------------------------------------------------
+ * K1  EmbeddingBag(mode="sum") forward for ALL tables in one launch.
+ * Replaces: the per-table `nn.EmbeddingBag.__call__` loop in DLRM_Net.apply_emb
+ *           (dlrm_s_pytorch.py:407-462; operator created at :277).
+ *   out[b*out_ld + t*D + d] = sum_{i in bag(t,b)} psw_t[i] * W_t[idx_t[i]*D + d]
+ *   bag(t,b) = [off_t[b], off_t[b+1])  with off_t[B] := nnz[t]   (no trailing offset needed)
+ * Summation is the in-order sequential fp32 sum from +0.0 per output column (FMA chain when
+ * weighted) — the torch CPU kernel's order, so results are bit-identical.
+ *   weight_host[t]  : device float*  [rows_host[t], D]
+ *   indices_host[t] : device int32/int64* [nnz_host[t]]   (idx_bits = 32 | 64)
+ *   offsets_host[t] : device int32/int64* [B]
+ *   psw_host        : NULL, or array[T] whose entries are NULL or device float* [nnz_host[t]]
+ *   out             : device float*, row b at out + b*out_ld, table t at column t*D
+ *                     (out_ld = T*D gives the torch.cat(ly,1) layout; out_ld = (T+1)*D with
+ *                      out = feat + D writes straight into the [B, 1+T, D] interaction buffer)
+ * Empty bags produce zeros.  Indices are NOT range-checked on the device.
+ */
+int dlrm_emb_fwd(int T, int64_t B, int D,
+                 const void* const* weight_host, const int64_t* rows_host,
+                 const void* const* indices_host, const void* const* offsets_host,
+                 const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
+                 float* out, int64_t out_ld, void* stream);
+
+/* K2+K3  fused EmbeddingBag backward + sparse SGD step, all tables, no gradient materialised.
+ * Replaces: autograd `EmbeddingBagBackward` (sparse COO grad) followed by
+ *           `torch.optim.SGD.step` on that grad (dlrm_s_pytorch.py:1613,1620; optimizer :1343-1369).
+ *   for every lookup i of bag (t,b), in input order:  W_t[idx_t[i],:] = fma(-lr*psw, dout[b, t*D:(t+1)*D], W_t[idx_t[i],:])
+ * mode = DLRM_UPD_ATOMIC: order of duplicate-row accumulation is unspecified (fp32 atomics).
+ * mode = DLRM_UPD_DETERMINISTIC: bit-exact with the reference (one owner per row, input order).
+ */
+int dlrm_emb_bwd_sgd(int T, int64_t B, int D,
+                     void* const* weight_host, const int64_t* rows_host,
+                     const void* const* indices_host, const void* const* offsets_host,
+                     const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
+                     const float* dout, int64_t dout_ld, float lr, int mode, void* stream);
+
+/* K4  fused EmbeddingBag backward + row-wise sparse Adagrad (optim/rwsadagrad.py:117-143).
+ *   per table, per UNIQUE row r touched this step (duplicates summed first, in input order):
+ *     g_r      = sum_i psw_i * dout[bag(i), :]
+ *     state[r] += mean_d(g_r[d]^2)
+ *     W[r,:]  -= lr * g_r / (sqrt(state[r]) + eps)
+ * workspace: device scratch of at least dlrm_emb_adagrad_workspace_bytes(...) bytes.
+ */
+int64_t dlrm_emb_adagrad_workspace_bytes(int T, const int64_t* nnz_host, const int64_t* rows_host);
+int dlrm_emb_bwd_rowwise_adagrad(int T, int64_t B, int D,
+                     void* const* weight_host, void* const* state_host, const int64_t* rows_host,
+                     const void* const* indices_host, const void* const* offsets_host,
+                     const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
+                     const float* dout, int64_t dout_ld, float lr, float eps,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K6  dot interaction forward.
+ * Replaces: torch.cat + torch.bmm + Z[:, li, lj] + torch.cat in DLRM_Net.interact_features
+ *           (dlrm_s_pytorch.py:483-504).
+ *   feature f of sample b is the D-vector at feat_host[f] + b*feat_ld_host[f]   (f = 0 is the
+ *   bottom-MLP output x, f = 1..F-1 the pooled embeddings, in table order)
+ *   R[b, 0:D]            = feature 0
+ *   R[b, D + p(i,j)]     = <feature i, feature j>,  j < i (j <= i if self_interaction),
+ *                          p enumerates pairs row-major: (1,0),(2,0),(2,1),(3,0)...  (:499-501)
+ *   columns [D+P, ldr) of R are zero-filled (ldr may pad the row for alignment).
+ */
+int dlrm_interact_fwd(int64_t B, int F, int D,
+                      const void* const* feat_host, const int64_t* feat_ld_host,
+                      int self_interaction, float* R, int64_t ldr, void* stream);
+
+/* K6 backward:  dfeat_i = sum_j (dZ[i,j] + dZ[j,i]) * feat_j  (+ dR[:,0:D] for i = 0).
+ * dfeat_host/dfeat_ld_host address the gradient rows exactly like feat_host addresses inputs. */
+int dlrm_interact_bwd(int64_t B, int F, int D,
+                      const void* const* feat_host, const int64_t* feat_ld_host,
+                      int self_interaction, const float* dR, int64_t ldr,
+                      void* const* dfeat_host, const int64_t* dfeat_ld_host, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K5  MLP layer = nn.Linear + activation  (dlrm_s_pytorch.py:216,238-241,405), fp32 MFMA.
+ *   Y[M,N] = act(X[M,K] · W[N,K]^T + bias[N])
+ */
+int dlrm_linear_fwd(int64_t M, int N, int K,
+                    const float* X, int64_t ldx, const float* W, int64_t ldw,
+                    const float* bias, int act, float* Y, int64_t ldy, void* stream);
+
+/* data gradient with the PREVIOUS layer's activation backward and bias gradient fused in:
+ *   dX[M,K] = (dY[M,N] · W[N,K]) ⊙ act'(Xact[M,K])        (Xact = this layer's input = previous
+ *                                                           layer's activated output; xact_kind
+ *                                                           ACT_NONE -> no mask)
+ *   dbias_prev[K] += column sums of dX                      (if dbias_prev != NULL; caller zeroes)
+ */
+int dlrm_linear_bwd_data(int64_t M, int N, int K,
+                         const float* dY, int64_t lddy, const float* W, int64_t ldw,
+                         const float* Xact, int64_t ldxa, int xact_kind,
+                         float* dX, int64_t lddx, float* dbias_prev, void* stream);
+
+/* weight gradient:  dW[N,K] (+)= dY[M,N]^T · X[M,K]   (reduction over the batch, split over
+ * workgroups; accumulate != 0 adds into dW, else dW is overwritten — implemented as zero + atomics). */
+int dlrm_linear_bwd_weight(int64_t M, int N, int K,
+                           const float* dY, int64_t lddy, const float* X, int64_t ldx,
+                           float* dW, int64_t lddw, int accumulate, void* stream);
+
+/* activation backward + bias gradient for a layer whose dY does not come out of
+ * dlrm_linear_bwd_data (i.e. the last layer of a tower):
+ *   dZ = dY ⊙ act'(Y);  dbias[N] += column sums of dZ  (if dbias != NULL; caller zeroes) */
+int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, const float* Y, int64_t ldy,
+                 int act, float* dZ, int64_t lddz, float* dbias, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K7  BCELoss(reduction="mean") forward + backward (dlrm_s_pytorch.py:386-393,148-156).
+ *   loss = -mean_b w_b*(t_b*max(log p_b,-100) + (1-t_b)*max(log(1-p_b),-100))
+ *   dp_b = w_b*(p_b - t_b) / max(p_b*(1-p_b), 1e-12) / B * grad_scale       (torch's formulas)
+ * weights may be NULL (w_b = 1).  loss_out: device float[1].  dp may be NULL (forward only).
+ * partials: device scratch, >= dlrm_loss_workspace_bytes(B) bytes.
+ */
+int64_t dlrm_loss_workspace_bytes(int64_t B);
+int dlrm_bce_loss(int64_t B, const float* p, const float* target, const float* weights,
+                  float grad_scale, float* loss_out, float* dp, void* partials, void* stream);
+/* MSELoss(mean): loss = mean((p-t)^2), dp = 2(p-t)/B*grad_scale */
+int dlrm_mse_loss(int64_t B, const float* p, const float* target,
+                  float grad_scale, float* loss_out, float* dp, void* partials, void* stream);
+
+/* dense SGD step over a flat parameter buffer: w -= lr * g   (torch.optim.SGD, no momentum) */
+int dlrm_sgd_dense(int64_t n, float* w, const float* g, float lr, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * C1 helpers for the pooled-embedding all-to-all (extend_distributed.py:389-486).  The exchange
+ * itself is RCCL (ncclSend/ncclRecv grouped) driven by the host; these kernels are only needed
+ * when a caller wants the reference's tensor shapes back (tuple of [B/N, T_s*D]) as one
+ * [B/N, T*D] matrix; the native path lets dlrm_interact_* read the receive buffer in place. */
+int dlrm_a2a_unpack(int nranks, int64_t b_local, int D, const int* tables_per_rank_host,
+                    const float* recv, float* out /* [b_local, T*D] */, int64_t out_ld,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLRM_HIP_H */
