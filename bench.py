@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py — samples/sec of the DLRM training step on MI355X (BASELINE.json metric), one JSON line.
+
+    python bench.py [--gpus 1] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[2] — MLPerf Criteo-Terabyte shapes: 26 tables with the
+row counts of the reference (tools/visualize.py:1195-1223), D = 128, bottom MLP 13-512-256-128, top MLP
+479-1024-1024-512-256-1, dot interaction, one-hot lookups, GLOBAL batch 65536, fp32, BCE loss, SGD.
+Synthetic data (uniform indices / dense features, rounded targets) resident in HBM before the timed
+region.  A "step" = forward + loss + zero_grad + backward + optimizer.step — the region the reference
+times between its time_wrap calls (dlrm_s_pytorch.py:1558-1626).  For N > 1 the global batch stays
+65536 (strong scaling): tables are sharded table-wise over the ranks, pooled embeddings cross one RCCL
+all-to-all per direction, MLP gradients one DDP all-reduce (extend_distributed.py semantics).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# MLPerf Criteo-Terabyte table sizes (max-ind-range 40M), as recorded in the reference, tools/visualize.py:1195-1223
+CRITEO_TB_ROWS = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155,
+                  4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]
+# Criteo-Kaggle table sizes, tools/visualize.py:1123-1152
+CRITEO_KAGGLE_ROWS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306,
+                      10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+WORKLOADS = {
+    "criteo_terabyte": dict(rows=CRITEO_TB_ROWS, D=128, bot=[13, 512, 256, 128], top=[1024, 1024, 512, 256, 1], batch=65536),
+    "criteo_kaggle": dict(rows=CRITEO_KAGGLE_ROWS, D=16, bot=[13, 512, 256, 64, 16], top=[512, 256, 1], batch=2048),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_MFMA_PEAK_TF = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="criteo_terabyte", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="override the global batch (default: the workload's)")
+    ap.add_argument("--row-cap", type=int, default=0, help="cap table rows (debug / small-memory runs)")
+    ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-row-cap", type=int, default=1000000)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--deterministic-update", action="store_true")
+    return ap.parse_args()
+
+
+def make_batches(n, B, rows, device, seed):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = []
+    for _ in range(n):
+        X = torch.rand((B, 13), generator=g, device=device)
+        idx = [torch.randint(0, r, (B,), generator=g, device=device, dtype=torch.int64) for r in rows]
+        off = torch.arange(B, device=device, dtype=torch.int64)
+        T = torch.round(torch.rand((B, 1), generator=g, device=device))
+        out.append((X, [off] * len(rows), idx, T))
+    return out
+
+
+def cpu_baseline(wl, args):
+    """oracle/torch_port.py (the reference's own CPU operator calls) on the host cores, bounded sample."""
+    from oracle.torch_port import TorchPortDLRM
+    torch.manual_seed(0)
+    rows = [min(r, args.cpu_row_cap) for r in wl["rows"]]
+    D, B = wl["D"], wl["batch"]
+    nf = len(rows) + 1
+    ln_top = [D + nf * (nf - 1) // 2] + wl["top"]
+    params = {}
+    for k, n in enumerate(rows):
+        params[f"emb_l.{k}.weight"] = torch.empty(n, D).uniform_(-np.sqrt(1 / n), np.sqrt(1 / n))
+    for name, ln in (("bot_l", wl["bot"]), ("top_l", ln_top)):
+        for i in range(len(ln) - 1):
+            params[f"{name}.{2 * i}.weight"] = torch.randn(ln[i + 1], ln[i]) * np.sqrt(2 / (ln[i] + ln[i + 1]))
+            params[f"{name}.{2 * i}.bias"] = torch.randn(ln[i + 1]) * np.sqrt(1 / ln[i + 1])
+    m = TorchPortDLRM(params, sigmoid_top=len(ln_top) - 2, loss="bce", lr=args.lr)
+    X = torch.rand(B, 13)
+    idx = [torch.randint(0, r, (B,)) for r in rows]
+    off = [torch.arange(B)] * len(rows)
+    T = torch.round(torch.rand(B, 1))
+    m.train_step(X, off, idx, T)                      # warm-up
+    t0 = time.time()
+    for _ in range(args.cpu_steps):
+        m.train_step(X, off, idx, T)
+    dt = (time.time() - t0) / args.cpu_steps
+    return {"value": B / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "ms_per_step": dt * 1e3,
+            "sample": f"{args.cpu_steps} steps of global batch {B}, tables capped at {args.cpu_row_cap} rows "
+                      f"(oracle/torch_port.py: the reference's torch CPU operator calls, {torch.get_num_threads()} threads)"}
+
+
+def main():
+    args = parse()
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["batch"] = args.batch
+    if args.row_cap:
+        wl["rows"] = [min(r, args.row_cap) for r in wl["rows"]]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    N = world
+
+    import dlrm_amd
+    from dlrm_amd import ext_dist, ops
+    from dlrm_amd.optim import FusedSGD
+
+    if N > 1:
+        ext_dist.init_distributed(use_gpu=True, backend="nccl")   # RCCL
+        device = torch.device("cuda", ext_dist.my_local_rank)
+    else:
+        ext_dist.my_size, ext_dist.my_rank = 1, 0
+        device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    rank = max(ext_dist.my_rank, 0)
+
+    rows, D, B = wl["rows"], wl["D"], wl["batch"]
+    nf = len(rows) + 1
+    ln_top = np.asarray([D + nf * (nf - 1) // 2] + wl["top"])
+    np.random.seed(123)          # identical MLP parameters on every rank
+    torch.manual_seed(123 + rank)
+    dlrm_amd.set_embedding_init(device)
+    model = dlrm_amd.DLRM_Net(D, np.asarray(rows), np.asarray(wl["bot"]), ln_top, "dot", sigmoid_top=ln_top.size - 2,
+                              loss_function="bce").to(device)
+    if args.deterministic_update:
+        model.emb_update_mode = ops.UPD_DETERMINISTIC
+    if N > 1:
+        model.bot_l = ext_dist.DDP(model.bot_l, device_ids=[device.index])
+        model.top_l = ext_dist.DDP(model.top_l, device_ids=[device.index])
+        groups = [{"params": [p for e in model.emb_l for p in e.parameters()], "lr": args.lr},
+                  {"params": model.bot_l.parameters(), "lr": args.lr},
+                  {"params": model.top_l.parameters(), "lr": args.lr}]
+        opt = FusedSGD(groups, lr=args.lr)
+    else:
+        opt = FusedSGD(model.parameters(), lr=args.lr)
+
+    batches = make_batches(4, B, rows, device, seed=727)     # every rank reads the whole global batch (reference :1541)
+    my_rows = ext_dist.get_my_slice(B) if N > 1 else slice(0, B)
+    local_tables = list(range(len(rows)))[model.local_emb_slice] if N > 1 else list(range(len(rows)))
+
+    def step(i):
+        X, off, idx, T = batches[i % len(batches)]
+        Z = model(X, off, idx)
+        E = model.loss_fn(Z, T[my_rows])
+        opt.zero_grad()
+        E.backward()
+        opt.step()
+        return E
+
+    for i in range(args.warmup):
+        step(i)
+    if N > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    ops.timers = ops.KernelTimers()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if N > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    ksum = ops.timers.summary()
+    ops.timers = None
+    if N > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    value = B / (dt / args.steps)
+    final_loss = float(loss)
+
+    # ---- algorithmic work per launch -------------------------------
+    Bl = B // N if N > 1 else B
+    R = 4 * D
+    Tl = len(local_tables)
+    emb_fwd_bytes = Tl * B * (R + 8 + R + 8)            # one-hot: row read + index + pooled row write + offset
+    emb_bwd_bytes = Tl * B * (3 * R + 8)                # dV row read + W row read + W row write + index
+    bot, top = list(wl["bot"]), list(ln_top)
+    fwd_fl = sum(2.0 * Bl * a * b for ln in (bot, top) for a, b in zip(ln[:-1], ln[1:]))
+    wgrad_fl = fwd_fl
+    dgrad_fl = fwd_fl - 2.0 * Bl * bot[0] * bot[1]      # the first bottom layer needs no data gradient
+    F = nf
+    inter_bytes = Bl * (F * D * 4 + (D + F * (F - 1) // 2) * 4)
+
+    kernels = {}
+    for name, work, unit, peak, bound in (
+            ("emb_fwd", emb_fwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
+            ("emb_bwd_sgd", emb_bwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
+            ("interact_fwd", inter_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
+            ("interact_bwd", 2 * inter_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
+            ("linear_fwd", fwd_fl, "TFLOP/s", FP32_MFMA_PEAK_TF, "mfma"),
+            ("linear_bwd_data", dgrad_fl, "TFLOP/s", FP32_MFMA_PEAK_TF, "mfma"),
+            ("linear_bwd_weight", wgrad_fl, "TFLOP/s", FP32_MFMA_PEAK_TF, "mfma")):
+        k = ksum.get(name)
+        if not k:
+            continue
+        per_step_ms = k["total_ms"] / args.steps
+        scale = 1e9 if unit == "GB/s" else 1e12
+        ach = work / (per_step_ms * 1e-3) / scale
+        kernels[name] = {"ms_per_step": per_step_ms, "launches_per_step": k["calls"] / args.steps,
+                         "avg_launch_ms": k["avg_ms"], "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                         "frac": ach / peak, "algorithmic_work_per_step": work}
+    for name in ("act_bwd", "bce_loss", "sgd_dense"):
+        if name in ksum:
+            kernels[name] = {"ms_per_step": ksum[name]["total_ms"] / args.steps,
+                             "launches_per_step": ksum[name]["calls"] / args.steps}
+    heavy = [n for n in kernels if "achieved" in kernels[n]]
+    dom = max(heavy, key=lambda n: kernels[n]["ms_per_step"]) if heavy else None
+    kname = {"linear_fwd": "gemm_f32_kernel<true,true> (Y = X*W^T + bias, act)",
+             "linear_bwd_data": "gemm_f32_kernel<true,false> (dX = dY*W, mask + bias-grad epilogue)",
+             "linear_bwd_weight": "gemm_f32_kernel<false,false> (dW = dY^T*X, split over the batch)",
+             "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "emb_bwd_sgd_{atomic,lds}_kernel",
+             "interact_fwd": "interact_fwd_kernel", "interact_bwd": "interact_bwd_kernel"}
+
+    def roof(n):
+        k = kernels[n]
+        return {"kernel": kname.get(n, n), "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
+                "unit": k["unit"], "frac": k["frac"], "traffic": None, "avg_launch_ms": k["avg_launch_ms"],
+                "ms_per_step": k["ms_per_step"]}
+
+    result = {
+        "metric": "samples/sec (global batch) + embedding HBM GB/s, Criteo-TB config",
+        "value": value, "unit": "samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (uniform one-hot indices, uniform dense features, rounded targets; random-init parameters)",
+        "config": {"workload": args.workload + (": MLPerf Criteo-Terabyte shapes (BASELINE.json configs[2])"
+                                                if args.workload == "criteo_terabyte" else ""),
+                   "tables": len(rows), "emb_dim": D, "global_batch": B, "table_rows_total": int(sum(rows)),
+                   "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": "sgd",
+                   "loss": "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
+                   "embedding_update": "deterministic" if args.deterministic_update else "atomic"},
+        "final_loss": final_loss,
+        "roofline": roof(dom) if dom else None,
+        "roofline_embedding": roof("emb_fwd") if "emb_fwd" in kernels else None,
+        "embedding_hbm_gbps": {"fwd": kernels.get("emb_fwd", {}).get("achieved"),
+                               "bwd_sgd": kernels.get("emb_bwd_sgd", {}).get("achieved")},
+        "kernels": kernels,
+    }
+    if rank == 0 and N == 1 and not args.no_cpu_baseline:
+        del model, opt, batches
+        torch.cuda.empty_cache()
+        result["cpu_baseline"] = cpu_baseline(wl, args)
+    if rank == 0:
+        print(json.dumps(result))
+    if N > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,6 +149,23 @@ class _Exchange:
         self.buffer = None
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_counts: List[int], in_counts: List[int]):
+    """One asynchronous all_to_all_single.  On RCCL ("nccl") and on gloo with host tensors this is the
+    collective itself.  gloo has no device all-to-all: GPU tensors under gloo (the 1-GPU test rig that runs
+    several ranks on one device) are staged through host memory, synchronously."""
+    if inp.is_cuda and dist.get_backend() == "gloo":
+        h_in, h_out = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, h_in, out_counts, in_counts)
+        out.copy_(h_out)
+        return _Done()
+    return dist.all_to_all_single(out, inp, out_counts, in_counts, async_op=True)
+
+
 class _A2AStart(Function):
     @staticmethod
     def forward(ctx, ex: _Exchange, *blocks):
@@ -158,7 +175,7 @@ class _A2AStart(Function):
         else:
             send = torch.cat([b.reshape(ex.batch, -1) for b in blocks], dim=1).view(-1)
         recv = send.new_empty(sum(ex.recv_counts))
-        ex.work = dist.all_to_all_single(recv, send, ex.recv_counts, ex.send_counts, async_op=True)
+        ex.work = _all_to_all(recv, send, ex.recv_counts, ex.send_counts)
         ex.buffer = recv
         ex.send_keepalive = send
         ctx.ex = ex
@@ -206,7 +223,7 @@ class _A2AWait(Function):
         if packed is None:
             packed = torch.cat([g.contiguous().view(-1) for g in grads])
         back = packed.new_empty(ex.batch * ex.local_tables * ex.emb_dim)
-        ex.work = dist.all_to_all_single(back, packed, ex.send_counts, ex.recv_counts, async_op=True)
+        ex.work = _all_to_all(back, packed, ex.send_counts, ex.recv_counts)
         ex.buffer = back
         ex.send_keepalive = packed
         return (None, packed)   # shape-only gradient for the flat receive buffer; data travels via `ex`

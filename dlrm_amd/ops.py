@@ -20,6 +20,46 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimers:
+    """Optional per-call HIP-event timing of the C-ABI launches, on the stream they are enqueued on.
+    Enabled by bench.py inside its timed region (two hipEventRecord per call, no synchronisation until
+    `summary()`); disabled (None) by default."""
+
+    def __init__(self):
+        self.records = {}   # name -> list[(start_event, end_event)]
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = {"calls": len(ms), "total_ms": float(sum(ms)), "avg_ms": float(sum(ms) / max(len(ms), 1))}
+        return out
+
+
+timers: Optional[KernelTimers] = None
+
+
+class _timed:
+    __slots__ = ("name", "a")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if timers is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if timers is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            timers.records.setdefault(self.name, []).append((self.a, b))
+        return False
+
+
 def _req(t: torch.Tensor, name: str, dtype=torch.float32, ndim: Optional[int] = None) -> None:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f"dlrm_amd: `{name}` must be a GPU tensor (the HIP path has no CPU fallback)")
@@ -118,8 +158,9 @@ def emb_fwd(weights: Sequence[torch.Tensor], bags: BagBatch, out: torch.Tensor) 
     _req(out, "out", ndim=2)
     if out.size(0) != bags.B or out.size(1) < bags.T * D or len(weights) != bags.T:
         raise RuntimeError("dlrm_amd: emb_fwd shape mismatch")
-    rc = lib.dlrm_emb_fwd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
-                          bags.idx_bits, C.c_void_p(out.data_ptr()), _ld(out), _stream())
+    with _timed("emb_fwd"):
+        rc = lib.dlrm_emb_fwd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
+                              bags.idx_bits, C.c_void_p(out.data_ptr()), _ld(out), _stream())
     _lib.check(rc, "dlrm_emb_fwd")
     return out
 
@@ -132,9 +173,10 @@ def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Ten
     _req(dout, "dout", ndim=2)
     if dout.size(0) != bags.B or dout.size(1) < bags.T * D or len(weights) != bags.T:
         raise RuntimeError("dlrm_amd: emb_bwd_sgd shape mismatch")
-    rc = lib.dlrm_emb_bwd_sgd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
-                              bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout), float(lr), int(mode),
-                              _stream())
+    with _timed("emb_bwd_sgd"):
+        rc = lib.dlrm_emb_bwd_sgd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
+                                  bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout), float(lr), int(mode),
+                                  _stream())
     _lib.check(rc, "dlrm_emb_bwd_sgd")
 
 
@@ -187,8 +229,9 @@ def interact_fwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool,
     F = len(ptrs)
     if R.size(0) != B or R.size(1) < interact_out_width(F, D, self_interaction):
         raise RuntimeError("dlrm_amd: interact_fwd output shape mismatch")
-    rc = lib.dlrm_interact_fwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(bool(self_interaction)),
-                               C.c_void_p(R.data_ptr()), _ld(R), _stream())
+    with _timed("interact_fwd"):
+        rc = lib.dlrm_interact_fwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(bool(self_interaction)),
+                                   C.c_void_p(R.data_ptr()), _ld(R), _stream())
     _lib.check(rc, "dlrm_interact_fwd")
     return R
 
@@ -202,9 +245,10 @@ def interact_bwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool,
     if B != B2 or len(ptrs) != len(dptrs) or dR.size(0) != B:
         raise RuntimeError("dlrm_amd: interact_bwd shape mismatch")
     F = len(ptrs)
-    rc = lib.dlrm_interact_bwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(bool(self_interaction)),
-                               C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
-                               _stream())
+    with _timed("interact_bwd"):
+        rc = lib.dlrm_interact_bwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(bool(self_interaction)),
+                                   C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
+                                   _stream())
     _lib.check(rc, "dlrm_interact_bwd")
 
 
@@ -220,9 +264,10 @@ def linear_fwd(X: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], a
         raise RuntimeError(f"dlrm_amd: linear_fwd shape mismatch X{tuple(X.shape)} W{tuple(W.shape)} Y{tuple(Y.shape)}")
     if bias is not None:
         _req(bias, "bias", ndim=1)
-    rc = lib.dlrm_linear_fwd(M, N, K, C.c_void_p(X.data_ptr()), _ld(X), C.c_void_p(W.data_ptr()), _ld(W),
-                             C.c_void_p(bias.data_ptr()) if bias is not None else None, int(act),
-                             C.c_void_p(Y.data_ptr()), _ld(Y), _stream())
+    with _timed("linear_fwd"):
+        rc = lib.dlrm_linear_fwd(M, N, K, C.c_void_p(X.data_ptr()), _ld(X), C.c_void_p(W.data_ptr()), _ld(W),
+                                 C.c_void_p(bias.data_ptr()) if bias is not None else None, int(act),
+                                 C.c_void_p(Y.data_ptr()), _ld(Y), _stream())
     _lib.check(rc, "dlrm_linear_fwd")
     return Y
 
@@ -237,11 +282,12 @@ def linear_bwd_data(dY: torch.Tensor, W: torch.Tensor, Xact: Optional[torch.Tens
         raise RuntimeError("dlrm_amd: linear_bwd_data shape mismatch")
     if Xact is not None:
         _req(Xact, "Xact", ndim=2)
-    rc = lib.dlrm_linear_bwd_data(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(W.data_ptr()), _ld(W),
-                                  C.c_void_p(Xact.data_ptr()) if Xact is not None else None,
-                                  _ld(Xact) if Xact is not None else 0, int(xact_kind if Xact is not None else ACT_NONE),
-                                  C.c_void_p(dX.data_ptr()), _ld(dX),
-                                  C.c_void_p(dbias_prev.data_ptr()) if dbias_prev is not None else None, _stream())
+    with _timed("linear_bwd_data"):
+        rc = lib.dlrm_linear_bwd_data(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(W.data_ptr()), _ld(W),
+                                      C.c_void_p(Xact.data_ptr()) if Xact is not None else None,
+                                      _ld(Xact) if Xact is not None else 0, int(xact_kind if Xact is not None else ACT_NONE),
+                                      C.c_void_p(dX.data_ptr()), _ld(dX),
+                                      C.c_void_p(dbias_prev.data_ptr()) if dbias_prev is not None else None, _stream())
     _lib.check(rc, "dlrm_linear_bwd_data")
     return dX
 
@@ -253,8 +299,9 @@ def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, accum
     K = X.size(1)
     if X.size(0) != M or dW.size(0) != N or dW.size(1) != K:
         raise RuntimeError("dlrm_amd: linear_bwd_weight shape mismatch")
-    rc = lib.dlrm_linear_bwd_weight(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(X.data_ptr()), _ld(X),
-                                    C.c_void_p(dW.data_ptr()), _ld(dW), int(bool(accumulate)), _stream())
+    with _timed("linear_bwd_weight"):
+        rc = lib.dlrm_linear_bwd_weight(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(X.data_ptr()), _ld(X),
+                                        C.c_void_p(dW.data_ptr()), _ld(dW), int(bool(accumulate)), _stream())
     _lib.check(rc, "dlrm_linear_bwd_weight")
     return dW
 
@@ -263,9 +310,10 @@ def act_bwd(dY: torch.Tensor, Y: torch.Tensor, act: int, dZ: torch.Tensor, dbias
     lib = _lib.load()
     _req(dY, "dY", ndim=2); _req(Y, "Y", ndim=2); _req(dZ, "dZ", ndim=2)
     M, N = dY.shape
-    rc = lib.dlrm_act_bwd(M, N, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(Y.data_ptr()), _ld(Y), int(act),
-                          C.c_void_p(dZ.data_ptr()), _ld(dZ),
-                          C.c_void_p(dbias.data_ptr()) if dbias is not None else None, _stream())
+    with _timed("act_bwd"):
+        rc = lib.dlrm_act_bwd(M, N, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(Y.data_ptr()), _ld(Y), int(act),
+                              C.c_void_p(dZ.data_ptr()), _ld(dZ),
+                              C.c_void_p(dbias.data_ptr()) if dbias is not None else None, _stream())
     _lib.check(rc, "dlrm_act_bwd")
     return dZ
 
@@ -292,10 +340,11 @@ def bce_loss(p: torch.Tensor, target: torch.Tensor, weights: Optional[torch.Tens
     if weights is not None:
         _req(weights, "weights")
         weights = weights.contiguous()
-    rc = lib.dlrm_bce_loss(B, C.c_void_p(p.data_ptr()), C.c_void_p(target.data_ptr()),
-                           C.c_void_p(weights.data_ptr()) if weights is not None else None, float(grad_scale),
-                           C.c_void_p(loss.data_ptr()), C.c_void_p(dp.data_ptr()) if dp is not None else None,
-                           C.c_void_p(ws.data_ptr()), _stream())
+    with _timed("bce_loss"):
+        rc = lib.dlrm_bce_loss(B, C.c_void_p(p.data_ptr()), C.c_void_p(target.data_ptr()),
+                               C.c_void_p(weights.data_ptr()) if weights is not None else None, float(grad_scale),
+                               C.c_void_p(loss.data_ptr()), C.c_void_p(dp.data_ptr()) if dp is not None else None,
+                               C.c_void_p(ws.data_ptr()), _stream())
     _lib.check(rc, "dlrm_bce_loss")
     return loss, dp
 
@@ -321,7 +370,8 @@ def sgd_dense(w: torch.Tensor, g: torch.Tensor, lr: float) -> None:
     _req(w, "w"); _req(g, "g")
     if not w.is_contiguous() or not g.is_contiguous() or w.numel() != g.numel():
         raise RuntimeError("dlrm_amd: sgd_dense needs contiguous tensors of equal size")
-    rc = lib.dlrm_sgd_dense(w.numel(), C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), float(lr), _stream())
+    with _timed("sgd_dense"):
+        rc = lib.dlrm_sgd_dense(w.numel(), C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), float(lr), _stream())
     _lib.check(rc, "dlrm_sgd_dense")
 
 

@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz|json by RUNNING THE REFERENCE (facebookresearch/dlrm at /root/reference)
+on CPU in the build container.  TEST INFRASTRUCTURE ONLY — not shipped, not imported by dlrm_amd/.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py            # all fixtures
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py dist       # one group
+
+The reference is imported as a library (its `DLRM_Net`, its data generator, its `extend_distributed`
+and its `RWSAdagrad`); `torch.utils.tensorboard` (absent here, imported at dlrm_s_pytorch.py:101) is
+stubbed.  Nothing is copied from the reference: the fixtures hold only inputs, initial parameters and
+the numbers the reference produced (outputs, losses, updated parameters).  /root/reference does not
+exist on the GPU box, which is why the vectors are committed.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import tempfile
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+REF = os.environ.get("DLRM_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def import_reference():
+    tb = types.ModuleType("torch.utils.tensorboard")
+
+    class SummaryWriter:  # noqa: D401 - stub
+        def __init__(self, *a, **k): pass
+        def add_scalar(self, *a, **k): pass
+        def close(self): pass
+    tb.SummaryWriter = SummaryWriter
+    sys.modules["torch.utils.tensorboard"] = tb
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp(prefix="dlrm_ref_"))
+    try:
+        import dlrm_s_pytorch as ref
+        import dlrm_data_pytorch as dp
+        import extend_distributed as ext
+    finally:
+        os.chdir(cwd)
+    return ref, dp, ext
+
+
+def gen_batch(dp, m_den, ln_emb, n, num_idx, fixed, round_targets=True):
+    X, lS_o, lS_i = dp.generate_dist_input_batch(m_den, ln_emb, n, num_idx, fixed, rand_data_dist="uniform",
+                                                 rand_data_min=0, rand_data_max=1, rand_data_mu=-1, rand_data_sigma=1)
+    T = dp.generate_random_output_batch(n, 1, round_targets)
+    return X, lS_o, lS_i, T
+
+
+def pack_batches(batches):
+    d = {}
+    for s, (X, lS_o, lS_i, T) in enumerate(batches):
+        d[f"s{s}.X"] = X.numpy().copy()
+        d[f"s{s}.T"] = T.numpy().copy()
+        for k in range(len(lS_i)):
+            d[f"s{s}.off{k}"] = lS_o[k].numpy().astype(np.int64).copy()
+            d[f"s{s}.idx{k}"] = lS_i[k].numpy().astype(np.int64).copy()
+    return d
+
+
+def sd_np(model, prefix):
+    return {f"{prefix}.{k}": v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, lr, loss, itself=False,
+                     num_idx=10, fixed=False, seed=123, round_targets=True):
+    ln_emb = np.asarray(ln_emb)
+    ln_bot = np.asarray(ln_bot)
+    F = ln_emb.size + 1
+    num_int = (F * (F + 1)) // 2 + ln_bot[-1] if itself else (F * (F - 1)) // 2 + ln_bot[-1]
+    ln_top = np.asarray([num_int] + list(top_tail))
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    model = ref.DLRM_Net(m_spa, ln_emb, ln_bot, ln_top, arch_interaction_op="dot", arch_interaction_itself=itself,
+                         sigmoid_bot=-1, sigmoid_top=ln_top.size - 2, loss_function=loss)
+    out = {}
+    out.update(sd_np(model, "init"))
+    batches = [gen_batch(dp, int(ln_bot[0]), ln_emb, B, num_idx, fixed, round_targets) for _ in range(steps)]
+    out.update(pack_batches(batches))
+    opt = torch.optim.SGD(model.parameters(), lr=lr)
+    losses = []
+    for s, (X, lS_o, lS_i, T) in enumerate(batches):
+        Z = model(X, lS_o, lS_i)
+        E = model.loss_fn(Z, T)
+        out[f"s{s}.Z"] = Z.detach().numpy().copy()
+        losses.append(float(E.detach().numpy()))
+        opt.zero_grad()
+        E.backward()
+        if s == 0:
+            g = model.emb_l[0].weight.grad
+            out["s0.emb0_grad_indices"] = g._indices().numpy().copy()
+            out["s0.emb0_grad_values"] = g._values().numpy().copy()
+            out["s0.top0_weight_grad"] = model.top_l[0].weight.grad.numpy().copy()
+            out["s0.bot0_bias_grad"] = model.bot_l[0].bias.grad.numpy().copy()
+        opt.step()
+        if s == 0:
+            out.update(sd_np(model, "after1"))
+    out.update(sd_np(model, "final"))
+    out["losses"] = np.asarray(losses, dtype=np.float64)
+    meta = dict(name=name, m_spa=int(m_spa), ln_emb=ln_emb.tolist(), ln_bot=ln_bot.tolist(), ln_top=ln_top.tolist(),
+                B=B, steps=steps, lr=lr, loss=loss, itself=bool(itself), sigmoid_top=int(ln_top.size - 2),
+                torch=torch.__version__, reference="facebookresearch/dlrm @ /root/reference (2025-10-03)")
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}: losses {losses}")
+
+
+def capture_adagrad(ref, dp, name="rwsadagrad_tiny"):
+    sys.path.insert(0, os.path.join(REF, "optim"))
+    import rwsadagrad as RowWiseSparseAdagrad
+    ln_emb, ln_bot, m_spa = np.asarray([40, 7, 3]), np.asarray([5, 8, 4]), 4
+    F = 4
+    ln_top = np.asarray([F * (F - 1) // 2 + 4, 8, 1])
+    np.random.seed(7)
+    torch.manual_seed(7)
+    model = ref.DLRM_Net(m_spa, ln_emb, ln_bot, ln_top, arch_interaction_op="dot", sigmoid_top=1, loss_function="bce")
+    out = {}
+    out.update(sd_np(model, "init"))
+    batches = [gen_batch(dp, 5, ln_emb, 16, 5, False) for _ in range(3)]
+    out.update(pack_batches(batches))
+    opt = RowWiseSparseAdagrad.RWSAdagrad(model.parameters(), lr=0.05)
+    losses = []
+    for s, (X, lS_o, lS_i, T) in enumerate(batches):
+        Z = model(X, lS_o, lS_i)
+        E = model.loss_fn(Z, T)
+        losses.append(float(E.detach().numpy()))
+        opt.zero_grad()
+        E.backward()
+        if s == 0:
+            # dense dV of every table, recovered from the MLP-side autograd graph is not exposed; store the
+            # coalesced sparse grads instead (what RWSAdagrad consumes)
+            for k in range(3):
+                g = model.emb_l[k].weight.grad.coalesce()
+                out[f"s0.emb{k}_cgrad_indices"] = g._indices().numpy().copy()
+                out[f"s0.emb{k}_cgrad_values"] = g._values().numpy().copy()
+        opt.step()
+        if s == 0:
+            out.update(sd_np(model, "after1"))
+            for k in range(3):
+                out[f"after1.mom{k}"] = opt.state[model.emb_l[k].weight]["momentum"].numpy().copy()
+    out.update(sd_np(model, "final"))
+    for k in range(3):
+        out[f"final.mom{k}"] = opt.state[model.emb_l[k].weight]["momentum"].numpy().copy()
+    out["losses"] = np.asarray(losses)
+    meta = dict(name=name, m_spa=4, ln_emb=ln_emb.tolist(), ln_bot=ln_bot.tolist(), ln_top=ln_top.tolist(), B=16,
+                steps=3, lr=0.05, eps=1e-10, loss="bce", sigmoid_top=1)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}: losses {losses}")
+
+
+def capture_bookkeeping(ref, ext):
+    cases = []
+    for size in (1, 2, 3, 4, 8):
+        for n in (1, 2, 3, 7, 8, 26, 128, 2048, 65536):
+            if n < size:
+                continue
+            per_rank = []
+            for rank in range(size):
+                ext.my_size, ext.my_rank = size, rank
+                sl = ext.get_my_slice(n)
+                mine, splits = ext.get_split_lengths(n)
+                per_rank.append(dict(slice=[sl.start, sl.stop, sl.step], my_len=mine, splits=splits))
+            cases.append(dict(n=n, size=size, ranks=per_rank))
+    ext.my_size, ext.my_rank = -1, -1
+    # interaction pair order as the reference builds it (dlrm_s_pytorch.py:499-501)
+    pairs = {}
+    for F in (2, 3, 4, 8, 27):
+        for off in (0, 1):
+            li = [i for i in range(F) for j in range(i + off)]
+            lj = [j for i in range(F) for j in range(i + off)]
+            pairs[f"F{F}_self{off}"] = dict(li=li, lj=lj)
+    with open(os.path.join(OUT, "bookkeeping.json"), "w") as f:
+        json.dump(dict(partition=cases, pairs=pairs), f)
+    print("bookkeeping.json:", len(cases), "partition cases")
+
+
+# ---------------------------------------------------------------------------------------------
+# distributed reference run (2 gloo ranks): pins the table-sharded forward, the all-to-all layout
+# and the N x embedding-gradient quirk
+# ---------------------------------------------------------------------------------------------
+def _dist_worker(rank, size, port, full_init, batches, cfg, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size),
+                      LOCAL_RANK=str(rank))
+    ref, dp, ext = import_reference()
+    ext.init_distributed(rank=rank, local_rank=rank, size=size, use_gpu=False, backend="gloo")
+    ln_emb, ln_bot, ln_top = (np.asarray(cfg[k]) for k in ("ln_emb", "ln_bot", "ln_top"))
+    np.random.seed(1)
+    model = ref.DLRM_Net(cfg["m_spa"], ln_emb, ln_bot, ln_top, arch_interaction_op="dot", sigmoid_top=ln_top.size - 2,
+                         loss_function="bce")
+    # identical parameters on every rank, local tables taken from the full list
+    with torch.no_grad():
+        for j, g in enumerate(model.local_emb_indices):
+            model.emb_l[j].weight.copy_(torch.tensor(full_init[f"init.emb_l.{g}.weight"]))
+        for name, p in list(model.bot_l.named_parameters()) + []:
+            p.copy_(torch.tensor(full_init[f"init.bot_l.{name}"]))
+        for name, p in model.top_l.named_parameters():
+            p.copy_(torch.tensor(full_init[f"init.top_l.{name}"]))
+    model.bot_l = ext.DDP(model.bot_l)
+    model.top_l = ext.DDP(model.top_l)
+    params = [{"params": [p for emb in model.emb_l for p in emb.parameters()], "lr": cfg["lr"]},
+              {"params": model.bot_l.parameters(), "lr": cfg["lr"]},
+              {"params": model.top_l.parameters(), "lr": cfg["lr"]}]
+    opt = torch.optim.SGD(params, lr=cfg["lr"])
+    res = {}
+    for s, (X, lS_o, lS_i, T) in enumerate(batches):
+        Z = model(X, torch.stack(lS_o), lS_i)
+        Tl = T[ext.get_my_slice(T.shape[0])]
+        E = model.loss_fn(Z, Tl)
+        res[f"s{s}.Z"] = Z.detach().numpy().copy()
+        res[f"s{s}.loss"] = float(E.detach().numpy())
+        opt.zero_grad()
+        E.backward()
+        opt.step()
+    for j, g in enumerate(model.local_emb_indices):
+        res[f"final.emb_l.{g}.weight"] = model.emb_l[j].weight.detach().numpy().copy()
+    if rank == 0:
+        for name, p in model.bot_l.module.named_parameters():
+            res[f"final.bot_l.{name}"] = p.detach().numpy().copy()
+        for name, p in model.top_l.module.named_parameters():
+            res[f"final.top_l.{name}"] = p.detach().numpy().copy()
+    res["local_emb_indices"] = list(model.local_emb_indices)
+    res["n_emb_per_rank"] = model.n_emb_per_rank
+    q.put((rank, res))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def capture_distributed(name="dist2_tiny"):
+    import torch.multiprocessing as mp
+    ref, dp, ext = import_reference()
+    cfg = dict(m_spa=4, ln_emb=[30, 20, 10], ln_bot=[5, 8, 4], lr=0.5, B=8, steps=2)
+    F = 4
+    cfg["ln_top"] = [F * (F - 1) // 2 + 4, 8, 1]
+    np.random.seed(11)
+    torch.manual_seed(11)
+    full = ref.DLRM_Net(cfg["m_spa"], np.asarray(cfg["ln_emb"]), np.asarray(cfg["ln_bot"]), np.asarray(cfg["ln_top"]),
+                        arch_interaction_op="dot", sigmoid_top=1, loss_function="bce")
+    out = {}
+    full_init = sd_np(full, "init")
+    out.update(full_init)
+    batches = [gen_batch(dp, 5, np.asarray(cfg["ln_emb"]), cfg["B"], 3, False) for _ in range(cfg["steps"])]
+    out.update(pack_batches(batches))
+    # single-process reference on the same data (for the N x quirk comparison)
+    opt = torch.optim.SGD(full.parameters(), lr=cfg["lr"])
+    for s, (X, lS_o, lS_i, T) in enumerate(batches):
+        Z = full(X, lS_o, lS_i)
+        E = full.loss_fn(Z, T)
+        out[f"single.s{s}.Z"] = Z.detach().numpy().copy()
+        out[f"single.s{s}.loss"] = np.float64(E.detach().numpy())
+        opt.zero_grad(); E.backward(); opt.step()
+    out.update(sd_np(full, "single.final"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    size, port = 2, 29631
+    procs = [ctx.Process(target=_dist_worker, args=(r, size, port, full_init, batches, cfg, q)) for r in range(size)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(size))
+    for p in procs:
+        p.join(60)
+    for r, res in results.items():
+        for k, v in res.items():
+            out[f"rank{r}.{k}"] = np.asarray(v)
+    meta = dict(name=name, size=size, **cfg, loss="bce", sigmoid_top=1)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(name, "rank losses", [[float(results[r][f"s{s}.loss"]) for s in range(cfg["steps"])] for r in range(size)])
+
+
+def main(which):
+    os.makedirs(OUT, exist_ok=True)
+    ref, dp, ext = import_reference()
+    if which in ("all", "train"):
+        # BASELINE.json configs[0]: 3 tables x 1000 x 16, bot 13-512-16, batch 128 (top tower 128-64-1)
+        capture_training(ref, dp, "config1_b128", 16, [1000, 1000, 1000], [13, 512, 16], [128, 64, 1], B=128, steps=3,
+                         lr=0.1, loss="bce")
+        # the reference CLI's default tiny model (test/dlrm_s_test.sh): m_spa 2, emb 4-3-2, bot 4-3-2, top 4-2-1, mse
+        capture_training(ref, dp, "cli_default_mse", 2, [4, 3, 2], [4, 3, 2], [4, 2, 1], B=2, steps=3, lr=0.1, loss="mse",
+                         round_targets=False)
+        # self-interaction, one-hot fixed lookups, odd embedding dim
+        capture_training(ref, dp, "self_interact_d12", 12, [50, 7, 3, 19, 5], [6, 16, 12], [16, 1], B=33, steps=2, lr=0.2,
+                         loss="bce", itself=True, num_idx=1, fixed=True)
+        # multi-hot with many duplicates across bags (hot rows)
+        capture_training(ref, dp, "multihot_hotrows", 8, [3, 4, 100], [9, 8], [8, 1], B=64, steps=2, lr=0.3, loss="bce",
+                         num_idx=8)
+    if which in ("all", "adagrad"):
+        capture_adagrad(ref, dp)
+    if which in ("all", "book"):
+        capture_bookkeeping(ref, ext)
+    if which in ("all", "dist"):
+        capture_distributed()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "all")

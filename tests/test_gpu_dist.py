@@ -1,0 +1,96 @@
+"""Table-sharded distributed DLRM_Net on the GPU: 2 ranks on ONE MI355X (gloo rendezvous, all-to-all staged
+through the host — the RCCL path needs one GPU per rank) against the 2-rank run of the reference
+(tests/golden/dist2_tiny.npz): per-rank outputs, losses, DDP-averaged MLP parameters and the reference's
+N x embedding-gradient behaviour."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import golden_batches, load_golden, params_with_prefix
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, size, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK="0")
+    import dlrm_amd
+    from dlrm_amd import ext_dist, ops
+    d, meta = load_golden("dist2_tiny")
+    ext_dist.init_distributed(rank=rank, local_rank=0, size=size, use_gpu=True, backend="gloo")
+    dev = torch.device("cuda:0")
+    np.random.seed(3)
+    model = dlrm_amd.DLRM_Net(meta["m_spa"], np.asarray(meta["ln_emb"]), np.asarray(meta["ln_bot"]), np.asarray(meta["ln_top"]),
+                              "dot", sigmoid_top=meta["sigmoid_top"], loss_function="bce")
+    init = params_with_prefix(d, "init")
+    with torch.no_grad():
+        for j, g in enumerate(model.local_emb_indices):
+            model.emb_l[j].weight.copy_(torch.from_numpy(init[f"emb_l.{g}.weight"]))
+        for name, p in model.bot_l.named_parameters():
+            p.copy_(torch.from_numpy(init[f"bot_l.{name}"]))
+        for name, p in model.top_l.named_parameters():
+            p.copy_(torch.from_numpy(init[f"top_l.{name}"]))
+    model = model.to(dev)
+    model.emb_update_mode = ops.UPD_DETERMINISTIC
+    model.bot_l = ext_dist.DDP(model.bot_l, device_ids=[0])
+    model.top_l = ext_dist.DDP(model.top_l, device_ids=[0])
+    opt = torch.optim.SGD([{"params": [p for e in model.emb_l for p in e.parameters()], "lr": meta["lr"]},
+                           {"params": model.bot_l.parameters(), "lr": meta["lr"]},
+                           {"params": model.top_l.parameters(), "lr": meta["lr"]}], lr=meta["lr"])
+    res = {}
+    for s, (X, lS_o, lS_i, T) in enumerate(golden_batches(d, meta)):
+        Z = model(torch.from_numpy(X).to(dev), torch.stack([torch.from_numpy(o) for o in lS_o]).to(dev),
+                  [torch.from_numpy(i).to(dev) for i in lS_i])
+        Tl = torch.from_numpy(T)[ext_dist.get_my_slice(T.shape[0])].to(dev)
+        E = model.loss_fn(Z, Tl)
+        res[f"s{s}.Z"] = Z.detach().cpu().numpy()
+        res[f"s{s}.loss"] = float(E)
+        opt.zero_grad()
+        E.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    for j, g in enumerate(model.local_emb_indices):
+        res[f"final.emb_l.{g}.weight"] = model.emb_l[j].weight.detach().cpu().numpy()
+    for name, p in model.bot_l.module.named_parameters():
+        res[f"final.bot_l.{name}"] = p.detach().cpu().numpy()
+    for name, p in model.top_l.module.named_parameters():
+        res[f"final.top_l.{name}"] = p.detach().cpu().numpy()
+    q.put((rank, res))
+    ext_dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_training_matches_reference_two_rank_run():
+    d, meta = load_golden("dist2_tiny")
+    size = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, size, port, q)) for r in range(size)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(size))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in range(size):
+        for s in range(meta["steps"]):
+            np.testing.assert_allclose(results[r][f"s{s}.Z"], d[f"rank{r}.s{s}.Z"], rtol=2e-5, atol=1e-6)
+            want = float(d[f"rank{r}.s{s}.loss"])
+            assert abs(results[r][f"s{s}.loss"] - want) <= 1e-5 * abs(want)
+        for k, v in results[r].items():
+            if k.startswith("final.emb_l"):
+                np.testing.assert_allclose(v, d[f"rank{r}.{k}"], rtol=1e-4, atol=2e-6, err_msg=k)
+            elif k.startswith("final."):
+                np.testing.assert_allclose(v, d[f"rank0.{k}"], rtol=1e-4, atol=2e-6, err_msg=k)

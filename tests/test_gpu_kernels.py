@@ -1,0 +1,224 @@
+"""HIP kernels (through the C ABI, dlrm_amd.ops) against the CPU oracle on identical seeded inputs.
+Integer/byte-order contracts are bit-exact; MFMA fp32 GEMMs/dots use the tolerance written in each test."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    return torch.device("cuda:0")
+
+
+def ragged(rng, B, rows, max_len, empty_frac=0.2):
+    lens = rng.integers(0, max_len + 1, size=B)
+    lens[rng.random(B) < empty_frac] = 0
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    idx = rng.integers(0, rows, size=int(lens.sum())).astype(np.int64)
+    return off, idx
+
+
+def to_dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev())
+
+
+# ------------------------------------------------------------------------------------------ embeddings
+@pytest.mark.parametrize("D", [1, 2, 12, 16, 64, 128, 200, 256, 512])
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_emb_fwd_bit_exact(D, idx_dtype):
+    from dlrm_amd import ops
+    rng = np.random.default_rng(D)
+    rows = [1, 3, 50, 1000, 7]
+    B = 203
+    Ws = [rng.standard_normal((n, D)).astype(np.float32) for n in rows]
+    bags = [ragged(rng, B, n, 9) for n in rows]
+    bags[1] = (np.arange(B, dtype=np.int64), rng.integers(0, 3, size=B).astype(np.int64))  # one-hot table
+    bags[4] = (np.zeros(B, dtype=np.int64), np.zeros(0, dtype=np.int64))                    # all bags empty
+    psw = [None, None, rng.standard_normal(bags[2][1].shape[0]).astype(np.float32), None, None]
+    want = np.concatenate([O.emb_fwd(W, i, o, psw=w) for W, (o, i), w in zip(Ws, bags, psw)], axis=1)
+    dW = [to_dev(W) for W in Ws]
+    bb = ops.BagBatch([to_dev(o, idx_dtype) for o, _ in bags], [to_dev(i, idx_dtype) for _, i in bags],
+                      [None if w is None else to_dev(w) for w in psw])
+    # write into a strided slot of a wider buffer, like the [B, F*D] interaction buffer
+    buf = torch.full((B, (len(rows) + 1) * D + 4), -7.0, device=dev())
+    out = buf[:, D:D + len(rows) * D]
+    ops.emb_fwd(dW, bb, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got, want)
+    assert torch.all(buf[:, :D] == -7.0) and torch.all(buf[:, D + len(rows) * D:] == -7.0)
+
+
+@pytest.mark.parametrize("D", [2, 16, 128, 200])
+def test_emb_bwd_sgd_deterministic_bit_exact(D):
+    from dlrm_amd import ops
+    rng = np.random.default_rng(100 + D)
+    rows = [3, 40, 500]
+    B = 150
+    Ws = [rng.standard_normal((n, D)).astype(np.float32) for n in rows]
+    bags = [ragged(rng, B, n, 5, empty_frac=0.1) for n in rows]
+    psw = [None, rng.standard_normal(bags[1][1].shape[0]).astype(np.float32), None]
+    dV = rng.standard_normal((B, len(rows) * D)).astype(np.float32)
+    want = [O.emb_bwd_sgd(W.copy(), i, o, np.ascontiguousarray(dV[:, t * D:(t + 1) * D]), 0.3, psw=w)
+            for t, (W, (o, i), w) in enumerate(zip(Ws, bags, psw))]
+    dW = [to_dev(W) for W in Ws]
+    bb = ops.BagBatch([to_dev(o) for o, _ in bags], [to_dev(i) for _, i in bags],
+                      [None if w is None else to_dev(w) for w in psw])
+    ops.emb_bwd_sgd(dW, bb, to_dev(dV), 0.3, ops.UPD_DETERMINISTIC)
+    torch.cuda.synchronize()
+    for t in range(len(rows)):
+        assert np.array_equal(dW[t].cpu().numpy(), want[t]), t
+
+
+@pytest.mark.parametrize("D,rows", [(16, [3, 40, 5000]), (128, [4, 10, 130, 100000]), (6, [2, 9])])
+def test_emb_bwd_sgd_atomic_matches_oracle(D, rows):
+    """fast mode: duplicate-row sums are re-associated (fp32 atomics, LDS pre-reduction) -> tolerance"""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(7 + D)
+    B = 4096
+    Ws = [rng.standard_normal((n, D)).astype(np.float32) for n in rows]
+    bags = [(np.arange(B, dtype=np.int64), rng.integers(0, n, size=B).astype(np.int64)) for n in rows]
+    bags[-1] = ragged(rng, B, rows[-1], 6)
+    dV = (rng.standard_normal((B, len(rows) * D)) * 0.1).astype(np.float32)
+    want = [O.emb_bwd_sgd(W.copy(), i, o, np.ascontiguousarray(dV[:, t * D:(t + 1) * D]), 0.05)
+            for t, (W, (o, i)) in enumerate(zip(Ws, bags))]
+    dW = [to_dev(W) for W in Ws]
+    bb = ops.BagBatch([to_dev(o) for o, _ in bags], [to_dev(i) for _, i in bags])
+    ops.emb_bwd_sgd(dW, bb, to_dev(dV), 0.05, ops.UPD_ATOMIC)
+    torch.cuda.synchronize()
+    for t in range(len(rows)):
+        np.testing.assert_allclose(dW[t].cpu().numpy(), want[t], rtol=1e-5, atol=2e-5, err_msg=str(t))
+
+
+# ------------------------------------------------------------------------------------------ interaction
+@pytest.mark.parametrize("F,D,itself", [(4, 16, False), (27, 128, False), (27, 16, False), (6, 12, True), (2, 2, False),
+                                        (9, 64, False), (33, 32, False), (49, 8, True)])
+def test_interact_fwd_bwd(F, D, itself):
+    from dlrm_amd import ops
+    rng = np.random.default_rng(F * 1000 + D)
+    B = 67
+    feat = rng.standard_normal((B, F, D)).astype(np.float32)
+    want = O.interact_fwd(feat, itself)
+    Wd = want.shape[1]
+    ldr = (Wd + 3) & ~3
+    x = to_dev(feat[:, 0, :])
+    E = to_dev(feat[:, 1:, :].reshape(B, (F - 1) * D))
+    R = torch.full((B, ldr), 3.0, device=dev())
+    ops.interact_fwd([x, E], D, itself, R)
+    torch.cuda.synchronize()
+    got = R.cpu().numpy()
+    np.testing.assert_allclose(got[:, :Wd], want, rtol=1e-5, atol=1e-5)   # fp32 MFMA vs fp64-accumulated oracle
+    assert np.array_equal(got[:, :D], feat[:, 0, :])                      # the copied x block is exact
+    assert np.all(got[:, Wd:] == 0)
+    dR = rng.standard_normal((B, Wd)).astype(np.float32)
+    dwant = O.interact_bwd(feat, dR, itself)
+    dRd = torch.zeros((B, ldr), device=dev())
+    dRd[:, :Wd] = to_dev(dR)
+    dx = torch.empty((B, D), device=dev())
+    dE = torch.empty((B, (F - 1) * D), device=dev())
+    ops.interact_bwd([x, E], D, itself, dRd, [dx, dE])
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dx.cpu().numpy(), dwant[:, 0, :], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(dE.cpu().numpy().reshape(B, F - 1, D), dwant[:, 1:, :], rtol=1e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------ MLP layers
+@pytest.mark.parametrize("M,N,K,act", [(128, 512, 13, 1), (300, 16, 512, 1), (257, 1024, 479, 1), (64, 1, 256, 2),
+                                       (1, 3, 2, 0), (513, 130, 36, 1), (1000, 128, 256, 1)])
+def test_linear_fwd_bwd(M, N, K, act):
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    # asymmetric, non-identity data so that a transposed fragment cannot pass
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    Y = O.linear_fwd(X, W, b, act)
+    ldx = (K + 3) & ~3
+    Xd = torch.zeros((M, ldx), device=dev())[:, :K]
+    Xd.copy_(to_dev(X))
+    Wd, bd = to_dev(W), to_dev(b)
+    Yd = torch.empty((M, N), device=dev())
+    ops.linear_fwd(Xd, Wd, bd, act, Yd)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(Yd.cpu().numpy(), Y, rtol=1e-5, atol=1e-5)
+
+    dY = rng.standard_normal((M, N)).astype(np.float32)
+    dX, dW, db = O.linear_bwd(X, W, act, Y, dY)
+    dZd = torch.empty((M, N), device=dev())
+    dbd = torch.zeros(N, device=dev())
+    ops.act_bwd(to_dev(dY), Yd, act, dZd, dbd)
+    dWd = torch.empty((N, K), device=dev())
+    ops.linear_bwd_weight(dZd, Xd, dWd)
+    dXd = torch.empty((M, ldx), device=dev())[:, :K]
+    ops.linear_bwd_data(dZd, Wd, None, 0, dXd, None)
+    torch.cuda.synchronize()
+    scale = max(1.0, float(np.abs(dW).max()))
+    np.testing.assert_allclose(dbd.cpu().numpy(), db, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(db).max())))
+    np.testing.assert_allclose(dWd.cpu().numpy(), dW, rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(dXd.cpu().numpy(), dX, rtol=1e-5, atol=1e-5)
+
+
+def test_linear_bwd_data_fused_mask_and_bias_grad():
+    """dgrad epilogue: previous layer's ReLU mask and its bias gradient (column sums) fused in"""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(5)
+    M, N, K = 777, 96, 200
+    dZ = rng.standard_normal((M, N)).astype(np.float32)
+    W = rng.standard_normal((N, K)).astype(np.float32)
+    Xact = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    want = (dZ.astype(np.float64) @ W.astype(np.float64)) * (Xact > 0)
+    dXd = torch.empty((M, K), device=dev())
+    dbp = torch.zeros(K, device=dev())
+    ops.linear_bwd_data(to_dev(dZ), to_dev(W), to_dev(Xact), 1, dXd, dbp)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dXd.cpu().numpy(), want, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(dbp.cpu().numpy(), want.sum(0), rtol=1e-4, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------ loss / SGD
+@pytest.mark.parametrize("B", [1, 7, 128, 65536])
+def test_bce_and_mse(B):
+    from dlrm_amd import ops
+    rng = np.random.default_rng(B)
+    p = rng.random(B).astype(np.float32)
+    p[: min(B, 3)] = [0.0, 1.0, 1e-30][: min(B, 3)]          # clamp paths (log -> -100, denominator -> 1e-12)
+    t = np.round(rng.random(B)).astype(np.float32)
+    want, dwant = O.bce(p, t)
+    loss, dp = ops.bce_loss(to_dev(p), to_dev(t), None, 1.0, True)
+    torch.cuda.synchronize()
+    assert abs(float(loss.cpu()) - want) <= 1e-5 * max(abs(want), 1e-6)
+    np.testing.assert_allclose(dp.cpu().numpy(), dwant, rtol=1e-5, atol=1e-12)
+    want, dwant = O.mse(p, t)
+    loss, dp = ops.mse_loss(to_dev(p), to_dev(t), 1.0, True)
+    assert abs(float(loss.cpu()) - want) <= 1e-5 * max(abs(want), 1e-6)
+    np.testing.assert_allclose(dp.cpu().numpy(), dwant, rtol=1e-6, atol=1e-12)
+
+
+def test_sgd_dense():
+    from dlrm_amd import ops
+    rng = np.random.default_rng(9)
+    for n in (1, 5, 1024, 2368897):
+        w = rng.standard_normal(n).astype(np.float32)
+        g = rng.standard_normal(n).astype(np.float32)
+        wd = to_dev(w)
+        ops.sgd_dense(wd, to_dev(g), 0.1)
+        want = (w.astype(np.float64) - 0.1 * g.astype(np.float64))
+        np.testing.assert_allclose(wd.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+
+
+def test_a2a_unpack_layout():
+    from dlrm_amd import ops
+    rng = np.random.default_rng(3)
+    tables, bl, D = [2, 1, 3], 5, 4
+    chunks = [rng.standard_normal((bl, t * D)).astype(np.float32) for t in tables]
+    recv = to_dev(np.concatenate([c.reshape(-1) for c in chunks]))
+    out = torch.empty((bl, sum(tables) * D), device=dev())
+    ops.a2a_unpack(recv, tables, bl, D, out)
+    assert np.array_equal(out.cpu().numpy(), np.concatenate(chunks, axis=1))

@@ -1,0 +1,96 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/dlrm_hip.h declares, the
+drop-in module has the reference's surface, host bookkeeping is bit-exact, and the product path refuses
+to run without a GPU instead of falling back."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, load_golden, params_with_prefix
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "dlrm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dlrm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dlrm_amd import _lib
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert lib.dlrm_hip_abi_version() == 1
+    assert b"gfx950" in lib.dlrm_hip_build_info()
+
+
+def test_no_cpu_fallback():
+    from dlrm_amd import ops
+    W = [torch.zeros(4, 4)]
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.BagBatch([torch.zeros(2, dtype=torch.int64)], [torch.zeros(2, dtype=torch.int64)])
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.linear_fwd(torch.zeros(2, 2), torch.zeros(2, 2), None, 0, torch.zeros(2, 2))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "dlrm_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            assert "oracle" not in open(os.path.join(pkg, f)).read().replace("# oracle", ""), f
+
+
+def test_module_surface_and_rng_order_match_reference():
+    """same numpy seed -> bit-identical initial parameters and the reference's state_dict keys"""
+    import dlrm_amd
+    d, meta = load_golden("config1_b128")
+    np.random.seed(123)
+    m = dlrm_amd.DLRM_Net(meta["m_spa"], np.asarray(meta["ln_emb"]), np.asarray(meta["ln_bot"]), np.asarray(meta["ln_top"]),
+                          arch_interaction_op="dot", sigmoid_top=meta["sigmoid_top"], loss_function="bce")
+    init = params_with_prefix(d, "init")
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(init.keys())
+    for k, v in init.items():
+        assert np.array_equal(sd[k].numpy(), v), k
+    for attr in ("emb_l", "v_W_l", "bot_l", "top_l", "loss_fn", "ndevices", "loss_threshold", "weighted_pooling",
+                 "quantize_emb", "apply_mlp", "apply_emb", "interact_features", "create_emb", "create_mlp",
+                 "sequential_forward", "distributed_forward"):
+        assert hasattr(m, attr), attr
+    assert isinstance(m.top_l, torch.nn.Sequential) and isinstance(m.top_l[0], torch.nn.Linear) and len(m.top_l) == 6
+    assert all(p.requires_grad for p in m.parameters())
+    empty = dlrm_amd.DLRM_Net()
+    assert len(list(empty.parameters())) == 0
+
+
+def test_ext_dist_partition_bit_exact():
+    from dlrm_amd import ext_dist
+    with open(os.path.join(GOLDEN, "bookkeeping.json")) as f:
+        book = json.load(f)
+    saved = (ext_dist.my_rank, ext_dist.my_size)
+    try:
+        for case in book["partition"]:
+            for rank, want in enumerate(case["ranks"]):
+                ext_dist.my_rank, ext_dist.my_size = rank, case["size"]
+                sl = ext_dist.get_my_slice(case["n"])
+                assert [sl.start, sl.stop, sl.step] == want["slice"]
+                mine, splits = ext_dist.get_split_lengths(case["n"])
+                assert mine == want["my_len"] and splits == want["splits"]
+    finally:
+        ext_dist.my_rank, ext_dist.my_size = saved
+
+
+def test_error_strings_match_reference():
+    import dlrm_amd
+    np.random.seed(0)
+    with pytest.raises(SystemExit, match="--loss-function=huber is not supported"):
+        dlrm_amd.DLRM_Net(2, np.asarray([4, 3]), np.asarray([4, 2]), np.asarray([5, 1]), "dot", loss_function="huber")
+    m = dlrm_amd.DLRM_Net(2, np.asarray([4, 3]), np.asarray([4, 2]), np.asarray([5, 1]), "foo")
+    with pytest.raises(SystemExit, match="--arch-interaction-op=foo is not supported"):
+        m.interact_features(torch.zeros(1, 2), [torch.zeros(1, 2)])

@@ -1,0 +1,156 @@
+"""The CPU oracle (oracle/) against the golden vectors produced by the live reference.
+This is what makes the oracle PINNED: every number here came out of facebookresearch/dlrm itself
+(oracle/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_batches, load_golden, params_with_prefix
+from oracle import oracle as O
+
+TRAIN_FIXTURES = ["config1_b128", "cli_default_mse", "self_interact_d12", "multihot_hotrows"]
+
+
+@pytest.mark.parametrize("name", TRAIN_FIXTURES)
+def test_training_steps_match_reference(name):
+    d, meta = load_golden(name)
+    model = O.OracleDLRM(params_with_prefix(d, "init"), sigmoid_top=meta["sigmoid_top"],
+                         self_interaction=meta["itself"], loss=meta["loss"])
+    for s, (X, lS_o, lS_i, T) in enumerate(golden_batches(d, meta)):
+        loss, Z = model.train_step(X, lS_o, lS_i, T, meta["lr"])
+        np.testing.assert_allclose(Z, d[f"s{s}.Z"], rtol=2e-5, atol=1e-6)
+        assert abs(loss - d["losses"][s]) <= 1e-5 * abs(d["losses"][s]), (s, loss, d["losses"][s])
+        if s == 0:
+            for k, v in params_with_prefix(d, "after1").items():
+                np.testing.assert_allclose(model.p[k], v, rtol=1e-4, atol=2e-6, err_msg=k)
+    for k, v in params_with_prefix(d, "final").items():
+        np.testing.assert_allclose(model.p[k], v, rtol=1e-4, atol=5e-6, err_msg=k)
+
+
+def test_embedding_bag_forward_is_bit_exact():
+    """in-order fp32 sum == torch's EmbeddingBag CPU kernel, bit for bit"""
+    import torch
+    rng = np.random.default_rng(0)
+    for D in (1, 2, 12, 16, 128):
+        E = rng.standard_normal((97, D)).astype(np.float32)
+        lens = rng.integers(0, 9, size=41)
+        off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        idx = rng.integers(0, 97, size=int(lens.sum())).astype(np.int64)
+        got = O.emb_fwd(E, idx, off)
+        bag = torch.nn.EmbeddingBag(97, D, mode="sum", _weight=torch.tensor(E))
+        want = bag(torch.tensor(idx), torch.tensor(off)).detach().numpy()
+        assert np.array_equal(got, want), D
+        w = rng.standard_normal(idx.shape[0]).astype(np.float32)
+        got = O.emb_fwd(E, idx, off, psw=w)
+        want = bag(torch.tensor(idx), torch.tensor(off), per_sample_weights=torch.tensor(w)).detach().numpy()
+        assert np.array_equal(got, want), ("weighted", D)
+
+
+def test_sparse_sgd_is_bit_exact():
+    """per-lookup in-order fma chain == p.add_(uncoalesced sparse grad, alpha=-lr) on torch CPU"""
+    import torch
+    rng = np.random.default_rng(1)
+    E = rng.standard_normal((5, 16)).astype(np.float32)
+    B = 300                                   # ~60 duplicates per row
+    off = np.arange(B, dtype=np.int64)
+    idx = rng.integers(0, 5, size=B).astype(np.int64)
+    dV = rng.standard_normal((B, 16)).astype(np.float32)
+    bag = torch.nn.EmbeddingBag(5, 16, mode="sum", sparse=True, _weight=torch.tensor(E.copy()))
+    out = bag(torch.tensor(idx), torch.tensor(off))
+    out.backward(torch.tensor(dV))
+    torch.optim.SGD(bag.parameters(), lr=0.37).step()
+    got = O.emb_bwd_sgd(E.copy(), idx, off, dV, 0.37)
+    assert np.array_equal(got, bag.weight.detach().numpy())
+
+
+def test_coo_gradient_of_reference_matches_oracle_backward():
+    d, meta = load_golden("config1_b128")
+    model = O.OracleDLRM(params_with_prefix(d, "init"), sigmoid_top=meta["sigmoid_top"])
+    X, lS_o, lS_i, T = golden_batches(d, meta)[0]
+    Z = model.forward(X, lS_o, lS_i)
+    _, dp = O.bce(Z, T)
+    bot, feat, R, top = model._cache
+    dR, gtop = model._mlp_bwd(top, model._tower("top_l", model.ntop, model.sigmoid_top), dp.reshape(Z.shape), True)
+    dfeat = O.interact_bwd(feat, dR)
+    # reference COO grad of table 0: indices are the input indices verbatim, values = dV[bag(i)]
+    assert np.array_equal(d["s0.emb0_grad_indices"][0], lS_i[0])
+    bag_of = np.searchsorted(lS_o[0], np.arange(lS_i[0].shape[0]), side="right") - 1
+    np.testing.assert_allclose(dfeat[:, 1, :][bag_of], d["s0.emb0_grad_values"], rtol=1e-4, atol=1e-7)
+    g = dict((i, (dW, db)) for i, dW, db in gtop)
+    np.testing.assert_allclose(g[0][0], d["s0.top0_weight_grad"], rtol=1e-4, atol=1e-7)
+
+
+def test_rowwise_adagrad_matches_reference():
+    d, meta = load_golden("rwsadagrad_tiny")
+    # the fixture stores the coalesced sparse grads RWSAdagrad consumed at step 0; rebuild dV-equivalent
+    # inputs: one bag per coalesced row with the stored value as its gradient
+    for k in range(3):
+        E = d[f"init.emb_l.{k}.weight"].copy()
+        rows = d[f"s0.emb{k}_cgrad_indices"][0].astype(np.int64)
+        vals = d[f"s0.emb{k}_cgrad_values"]
+        mom = np.zeros(E.shape[0], dtype=np.float32)
+        O.emb_bwd_rowwise_adagrad(E, mom, rows, np.arange(rows.shape[0], dtype=np.int64), vals, meta["lr"], meta["eps"])
+        np.testing.assert_allclose(E, d[f"after1.emb_l.{k}.weight"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(mom, d[f"after1.mom{k}"], rtol=1e-5, atol=1e-9)
+
+
+def test_bookkeeping_is_bit_exact():
+    with open(os.path.join(GOLDEN, "bookkeeping.json")) as f:
+        book = json.load(f)
+    for case in book["partition"]:
+        for rank, want in enumerate(case["ranks"]):
+            sl = O.my_slice(case["n"], rank, case["size"])
+            assert [sl.start, sl.stop, sl.step] == want["slice"]
+            mine, splits = O.split_lengths(case["n"], rank, case["size"])
+            assert mine == want["my_len"] and splits == want["splits"]
+    for key, want in book["pairs"].items():
+        F = int(key.split("_")[0][1:])
+        li, lj = O.pair_order(F, key.endswith("self1"))
+        assert li.tolist() == want["li"] and lj.tolist() == want["lj"]
+
+
+def test_distributed_reference_semantics():
+    """2-rank reference run: rank outputs are the batch slices of the single-process forward, the mean of
+    the rank losses is the single-process loss, and (the reference's quirk) embedding rows
+    move N x as far as in the single-process run while MLP parameters move identically."""
+    d, meta = load_golden("dist2_tiny")
+    N, B = meta["size"], meta["B"]
+    for r in range(N):
+        sl = O.my_slice(B, r, N)
+        np.testing.assert_allclose(d[f"rank{r}.s0.Z"], d["single.s0.Z"][sl], rtol=1e-5, atol=1e-7)
+    mean_loss = np.mean([d[f"rank{r}.s0.loss"] for r in range(N)])
+    assert abs(mean_loss - d["single.s0.loss"]) < 1e-6
+    assert d["rank0.n_emb_per_rank"].tolist() == [2, 1]
+    assert d["rank0.local_emb_indices"].tolist() == [0, 1] and d["rank1.local_emb_indices"].tolist() == [2]
+    # oracle, one step: embedding lr scaled by N reproduces the distributed tables
+    model = O.OracleDLRM(params_with_prefix(d, "init"), sigmoid_top=meta["sigmoid_top"])
+    X, lS_o, lS_i, T = golden_batches(d, meta)[0]
+    model.train_step(X, lS_o, lS_i, T, meta["lr"], emb_lr_scale=float(N))
+    m2 = O.OracleDLRM(params_with_prefix(d, "init"), sigmoid_top=meta["sigmoid_top"])
+    for s, (X, lS_o, lS_i, T) in enumerate(golden_batches(d, meta)):
+        m2.train_step(X, lS_o, lS_i, T, meta["lr"], emb_lr_scale=float(N))
+    owner = {0: 0, 1: 0, 2: 1}
+    for g in range(3):
+        np.testing.assert_allclose(m2.p[f"emb_l.{g}.weight"], d[f"rank{owner[g]}.final.emb_l.{g}.weight"], rtol=2e-4,
+                                   atol=2e-6)
+    for k in ("bot_l.0.weight", "top_l.2.bias", "top_l.0.weight"):
+        np.testing.assert_allclose(m2.p[k], d[f"rank0.final.{k}"], rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", TRAIN_FIXTURES)
+def test_torch_port_is_bit_identical_to_reference(name):
+    """oracle/torch_port.py (bench.py's cpu_baseline) makes the reference's own operator calls: same bits."""
+    import torch
+    from oracle.torch_port import TorchPortDLRM
+    d, meta = load_golden(name)
+    init = {k: torch.from_numpy(v) for k, v in params_with_prefix(d, "init").items()}
+    m = TorchPortDLRM(init, meta["sigmoid_top"], meta["itself"], meta["loss"], meta["lr"])
+    for s, (X, lS_o, lS_i, T) in enumerate(golden_batches(d, meta)):
+        loss, Z = m.train_step(torch.from_numpy(X), [torch.from_numpy(o) for o in lS_o],
+                               [torch.from_numpy(i) for i in lS_i], torch.from_numpy(T))
+        assert np.array_equal(Z.numpy(), d[f"s{s}.Z"])
+        assert loss == float(np.float32(d["losses"][s]))
+    for k, v in params_with_prefix(d, "final").items():
+        assert np.array_equal(m.p[k].detach().numpy(), v), k
