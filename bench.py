@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-row-cap", type=int, default=1000000)
     ap.add_argument("--cpu-steps", type=int, default=3)
-    ap.add_argument("--deterministic-update", action="store_true")
+    ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
     return ap.parse_args()
 
 
@@ -136,8 +136,7 @@ def main():
     dlrm_amd.set_embedding_init(device)
     model = dlrm_amd.DLRM_Net(D, np.asarray(rows), np.asarray(wl["bot"]), ln_top, "dot", sigmoid_top=ln_top.size - 2,
                               loss_function="bce").to(device)
-    if args.deterministic_update:
-        model.emb_update_mode = ops.UPD_DETERMINISTIC
+    model.emb_update_mode = {"sorted": ops.UPD_SORTED, "atomic": ops.UPD_ATOMIC, "deterministic": ops.UPD_DETERMINISTIC}[args.emb_update]
     if N > 1:
         model.bot_l = ext_dist.DDP(model.bot_l, device_ids=[device.index])
         model.top_l = ext_dist.DDP(model.top_l, device_ids=[device.index])
@@ -224,7 +223,7 @@ def main():
     kname = {"linear_fwd": "gemm_f32_kernel<true,true> (Y = X*W^T + bias, act)",
              "linear_bwd_data": "gemm_f32_kernel<true,false> (dX = dY*W, mask + bias-grad epilogue)",
              "linear_bwd_weight": "gemm_f32_kernel<false,false> (dW = dY^T*X, split over the batch)",
-             "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "emb_bwd_sgd_{atomic,lds}_kernel",
+             "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "expand + rocprim radix sort + sorted_update_kernel" if args.emb_update == "sorted" else "emb_bwd_sgd_{atomic,lds}_kernel",
              "interact_fwd": "interact_fwd_kernel", "interact_bwd": "interact_bwd_kernel"}
 
     def roof(n):
@@ -243,7 +242,7 @@ def main():
                    "tables": len(rows), "emb_dim": D, "global_batch": B, "table_rows_total": int(sum(rows)),
                    "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": "sgd",
                    "loss": "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
-                   "embedding_update": "deterministic" if args.deterministic_update else "atomic"},
+                   "embedding_update": args.emb_update},
         "final_loss": final_loss,
         "roofline": roof(dom) if dom else None,
         "roofline_embedding": roof("emb_fwd") if "emb_fwd" in kernels else None,

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdlrm_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-UPD_ATOMIC, UPD_DETERMINISTIC = 0, 1
+UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED = 0, 1, 2
 
 _lock = threading.Lock()
 _lib = None
@@ -31,8 +31,9 @@ SIGNATURES = {
     "dlrm_hip_build_info": (C.c_char_p, []),
     "dlrm_hip_device_info": (_i32, [_i32, C.POINTER(_i32), C.POINTER(_i32), _pi64, C.c_char_p, _i32]),
     "dlrm_emb_fwd": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64, _vp]),
+    "dlrm_emb_bwd_workspace_bytes": (_i64, [_i32, _pi64, _pi64]),
     "dlrm_emb_bwd_sgd": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64,
-                                _f32, _i32, _vp]),
+                                _f32, _i32, _vp, _i64, _vp]),
     "dlrm_emb_adagrad_workspace_bytes": (_i64, [_i32, _pi64, _pi64]),
     "dlrm_emb_bwd_rowwise_adagrad": (_i32, [_i32, _i64, _i32, _pp, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32,
                                             _vp, _i64, _f32, _f32, _vp, _i64, _vp]),

@@ -42,3 +42,10 @@ struct EmbArgs {
     long long   rows[DLRM_MAX_TABLES_PER_LAUNCH];
     int         slot[DLRM_MAX_TABLES_PER_LAUNCH];  // feature slot (column block) of the table in out/dout
 };
+
+// emb_sorted.hip: sort-based fused backward + SGD (mode DLRM_UPD_SORTED of dlrm_emb_bwd_sgd)
+int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_host, const int64_t* rows_host,
+                                 const void* const* indices_host, const void* const* offsets_host,
+                                 const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
+                                 const float* dout, int64_t dout_ld, float lr, void* workspace,
+                                 int64_t workspace_bytes, void* stream);

@@ -418,12 +418,16 @@ extern "C" int dlrm_emb_bwd_sgd(int T, int64_t B, int D, void* const* weight_hos
                                 const int64_t* rows_host, const void* const* indices_host,
                                 const void* const* offsets_host, const int64_t* nnz_host,
                                 const void* const* psw_host, int idx_bits, const float* dout,
-                                int64_t dout_ld, float lr, int mode, void* stream) {
+                                int64_t dout_ld, float lr, int mode, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
     int rc = check_common(T, B, D, (const void* const*)weight_host, rows_host, indices_host, offsets_host,
                           nnz_host, idx_bits);
     if (rc) return rc;
     if (!dout || dout_ld < (int64_t)T * D) return DLRM_E_ARG;
-    if (mode != DLRM_UPD_ATOMIC && mode != DLRM_UPD_DETERMINISTIC) return DLRM_E_MODE;
+    if (mode != DLRM_UPD_ATOMIC && mode != DLRM_UPD_DETERMINISTIC && mode != DLRM_UPD_SORTED) return DLRM_E_MODE;
+    if (mode == DLRM_UPD_SORTED)
+        return dlrm_emb_bwd_sgd_sorted_impl(T, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host,
+                                            psw_host, idx_bits, dout, dout_ld, lr, workspace, workspace_bytes, stream);
     hipStream_t st = (hipStream_t)stream;
     const float neg_lr = -lr;
     dim3 block(256, 1, 1);

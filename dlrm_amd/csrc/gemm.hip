@@ -21,6 +21,7 @@
 //
 // Fused epilogues: +bias and ReLU/sigmoid (forward); activation-derivative mask of the previous
 // layer and bias-gradient column sums (dgrad); atomic accumulation of k-splits (wgrad).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -46,6 +47,7 @@ struct GemmArgs {
     float* colsum;                 // [N] += column sums of the result        (nullable)
     int atomic_out;                // 1: atomicAdd into C instead of store
     int tiles_m, tiles_n;
+    int debug;                     // tuning aid (env DLRM_GEMM_DEBUG): 1 skip global loads in the k-loop, 2 skip LDS refill + barrier, 4 skip epilogue
 };
 
 template <bool KC>
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         const float* sA = lds + (kt & 1) * 2 * TILE_F;
         const float* sB = sA + TILE_F;
         const bool more = kt + 1 < nk;
-        if (more) {
+        if (more && !(g.debug & 1)) {
             const long long k0 = k_begin + (long long)(kt + 1) * BK;
             load_tile<A_KC>(ra, g.A, g.lda, g.vecA, m0, g.M, k0, k_end, tid);
             load_tile<B_KC>(rb, g.B, g.ldb, g.vecB, n0, g.N, k0, k_end, tid);
@@ -173,12 +175,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].w, fb[tn].w, acc[tm][tn], 0, 0, 0);
                 }
         }
-        if (more) {
+        if (more && !(g.debug & 2)) {
             float* dA = lds + ((kt + 1) & 1) * 2 * TILE_F;
             store_tile<A_KC>(dA, ra, tid);
             store_tile<B_KC>(dA + TILE_F, rb, tid);
         }
-        __syncthreads();
+        if (!(g.debug & 2)) __syncthreads();
+    }
+    if (g.debug & 4) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 123.456f) g.C[0] = s;   // keeps the accumulators live
+        return;
     }
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -249,6 +262,9 @@ template <bool A_KC, bool B_KC>
 static int launch_gemm(GemmArgs& g, int splits, hipStream_t st) {
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (int)((g.N + BN - 1) / BN);
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("DLRM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+    g.debug = dbg;
     const size_t lds = 2 * 2 * TILE_F * sizeof(float);   // 73,728 B: two workgroups per CU
     static bool attr_done = false;
     if (!attr_done) {
@@ -262,7 +278,10 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st) {
 }
 
 static int vec_ok_kc(const float* p, long long ld, long long kext) { return dlrm_aligned16(p) && ld % 4 == 0 && kext % 4 == 0; }
-static int vec_ok_ks(const float* p, long long ld, long long cext) { return dlrm_aligned16(p) && ld % 4 == 0 && cext % 4 == 0; }
+// k-strided operand: a 16-byte load may run past the logical column extent as long as it stays inside the
+// row pitch (ld % 4 == 0 guarantees that); the extra columns only feed output rows/columns >= M/N, which
+// the epilogue never stores.
+static int vec_ok_ks(const float* p, long long ld, long long cext) { (void)cext; return dlrm_aligned16(p) && ld % 4 == 0; }
 
 }  // namespace
 

@@ -158,7 +158,7 @@ class DLRM_Net(nn.Module):
                  loss_function="bce"):
         super().__init__()
         self._pending_emb: list = []
-        self.emb_update_mode = ops.UPD_ATOMIC
+        self.emb_update_mode = ops.UPD_SORTED
         if m_spa is None or ln_emb is None or ln_bot is None or ln_top is None or arch_interaction_op is None:
             return  # empty shell, like the reference's guard (dlrm_s_pytorch.py:320-326)
 

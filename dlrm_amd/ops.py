@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, UPD_ATOMIC, UPD_DETERMINISTIC  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED  # noqa: F401
 
 
 def _stream() -> C.c_void_p:
@@ -165,18 +165,36 @@ def emb_fwd(weights: Sequence[torch.Tensor], bags: BagBatch, out: torch.Tensor) 
     return out
 
 
+_emb_ws = {}   # device -> cached workspace tensor for the sorted update
+
+
+def _emb_workspace(need: int, device) -> torch.Tensor:
+    ws = _emb_ws.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=device)
+        _emb_ws[device] = ws
+    return ws
+
+
 def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Tensor, lr: float,
-                mode: int = UPD_ATOMIC) -> None:
+                mode: int = UPD_SORTED) -> None:
     """Fused EmbeddingBag backward + sparse SGD: W_t[idx] -= lr * dout[bag, t*D:(t+1)*D] (in place)."""
     lib = _lib.load()
     D, wp, rows = _weights_desc(weights)
     _req(dout, "dout", ndim=2)
     if dout.size(0) != bags.B or dout.size(1) < bags.T * D or len(weights) != bags.T:
         raise RuntimeError("dlrm_amd: emb_bwd_sgd shape mismatch")
+    ws_ptr, ws_bytes = None, 0
+    if mode == UPD_SORTED:
+        need = lib.dlrm_emb_bwd_workspace_bytes(bags.T, bags._nnz, rows)
+        if need < 0:
+            raise RuntimeError("dlrm_amd: dlrm_emb_bwd_workspace_bytes failed")
+        ws = _emb_workspace(need, dout.device)
+        ws_ptr, ws_bytes = C.c_void_p(ws.data_ptr()), ws.numel()
     with _timed("emb_bwd_sgd"):
         rc = lib.dlrm_emb_bwd_sgd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
                                   bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout), float(lr), int(mode),
-                                  _stream())
+                                  ws_ptr, ws_bytes, _stream())
     _lib.check(rc, "dlrm_emb_bwd_sgd")
 
 

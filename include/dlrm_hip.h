@@ -37,6 +37,8 @@ extern "C" {
 /* embedding-update modes */
 #define DLRM_UPD_ATOMIC        0  /* fast: LDS pre-reduction for tiny tables + HW fp32 atomics */
 #define DLRM_UPD_DETERMINISTIC 1  /* exact: per-row in-input-order FMA chain (bit-exact vs torch sparse SGD) */
+#define DLRM_UPD_SORTED        2  /* fast: lookups radix-sorted by (table,row), plain read-modify-write per row run;
+                                     needs workspace (dlrm_emb_bwd_workspace_bytes); atomics only where a run straddles chunks */
 
 /* library / device introspection ------------------------------------------------------- */
 int         dlrm_hip_abi_version(void);          /* bumps when a signature changes */
@@ -73,12 +75,17 @@ int dlrm_emb_fwd(int T, int64_t B, int D,
  *   for every lookup i of bag (t,b), in input order:  W_t[idx_t[i],:] = fma(-lr*psw, dout[b, t*D:(t+1)*D], W_t[idx_t[i],:])
  * mode = DLRM_UPD_ATOMIC: order of duplicate-row accumulation is unspecified (fp32 atomics).
  * mode = DLRM_UPD_DETERMINISTIC: bit-exact with the reference (one owner per row, input order).
+ * mode = DLRM_UPD_SORTED: rows whose lookups fall into one chunk of the sorted list (all rows of large
+ *        tables in practice) are bit-exact; hot rows are re-associated.  workspace: device scratch of
+ *        dlrm_emb_bwd_workspace_bytes(...) bytes (may be NULL for the other modes).
  */
+int64_t dlrm_emb_bwd_workspace_bytes(int T, const int64_t* nnz_host, const int64_t* rows_host);
 int dlrm_emb_bwd_sgd(int T, int64_t B, int D,
                      void* const* weight_host, const int64_t* rows_host,
                      const void* const* indices_host, const void* const* offsets_host,
                      const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
-                     const float* dout, int64_t dout_ld, float lr, int mode, void* stream);
+                     const float* dout, int64_t dout_ld, float lr, int mode,
+                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /* K4  fused EmbeddingBag backward + row-wise sparse Adagrad (optim/rwsadagrad.py:117-143).
  *   per table, per UNIQUE row r touched this step (duplicates summed first, in input order):

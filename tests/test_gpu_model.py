@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 FIXTURES = ["config1_b128", "cli_default_mse", "self_interact_d12", "multihot_hotrows"]
 
 
-def build_model(meta, init, device, deterministic=True):
+def build_model(meta, init, device, deterministic=True, mode=None):
     import dlrm_amd
     np.random.seed(0)
     m = dlrm_amd.DLRM_Net(meta["m_spa"], np.asarray(meta["ln_emb"]), np.asarray(meta["ln_bot"]), np.asarray(meta["ln_top"]),
@@ -24,17 +24,19 @@ def build_model(meta, init, device, deterministic=True):
         for k, v in init.items():
             sd[k].copy_(torch.from_numpy(v))
     m = m.to(device)
-    if deterministic:
+    if mode is not None:
+        m.emb_update_mode = mode
+    elif deterministic:
         m.emb_update_mode = dlrm_amd.ops.UPD_DETERMINISTIC
     return m
 
 
 @pytest.mark.parametrize("name", FIXTURES)
-@pytest.mark.parametrize("deterministic", [True, False])
-def test_training_matches_reference_golden(name, deterministic):
+@pytest.mark.parametrize("mode", [1, 2, 0], ids=["deterministic", "sorted", "atomic"])
+def test_training_matches_reference_golden(name, mode):
     d, meta = load_golden(name)
     device = torch.device("cuda:0")
-    model = build_model(meta, params_with_prefix(d, "init"), device, deterministic)
+    model = build_model(meta, params_with_prefix(d, "init"), device, mode=mode)
     opt = torch.optim.SGD(model.parameters(), lr=meta["lr"])
     for s, (X, lS_o, lS_i, T) in enumerate(golden_batches(d, meta)):
         Xd = torch.from_numpy(X).to(device)
@@ -97,7 +99,7 @@ def test_full_batch_properties_criteo_shape():
     # SGD update is linear: applying +g then -g (deterministic order not needed) restores the tables to rounding
     dV = torch.randn(B, T * D, generator=g).to(device) * 0.01
     before = [w.clone() for w in Ws]
-    ops.emb_bwd_sgd(Ws, bags, dV, 0.1, ops.UPD_ATOMIC)
+    ops.emb_bwd_sgd(Ws, bags, dV, 0.1, ops.UPD_SORTED)
     changed = sum(int(not torch.equal(a, b)) for a, b in zip(before, Ws))
     assert changed == T
     # checksum: total mass moved equals -lr * sum of gradients (sum over all rows of a table, fp64)
@@ -105,7 +107,7 @@ def test_full_batch_properties_criteo_shape():
         moved = (Ws[t].double().sum(0) - before[t].double().sum(0))
         want = -0.1 * dV[:, t * D:(t + 1) * D].double().sum(0)
         assert torch.allclose(moved, want, rtol=1e-3, atol=1e-3), t
-    ops.emb_bwd_sgd(Ws, bags, -dV, 0.1, ops.UPD_ATOMIC)
+    ops.emb_bwd_sgd(Ws, bags, -dV, 0.1, ops.UPD_SORTED)
     for t in range(T):
         assert torch.allclose(Ws[t], before[t], rtol=0, atol=2e-5), t
     # interaction: symmetric in the order of two embedding features up to a permutation of output columns

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks on the GPU box (tuning aid; not part of the product or of bench.py)."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dlrm_amd import ops  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def gemm(shapes):
+    out = []
+    for (M, N, K) in shapes:
+        ldk = (K + 3) & ~3
+        X = torch.randn(M, ldk, device=DEV)[:, :K]
+        W = torch.randn(N, K, device=DEV) * 0.03
+        b = torch.randn(N, device=DEV)
+        Y = torch.empty(M, N, device=DEV)
+        dY = torch.randn(M, N, device=DEV)
+        dX = torch.empty(M, ldk, device=DEV)[:, :K]
+        dW = torch.empty(N, K, device=DEV)
+        db = torch.zeros(K, device=DEV)
+        fl = 2.0 * M * N * K
+        t_f = timeit(lambda: ops.linear_fwd(X, W, b, 1, Y))
+        t_d = timeit(lambda: ops.linear_bwd_data(dY, W, X, 1, dX, db))
+        t_d0 = timeit(lambda: ops.linear_bwd_data(dY, W, None, 0, dX, None))
+        t_w = timeit(lambda: ops.linear_bwd_weight(dY, X, dW))
+        r = dict(M=M, N=N, K=K, fwd_us=t_f * 1e3, fwd_tf=fl / t_f / 1e9, dgrad_us=t_d * 1e3, dgrad_tf=fl / t_d / 1e9,
+                 dgrad_plain_us=t_d0 * 1e3, dgrad_plain_tf=fl / t_d0 / 1e9, wgrad_us=t_w * 1e3, wgrad_tf=fl / t_w / 1e9)
+        out.append(r)
+        print("gemm M=%d N=%d K=%d | fwd %.1f us %.1f TF | dgrad %.1f us %.1f TF (plain %.1f us %.1f TF) | wgrad %.1f us %.1f TF"
+              % (M, N, K, r["fwd_us"], r["fwd_tf"], r["dgrad_us"], r["dgrad_tf"], r["dgrad_plain_us"], r["dgrad_plain_tf"],
+                 r["wgrad_us"], r["wgrad_tf"]), flush=True)
+    return out
+
+
+def emb(B=65536, D=128, cap=0):
+    rows = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155, 4, 976, 14,
+            39979771, 25641295, 39664984, 585935, 12972, 108, 36]
+    if cap:
+        rows = [min(r, cap) for r in rows]
+    T = len(rows)
+    Ws = [torch.empty(n, D, device=DEV).uniform_(-0.01, 0.01) for n in rows]
+    idx = [torch.randint(0, n, (B,), device=DEV) for n in rows]
+    off = [torch.arange(B, device=DEV)] * T
+    bags = ops.BagBatch(off, idx)
+    feat = torch.empty(B, (T + 1) * D, device=DEV)
+    dout = torch.randn(B, T * D, device=DEV) * 1e-3
+    res = {}
+    t = timeit(lambda: ops.emb_fwd(Ws, bags, feat[:, D:]))
+    res["emb_fwd_us"] = t * 1e3
+    res["emb_fwd_gbs"] = T * B * (4 * D * 2 + 16) / t / 1e6
+    for name, mode in (("sorted", ops.UPD_SORTED), ("atomic", ops.UPD_ATOMIC)):
+        t = timeit(lambda: ops.emb_bwd_sgd(Ws, bags, dout, 0.01, mode), iters=5, warm=2)
+        res[f"emb_bwd_{name}_us"] = t * 1e3
+        res[f"emb_bwd_{name}_gbs"] = T * B * (4 * D * 3 + 8) / t / 1e6
+    x = torch.randn(B, D, device=DEV)
+    feat[:, :D] = x
+    R = torch.empty(B, 480, device=DEV)
+    t = timeit(lambda: ops.interact_fwd([feat[:, :D], feat[:, D:]], D, False, R))
+    res["interact_fwd_us"] = t * 1e3
+    dR = torch.randn(B, 480, device=DEV)
+    dfeat = torch.empty(B, (T + 1) * D, device=DEV)
+    t = timeit(lambda: ops.interact_bwd([feat[:, :D], feat[:, D:]], D, False, dR, [dfeat[:, :D], dfeat[:, D:]]))
+    res["interact_bwd_us"] = t * 1e3
+    print(json.dumps(res), flush=True)
+    return res
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["gemm", "gemm_big", "emb", "all"])
+    a = ap.parse_args()
+    B = 65536
+    layer_shapes = [(B, 512, 13), (B, 256, 512), (B, 128, 256), (B, 1024, 479), (B, 1024, 1024), (B, 512, 1024), (B, 256, 512), (B, 1, 256)]
+    if a.what in ("gemm", "all"):
+        gemm(layer_shapes)
+    if a.what == "gemm_big":
+        gemm([(B, 1024, 1024), (B, 512, 1024)])
+    if a.what in ("emb", "all"):
+        emb()
