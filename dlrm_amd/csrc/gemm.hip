@@ -19,8 +19,10 @@
 // MFMAs of the current one.  Workgroup ids are remapped so that the n-tiles sharing an A row panel
 // run on the same XCD (private L2).
 //
-// Fused epilogues: +bias and ReLU/sigmoid (forward); activation-derivative mask of the previous
-// layer and bias-gradient column sums (dgrad); atomic accumulation of k-splits (wgrad).
+// Fused: +bias and ReLU/sigmoid (forward epilogue); activation-derivative mask of the previous layer (dgrad
+// epilogue); bias gradient as row sums of the dY^T fragments inside the wgrad main loop; atomic accumulation of
+// the batch splits (wgrad).  Accumulators hold the TRANSPOSED sub-tiles so that the epilogue moves 16 bytes
+// per lane through a wave-private LDS staging area and writes/reads whole 256-byte row segments.
 #include <stdlib.h>
 #include "common.h"
 
@@ -44,7 +46,8 @@ struct GemmArgs {
     const float* bias;             // [N] added before activation            (nullable)
     int act;                       // DLRM_ACT_* applied to the result
     const float* mask; long long ldmask; int mask_act;   // result *= act'(mask[m,n])   (nullable)
-    float* colsum;                 // [N] += column sums of the result        (nullable)
+    float* rowsumA;                // [M] += row sums of the A operand over this k-slice (wgrad: bias gradient)  (nullable)
+    int vecC;                      // 16-byte accesses to C (and mask) are legal
     int atomic_out;                // 1: atomicAdd into C instead of store
     int tiles_m, tiles_n;
     int debug;                     // tuning aid (env DLRM_GEMM_DEBUG): 1 skip global loads in the k-loop, 2 skip LDS refill + barrier, 4 skip epilogue
@@ -111,6 +114,10 @@ __device__ __forceinline__ float act_grad(float g, float y, int act) {
     return g;
 }
 
+// staging region of one wave in the epilogue: its 64 (m) x 64 (n) result, rows padded to 68 floats
+constexpr int EPI_LD = 64 + 4;
+static_assert(4 * 64 * EPI_LD <= 2 * 2 * TILE_F, "epilogue staging does not fit the tile buffers");
+
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][A tile | B tile]
@@ -131,6 +138,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const long long k_end = (k_begin + g.kchunk < g.K) ? k_begin + g.kchunk : g.K;
     const int nk = (int)((k_end - k_begin + BK - 1) / BK);
 
+    // acc[tm][tn] holds the TRANSPOSED 32x32 sub-tile (MFMA row index = n, column index = m), so that
+    // a lane owns 4 consecutive n of one m per register quad -> 16-byte epilogue traffic.
     floatx16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -138,6 +147,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // bias gradient of the wgrad GEMM = row sums of the A operand (dZ^T), taken from the fragments the
+    // MFMAs consume anyway; only the workgroups of the first n-tile column and their wn == 0 waves add it.
+    const bool do_rowsum = g.rowsumA != nullptr && tile_n == 0 && wn == 0;
+    float rs[2] = {0.f, 0.f};
 
     float4 ra[4], rb[4];
     if (nk > 0) {
@@ -157,22 +170,37 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
             load_tile<A_KC>(ra, g.A, g.lda, g.vecA, m0, g.M, k0, k_end, tid);
             load_tile<B_KC>(rb, g.B, g.ldb, g.vecB, n0, g.N, k0, k_end, tid);
         }
+        // fragments are double buffered in registers: the LDS reads of k-group kk+1 are in flight
+        // while the 16 MFMAs of k-group kk issue
+        float4 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fa[0][t] = load_frag<A_KC>(sA, wm * 64 + t * 32, 0, lane);
+            fb[0][t] = load_frag<B_KC>(sB, wn * 64 + t * 32, 0, lane);
+        }
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            float4 fa[2], fb[2];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 8) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                fa[t] = load_frag<A_KC>(sA, wm * 64 + t * 32, kk, lane);
-                fb[t] = load_frag<B_KC>(sB, wn * 64 + t * 32, kk, lane);
+                for (int t = 0; t < 2; ++t) {
+                    fa[nxt][t] = load_frag<A_KC>(sA, wm * 64 + t * 32, kk + 1, lane);
+                    fb[nxt][t] = load_frag<B_KC>(sB, wn * 64 + t * 32, kk + 1, lane);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this k-group's MFMAs
+            if (do_rowsum) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) rs[t] += (fa[cur][t].x + fa[cur][t].y) + (fa[cur][t].z + fa[cur][t].w);
             }
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) {
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].x, fb[tn].x, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].y, fb[tn].y, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].z, fb[tn].z, acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm].w, fb[tn].w, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][tn].x, fa[cur][tm].x, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][tn].y, fa[cur][tm].y, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][tn].z, fa[cur][tm].z, acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][tn].w, fa[cur][tm].w, acc[tm][tn], 0, 0, 0);
                 }
         }
         if (more && !(g.debug & 2)) {
@@ -194,32 +222,69 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         return;
     }
 
-    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int col_l = lane & 31, rofs = 4 * (lane >> 5);
+    if (do_rowsum) {
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-        const long long n = n0 + wn * 64 + tn * 32 + col_l;
-        const bool n_ok = n < g.N;
-        const float bv = (g.bias && n_ok) ? g.bias[n] : 0.f;
-        float cs = 0.f;
+        for (int t = 0; t < 2; ++t) {
+            const float v = rs[t] + __shfl_xor(rs[t], 32, 64);   // the two half-waves hold different k of the same row
+            const long long m = m0 + wm * 64 + t * 32 + (lane & 31);
+            if (lane < 32 && m < g.M) atomicAdd(g.rowsumA + m, v);
+        }
+    }
+
+    // ---- epilogue: registers -> wave-private LDS staging (transposes back to [m][n]) -> 16-byte rows.
+    // The k-loop ended with a barrier, so the tile buffers are free.  Transposed C/D layout of the 32x32
+    // MFMA: lane owns m_local = lane & 31 and n_local = 8*q + 4*(lane>>5) + {0,1,2,3} for q = reg>>2.
+    float* S = lds + wave * (64 * EPI_LD);
+    {
+        const int ml = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
+        for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + rofs;
-                if (n_ok && m < g.M) {
-                    float v = acc[tm][tn][r] + bv;
-                    v = act_apply(v, g.act);
-                    if (g.mask) v = act_grad(v, g.mask[m * g.ldmask + n], g.mask_act);
-                    cs += v;
-                    float* c = g.C + m * g.ldc + n;
-                    if (g.atomic_out) atomicAdd(c, v); else *c = v;
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
+                    *(float4*)__builtin_assume_aligned(S + (tm * 32 + ml) * EPI_LD + tn * 32 + 8 * q + 4 * h, 16) = v;
+                }
+    }
+    // same wave wrote and reads: LDS operations of a wave complete in order
+    const int c4 = (lane & 15) * 4;
+    const long long nb = n0 + wn * 64 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) {
+        if (nb + 0 < g.N) bv.x = g.bias[nb + 0];
+        if (nb + 1 < g.N) bv.y = g.bias[nb + 1];
+        if (nb + 2 < g.N) bv.z = g.bias[nb + 2];
+        if (nb + 3 < g.N) bv.w = g.bias[nb + 3];
+    }
+    const bool full_n = nb + 3 < g.N;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const long long m = m0 + wm * 64 + row;
+        if (m >= g.M || nb >= g.N) continue;
+        float4 v = *(const float4*)__builtin_assume_aligned(S + row * EPI_LD + c4, 16);
+        v.x = act_apply(v.x + bv.x, g.act); v.y = act_apply(v.y + bv.y, g.act);
+        v.z = act_apply(v.z + bv.z, g.act); v.w = act_apply(v.w + bv.w, g.act);
+        float* c = g.C + m * g.ldc + nb;
+        if (g.vecC && full_n) {
+            if (g.mask) {
+                const float4 y = *(const float4*)(g.mask + m * g.ldmask + nb);
+                v.x = act_grad(v.x, y.x, g.mask_act); v.y = act_grad(v.y, y.y, g.mask_act);
+                v.z = act_grad(v.z, y.z, g.mask_act); v.w = act_grad(v.w, y.w, g.mask_act);
+            }
+            if (g.atomic_out) { atomicAdd(c, v.x); atomicAdd(c + 1, v.y); atomicAdd(c + 2, v.z); atomicAdd(c + 3, v.w); }
+            else *(float4*)c = v;
+        } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                if (nb + x < g.N) {
+                    float o = e[x];
+                    if (g.mask) o = act_grad(o, g.mask[m * g.ldmask + nb + x], g.mask_act);
+                    if (g.atomic_out) atomicAdd(c + x, o); else c[x] = o;
                 }
             }
-        }
-        if (g.colsum) {
-            cs += __shfl_xor(cs, 32, 64);
-            if (lane < 32 && n_ok) atomicAdd(g.colsum + n, cs);
         }
     }
 }
@@ -295,6 +360,7 @@ extern "C" int dlrm_linear_fwd(int64_t M, int N, int K, const float* X, int64_t 
     g.M = M; g.N = N; g.K = K;
     g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
     g.vecA = vec_ok_kc(X, ldx, K); g.vecB = vec_ok_kc(W, ldw, K);
+    g.vecC = dlrm_aligned16(Y) && ldy % 4 == 0;
     g.kchunk = ((K + BK - 1) / BK) * BK;
     g.bias = bias; g.act = act;
     return launch_gemm<true, true>(g, 1, (hipStream_t)stream);
@@ -302,8 +368,7 @@ extern "C" int dlrm_linear_fwd(int64_t M, int N, int K, const float* X, int64_t 
 
 extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, int64_t lddy,
                                     const float* W, int64_t ldw, const float* Xact, int64_t ldxa,
-                                    int xact_kind, float* dX, int64_t lddx, float* dbias_prev,
-                                    void* stream) {
+                                    int xact_kind, float* dX, int64_t lddx, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !dY || !W || !dX) return DLRM_E_ARG;
     if (lddy < N || ldw < K || lddx < K) return DLRM_E_ARG;
     if (xact_kind < DLRM_ACT_NONE || xact_kind > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
@@ -312,16 +377,19 @@ extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, in
     g.M = M; g.N = K; g.K = N;                       // output [M, K_layer], reduce over N_layer
     g.A = dY; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = lddx;
     g.vecA = vec_ok_kc(dY, lddy, N); g.vecB = vec_ok_ks(W, ldw, K);
+    g.vecC = dlrm_aligned16(dX) && lddx % 4 == 0;
     g.kchunk = ((N + BK - 1) / BK) * BK;
     g.act = DLRM_ACT_NONE;
-    if (xact_kind != DLRM_ACT_NONE) { g.mask = Xact; g.ldmask = ldxa; g.mask_act = xact_kind; }
-    g.colsum = dbias_prev;
+    if (xact_kind != DLRM_ACT_NONE) {
+        g.mask = Xact; g.ldmask = ldxa; g.mask_act = xact_kind;
+        g.vecC = g.vecC && dlrm_aligned16(Xact) && ldxa % 4 == 0;
+    }
     return launch_gemm<true, false>(g, 1, (hipStream_t)stream);
 }
 
 extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, int64_t lddy,
                                       const float* X, int64_t ldx, float* dW, int64_t lddw,
-                                      int accumulate, void* stream) {
+                                      float* dbias, int accumulate, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !dY || !X || !dW) return DLRM_E_ARG;
     if (lddy < N || ldx < K || lddw < K) return DLRM_E_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -329,7 +397,9 @@ extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, 
     g.M = N; g.N = K; g.K = M;                       // output [N_layer, K_layer], reduce over the batch
     g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx; g.C = dW; g.ldc = lddw;
     g.vecA = vec_ok_ks(dY, lddy, N); g.vecB = vec_ok_ks(X, ldx, K);
+    g.vecC = dlrm_aligned16(dW) && lddw % 4 == 0;
     g.act = DLRM_ACT_NONE;
+    g.rowsumA = dbias;                               // db[n] = sum_m dY[m, n], from the A fragments
     // split the batch reduction so that >= ~4 workgroups per CU exist; slices of >= 512 rows
     const int tiles = (int)(((N + BM - 1) / BM) * ((K + BN - 1) / BN));
     int splits = (1024 + tiles - 1) / tiles;
@@ -341,8 +411,10 @@ extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, 
     splits = (int)((M + kchunk - 1) / kchunk);
     g.kchunk = kchunk;
     g.atomic_out = (splits > 1 || accumulate) ? 1 : 0;
-    if (g.atomic_out && !accumulate) {
-        hipError_t e = hipMemset2DAsync(dW, (size_t)lddw * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)N, st);
+    if (!accumulate) {
+        hipError_t e = hipSuccess;
+        if (g.atomic_out) e = hipMemset2DAsync(dW, (size_t)lddw * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)N, st);
+        if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
     return launch_gemm<false, false>(g, splits, st);

@@ -249,7 +249,7 @@ class DLRM_Net(nn.Module):
     def interact_features(self, x, ly):
         if self.arch_interaction_op == "dot":
             D = x.size(1)
-            return InteractFunction.apply(D, bool(self.arch_interaction_itself), x, *ly)
+            return InteractFunction.apply(D, bool(self.arch_interaction_itself), False, x, *ly)
         if self.arch_interaction_op == "cat":
             return torch.cat([x] + list(ly), dim=1)
         sys.exit("ERROR: --arch-interaction-op=" + str(self.arch_interaction_op) + " is not supported")
@@ -303,7 +303,7 @@ class DLRM_Net(nn.Module):
         if x.size(1) != D:
             sys.exit("ERROR: bottom MLP output (%d) and embedding dimension (%d) differ" % (x.size(1), D))
         E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l, out_slot=OutSlot(feat[:, D:]))
-        z = InteractFunction.apply(D, bool(self.arch_interaction_itself), x, E)
+        z = InteractFunction.apply(D, bool(self.arch_interaction_itself), True, x, E)   # [B, round4(width)], zero padded
         return self._clamp(self.apply_mlp(z, self.top_l))
 
     def distributed_forward(self, dense_x, lS_o, lS_i):
@@ -325,7 +325,10 @@ class DLRM_Net(nn.Module):
         req = ext_dist.alltoall([E], self.n_emb_per_rank, emb_dim=D)
         x = self.apply_mlp(dense_x, self.bot_l)                             # overlaps the exchange
         ly = list(req.wait())                                               # N x [B/N, T_s*D], read in place
-        z = self.interact_features(x, ly)
+        if self.arch_interaction_op == "dot":
+            z = InteractFunction.apply(D, bool(self.arch_interaction_itself), True, x, *ly)
+        else:
+            z = self.interact_features(x, ly)
         return self._clamp(self.apply_mlp(z, self.top_l))
 
 

@@ -47,17 +47,40 @@ class MLPFunction(Function):
     """nn.Sequential(Linear, act, Linear, act, ...) as one chain of fused GEMM(+bias+act) kernels.
 
     forward(x, acts, out_slot, W0, b0, W1, b1, ...) -> activated output of the last layer.
-    Reference: DLRM_Net.create_mlp / apply_mlp (dlrm_s_pytorch.py:208-246, 399-405)."""
+    Reference: DLRM_Net.create_mlp / apply_mlp (dlrm_s_pytorch.py:208-246, 399-405).
+
+    Input widths that are not a multiple of 4 floats (13 dense features, 479 interaction outputs) would
+    force 4-byte loads in the first GEMM: the first layer then runs on a zero-padded copy of its weight
+    [N, round4(K)] and on a zero-padded input.  `x` may already BE that padded input (width round4(K) with
+    zero padding columns, which is what InteractFunction(padded=True) emits); otherwise a padded copy of
+    `x` is made (cheap: it only happens for the narrow dense-feature input)."""
 
     @staticmethod
     def forward(ctx, x, acts, out_slot, *params):
         x = _rowmajor(x)
         L = len(acts)
         M = x.size(0)
+        W0 = params[0]
+        K0, Kp = W0.size(1), _round4(W0.size(1))
+        ctx.in_width = x.size(1)
+        W0p = None
+        if Kp != K0:
+            if x.size(1) != Kp:
+                if x.size(1) != K0:
+                    raise RuntimeError("dlrm_amd: MLP input width %d does not match the first layer (%d)" % (x.size(1), K0))
+                xp = torch.zeros((M, Kp), dtype=torch.float32, device=x.device)
+                xp[:, :K0].copy_(x)
+                x = xp
+            W0p = torch.zeros((W0.size(0), Kp), dtype=torch.float32, device=x.device)
+            W0p[:, :K0].copy_(W0)
+        elif x.size(1) != K0:
+            raise RuntimeError("dlrm_amd: MLP input width %d does not match the first layer (%d)" % (x.size(1), K0))
         cur = x
         outs = []
         for i in range(L):
             W, b = params[2 * i], params[2 * i + 1]
+            if i == 0 and W0p is not None:
+                W = W0p
             N = W.size(0)
             if i == L - 1 and out_slot is not None:
                 y = out_slot.get()
@@ -67,7 +90,8 @@ class MLPFunction(Function):
             outs.append(y)
             cur = y
         ctx.acts = acts
-        ctx.save_for_backward(x, *params, *outs)
+        ctx.padded = W0p is not None
+        ctx.save_for_backward(x, *params, *outs, *([W0p] if W0p is not None else []))
         return outs[-1]
 
     @staticmethod
@@ -77,35 +101,36 @@ class MLPFunction(Function):
         saved = ctx.saved_tensors
         x = saved[0]
         params = saved[1:1 + 2 * L]
-        outs = saved[1 + 2 * L:]
+        outs = saved[1 + 2 * L:1 + 3 * L]
+        W0p = saved[1 + 3 * L] if ctx.padded else None
         M = x.size(0)
         dY = _rowmajor(dY)
         grads: List[Optional[torch.Tensor]] = [None] * (2 * L)
 
-        # last layer: activation backward + bias gradient (dY comes from outside, e.g. the loss)
+        # last layer: activation backward (its dY comes from outside, e.g. the loss or the interaction)
         N_last = params[2 * (L - 1)].size(0)
-        db = torch.zeros(N_last, dtype=torch.float32, device=x.device)
         dZ = alloc2d(M, N_last, x)
-        ops.act_bwd(dY, outs[L - 1], acts[L - 1], dZ, db)
-        grads[2 * (L - 1) + 1] = db
+        ops.act_bwd(dY, outs[L - 1], acts[L - 1], dZ, None)
         dX = None
         for i in range(L - 1, -1, -1):
-            W = params[2 * i]
+            W = params[2 * i] if not (i == 0 and W0p is not None) else W0p
             X_i = x if i == 0 else outs[i - 1]
             dW = torch.empty_like(W)
-            ops.linear_bwd_weight(dZ, X_i, dW)
-            grads[2 * i] = dW
+            db = torch.empty(W.size(0), dtype=torch.float32, device=x.device)
+            ops.linear_bwd_weight(dZ, X_i, dW, db)          # dW and db (row sums of dZ^T) in one GEMM
+            if i == 0 and W0p is not None:
+                dW = dW[:, :params[0].size(1)]               # padding column of the weight gradient is exactly 0
+            grads[2 * i], grads[2 * i + 1] = dW, db
             if i > 0:
-                K = W.size(1)
-                dprev = alloc2d(M, K, x)
-                dbp = torch.zeros(K, dtype=torch.float32, device=x.device)
-                # dgrad GEMM with the previous layer's activation derivative and bias-grad fused in
-                ops.linear_bwd_data(dZ, W, X_i, acts[i - 1], dprev, dbp)
-                grads[2 * (i - 1) + 1] = dbp
+                dprev = alloc2d(M, W.size(1), x)
+                # dgrad GEMM with the previous layer's activation derivative fused into the epilogue
+                ops.linear_bwd_data(dZ, W, X_i, acts[i - 1], dprev)
                 dZ = dprev
             elif ctx.needs_input_grad[0]:
                 dX = alloc2d(M, W.size(1), x)
-                ops.linear_bwd_data(dZ, W, None, ACT_NONE, dX, None)
+                ops.linear_bwd_data(dZ, W, None, ACT_NONE, dX)
+                if dX.size(1) != ctx.in_width:
+                    dX = dX[:, :ctx.in_width]
         return (dX, None, None, *grads)
 
 
@@ -136,11 +161,11 @@ class EmbeddingBagsFunction(Function):
 class InteractFunction(Function):
     """R = [x | strictly-lower-triangular pairwise dots of the F feature vectors].
 
-    forward(D, self_interaction, block0, block1, ...): each block is [B, k*D] and contributes k
+    forward(D, self_interaction, padded, block0, block1, ...): each block is [B, k*D] and contributes k
     features (block0 = bottom-MLP output).  Reference: interact_features (dlrm_s_pytorch.py:483-504)."""
 
     @staticmethod
-    def forward(ctx, D, self_interaction, *blocks):
+    def forward(ctx, D, self_interaction, padded, *blocks):
         blocks = tuple(_rowmajor(b) for b in blocks)
         B = blocks[0].size(0)
         F = sum(b.size(1) // D for b in blocks)
@@ -150,7 +175,8 @@ class InteractFunction(Function):
         ops.interact_fwd(blocks, D, self_interaction, Rfull)
         ctx.D, ctx.self_interaction, ctx.width = D, self_interaction, Wd
         ctx.save_for_backward(*blocks)
-        return Rfull if ldr == Wd else Rfull[:, :Wd]
+        # padded=True hands out the whole [B, round4(width)] buffer (zero padding columns) for MLPFunction
+        return Rfull if (ldr == Wd or padded) else Rfull[:, :Wd]
 
     @staticmethod
     def backward(ctx, dR):
@@ -167,7 +193,7 @@ class InteractFunction(Function):
             dblocks.append(flat[o:o + n].view(B, b.size(1)))
             o += n
         ops.interact_bwd(blocks, ctx.D, ctx.self_interaction, dR, dblocks)
-        return (None, None, *dblocks)
+        return (None, None, None, *dblocks)
 
 
 class BCELossFunction(Function):

@@ -291,7 +291,8 @@ def linear_fwd(X: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], a
 
 
 def linear_bwd_data(dY: torch.Tensor, W: torch.Tensor, Xact: Optional[torch.Tensor], xact_kind: int,
-                    dX: torch.Tensor, dbias_prev: Optional[torch.Tensor]) -> torch.Tensor:
+                    dX: torch.Tensor) -> torch.Tensor:
+    """dX = (dY @ W) * act'(Xact)   (Xact None -> no mask)"""
     lib = _lib.load()
     _req(dY, "dY", ndim=2); _req(W, "W", ndim=2); _req(dX, "dX", ndim=2)
     M, N = dY.shape
@@ -304,22 +305,29 @@ def linear_bwd_data(dY: torch.Tensor, W: torch.Tensor, Xact: Optional[torch.Tens
         rc = lib.dlrm_linear_bwd_data(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(W.data_ptr()), _ld(W),
                                       C.c_void_p(Xact.data_ptr()) if Xact is not None else None,
                                       _ld(Xact) if Xact is not None else 0, int(xact_kind if Xact is not None else ACT_NONE),
-                                      C.c_void_p(dX.data_ptr()), _ld(dX),
-                                      C.c_void_p(dbias_prev.data_ptr()) if dbias_prev is not None else None, _stream())
+                                      C.c_void_p(dX.data_ptr()), _ld(dX), _stream())
     _lib.check(rc, "dlrm_linear_bwd_data")
     return dX
 
 
-def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor] = None,
+                      accumulate: bool = False) -> torch.Tensor:
+    """dW = dY^T @ X and (optionally) dbias = column sums of dY, one kernel"""
     lib = _lib.load()
     _req(dY, "dY", ndim=2); _req(X, "X", ndim=2); _req(dW, "dW", ndim=2)
     M, N = dY.shape
     K = X.size(1)
     if X.size(0) != M or dW.size(0) != N or dW.size(1) != K:
         raise RuntimeError("dlrm_amd: linear_bwd_weight shape mismatch")
+    if dbias is not None:
+        _req(dbias, "dbias", ndim=1)
+        if dbias.numel() != N:
+            raise RuntimeError("dlrm_amd: linear_bwd_weight dbias size mismatch")
     with _timed("linear_bwd_weight"):
         rc = lib.dlrm_linear_bwd_weight(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(X.data_ptr()), _ld(X),
-                                        C.c_void_p(dW.data_ptr()), _ld(dW), int(bool(accumulate)), _stream())
+                                        C.c_void_p(dW.data_ptr()), _ld(dW),
+                                        C.c_void_p(dbias.data_ptr()) if dbias is not None else None,
+                                        int(bool(accumulate)), _stream())
     _lib.check(rc, "dlrm_linear_bwd_weight")
     return dW
 

@@ -132,26 +132,27 @@ int dlrm_linear_fwd(int64_t M, int N, int K,
                     const float* X, int64_t ldx, const float* W, int64_t ldw,
                     const float* bias, int act, float* Y, int64_t ldy, void* stream);
 
-/* data gradient with the PREVIOUS layer's activation backward and bias gradient fused in:
+/* data gradient with the PREVIOUS layer's activation backward fused into the epilogue:
  *   dX[M,K] = (dY[M,N] · W[N,K]) ⊙ act'(Xact[M,K])        (Xact = this layer's input = previous
  *                                                           layer's activated output; xact_kind
- *                                                           ACT_NONE -> no mask)
- *   dbias_prev[K] += column sums of dX                      (if dbias_prev != NULL; caller zeroes)
+ *                                                           ACT_NONE -> no mask, Xact may be NULL)
  */
 int dlrm_linear_bwd_data(int64_t M, int N, int K,
                          const float* dY, int64_t lddy, const float* W, int64_t ldw,
                          const float* Xact, int64_t ldxa, int xact_kind,
-                         float* dX, int64_t lddx, float* dbias_prev, void* stream);
+                         float* dX, int64_t lddx, void* stream);
 
-/* weight gradient:  dW[N,K] (+)= dY[M,N]^T · X[M,K]   (reduction over the batch, split over
- * workgroups; accumulate != 0 adds into dW, else dW is overwritten — implemented as zero + atomics). */
+/* weight AND bias gradient:  dW[N,K] (+)= dY[M,N]^T · X[M,K],  dbias[N] (+)= column sums of dY
+ * (reduction over the batch, split over workgroups; the bias gradient is taken from the dY fragments
+ * the MFMAs consume, so it costs no extra pass over dY).  accumulate != 0 adds into dW/dbias, else
+ * they are overwritten.  dbias may be NULL. */
 int dlrm_linear_bwd_weight(int64_t M, int N, int K,
                            const float* dY, int64_t lddy, const float* X, int64_t ldx,
-                           float* dW, int64_t lddw, int accumulate, void* stream);
+                           float* dW, int64_t lddw, float* dbias, int accumulate, void* stream);
 
-/* activation backward + bias gradient for a layer whose dY does not come out of
- * dlrm_linear_bwd_data (i.e. the last layer of a tower):
- *   dZ = dY ⊙ act'(Y);  dbias[N] += column sums of dZ  (if dbias != NULL; caller zeroes) */
+/* activation backward for a layer whose dY does not come out of dlrm_linear_bwd_data (i.e. the last
+ * layer of a tower):  dZ = dY ⊙ act'(Y);  optionally dbias[N] += column sums of dZ (dbias != NULL; the
+ * caller zeroes it — normally NULL because dlrm_linear_bwd_weight produces the bias gradient). */
 int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, const float* Y, int64_t ldy,
                  int act, float* dZ, int64_t lddz, float* dbias, void* stream);
 

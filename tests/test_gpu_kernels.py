@@ -181,12 +181,12 @@ def test_linear_fwd_bwd(M, N, K, act):
     dY = rng.standard_normal((M, N)).astype(np.float32)
     dX, dW, db = O.linear_bwd(X, W, act, Y, dY)
     dZd = torch.empty((M, N), device=dev())
-    dbd = torch.zeros(N, device=dev())
-    ops.act_bwd(to_dev(dY), Yd, act, dZd, dbd)
+    ops.act_bwd(to_dev(dY), Yd, act, dZd, None)
     dWd = torch.empty((N, K), device=dev())
-    ops.linear_bwd_weight(dZd, Xd, dWd)
+    dbd = torch.full((N,), 7.0, device=dev())          # overwritten, not accumulated
+    ops.linear_bwd_weight(dZd, Xd, dWd, dbd)
     dXd = torch.empty((M, ldx), device=dev())[:, :K]
-    ops.linear_bwd_data(dZd, Wd, None, 0, dXd, None)
+    ops.linear_bwd_data(dZd, Wd, None, 0, dXd)
     torch.cuda.synchronize()
     scale = max(1.0, float(np.abs(dW).max()))
     np.testing.assert_allclose(dbd.cpu().numpy(), db, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(db).max())))
@@ -194,8 +194,8 @@ def test_linear_fwd_bwd(M, N, K, act):
     np.testing.assert_allclose(dXd.cpu().numpy(), dX, rtol=1e-5, atol=1e-5)
 
 
-def test_linear_bwd_data_fused_mask_and_bias_grad():
-    """dgrad epilogue: previous layer's ReLU mask and its bias gradient (column sums) fused in"""
+def test_linear_bwd_data_fused_mask():
+    """dgrad epilogue: previous layer's ReLU mask fused in (aligned and unaligned leading dimensions)"""
     from dlrm_amd import ops
     rng = np.random.default_rng(5)
     M, N, K = 777, 96, 200
@@ -204,11 +204,21 @@ def test_linear_bwd_data_fused_mask_and_bias_grad():
     Xact = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
     want = (dZ.astype(np.float64) @ W.astype(np.float64)) * (Xact > 0)
     dXd = torch.empty((M, K), device=dev())
-    dbp = torch.zeros(K, device=dev())
-    ops.linear_bwd_data(to_dev(dZ), to_dev(W), to_dev(Xact), 1, dXd, dbp)
+    ops.linear_bwd_data(to_dev(dZ), to_dev(W), to_dev(Xact), 1, dXd)
     torch.cuda.synchronize()
     np.testing.assert_allclose(dXd.cpu().numpy(), want, rtol=1e-5, atol=2e-5)
-    np.testing.assert_allclose(dbp.cpu().numpy(), want.sum(0), rtol=1e-4, atol=1e-3)
+    # unaligned: K = 199 (ld 199) forces the scalar epilogue
+    K2 = 199
+    dX2 = torch.empty((M, K2), device=dev())
+    ops.linear_bwd_data(to_dev(dZ), to_dev(W[:, :K2].copy()), to_dev(Xact[:, :K2].copy()), 1, dX2)
+    np.testing.assert_allclose(dX2.cpu().numpy(), want[:, :K2], rtol=1e-5, atol=2e-5)
+    # accumulate mode of the weight gradient
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    dW = torch.ones((N, K), device=dev())
+    db = torch.ones(N, device=dev())
+    ops.linear_bwd_weight(to_dev(dZ), to_dev(X), dW, db, accumulate=True)
+    np.testing.assert_allclose(dW.cpu().numpy(), 1.0 + dZ.astype(np.float64).T @ X.astype(np.float64), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), 1.0 + dZ.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)
 
 
 # ------------------------------------------------------------------------------------------ loss / SGD

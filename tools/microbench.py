@@ -37,12 +37,12 @@ def gemm(shapes):
         dY = torch.randn(M, N, device=DEV)
         dX = torch.empty(M, ldk, device=DEV)[:, :K]
         dW = torch.empty(N, K, device=DEV)
-        db = torch.zeros(K, device=DEV)
+        db = torch.zeros(N, device=DEV)
         fl = 2.0 * M * N * K
         t_f = timeit(lambda: ops.linear_fwd(X, W, b, 1, Y))
-        t_d = timeit(lambda: ops.linear_bwd_data(dY, W, X, 1, dX, db))
-        t_d0 = timeit(lambda: ops.linear_bwd_data(dY, W, None, 0, dX, None))
-        t_w = timeit(lambda: ops.linear_bwd_weight(dY, X, dW))
+        t_d = timeit(lambda: ops.linear_bwd_data(dY, W, X, 1, dX))
+        t_d0 = timeit(lambda: ops.linear_bwd_data(dY, W, None, 0, dX))
+        t_w = timeit(lambda: ops.linear_bwd_weight(dY, X, dW, db))
         r = dict(M=M, N=N, K=K, fwd_us=t_f * 1e3, fwd_tf=fl / t_f / 1e9, dgrad_us=t_d * 1e3, dgrad_tf=fl / t_d / 1e9,
                  dgrad_plain_us=t_d0 * 1e3, dgrad_plain_tf=fl / t_d0 / 1e9, wgrad_us=t_w * 1e3, wgrad_tf=fl / t_w / 1e9)
         out.append(r)
