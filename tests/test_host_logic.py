@@ -94,3 +94,28 @@ def test_error_strings_match_reference():
     m = dlrm_amd.DLRM_Net(2, np.asarray([4, 3]), np.asarray([4, 2]), np.asarray([5, 1]), "foo")
     with pytest.raises(SystemExit, match="--arch-interaction-op=foo is not supported"):
         m.interact_features(torch.zeros(1, 2), [torch.zeros(1, 2)])
+
+
+REFERENCE = os.environ.get("DLRM_REFERENCE", "/root/reference")
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REFERENCE, "dlrm_s_pytorch.py")),
+                    reason="reference checkout not present (it is absent on the GPU box by design)")
+def test_launcher_swaps_the_hot_path_under_the_unmodified_reference_run(tmp_path):
+    """python -m dlrm_amd.launch: the reference's own run() builds OUR DLRM_Net from its CLI (construction only here —
+    zero epochs — because the product path has no CPU fallback); with one epoch it must fail loudly, not fall back."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT, PYTHONDONTWRITEBYTECODE="1")
+    probe = ("import sys, numpy as np; sys.argv=['x']; from dlrm_amd import launch; import dlrm_amd; "
+             "ref = launch.load_reference(%r); assert ref.DLRM_Net is dlrm_amd.DLRM_Net; "
+             "assert ref.ext_dist is dlrm_amd.ext_dist; print('swapped')" % REFERENCE)
+    r = subprocess.run([sys.executable, "-c", probe], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "swapped" in r.stdout, r.stderr[-2000:]
+    cli = ["--arch-sparse-feature-size=16", "--arch-embedding-size=1000-1000-1000", "--arch-mlp-bot=13-512-16",
+           "--arch-mlp-top=22-256-1", "--mini-batch-size=128", "--data-generation=random", "--num-batches=2"]
+    base = [sys.executable, "-m", "dlrm_amd.launch", "--reference", REFERENCE, "--"]
+    r = subprocess.run(base + cli + ["--nepochs=0"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run(base + cli + ["--nepochs=1"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
