@@ -49,6 +49,7 @@ struct GemmArgs {
     float* rowsumA;                // [M] += row sums of the A operand over this k-slice (wgrad: bias gradient)  (nullable)
     int vecC;                      // 16-byte accesses to C (and mask) are legal
     int atomic_out;                // 1: atomicAdd into C instead of store
+    long long c_split_stride;      // elements between the C slabs of consecutive k-slices (split-K partials in a workspace), else 0
     int tiles_m, tiles_n;
     int debug;                     // tuning aid (env DLRM_GEMM_DEBUG): 1 skip global loads in the k-loop, 2 skip LDS refill + barrier, 4 skip epilogue
 };
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         float4 v = *(const float4*)__builtin_assume_aligned(S + row * EPI_LD + c4, 16);
         v.x = act_apply(v.x + bv.x, g.act); v.y = act_apply(v.y + bv.y, g.act);
         v.z = act_apply(v.z + bv.z, g.act); v.w = act_apply(v.w + bv.w, g.act);
-        float* c = g.C + m * g.ldc + nb;
+        float* c = g.C + (long long)blockIdx.z * g.c_split_stride + m * g.ldc + nb;
         if (g.vecC && full_n) {
             if (g.mask) {
                 const float4 y = *(const float4*)(g.mask + m * g.ldmask + nb);
@@ -285,6 +286,270 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
                     if (g.atomic_out) atomicAdd(c + x, o); else c[x] = o;
                 }
             }
+        }
+    }
+}
+
+// =============================================================================================
+// v3: LDS-DMA fed kernel (the fast path; gemm_f32_kernel above stays as the any-shape fallback).
+//
+// What limits gemm_f32_kernel (measured, profiles/r01): at a 128x128 tile the L2->LDS stream is
+// 32 FLOP/B (~7 B/clk/CU at the fp32 MFMA rate, against ~10 B/clk/CU the vector memory path
+// sustains), the register-staged refill costs 8 global loads + 8 ds_write_b128 + exec-masked
+// bounds code per k-tile, and the single barrier per k-tile sits behind a vmcnt(0).  v3:
+//   * tile 256x128x16 (TM=4: four waves of 128x64) or 128x128x16 (TM=2): 43.7 / 32 FLOP per byte;
+//   * global -> LDS by `global_load_lds_dwordx4` (no staging registers, no ds_write, no VALU
+//     address math: per-lane 32-bit offsets are loop invariant, the k advance is one scalar add
+//     on the SGPR base), 3-stage ring, tile kt+2 is issued right after the barrier of tile kt and
+//     retired by a COUNTED `s_waitcnt vmcnt(P)` — a prefetch is always in flight across the barrier;
+//   * k-contiguous tiles ([rows][16] floats, 64-B rows) are XOR-swizzled through the SOURCE
+//     address (the DMA destination is lane-linear): 16-B slot s of row r holds k-quad
+//     s ^ ((r>>2)&3), which makes every ds_read_b128 fragment read conflict free;
+//     k-strided tiles ([16][cols]) are read with conflict-free ds_read_b32.
+// Preconditions (checked by the host dispatch, otherwise the fallback runs): 16-byte aligned
+// operands, leading dimensions % 4 == 0, reduction length of every k-slice % 16 == 0.
+// Rows/columns past the matrix edge are clamped to a valid address (their results are never
+// stored), so M and N are unrestricted.
+// =============================================================================================
+constexpr int BK3 = 16;
+constexpr int NSTAGE3 = 3;
+
+__device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
+    // M0 carries the wave-uniform LDS destination; written in the same statement that uses it
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// per-lane byte offset (relative to the tile origin pointer) of DMA chunk `c` (1 KiB of the LDS tile image)
+template <bool KC, int ROWS>
+__device__ __forceinline__ unsigned dma_offset(int c, int lane, long long ld, long long row0, long long rows_max) {
+    if (KC) {        // tile image [ROWS][16]: chunk = 16 rows x 4 slots
+        const int r = 16 * c + (lane >> 2);
+        const int kq = (lane & 3) ^ ((r >> 2) & 3);
+        long long rg = row0 + r; if (rg > rows_max - 1) rg = rows_max - 1;
+        return (unsigned)(((rg - row0) * ld + 4 * kq) * 4);
+    } else {         // tile image [16][ROWS]: chunk = 256 consecutive floats
+        const int e = 256 * c + 4 * lane;
+        const int k = e / ROWS, col = e - k * ROWS;
+        const long long cg = row0 + col;
+        return (unsigned)((k * ld + (cg < rows_max ? col : 0)) * 4);
+    }
+}
+
+template <bool A_KC, bool B_KC, int TM>
+__global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
+    constexpr int TN = 2;
+    constexpr int BMt = 64 * TM, BNt = 64 * TN;
+    constexpr int A_BYTES = BMt * BK3 * 4, B_BYTES = BNt * BK3 * 4, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    int id = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, local = id >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int tile_m = id / g.tiles_n, tile_n = id - tile_m * g.tiles_n;
+    const long long m0 = (long long)tile_m * BMt, n0 = (long long)tile_n * BNt;
+    const long long k_begin = (long long)blockIdx.z * g.kchunk;
+    const long long k_end = (k_begin + g.kchunk < g.K) ? k_begin + g.kchunk : g.K;
+    const int nk = (int)((k_end - k_begin) / BK3);
+
+    // ---- DMA plan: wave w owns chunks w, w+4, ... of the A image (TM of them) and of the B image (TN)
+    unsigned offA[TM], offB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offA[i] = dma_offset<A_KC, BMt>(wave + 4 * i, lane, g.lda, m0, g.M);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) offB[i] = dma_offset<B_KC, BNt>(wave + 4 * i, lane, g.ldb, n0, g.N);
+    const char* baseA = (const char*)(A_KC ? g.A + m0 * g.lda + k_begin : g.A + k_begin * g.lda + m0);
+    const char* baseB = (const char*)(B_KC ? g.B + n0 * g.ldb + k_begin : g.B + k_begin * g.ldb + n0);
+    const long long stepA = A_KC ? (long long)BK3 * 4 : (long long)BK3 * 4 * g.lda;
+    const long long stepB = B_KC ? (long long)BK3 * 4 : (long long)BK3 * 4 * g.ldb;
+    const unsigned dstA = lds_base + wave * 1024, dstB = lds_base + A_BYTES + wave * 1024;
+
+#define GEMM3_ISSUE(stage_off)                                                            \
+    do {                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) glds16(offA[i], baseA, dstA + (stage_off) + i * 4096); \
+        _Pragma("unroll") for (int i = 0; i < TN; ++i) glds16(offB[i], baseB, dstB + (stage_off) + i * 4096); \
+        baseA += stepA; baseB += stepB;                                                   \
+    } while (0)
+
+    // ---- fragment read offsets (bytes inside a stage)
+    const int l31 = lane & 31, h = lane >> 5;
+    unsigned fa_off[2], fb_off[2];      // j = 0, 1 (the two 8-k groups of a 16-k tile)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        fa_off[j] = A_KC ? (unsigned)((wm * 32 * TM + l31) * 64 + (((2 * j + h) ^ ((l31 >> 2) & 3)) * 16))
+                         : (unsigned)((((8 * j + 4 * h) * BMt) + wm * 32 * TM + l31) * 4);
+        fb_off[j] = (unsigned)A_BYTES +
+                    (B_KC ? (unsigned)((wn * 32 * TN + l31) * 64 + (((2 * j + h) ^ ((l31 >> 2) & 3)) * 16))
+                          : (unsigned)((((8 * j + 4 * h) * BNt) + wn * 32 * TN + l31) * 4));
+    }
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool do_rowsum = g.rowsumA != nullptr && tile_n == 0 && wn == 0;
+    float rs[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) rs[i] = 0.f;
+
+    if (nk > 0) GEMM3_ISSUE(0);
+    if (nk > 1) GEMM3_ISSUE(STAGE);
+    unsigned cur = 0, nxt = 2 * STAGE;     // byte offsets of the stage being read / being refilled
+    const char* ldsb = (const char*)lds;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();   // my share of tile kt has landed
+        __builtin_amdgcn_s_barrier();      // everyone's share has; everyone is done reading stage `nxt`
+        if (kt + 2 < nk) GEMM3_ISSUE(nxt);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                if (A_KC) fa[t] = *(const float4*)(ldsb + cur + fa_off[j] + t * 32 * 64);
+                else {
+                    const float* p = (const float*)(ldsb + cur + fa_off[j]) + t * 32;
+                    fa[t] = make_float4(p[0], p[BMt], p[2 * BMt], p[3 * BMt]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                if (B_KC) fb[t] = *(const float4*)(ldsb + cur + fb_off[j] + t * 32 * 64);
+                else {
+                    const float* p = (const float*)(ldsb + cur + fb_off[j]) + t * 32;
+                    fb[t] = make_float4(p[0], p[BNt], p[2 * BNt], p[3 * BNt]);
+                }
+            }
+            if (do_rowsum) {
+#pragma unroll
+                for (int t = 0; t < TM; ++t) rs[t] += (fa[t].x + fa[t].y) + (fa[t].z + fa[t].w);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].x, fa[tm].x, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].y, fa[tm].y, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].z, fa[tm].z, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].w, fa[tm].w, acc[tm][tn], 0, 0, 0);
+        }
+        cur = (cur == 2 * STAGE) ? 0 : cur + STAGE;
+        nxt = (nxt == 2 * STAGE) ? 0 : nxt + STAGE;
+    }
+#undef GEMM3_ISSUE
+    __syncthreads();                       // all fragment reads done: the ring becomes epilogue staging
+
+    if (do_rowsum) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+            const float v = rs[t] + __shfl_xor(rs[t], 32, 64);
+            const long long m = m0 + wm * 32 * TM + t * 32 + l31;
+            if (lane < 32 && m < g.M) atomicAdd(g.rowsumA + m, v);
+        }
+    }
+
+    // ---- epilogue, one 32-row band of the wave tile at a time: registers -> wave-private LDS
+    // (transposes back to [m][n]) -> 16-byte row segments.  Transposed C/D layout of the 32x32 MFMA:
+    // lane owns m_local = lane & 31 and n_local = 8*q + 4*(lane>>5) + {0..3} for q = reg>>2.
+    static_assert(4 * 32 * EPI_LD * 4 <= NSTAGE3 * STAGE, "epilogue staging does not fit the ring");
+    float* S = lds + wave * (32 * EPI_LD);
+    const int c4 = (lane & 15) * 4;
+    const long long nb = n0 + wn * 64 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) {
+        if (nb + 0 < g.N) bv.x = g.bias[nb + 0];
+        if (nb + 1 < g.N) bv.y = g.bias[nb + 1];
+        if (nb + 2 < g.N) bv.z = g.bias[nb + 2];
+        if (nb + 3 < g.N) bv.w = g.bias[nb + 3];
+    }
+    const bool full_n = nb + 3 < g.N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
+                *(float4*)__builtin_assume_aligned(S + l31 * EPI_LD + tn * 32 + 8 * q + 4 * h, 16) = v;
+            }
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + (lane >> 4);
+            const long long m = m0 + wm * 32 * TM + tm * 32 + row;
+            if (m >= g.M || nb >= g.N) continue;
+            float4 v = *(const float4*)__builtin_assume_aligned(S + row * EPI_LD + c4, 16);
+            v.x = act_apply(v.x + bv.x, g.act); v.y = act_apply(v.y + bv.y, g.act);
+            v.z = act_apply(v.z + bv.z, g.act); v.w = act_apply(v.w + bv.w, g.act);
+            float* c = g.C + (long long)blockIdx.z * g.c_split_stride + m * g.ldc + nb;
+            if (g.vecC && full_n) {
+                if (g.mask) {
+                    const float4 y = *(const float4*)(g.mask + m * g.ldmask + nb);
+                    v.x = act_grad(v.x, y.x, g.mask_act); v.y = act_grad(v.y, y.y, g.mask_act);
+                    v.z = act_grad(v.z, y.z, g.mask_act); v.w = act_grad(v.w, y.w, g.mask_act);
+                }
+                if (g.atomic_out) { atomicAdd(c, v.x); atomicAdd(c + 1, v.y); atomicAdd(c + 2, v.z); atomicAdd(c + 3, v.w); }
+                else *(float4*)c = v;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    if (nb + x < g.N) {
+                        float o = e[x];
+                        if (g.mask) o = act_grad(o, g.mask[m * g.ldmask + nb + x], g.mask_act);
+                        if (g.atomic_out) atomicAdd(c + x, o); else c[x] = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// split-K reduction: dW[n,k] (+)= sum_s part[s][n][k]   (fixed summation order: deterministic)
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(int N, int K, int splits, const float* __restrict__ part,
+                                                            long long ldp, long long slab, float* __restrict__ dW,
+                                                            long long lddw, int accumulate) {
+    const int kq = (K + VEC - 1) / VEC;
+    const long long total = (long long)N * kq;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long n = e / kq;
+        const int k = (int)(e - n * kq) * VEC;
+        const float* p = part + n * ldp + k;
+        float* o = dW + n * lddw + k;
+        if (VEC == 4) {
+            float4 a = accumulate ? *(const float4*)o : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+            for (int s_ = 0; s_ < splits; ++s_) {
+                const float4 v = *(const float4*)(p + (long long)s_ * slab);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            *(float4*)o = a;
+        } else {
+            float a = accumulate ? *o : 0.f;
+            for (int s_ = 0; s_ < splits; ++s_) a += p[(long long)s_ * slab];
+            *o = a;
         }
     }
 }
@@ -323,8 +588,40 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(long long M, int N, const 
 
 static int pow2ceil_i(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
+template <bool A_KC, bool B_KC, int TM>
+static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
+    constexpr int BMt = 64 * TM, BNt = 128;
+    g.tiles_m = (int)((g.M + BMt - 1) / BMt);
+    g.tiles_n = (int)((g.N + BNt - 1) / BNt);
+    g.debug = 0;
+    const size_t lds = (size_t)NSTAGE3 * (BMt + BNt) * BK3 * 4;     // 72 KiB (TM=4) / 48 KiB (TM=2)
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), block(256);
+    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM>), grid, block, lds, st, g);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+static int gemm_path() {   // env DLRM_GEMM_PATH: 0 = auto (default), 2 = force the register-staged fallback kernel
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DLRM_GEMM_PATH"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 template <bool A_KC, bool B_KC>
 static int launch_gemm(GemmArgs& g, int splits, hipStream_t st) {
+    // fast path preconditions: 16-byte vector access to both operands, every k-slice a multiple of 16
+    const bool k16 = (g.K % BK3 == 0) && (g.kchunk % BK3 == 0);
+    if (gemm_path() != 2 && g.vecA && g.vecB && k16 && g.lda % 4 == 0 && g.ldb % 4 == 0) {
+        // 256-row tiles when they still give every CU two workgroups, else 128-row tiles
+        const long long wg256 = ((g.M + 255) / 256) * ((g.N + 127) / 128) * splits;
+        if (g.M >= 256 && wg256 >= 512) return launch_gemm3<A_KC, B_KC, 4>(g, splits, st);
+        return launch_gemm3<A_KC, B_KC, 2>(g, splits, st);
+    }
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (int)((g.N + BN - 1) / BN);
     static int dbg = -1;
@@ -387,9 +684,32 @@ extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, in
     return launch_gemm<true, false>(g, 1, (hipStream_t)stream);
 }
 
+static void wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* kchunk_out) {
+    // split the batch reduction so that >= ~4 workgroups per CU exist; slices of >= 512 rows
+    const int tiles = (int)(((N + BM - 1) / BM) * ((K + BN - 1) / BN));
+    int splits = (1024 + tiles - 1) / tiles;
+    const int64_t max_splits = (M + 511) / 512;
+    if (splits > max_splits) splits = (int)max_splits;
+    if (splits < 1) splits = 1;
+    int64_t kchunk = (M + splits - 1) / splits;
+    kchunk = ((kchunk + BK - 1) / BK) * BK;
+    *splits_out = (int)((M + kchunk - 1) / kchunk);
+    *kchunk_out = kchunk;
+}
+
+extern "C" int64_t dlrm_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int splits; int64_t kchunk;
+    wgrad_plan(M, N, K, &splits, &kchunk);
+    if (splits <= 1) return 0;
+    const int64_t ldp = ((int64_t)K + 3) & ~(int64_t)3;
+    return (int64_t)splits * N * ldp * (int64_t)sizeof(float);
+}
+
 extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, int64_t lddy,
                                       const float* X, int64_t ldx, float* dW, int64_t lddw,
-                                      float* dbias, int accumulate, void* stream) {
+                                      float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
+                                      void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !dY || !X || !dW) return DLRM_E_ARG;
     if (lddy < N || ldx < K || lddw < K) return DLRM_E_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -400,16 +720,35 @@ extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, 
     g.vecC = dlrm_aligned16(dW) && lddw % 4 == 0;
     g.act = DLRM_ACT_NONE;
     g.rowsumA = dbias;                               // db[n] = sum_m dY[m, n], from the A fragments
-    // split the batch reduction so that >= ~4 workgroups per CU exist; slices of >= 512 rows
-    const int tiles = (int)(((N + BM - 1) / BM) * ((K + BN - 1) / BN));
-    int splits = (1024 + tiles - 1) / tiles;
-    const int64_t max_splits = (M + 511) / 512;
-    if (splits > max_splits) splits = (int)max_splits;
-    if (splits < 1) splits = 1;
-    int64_t kchunk = (M + splits - 1) / splits;
-    kchunk = ((kchunk + BK - 1) / BK) * BK;
-    splits = (int)((M + kchunk - 1) / kchunk);
+    int splits; int64_t kchunk;
+    wgrad_plan(M, N, K, &splits, &kchunk);
     g.kchunk = kchunk;
+    // split-K partials: with a workspace every k-slice stores its own [N, ldp] slab with plain 16-byte
+    // stores and a second kernel sums the slabs in a fixed order (deterministic; ~2 x splits x N x K x 4 bytes
+    // of streaming traffic).  Without one the slices accumulate into dW with fp32 atomics (measured 2-3x
+    // slower on the small-output layers: up to 128 atomic adds land on every address).
+    const int64_t ldp = ((int64_t)K + 3) & ~(int64_t)3;
+    const int64_t slab = (int64_t)N * ldp;
+    const bool use_ws = splits > 1 && workspace && dlrm_aligned16(workspace) &&
+                        workspace_bytes >= (int64_t)splits * slab * (int64_t)sizeof(float);
+    if (use_ws) {
+        g.C = (float*)workspace; g.ldc = ldp; g.vecC = 1; g.c_split_stride = slab; g.atomic_out = 0;
+        if (dbias && !accumulate) {
+            hipError_t e = hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
+        int rc = launch_gemm<false, false>(g, splits, st);
+        if (rc) return rc;
+        const bool v4 = dlrm_aligned16(dW) && lddw % 4 == 0 && K % 4 == 0;
+        const long long items = (long long)N * (v4 ? K / 4 : K);
+        int blocks = (int)((items + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+        if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, N, K, splits, (const float*)workspace,
+                                   (long long)ldp, (long long)slab, dW, (long long)lddw, accumulate ? 1 : 0);
+        else    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, N, K, splits, (const float*)workspace,
+                                   (long long)ldp, (long long)slab, dW, (long long)lddw, accumulate ? 1 : 0);
+        DLRM_LAUNCH_CHECK();
+        return 0;
+    }
     g.atomic_out = (splits > 1 || accumulate) ? 1 : 0;
     if (!accumulate) {
         hipError_t e = hipSuccess;

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void a2a_unpack_kernel(UnpackArgs u, int nrank
 
 }  // namespace
 
-extern "C" int dlrm_hip_abi_version(void) { return 2; }
+extern "C" int dlrm_hip_abi_version(void) { return 3; }
 
 extern "C" const char* dlrm_hip_build_info(void) {
     return "libdlrm_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " clang " __clang_version__;

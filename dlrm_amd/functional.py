@@ -9,6 +9,7 @@ Backward runs on the autograd engine's thread: streams/devices are looked up at 
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -16,6 +17,21 @@ from torch.autograd import Function
 
 from . import ops
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
+
+
+# optional: weight-gradient GEMMs on a side stream, concurrent with the data-gradient chain (env DLRM_OVERLAP_WGRAD=1).
+# Measured on MI355X (profiles/r01, g02): 11.83 ms/step with the overlap vs 11.30 ms without — two chip-filling GEMMs
+# sharing the CUs thrash each other's L2 panels — so it is OFF by default.
+OVERLAP_WGRAD = os.environ.get("DLRM_OVERLAP_WGRAD", "0") == "1"
+_side_streams = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    st = _side_streams.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[device] = st
+    return st
 
 
 def _round4(n: int) -> int:
@@ -112,12 +128,24 @@ class MLPFunction(Function):
         dZ = alloc2d(M, N_last, x)
         ops.act_bwd(dY, outs[L - 1], acts[L - 1], dZ, None)
         dX = None
+        # The weight-gradient GEMM of layer i and the data-gradient GEMM that feeds layer i-1 both consume dZ_i and
+        # are independent: wgrad goes to a side HIP stream so the two kernels share the chip (their epilogue
+        # store bursts and tail rounds interleave with the other's MFMA phases instead of idling the matrix cores).
+        main = torch.cuda.current_stream()
+        side = _side_stream(x.device) if OVERLAP_WGRAD else None
+        keep = []                                          # tensors the side stream reads stay alive until the join
         for i in range(L - 1, -1, -1):
             W = params[2 * i] if not (i == 0 and W0p is not None) else W0p
             X_i = x if i == 0 else outs[i - 1]
             dW = torch.empty_like(W)
             db = torch.empty(W.size(0), dtype=torch.float32, device=x.device)
-            ops.linear_bwd_weight(dZ, X_i, dW, db)          # dW and db (row sums of dZ^T) in one GEMM
+            if side is not None:
+                side.wait_event(main.record_event())
+                with torch.cuda.stream(side):
+                    ops.linear_bwd_weight(dZ, X_i, dW, db)  # dW and db (row sums of dZ^T) in one GEMM
+                keep.append(dZ)
+            else:
+                ops.linear_bwd_weight(dZ, X_i, dW, db)
             if i == 0 and W0p is not None:
                 dW = dW[:, :params[0].size(1)]               # padding column of the weight gradient is exactly 0
             grads[2 * i], grads[2 * i + 1] = dW, db
@@ -131,6 +159,9 @@ class MLPFunction(Function):
                 ops.linear_bwd_data(dZ, W, None, ACT_NONE, dX)
                 if dX.size(1) != ctx.in_width:
                     dX = dX[:, :ctx.in_width]
+        if side is not None:
+            main.wait_stream(side)
+            del keep
         return (dX, None, None, *grads)
 
 

@@ -310,9 +310,24 @@ def linear_bwd_data(dY: torch.Tensor, W: torch.Tensor, Xact: Optional[torch.Tens
     return dX
 
 
+_wgrad_ws = {}   # (device, stream) -> cached split-K workspace (kernels of one stream are ordered, so one slab set suffices)
+
+
+def _wgrad_workspace(need: int, device) -> Optional[torch.Tensor]:
+    if need <= 0:
+        return None
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(int(need), dtype=torch.uint8, device=device)
+        _wgrad_ws[key] = ws
+    return ws
+
+
 def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor] = None,
-                      accumulate: bool = False) -> torch.Tensor:
-    """dW = dY^T @ X and (optionally) dbias = column sums of dY, one kernel"""
+                      accumulate: bool = False, use_workspace: bool = True) -> torch.Tensor:
+    """dW = dY^T @ X and (optionally) dbias = column sums of dY, one GEMM (+ the split-K slab reduction).
+    use_workspace=False exercises the atomic-accumulation variant (no scratch memory)."""
     lib = _lib.load()
     _req(dY, "dY", ndim=2); _req(X, "X", ndim=2); _req(dW, "dW", ndim=2)
     M, N = dY.shape
@@ -323,11 +338,14 @@ def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias
         _req(dbias, "dbias", ndim=1)
         if dbias.numel() != N:
             raise RuntimeError("dlrm_amd: linear_bwd_weight dbias size mismatch")
+    ws = _wgrad_workspace(lib.dlrm_linear_bwd_weight_workspace_bytes(M, N, K), dY.device) if use_workspace else None
     with _timed("linear_bwd_weight"):
         rc = lib.dlrm_linear_bwd_weight(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(X.data_ptr()), _ld(X),
                                         C.c_void_p(dW.data_ptr()), _ld(dW),
                                         C.c_void_p(dbias.data_ptr()) if dbias is not None else None,
-                                        int(bool(accumulate)), _stream())
+                                        int(bool(accumulate)),
+                                        C.c_void_p(ws.data_ptr()) if ws is not None else None,
+                                        ws.numel() if ws is not None else 0, _stream())
     _lib.check(rc, "dlrm_linear_bwd_weight")
     return dW
 

@@ -145,10 +145,15 @@ int dlrm_linear_bwd_data(int64_t M, int N, int K,
 /* weight AND bias gradient:  dW[N,K] (+)= dY[M,N]^T · X[M,K],  dbias[N] (+)= column sums of dY
  * (reduction over the batch, split over workgroups; the bias gradient is taken from the dY fragments
  * the MFMAs consume, so it costs no extra pass over dY).  accumulate != 0 adds into dW/dbias, else
- * they are overwritten.  dbias may be NULL. */
+ * they are overwritten.  dbias may be NULL.
+ * workspace: device scratch of dlrm_linear_bwd_weight_workspace_bytes(M,N,K) bytes (16-byte aligned) for the
+ * split-K partial slabs, summed in a fixed order by a second kernel (deterministic dW).  NULL / too small:
+ * the k-slices accumulate into dW with fp32 atomics instead (correct, slower, order-dependent rounding). */
+int64_t dlrm_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K);
 int dlrm_linear_bwd_weight(int64_t M, int N, int K,
                            const float* dY, int64_t lddy, const float* X, int64_t ldx,
-                           float* dW, int64_t lddw, float* dbias, int accumulate, void* stream);
+                           float* dW, int64_t lddw, float* dbias, int accumulate,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 
 /* activation backward for a layer whose dY does not come out of dlrm_linear_bwd_data (i.e. the last
  * layer of a tower):  dZ = dY ⊙ act'(Y);  optionally dbias[N] += column sums of dZ (dbias != NULL; the

@@ -160,7 +160,9 @@ def test_interact_fwd_bwd(F, D, itself):
 
 # ------------------------------------------------------------------------------------------ MLP layers
 @pytest.mark.parametrize("M,N,K,act", [(128, 512, 13, 1), (300, 16, 512, 1), (257, 1024, 479, 1), (64, 1, 256, 2),
-                                       (1, 3, 2, 0), (513, 130, 36, 1), (1000, 128, 256, 1)])
+                                       (1, 3, 2, 0), (513, 130, 36, 1), (1000, 128, 256, 1),
+                                       # LDS-DMA fast path: 128-row tiles, 256-row tiles (edge tiles in M and N), split-K
+                                       (512, 256, 64, 1), (4096, 200, 48, 2), (65536, 512, 256, 1), (66000, 384, 272, 1)])
 def test_linear_fwd_bwd(M, N, K, act):
     from dlrm_amd import ops
     rng = np.random.default_rng(M + N + K)
@@ -179,18 +181,23 @@ def test_linear_fwd_bwd(M, N, K, act):
     np.testing.assert_allclose(Yd.cpu().numpy(), Y, rtol=1e-5, atol=1e-5)
 
     dY = rng.standard_normal((M, N)).astype(np.float32)
-    dX, dW, db = O.linear_bwd(X, W, act, Y, dY)
+    # the activation mask is taken from the forward output the GPU produced: an output within rounding of 0 may fall on
+    # either side of the ReLU threshold, and a flipped mask bit is a forward-rounding artefact, not a backward error
+    dX, dW, db = O.linear_bwd(X, W, act, Yd.cpu().numpy(), dY)
     dZd = torch.empty((M, N), device=dev())
     ops.act_bwd(to_dev(dY), Yd, act, dZd, None)
     dWd = torch.empty((N, K), device=dev())
     dbd = torch.full((N,), 7.0, device=dev())          # overwritten, not accumulated
     ops.linear_bwd_weight(dZd, Xd, dWd, dbd)
+    dWa = torch.empty((N, K), device=dev())             # same GEMM, k-slices accumulated with atomics (no workspace)
+    ops.linear_bwd_weight(dZd, Xd, dWa, None, use_workspace=False)
     dXd = torch.empty((M, ldx), device=dev())[:, :K]
     ops.linear_bwd_data(dZd, Wd, None, 0, dXd)
     torch.cuda.synchronize()
     scale = max(1.0, float(np.abs(dW).max()))
     np.testing.assert_allclose(dbd.cpu().numpy(), db, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(db).max())))
     np.testing.assert_allclose(dWd.cpu().numpy(), dW, rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(dWa.cpu().numpy(), dW, rtol=1e-4, atol=1e-5 * scale)
     np.testing.assert_allclose(dXd.cpu().numpy(), dX, rtol=1e-5, atol=1e-5)
 
 

@@ -90,7 +90,7 @@ if __name__ == "__main__":
     ap.add_argument("what", choices=["gemm", "gemm_big", "emb", "all"])
     a = ap.parse_args()
     B = 65536
-    layer_shapes = [(B, 512, 13), (B, 256, 512), (B, 128, 256), (B, 1024, 479), (B, 1024, 1024), (B, 512, 1024), (B, 256, 512), (B, 1, 256)]
+    layer_shapes = [(B, 512, 16), (B, 256, 512), (B, 128, 256), (B, 1024, 480), (B, 1024, 1024), (B, 512, 1024), (B, 256, 512), (B, 1, 256)]
     if a.what in ("gemm", "all"):
         gemm(layer_shapes)
     if a.what == "gemm_big":
