@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--cpu-row-cap", type=int, default=1000000)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
+    ap.add_argument("--mlp-arith", default=os.environ.get("DLRM_MLP_ARITH", "f32"), choices=["f32", "bf16x6"],
+                    help="f32: native fp32 MFMA; bf16x6: exact 3-term bf16 split of the fp32 operands, 6 bf16 MFMA products, "
+                         "fp32 accumulation (fp32 round-off class)")
     return ap.parse_args()
 
 
@@ -128,6 +131,7 @@ def main():
     torch.cuda.set_device(device)
     rank = max(ext_dist.my_rank, 0)
 
+    ops.set_mlp_arith(args.mlp_arith)
     rows, D, B = wl["rows"], wl["D"], wl["batch"]
     nf = len(rows) + 1
     ln_top = np.asarray([D + nf * (nf - 1) // 2] + wl["top"])

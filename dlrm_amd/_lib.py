@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED = 0, 1, 2
+ARITH_F32, ARITH_BF16X6 = 0, 1
 
 _lock = threading.Lock()
 _lib = None
@@ -39,6 +40,8 @@ SIGNATURES = {
                                             _vp, _i64, _f32, _f32, _vp, _i64, _vp]),
     "dlrm_interact_fwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _vp]),
     "dlrm_interact_bwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _pp, _pi64, _vp]),
+    "dlrm_mlp_set_arith": (_i32, [_i32]),
+    "dlrm_mlp_get_arith": (_i32, []),
     "dlrm_linear_fwd": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
     "dlrm_linear_bwd_data": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
     "dlrm_linear_bwd_weight_workspace_bytes": (_i64, [_i64, _i32, _i32]),

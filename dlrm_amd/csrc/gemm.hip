@@ -24,6 +24,7 @@
 // the batch splits (wgrad).  Accumulators hold the TRANSPOSED sub-tiles so that the epilogue moves 16 bytes
 // per lane through a wave-private LDS staging area and writes/reads whole 256-byte row segments.
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 namespace {
@@ -314,6 +315,36 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 constexpr int BK3 = 16;
 constexpr int NSTAGE3 = 3;
 
+// ---- fp32 through the bf16 matrix pipe (ARITH = 1, "bf16x6") --------------------------------------
+// An fp32 value has a 24-bit significand; truncating to bf16 three times,
+//     h = trunc_bf16(x),  m = trunc_bf16(x - h),  l = x - h - m      (both subtractions exact in fp32),
+// gives three bf16 numbers with x == h + m + l EXACTLY (8 significant bits each; barring underflow below
+// 2^-126).  a*b is then the sum of nine exact bf16 products; the six of order >= 2^-16,
+//     ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm),
+// are issued as six v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped terms (am*bl, al*bm, al*bl) are
+// <= 2^-23 |a*b| in total — the size of ONE fp32 rounding of the product — so the result stays in the fp32
+// round-off class while the matrix pipe runs at 16/6 = 2.7x the native fp32 MFMA rate.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+struct Split3 { uintx4 h, m, l; };
+
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+    Split3 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+        r.h[i] = __builtin_amdgcn_perm(ub, ua, 0x07060302);            // upper halves = truncation to bf16
+        const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
+        const unsigned ura = __float_as_uint(ra), urb = __float_as_uint(rb);
+        r.m[i] = __builtin_amdgcn_perm(urb, ura, 0x07060302);
+        const float sa = ra - __uint_as_float(ura & 0xffff0000u), sb = rb - __uint_as_float(urb & 0xffff0000u);
+        r.l[i] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302);   // <= 8 bits left: exact
+    }
+    return r;
+}
+#define MFMA_BF16(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
+
 __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
     // M0 carries the wave-uniform LDS destination; written in the same statement that uses it
     unsigned keep;
@@ -339,7 +370,7 @@ __device__ __forceinline__ unsigned dma_offset(int c, int lane, long long ld, lo
     }
 }
 
-template <bool A_KC, bool B_KC, int TM>
+template <bool A_KC, bool B_KC, int TM, int ARITH, bool ROWSUM>
 __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     constexpr int TN = 2;
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
@@ -393,6 +424,17 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
                           : (unsigned)((((8 * j + 4 * h) * BNt) + wn * 32 * TN + l31) * 4));
     }
 
+    // bf16x6 operand layout: lane half h owns k = 8h..8h+7 -> k-quads 2h, 2h+1 (k-contiguous) or k-rows 8h.. (k-strided)
+    unsigned fas_off[2], fbs_off[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        fas_off[q] = A_KC ? (unsigned)((wm * 32 * TM + l31) * 64 + (((2 * h + q) ^ ((l31 >> 2) & 3)) * 16))
+                          : (unsigned)(((8 * h * BMt) + wm * 32 * TM + l31) * 4);
+        fbs_off[q] = (unsigned)A_BYTES +
+                     (B_KC ? (unsigned)((wn * 32 * TN + l31) * 64 + (((2 * h + q) ^ ((l31 >> 2) & 3)) * 16))
+                           : (unsigned)(((8 * h * BNt) + wn * 32 * TN + l31) * 4));
+    }
+
     floatx16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -400,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const bool do_rowsum = g.rowsumA != nullptr && tile_n == 0 && wn == 0;
+    const bool do_rowsum = ROWSUM && g.rowsumA != nullptr && tile_n == 0 && wn == 0;
     float rs[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) rs[i] = 0.f;
@@ -413,6 +455,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         if (kt + 1 < nk) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();   // my share of tile kt has landed
         __builtin_amdgcn_s_barrier();      // everyone's share has; everyone is done reading stage `nxt`
         if (kt + 2 < nk) GEMM3_ISSUE(nxt);
+        if constexpr (ARITH == 0) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float4 fa[TM], fb[TN];
@@ -452,6 +495,47 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].w, fa[tm].w, acc[tm][tn], 0, 0, 0);
+        }
+        } else {
+            // 32x32x16 bf16 operand: lane supplies row (lane & 31), k = 8*(lane>>5) + 0..7 -> the whole 16-k tile is one step
+            Split3 sb[TN];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                float x[8];
+                if (B_KC) {
+                    const float4 v0 = *(const float4*)(ldsb + cur + fbs_off[0] + t * 32 * 64);
+                    const float4 v1 = *(const float4*)(ldsb + cur + fbs_off[1] + t * 32 * 64);
+                    x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+                } else {
+                    const float* p = (const float*)(ldsb + cur + fbs_off[0]) + t * 32;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = p[e * BNt];
+                }
+                sb[t] = split3(x);
+            }
+            // one 32-row band of A at a time: read + split its 8 operands, then its 6 x TN products (smallest terms
+            // first; the TN accumulators of the band alternate).  Measured alternatives (profiles/r01/bf16x6_variants.md):
+            // forcing a 1 MFMA : 4 VALU interleave with sched_group_barrier, and issuing the products product-major over
+            // all bands, were both 10-15 % slower than letting the two waves of a SIMD overlap their VALU and MFMA phases.
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                float x[8];
+                if (A_KC) {
+                    const float4 v0 = *(const float4*)(ldsb + cur + fas_off[0] + tm * 32 * 64);
+                    const float4 v1 = *(const float4*)(ldsb + cur + fas_off[1] + tm * 32 * 64);
+                    x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+                } else {
+                    const float* p = (const float*)(ldsb + cur + fas_off[0]) + tm * 32;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = p[e * BMt];
+                }
+                if (do_rowsum) rs[tm] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                const Split3 sa = split3(x);
+#define GEMM3_PRODUCT(BP, AP) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA_BF16(sb[tn].BP, sa.AP, acc[tm][tn]);
+                GEMM3_PRODUCT(l, h) GEMM3_PRODUCT(h, l) GEMM3_PRODUCT(m, m)
+                GEMM3_PRODUCT(m, h) GEMM3_PRODUCT(h, m) GEMM3_PRODUCT(h, h)
+#undef GEMM3_PRODUCT
+            }
         }
         cur = (cur == 2 * STAGE) ? 0 : cur + STAGE;
         nxt = (nxt == 2 * STAGE) ? 0 : nxt + STAGE;
@@ -588,8 +672,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(long long M, int N, const 
 
 static int pow2ceil_i(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <bool A_KC, bool B_KC, int TM>
+template <bool A_KC, bool B_KC, int TM, int ARITH>
 static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
+    constexpr bool ROWSUM = !A_KC && !B_KC;          // only the weight-gradient GEMM carries the bias-gradient row sums
     constexpr int BMt = 64 * TM, BNt = 128;
     g.tiles_m = (int)((g.M + BMt - 1) / BMt);
     g.tiles_n = (int)((g.N + BNt - 1) / BNt);
@@ -597,13 +682,21 @@ static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     const size_t lds = (size_t)NSTAGE3 * (BMt + BNt) * BK3 * 4;     // 72 KiB (TM=4) / 48 KiB (TM=2)
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), block(256);
-    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM>), grid, block, lds, st, g);
+    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM>), grid, block, lds, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
+}
+
+static int g_mlp_arith = -1;   // DLRM_ARITH_*; -1 = not initialised (env DLRM_MLP_ARITH=f32|bf16x6, default f32)
+
+static void arith_init() {
+    if (g_mlp_arith >= 0) return;
+    const char* e = getenv("DLRM_MLP_ARITH");
+    g_mlp_arith = (e && (!strcmp(e, "bf16x6") || !strcmp(e, "1"))) ? DLRM_ARITH_BF16X6 : DLRM_ARITH_F32;
 }
 
 static int gemm_path() {   // env DLRM_GEMM_PATH: 0 = auto (default), 2 = force the register-staged fallback kernel
@@ -615,12 +708,15 @@ static int gemm_path() {   // env DLRM_GEMM_PATH: 0 = auto (default), 2 = force 
 template <bool A_KC, bool B_KC>
 static int launch_gemm(GemmArgs& g, int splits, hipStream_t st) {
     // fast path preconditions: 16-byte vector access to both operands, every k-slice a multiple of 16
+    arith_init();
     const bool k16 = (g.K % BK3 == 0) && (g.kchunk % BK3 == 0);
     if (gemm_path() != 2 && g.vecA && g.vecB && k16 && g.lda % 4 == 0 && g.ldb % 4 == 0) {
         // 256-row tiles when they still give every CU two workgroups, else 128-row tiles
         const long long wg256 = ((g.M + 255) / 256) * ((g.N + 127) / 128) * splits;
-        if (g.M >= 256 && wg256 >= 512) return launch_gemm3<A_KC, B_KC, 4>(g, splits, st);
-        return launch_gemm3<A_KC, B_KC, 2>(g, splits, st);
+        const bool big = g.M >= 256 && wg256 >= 512;
+        if (g_mlp_arith == DLRM_ARITH_BF16X6)
+            return big ? launch_gemm3<A_KC, B_KC, 4, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 1>(g, splits, st);
+        return big ? launch_gemm3<A_KC, B_KC, 4, 0>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0>(g, splits, st);
     }
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (int)((g.N + BN - 1) / BN);
@@ -773,3 +869,11 @@ extern "C" int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, con
     DLRM_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int dlrm_mlp_set_arith(int arith) {
+    if (arith != DLRM_ARITH_F32 && arith != DLRM_ARITH_BF16X6) return DLRM_E_MODE;
+    g_mlp_arith = arith;
+    return 0;
+}
+
+extern "C" int dlrm_mlp_get_arith(void) { arith_init(); return g_mlp_arith; }

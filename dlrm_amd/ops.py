@@ -273,6 +273,22 @@ def interact_bwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool,
 # ------------------------------------------------------------------------------------------------
 # MLP layers
 # ------------------------------------------------------------------------------------------------
+_ARITH_NAMES = {"f32": _lib.ARITH_F32, "bf16x6": _lib.ARITH_BF16X6}
+
+
+def set_mlp_arith(name: str) -> None:
+    """"f32": native fp32 MFMA.  "bf16x6": fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA products,
+    fp32 accumulation (fp32 round-off class, 2.7x the matrix rate) — see include/dlrm_hip.h."""
+    if name not in _ARITH_NAMES:
+        raise RuntimeError(f"dlrm_amd: unknown MLP arithmetic {name!r} (f32 | bf16x6)")
+    _lib.check(_lib.load().dlrm_mlp_set_arith(_ARITH_NAMES[name]), "dlrm_mlp_set_arith")
+
+
+def get_mlp_arith() -> str:
+    v = _lib.load().dlrm_mlp_get_arith()
+    return {b: a for a, b in _ARITH_NAMES.items()}[v]
+
+
 def linear_fwd(X: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], act: int, Y: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     _req(X, "X", ndim=2); _req(W, "W", ndim=2); _req(Y, "Y", ndim=2)

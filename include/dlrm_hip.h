@@ -128,6 +128,17 @@ int dlrm_interact_bwd(int64_t B, int F, int D,
  * K5  MLP layer = nn.Linear + activation  (dlrm_s_pytorch.py:216,238-241,405), fp32 MFMA.
  *   Y[M,N] = act(X[M,K] · W[N,K]^T + bias[N])
  */
+/* Arithmetic of the three MLP GEMMs (process-wide; default DLRM_ARITH_F32, or env DLRM_MLP_ARITH=f32|bf16x6 read once):
+ *   DLRM_ARITH_F32    v_mfma_f32_32x32x2_f32: every product and sum in fp32 (157 TFLOP/s matrix peak).
+ *   DLRM_ARITH_BF16X6 fp32 operands split EXACTLY into three bf16 terms inside the kernel (x = h + m + l), the six
+ *                     products of order >= 2^-16 issued on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; dropped
+ *                     terms total <= 2^-23 |a*b| (one fp32 rounding).  Inputs, outputs and accumulators stay fp32.
+ * Only operands that meet the fast-path preconditions (16-byte alignment, k % 16 == 0) use BF16X6; others run F32. */
+#define DLRM_ARITH_F32    0
+#define DLRM_ARITH_BF16X6 1
+int dlrm_mlp_set_arith(int arith);
+int dlrm_mlp_get_arith(void);
+
 int dlrm_linear_fwd(int64_t M, int N, int K,
                     const float* X, int64_t ldx, const float* W, int64_t ldw,
                     const float* bias, int act, float* Y, int64_t ldy, void* stream);

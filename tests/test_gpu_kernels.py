@@ -163,7 +163,19 @@ def test_interact_fwd_bwd(F, D, itself):
                                        (1, 3, 2, 0), (513, 130, 36, 1), (1000, 128, 256, 1),
                                        # LDS-DMA fast path: 128-row tiles, 256-row tiles (edge tiles in M and N), split-K
                                        (512, 256, 64, 1), (4096, 200, 48, 2), (65536, 512, 256, 1), (66000, 384, 272, 1)])
-def test_linear_fwd_bwd(M, N, K, act):
+@pytest.mark.parametrize("arith", ["f32", "bf16x6"])
+def test_linear_fwd_bwd(M, N, K, act, arith):
+    """both MLP arithmetics against the float64 oracle at the SAME fp32-class tolerances: "bf16x6" (exact 3-term bf16
+    split of the fp32 operands, 6 bf16 MFMA products, fp32 accumulation) must not be distinguishable from fp32 MFMA"""
+    from dlrm_amd import ops
+    ops.set_mlp_arith(arith)
+    try:
+        _linear_fwd_bwd(M, N, K, act)
+    finally:
+        ops.set_mlp_arith("f32")
+
+
+def _linear_fwd_bwd(M, N, K, act):
     from dlrm_amd import ops
     rng = np.random.default_rng(M + N + K)
     # asymmetric, non-identity data so that a transposed fragment cannot pass

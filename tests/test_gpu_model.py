@@ -32,8 +32,18 @@ def build_model(meta, init, device, deterministic=True, mode=None):
 
 
 @pytest.mark.parametrize("name", FIXTURES)
-@pytest.mark.parametrize("mode", [1, 2, 0], ids=["deterministic", "sorted", "atomic"])
-def test_training_matches_reference_golden(name, mode):
+@pytest.mark.parametrize("mode,arith", [(1, "f32"), (2, "f32"), (0, "f32"), (2, "bf16x6")],
+                         ids=["deterministic", "sorted", "atomic", "sorted-bf16x6"])
+def test_training_matches_reference_golden(name, mode, arith):
+    from dlrm_amd import ops
+    ops.set_mlp_arith(arith)
+    try:
+        _training_matches_reference_golden(name, mode)
+    finally:
+        ops.set_mlp_arith("f32")
+
+
+def _training_matches_reference_golden(name, mode):
     d, meta = load_golden(name)
     device = torch.device("cuda:0")
     model = build_model(meta, params_with_prefix(d, "init"), device, mode=mode)

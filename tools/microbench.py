@@ -88,7 +88,9 @@ def emb(B=65536, D=128, cap=0):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["gemm", "gemm_big", "emb", "all"])
+    ap.add_argument("--arith", default="f32")
     a = ap.parse_args()
+    ops.set_mlp_arith(a.arith)
     B = 65536
     layer_shapes = [(B, 512, 16), (B, 256, 512), (B, 128, 256), (B, 1024, 480), (B, 1024, 1024), (B, 512, 1024), (B, 256, 512), (B, 1, 256)]
     if a.what in ("gemm", "all"):
