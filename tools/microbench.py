@@ -85,9 +85,33 @@ def emb(B=65536, D=128, cap=0):
     return res
 
 
+def emb_classes(B=65536, D=128):
+    """sorted / atomic fused update per table class (where does the time go?)"""
+    rows_all = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155, 4, 976, 14,
+                39979771, 25641295, 39664984, 585935, 12972, 108, 36]
+    classes = {"huge(>=400k rows)": [r for r in rows_all if r >= 400000],
+               "mid(1k..40k rows)": [r for r in rows_all if 1000 <= r < 400000],
+               "tiny(<1k rows)": [r for r in rows_all if r < 1000],
+               "all": rows_all}
+    for name, rows in classes.items():
+        T = len(rows)
+        Ws = [torch.empty(n, D, device=DEV).uniform_(-0.01, 0.01) for n in rows]
+        idx = [torch.randint(0, n, (B,), device=DEV) for n in rows]
+        off = [torch.arange(B, device=DEV)] * T
+        bags = ops.BagBatch(off, idx)
+        dout = torch.randn(B, T * D, device=DEV) * 1e-3
+        res = {"class": name, "tables": T}
+        for mname, mode in (("sorted", ops.UPD_SORTED), ("atomic", ops.UPD_ATOMIC)):
+            t = timeit(lambda: ops.emb_bwd_sgd(Ws, bags, dout, 0.01, mode), iters=5, warm=2)
+            res[mname + "_us"] = round(t * 1e3, 1)
+            res[mname + "_gbs"] = round(T * B * (4 * D * 3 + 8) / t / 1e6, 1)
+        print(json.dumps(res), flush=True)
+        del Ws, idx, dout
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "gemm_big", "emb", "all"])
+    ap.add_argument("what", choices=["gemm", "gemm_big", "emb", "emb_classes", "all"])
     ap.add_argument("--arith", default="f32")
     a = ap.parse_args()
     ops.set_mlp_arith(a.arith)
@@ -99,3 +123,5 @@ if __name__ == "__main__":
         gemm([(B, 1024, 1024), (B, 512, 1024)])
     if a.what in ("emb", "all"):
         emb()
+    if a.what == "emb_classes":
+        emb_classes()
