@@ -15,6 +15,7 @@
 // backward: S = dZ + dZ^T is rebuilt in LDS from dR, dT = S·T on the same MFMA; dT rows are
 //           written through a second {pointer, stride} table (bottom-MLP grad buffer, embedding
 //           grad / all-to-all send buffer), with dR[:, 0:D] added into row 0.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -233,6 +234,274 @@ __global__ __launch_bounds__(256) void interact_bwd_kernel(FeatArgs fa, FeatArgs
     }
 }
 
+// =============================================================================================
+// D = 128 fast path: features arrive by LDS-DMA, double buffered per wave.
+//
+// What limited the kernels above (profiles/r01): one wave stages its sample through registers
+// (13.5 dependent load -> ds_write rounds), then computes, then stores: ~14 us per sample per wave, 2.3 TB/s.
+// Here every wave owns two 16-KiB LDS images [32 rows][128 floats]; the F feature rows of the NEXT sample
+// are fetched by ceil(F/2) `global_load_lds_dwordx4` (two 512-B rows per instruction, all in flight at once)
+// while the MFMAs of the current sample run; a counted `s_waitcnt vmcnt` retires exactly the current
+// sample.  Images are wave private: no barriers in the sample loop.  16-byte slot q of row r holds feature
+// quad q ^ (r & 15) (swizzle applied to the per-lane SOURCE address, the DMA destination is lane-linear):
+// the ds_read_b128 fragment reads of both kernels are conflict free without padding.  Rows F..31 are zeroed
+// once and never written again (lanes of the odd last row are masked out of the DMA).
+// =============================================================================================
+constexpr int IDMA_D = 128;
+constexpr int IDMA_ROWS = 32;
+constexpr int IDMA_IMG = IDMA_ROWS * IDMA_D * 4;        // 16 KiB
+constexpr int IDMA_MAXI = IDMA_ROWS / 2;                // DMA instructions per sample (two rows each)
+
+__device__ __forceinline__ void glds16_v(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt_i() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// wave-uniform runtime count (0..16) -> immediate
+__device__ __forceinline__ void wait_vmcnt_rt(int n) {
+    switch (n) {
+        case 0: wait_vmcnt_i<0>(); break;   case 1: wait_vmcnt_i<1>(); break;   case 2: wait_vmcnt_i<2>(); break;
+        case 3: wait_vmcnt_i<3>(); break;   case 4: wait_vmcnt_i<4>(); break;   case 5: wait_vmcnt_i<5>(); break;
+        case 6: wait_vmcnt_i<6>(); break;   case 7: wait_vmcnt_i<7>(); break;   case 8: wait_vmcnt_i<8>(); break;
+        case 9: wait_vmcnt_i<9>(); break;   case 10: wait_vmcnt_i<10>(); break; case 11: wait_vmcnt_i<11>(); break;
+        case 12: wait_vmcnt_i<12>(); break; case 13: wait_vmcnt_i<13>(); break; case 14: wait_vmcnt_i<14>(); break;
+        case 15: wait_vmcnt_i<15>(); break; case 16: wait_vmcnt_i<16>(); break; case 17: wait_vmcnt_i<17>(); break;
+        case 18: wait_vmcnt_i<18>(); break; case 19: wait_vmcnt_i<19>(); break; default: wait_vmcnt_i<20>(); break;
+    }
+}
+
+struct DmaPlan {            // per lane: source pointer of its 16 bytes in each of the sample's DMA instructions
+    const char* src[IDMA_MAXI];
+    long long step[IDMA_MAXI];   // bytes from one of this wave's samples to its next
+    bool on[IDMA_MAXI];
+};
+
+__device__ __forceinline__ void dma_plan_init(DmaPlan& pl, const long long* tp, const long long* tl, int F, int lane,
+                                              long long b_first, long long b_stride) {
+#pragma unroll
+    for (int c = 0; c < IDMA_MAXI; ++c) {
+        const int row = 2 * c + (lane >> 5);
+        const int quad = (lane & 31) ^ (row & 15);
+        pl.on[c] = row < F;
+        const int rr = pl.on[c] ? row : 0;
+        pl.src[c] = (const char*)tp[rr] + (b_first * tl[rr] + 4 * quad) * 4;
+        pl.step[c] = b_stride * tl[rr] * 4;
+    }
+}
+
+template <int NI>
+__device__ __forceinline__ void dma_issue(DmaPlan& pl, unsigned lds_img) {
+#pragma unroll
+    for (int c = 0; c < NI; ++c) {
+        if (pl.on[c]) glds16_v(pl.src[c], lds_img + c * 1024);
+        pl.src[c] += pl.step[c];
+    }
+}
+
+template <int NI>       // NI = ceil(F / 2)
+__global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, long long B, int F, int self,
+                                                               float* __restrict__ R, long long ldr) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    long long* tp = (long long*)lds;
+    long long* tl = tp + DLRM_MAX_FEATURES;
+    char* img0 = (char*)(tl + DLRM_MAX_FEATURES) + (size_t)wave * 2 * IDMA_IMG;
+    const unsigned img0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)img0;
+
+    table_to_lds(fa, tp, tl, F);
+    for (int e = lane; e < 2 * IDMA_IMG / 16; e += 64) ((float4*)img0)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const long long b_stride = (long long)gridDim.x * 4;
+    long long b = (long long)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    DmaPlan pl;
+    dma_plan_init(pl, tp, tl, F, lane, b, b_stride);
+
+    const int g = lane >> 4, li = lane & 15;
+    const int P = self ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    const int NB = (F + 15) >> 4;
+    int cur = 0;
+    dma_issue<NI>(pl, img0_lds);
+    for (; b < B; b += b_stride) {
+        const bool more = b + b_stride < B;
+        if (more) { dma_issue<NI>(pl, img0_lds + (cur ^ 1) * IDMA_IMG); wait_vmcnt_i<NI>(); }
+        else wait_vmcnt_i<0>();
+        const char* my = img0 + cur * IDMA_IMG;
+        float* Rb = R + b * ldr;
+        for (int r = 0; r < NB; ++r) {
+            for (int c = 0; c <= r; ++c) {
+                floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                const char* ap = my + (16 * r + li) * (IDMA_D * 4);
+                const char* bp = my + (16 * c + li) * (IDMA_D * 4);
+#pragma unroll
+                for (int s = 0; s < IDMA_D / 16; ++s) {
+                    const int q = ((4 * s + g) ^ li) * 16;      // (row & 15) == li for both operands
+                    const float4 av = *(const float4*)(ap + q);
+                    const float4 bv = *(const float4*)(bp + q);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
+                }
+                const floatx4 acc = acc0 + acc1;
+                const int j = 16 * c + li;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 16 * r + 4 * g + q;
+                    if (i < F && (self ? (j <= i) : (j < i))) {
+                        const int p = (self ? i * (i + 1) / 2 : i * (i - 1) / 2) + j;
+                        Rb[IDMA_D + p] = acc[q];
+                    }
+                }
+            }
+        }
+        // R[:, 0:D] = x (row 0 of the image, un-swizzled: row & 15 == 0), then the alignment padding
+        if (lane < 32) *(float4*)(Rb + 4 * lane) = *(const float4*)(my + lane * 16);
+        for (long long d = IDMA_D + P + lane; d < ldr; d += 64) Rb[d] = 0.f;
+        cur ^= 1;
+    }
+}
+
+// backward, D = 128: dT = (dZ + dZ^T) · T per sample, T by LDS-DMA (same images as the forward kernel), the
+// dR row by LDS-DMA too.  The symmetric S = dZ + dZ^T is never materialised: the 16x16x4 MFMA A fragment of a
+// lane is S[16r + li][4kk + g], whose source position inside the dR row depends only on the lane -> 4*NB*NB LDS
+// offsets computed once, 4*NB*NB ds_read_b32 per sample.  B fragments are ds_read_b128 of T rows: the four floats
+// of a lane feed four MFMAs whose output column n = li then stands for d = 64*dq + 4*li + s, so a lane ends up
+// with float4s of dT rows (16-byte, 256-B-per-row coalesced stores through the {pointer, stride} table).
+constexpr int IDMA_DR_BYTES = 3072;      // dR row image (<= 656 floats for F = 32 with self pairs)
+
+template <int NI>
+__global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, FeatArgs da, long long B, int F, int self,
+                                                               const float* __restrict__ dR, long long ldr) {
+    constexpr int NB = (2 * NI + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    long long* tp = (long long*)lds;
+    long long* tl = tp + DLRM_MAX_FEATURES;
+    long long* dp = tl + DLRM_MAX_FEATURES;
+    long long* dl = dp + DLRM_MAX_FEATURES;
+    char* img0 = (char*)(dl + DLRM_MAX_FEATURES) + (size_t)wave * (2 * IDMA_IMG + 2 * IDMA_DR_BYTES);
+    char* drow0 = img0 + 2 * IDMA_IMG;
+    const unsigned img0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)img0;
+    const unsigned drow0_lds = img0_lds + 2 * IDMA_IMG;
+
+    table_to_lds(fa, tp, tl, F);
+    table_to_lds(da, dp, dl, F);
+    for (int e = lane; e < (2 * IDMA_IMG + 2 * IDMA_DR_BYTES) / 16; e += 64) ((float4*)img0)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const long long b_stride = (long long)gridDim.x * 4;
+    long long b = (long long)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    DmaPlan pl;
+    dma_plan_init(pl, tp, tl, F, lane, b, b_stride);
+    // dR row: lane covers bytes [1024*c + 16*lane, +16) of the row, c < nr; lanes past the row pitch are masked
+    const int nr = __builtin_amdgcn_readfirstlane((int)((ldr * 4 + 1023) / 1024));
+    const char* dr_src = (const char*)(dR + b * ldr) + 16 * lane;
+    const long long dr_step = b_stride * ldr * 4;
+    auto issue_dr = [&](unsigned dst) {
+        for (int c = 0; c < nr; ++c)
+            if ((long long)(1024 * c + 16 * lane) < ldr * 4) glds16_v(dr_src + 1024 * c, dst + c * 1024);
+        dr_src += dr_step;
+    };
+
+    const int g = lane >> 4, li = lane & 15;
+    // A-fragment sources inside the dR row (float index; -1 = structural zero), doubled on the diagonal when self pairs exist
+    int a_off[NB][4 * NB];
+    float a_scale[NB][4 * NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int kk = 0; kk < 4 * NB; ++kk) {
+            const int i = 16 * r + li, j = 4 * kk + g;
+            int off = 0; float sc = 0.f;
+            if (i < F && j < F) {
+                if (i == j) { if (self) { off = IDMA_D + i * (i + 1) / 2 + i; sc = 2.f; } }
+                else {
+                    const int hi = i > j ? i : j, lo = i > j ? j : i;
+                    off = IDMA_D + (self ? hi * (hi + 1) / 2 : hi * (hi - 1) / 2) + lo; sc = 1.f;
+                }
+            }
+            a_off[r][kk] = off * 4; a_scale[r][kk] = sc;
+        }
+    // destination rows of this lane: i = 16r + 4g + q
+    char* orow[NB][4];
+    long long ostep[NB][4];
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = 16 * r + 4 * g + q;
+            const int ii = i < F ? i : 0;
+            orow[r][q] = (i < F) ? (char*)dp[ii] + (b * dl[ii] + 4 * li) * 4 : nullptr;
+            ostep[r][q] = b_stride * dl[ii] * 4;
+        }
+
+    int cur = 0;
+    dma_issue<NI>(pl, img0_lds);
+    issue_dr(drow0_lds);
+    for (; b < B; b += b_stride) {
+        const bool more = b + b_stride < B;
+        if (more) {
+            dma_issue<NI>(pl, img0_lds + (cur ^ 1) * IDMA_IMG);
+            issue_dr(drow0_lds + (cur ^ 1) * IDMA_DR_BYTES);
+            wait_vmcnt_rt(NI + nr);
+        } else wait_vmcnt_i<0>();
+        const char* my = img0 + cur * IDMA_IMG;
+        const char* dr = drow0 + cur * IDMA_DR_BYTES;
+        float aS[NB][4 * NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int kk = 0; kk < 4 * NB; ++kk) {
+                const float v = *(const float*)(dr + a_off[r][kk]);
+                aS[r][kk] = (a_scale[r][kk] != 0.f) ? a_scale[r][kk] * v : 0.f;     // structural zeros stay zero even for non-finite dR
+            }
+#pragma unroll
+        for (int dq = 0; dq < IDMA_D / 64; ++dq) {
+            float4 bT[4 * NB];
+#pragma unroll
+            for (int kk = 0; kk < 4 * NB; ++kk) {
+                const int jr = 4 * kk + g;                 // rows >= F of the image are zero
+                bT[kk] = *(const float4*)(my + jr * (IDMA_D * 4) + (((16 * dq + li) ^ (jr & 15)) * 16));
+            }
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+                floatx4 acc[4];
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) acc[s_] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4 * NB; ++kk) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aS[r][kk], bT[kk].x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aS[r][kk], bT[kk].y, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aS[r][kk], bT[kk].z, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aS[r][kk], bT[kk].w, acc[3], 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (orow[r][q]) {
+                        float4 v = make_float4(acc[0][q], acc[1][q], acc[2][q], acc[3][q]);
+                        if (r == 0 && q == 0 && g == 0) {       // feature 0 also feeds R[:, 0:D]
+                            const float4 x = *(const float4*)(dr + (64 * dq + 4 * li) * 4);
+                            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                        }
+                        *(float4*)(orow[r][q] + dq * 256) = v;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (orow[r][q]) orow[r][q] += ostep[r][q];
+        cur ^= 1;
+    }
+}
+
 static int fill_feat(FeatArgs& fa, int F, const void* const* p, const int64_t* ld) {
     for (int f = 0; f < DLRM_MAX_FEATURES; ++f) {
         fa.p[f] = (const float*)p[f < F ? f : 0];
@@ -245,6 +514,12 @@ static int fill_feat(FeatArgs& fa, int F, const void* const* p, const int64_t* l
 static int log2_exact(int x) {
     if (x <= 0 || (x & (x - 1))) return -1;
     int s = 0; while ((1 << s) < x) ++s; return s;
+}
+
+static bool interact_dma_ok(int F, int D, int vec) {
+    static int off = -1;      // env DLRM_INTERACT_PATH=1 forces the register-staged kernels
+    if (off < 0) { const char* e = getenv("DLRM_INTERACT_PATH"); off = (e && atoi(e) == 1) ? 1 : 0; }
+    return !off && D == IDMA_D && F >= 1 && F <= IDMA_ROWS && vec;
 }
 
 static int pick_grid(int64_t B) {
@@ -271,6 +546,26 @@ extern "C" int dlrm_interact_fwd(int64_t B, int F, int D, const void* const* fea
     if (rc) return rc;
     int vec = (D % 4 == 0);
     for (int f = 0; f < F; ++f) vec = vec && dlrm_aligned16(feat_host[f]) && (feat_ld_host[f] % 4 == 0);
+    if (interact_dma_ok(F, D, vec) && dlrm_aligned16(R) && ldr % 4 == 0) {
+        const size_t lds = 2 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * 2 * (size_t)IDMA_IMG;   // 129 KiB: one workgroup per CU
+        int64_t nb = (B + 3) / 4; if (nb > 256) nb = 256;
+        const int ni = (F + 1) / 2;
+#define FWD_DMA(NIV)                                                                                         \
+        do {                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)interact_fwd_dma_kernel<NIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(interact_fwd_dma_kernel<NIV>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, fa, \
+                               (long long)B, F, self_interaction ? 1 : 0, R, (long long)ldr);                \
+        } while (0)
+        switch (ni) {
+            case 1: FWD_DMA(1); break;   case 2: FWD_DMA(2); break;   case 3: FWD_DMA(3); break;   case 4: FWD_DMA(4); break;
+            case 5: FWD_DMA(5); break;   case 6: FWD_DMA(6); break;   case 7: FWD_DMA(7); break;   case 8: FWD_DMA(8); break;
+            case 9: FWD_DMA(9); break;   case 10: FWD_DMA(10); break; case 11: FWD_DMA(11); break; case 12: FWD_DMA(12); break;
+            case 13: FWD_DMA(13); break; case 14: FWD_DMA(14); break; case 15: FWD_DMA(15); break; default: FWD_DMA(16); break;
+        }
+#undef FWD_DMA
+        DLRM_LAUNCH_CHECK();
+        return 0;
+    }
     const int Dp = (D + 15) & ~15;
     const size_t lds = 2 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * (size_t)(((F + 15) >> 4) * 16) * (Dp + 4) * sizeof(float);
     if (lds > 160 * 1024) {
@@ -301,6 +596,30 @@ extern "C" int dlrm_interact_bwd(int64_t B, int F, int D, const void* const* fea
     if (rc) return rc;
     int vec = (D % 4 == 0);
     for (int f = 0; f < F; ++f) vec = vec && dlrm_aligned16(feat_host[f]) && (feat_ld_host[f] % 4 == 0);
+    {
+        int dvec = 1;
+        for (int f = 0; f < F; ++f) dvec = dvec && dlrm_aligned16(dfeat_host[f]) && (dfeat_ld_host[f] % 4 == 0);
+        if (interact_dma_ok(F, D, vec) && dvec && dlrm_aligned16(dR) && ldr % 4 == 0 && ldr * 4 <= IDMA_DR_BYTES) {
+            const size_t lds_dma = 4 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * (2 * (size_t)IDMA_IMG + 2 * (size_t)IDMA_DR_BYTES);
+            int64_t nb = (B + 3) / 4; if (nb > 256) nb = 256;
+            const int ni = (F + 1) / 2;
+#define BWD_DMA(NIV)                                                                                         \
+            do {                                                                                             \
+                (void)hipFuncSetAttribute((const void*)interact_bwd_dma_kernel<NIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma); \
+                hipLaunchKernelGGL(interact_bwd_dma_kernel<NIV>, dim3((unsigned)nb), dim3(256), lds_dma, (hipStream_t)stream, fa, da, \
+                                   (long long)B, F, self_interaction ? 1 : 0, dR, (long long)ldr);           \
+            } while (0)
+            switch (ni) {
+                case 1: BWD_DMA(1); break;   case 2: BWD_DMA(2); break;   case 3: BWD_DMA(3); break;   case 4: BWD_DMA(4); break;
+                case 5: BWD_DMA(5); break;   case 6: BWD_DMA(6); break;   case 7: BWD_DMA(7); break;   case 8: BWD_DMA(8); break;
+                case 9: BWD_DMA(9); break;   case 10: BWD_DMA(10); break; case 11: BWD_DMA(11); break; case 12: BWD_DMA(12); break;
+                case 13: BWD_DMA(13); break; case 14: BWD_DMA(14); break; case 15: BWD_DMA(15); break; default: BWD_DMA(16); break;
+            }
+#undef BWD_DMA
+            DLRM_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const int Dp = (D + 15) & ~15, NB = (F + 15) >> 4, rows = NB * 16;
     const size_t lds = 4 * DLRM_MAX_FEATURES * sizeof(long long) +
                        4 * ((size_t)F * (Dp + 16) + (size_t)F * (rows + 1)) * sizeof(float);

@@ -128,11 +128,15 @@ def test_emb_bwd_sgd_sorted_large_tables_bit_exact(D, idx_dtype):
 
 # ------------------------------------------------------------------------------------------ interaction
 @pytest.mark.parametrize("F,D,itself", [(4, 16, False), (27, 128, False), (27, 16, False), (6, 12, True), (2, 2, False),
-                                        (9, 64, False), (33, 32, False), (49, 8, True)])
-def test_interact_fwd_bwd(F, D, itself):
+                                        (9, 64, False), (33, 32, False), (49, 8, True),
+                                        # D = 128: LDS-DMA double-buffered path (odd / even / full / tiny F, self pairs)
+                                        (27, 128, True), (32, 128, False), (3, 128, False), (1, 128, True), (16, 128, False)])
+@pytest.mark.parametrize("B", [67, 5000])
+def test_interact_fwd_bwd(F, D, itself, B):
     from dlrm_amd import ops
+    if B > 67 and D != 128:
+        pytest.skip("large batch only exercises the multi-sample-per-wave loop of the D = 128 path")
     rng = np.random.default_rng(F * 1000 + D)
-    B = 67
     feat = rng.standard_normal((B, F, D)).astype(np.float32)
     want = O.interact_fwd(feat, itself)
     Wd = want.shape[1]
@@ -143,7 +147,10 @@ def test_interact_fwd_bwd(F, D, itself):
     ops.interact_fwd([x, E], D, itself, R)
     torch.cuda.synchronize()
     got = R.cpu().numpy()
-    np.testing.assert_allclose(got[:, :Wd], want, rtol=1e-5, atol=1e-5)   # fp32 MFMA vs fp64-accumulated oracle
+    # fp32 MFMA vs fp64-accumulated oracle: a 128-term fp32 dot of N(0,1) data carries ~1e-5 absolute round-off in its
+    # worst element out of millions, so the absolute floor scales with the number of outputs checked
+    atol = 1e-5 if B <= 67 else 3e-5
+    np.testing.assert_allclose(got[:, :Wd], want, rtol=1e-5, atol=atol)
     assert np.array_equal(got[:, :D], feat[:, 0, :])                      # the copied x block is exact
     assert np.all(got[:, Wd:] == 0)
     dR = rng.standard_normal((B, Wd)).astype(np.float32)
@@ -154,8 +161,8 @@ def test_interact_fwd_bwd(F, D, itself):
     dE = torch.empty((B, (F - 1) * D), device=dev())
     ops.interact_bwd([x, E], D, itself, dRd, [dx, dE])
     torch.cuda.synchronize()
-    np.testing.assert_allclose(dx.cpu().numpy(), dwant[:, 0, :], rtol=1e-5, atol=2e-5)
-    np.testing.assert_allclose(dE.cpu().numpy().reshape(B, F - 1, D), dwant[:, 1:, :], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(dx.cpu().numpy(), dwant[:, 0, :], rtol=1e-5, atol=2 * atol)
+    np.testing.assert_allclose(dE.cpu().numpy().reshape(B, F - 1, D), dwant[:, 1:, :], rtol=1e-5, atol=2 * atol)
 
 
 # ------------------------------------------------------------------------------------------ MLP layers
