@@ -53,6 +53,11 @@ def parse():
     ap.add_argument("--row-cap", type=int, default=0, help="cap table rows (debug / small-memory runs)")
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-arith", action="store_true", help="skip the extra bf16x6 measurement")
+    ap.add_argument("--no-kernel-timers", action="store_true", help="no per-kernel HIP events in the timed region (no roofline)")
+    ap.add_argument("--timer-every", type=int, default=4,
+                    help="per-kernel HIP events are recorded on every n-th step of the timed region (each event pair costs "
+                         "host time and a queue barrier: ~0.4 ms per fully instrumented step)")
     ap.add_argument("--cpu-row-cap", type=int, default=1000000)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
@@ -104,6 +109,17 @@ def cpu_baseline(wl, args):
             "ms_per_step": dt * 1e3,
             "sample": f"{args.cpu_steps} steps of global batch {B}, tables capped at {args.cpu_row_cap} rows "
                       f"(oracle/torch_port.py: the reference's torch CPU operator calls, {torch.get_num_threads()} threads)"}
+
+
+def load_pmc_traffic():
+    """Latest committed profiles/rNN/pmc_traffic.json (tools/gpu_pmc_traffic.sh + tools/pmc_to_json.py), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    d["_file"] = os.path.relpath(files[-1], ROOT)
+    return d
 
 
 def main():
@@ -169,15 +185,19 @@ def main():
     if N > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    ops.timers = ops.KernelTimers()
+    ops.timers = None if args.no_kernel_timers else ops.KernelTimers()
     t0 = time.perf_counter()
+    timed_steps = 0
     for i in range(args.steps):
+        if ops.timers is not None:
+            ops.timers.enabled = (i % max(args.timer_every, 1) == 0)
+            timed_steps += int(ops.timers.enabled)
         loss = step(args.warmup + i)
     torch.cuda.synchronize()
     if N > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
-    ksum = ops.timers.summary()
+    ksum = ops.timers.summary() if ops.timers is not None else {}
     ops.timers = None
     if N > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -185,7 +205,7 @@ def main():
         dt = float(tt.item())
     ms = dt / args.steps * 1e3
     value = B / (dt / args.steps)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     # ---- algorithmic work per launch -------------------------------
     Bl = B // N if N > 1 else B
@@ -212,29 +232,36 @@ def main():
         k = ksum.get(name)
         if not k:
             continue
-        per_step_ms = k["total_ms"] / args.steps
+        per_step_ms = k["total_ms"] / max(timed_steps, 1)
         scale = 1e9 if unit == "GB/s" else 1e12
         ach = work / (per_step_ms * 1e-3) / scale
-        kernels[name] = {"ms_per_step": per_step_ms, "launches_per_step": k["calls"] / args.steps,
+        kernels[name] = {"ms_per_step": per_step_ms, "launches_per_step": k["calls"] / max(timed_steps, 1),
                          "avg_launch_ms": k["avg_ms"], "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                          "frac": ach / peak, "algorithmic_work_per_step": work}
     for name in ("act_bwd", "bce_loss", "sgd_dense"):
         if name in ksum:
-            kernels[name] = {"ms_per_step": ksum[name]["total_ms"] / args.steps,
-                             "launches_per_step": ksum[name]["calls"] / args.steps}
+            kernels[name] = {"ms_per_step": ksum[name]["total_ms"] / max(timed_steps, 1),
+                             "launches_per_step": ksum[name]["calls"] / max(timed_steps, 1)}
     heavy = [n for n in kernels if "achieved" in kernels[n]]
     dom = max(heavy, key=lambda n: kernels[n]["ms_per_step"]) if heavy else None
-    kname = {"linear_fwd": "gemm_f32_kernel<true,true> (Y = X*W^T + bias, act)",
-             "linear_bwd_data": "gemm_f32_kernel<true,false> (dX = dY*W, mask + bias-grad epilogue)",
-             "linear_bwd_weight": "gemm_f32_kernel<false,false> (dW = dY^T*X, split over the batch)",
+    kname = {"linear_fwd": "gemm3_kernel<KC,KC> (Y = X*W^T + bias, act; LDS-DMA ring, 256x128x16 tiles)",
+             "linear_bwd_data": "gemm3_kernel<KC,KS> (dX = dY*W, previous layer's act' fused in the epilogue)",
+             "linear_bwd_weight": "gemm3_kernel<KS,KS> (dW = dY^T*X split over the batch + bias-grad row sums) + splitk_reduce_kernel",
              "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "expand + rocprim radix sort + sorted_update_kernel" if args.emb_update == "sorted" else "emb_bwd_sgd_{atomic,lds}_kernel",
-             "interact_fwd": "interact_fwd_kernel", "interact_bwd": "interact_bwd_kernel"}
+             "interact_fwd": "interact_fwd_dma_kernel", "interact_bwd": "interact_bwd_dma_kernel"}
+    pmc = load_pmc_traffic() if (N == 1 and args.workload == "criteo_terabyte" and not args.batch and not args.row_cap) else None
 
     def roof(n):
         k = kernels[n]
+        t = pmc["kernels"].get(n) if pmc else None
         return {"kernel": kname.get(n, n), "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
-                "unit": k["unit"], "frac": k["frac"], "traffic": None, "avg_launch_ms": k["avg_launch_ms"],
-                "ms_per_step": k["ms_per_step"]}
+                "unit": k["unit"], "frac": k["frac"],
+                "traffic": t["traffic_bytes"] if t else None,
+                "traffic_note": ("HBM bytes per call from rocprofv3 PMC passes of this workload (%s; FETCH_SIZE x2 gfx950 "
+                                 "correction + WRITE_SIZE), algorithmic bytes per call = %d" %
+                                 (pmc["_file"], k["algorithmic_work_per_step"] // max(int(round(k["launches_per_step"])), 1)))
+                if t and k["unit"] == "GB/s" else (("HBM bytes per call from rocprofv3 PMC passes (%s)" % pmc["_file"]) if t else None),
+                "avg_launch_ms": k["avg_launch_ms"], "ms_per_step": k["ms_per_step"]}
 
     result = {
         "metric": "samples/sec (global batch) + embedding HBM GB/s, Criteo-TB config",
@@ -246,14 +273,33 @@ def main():
                    "tables": len(rows), "emb_dim": D, "global_batch": B, "table_rows_total": int(sum(rows)),
                    "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": "sgd",
                    "loss": "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
-                   "embedding_update": args.emb_update},
+                   "embedding_update": args.emb_update,
+                   "mlp_arith": ("f32: native fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.mlp_arith == "f32" else
+                                 "bf16x6: fp32 operands split exactly into 3 bf16 terms in-kernel, 6 bf16 MFMA products, fp32 accumulate")},
         "final_loss": final_loss,
+        "kernel_timing": "HIP events on the launch stream around every C-ABI call, on %d of the %d timed steps" % (timed_steps, args.steps),
         "roofline": roof(dom) if dom else None,
         "roofline_embedding": roof("emb_fwd") if "emb_fwd" in kernels else None,
         "embedding_hbm_gbps": {"fwd": kernels.get("emb_fwd", {}).get("achieved"),
                                "bwd_sgd": kernels.get("emb_bwd_sgd", {}).get("achieved")},
         "kernels": kernels,
     }
+    if N == 1 and args.mlp_arith == "f32" and not args.no_alt_arith:
+        # the same step with the opt-in bf16x6 MLP arithmetic (fp32 round-off class, see include/dlrm_hip.h): reported
+        # beside the headline value, never instead of it
+        ops.set_mlp_arith("bf16x6")
+        for i in range(2):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss_alt = step(i)
+        torch.cuda.synchronize()
+        dta = (time.perf_counter() - t0) / args.steps
+        ops.set_mlp_arith("f32")
+        result["alt_mlp_arith"] = {"mlp_arith": "bf16x6", "value": B / dta, "unit": "samples/s", "ms_per_step": dta * 1e3,
+                                   "final_loss": float(loss_alt.detach()),
+                                   "note": "opt-in (--mlp-arith bf16x6); parity-tested at the fp32 tolerances"}
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         del model, opt, batches
         torch.cuda.empty_cache()

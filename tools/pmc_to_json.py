@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Fold the per-kernel PMC averages written by tools/gpu_pmc_traffic.sh (pmc_FETCH_SIZE.csv / pmc_WRITE_SIZE.csv, KB per
+dispatch) into per-C-ABI-call HBM traffic for bench.py's `roofline.traffic`.  FETCH_SIZE is doubled: on gfx950 rocprofv3
+tallies the 128-byte requests of wide (16 B/lane) coalesced reads at 64 B (MI355X_MICROARCH.md, HBM section) — confirmed
+here by interact_fwd_dma_kernel, whose only reads are the 65536 x 27 x 512 B feature rows (906 MB) and whose raw
+FETCH_SIZE is 453 MB.  WRITE_SIZE is exact in this access pattern (emb_fwd writes 26 x 65536 x 512 B = 851,968 KB:
+counter 851,968).   usage: python tools/pmc_to_json.py gpurun_out/pmc01 profiles/r01/pmc_traffic.json"""
+import csv
+import json
+import sys
+
+CATS = {
+    "emb_fwd": ["emb_fwd_kernel"],
+    "emb_bwd_sgd": ["expand_kernel", "rocprim::", "sorted_update_kernel"],
+    "interact_fwd": ["interact_fwd"],
+    "interact_bwd": ["interact_bwd"],
+    "linear_fwd": ["gemm3_kernel<true, true", "gemm_f32_kernel<true, true"],
+    "linear_bwd_data": ["gemm3_kernel<true, false", "gemm_f32_kernel<true, false"],
+    "linear_bwd_weight": ["gemm3_kernel<false, false", "gemm_f32_kernel<false, false", "splitk_reduce_kernel"],
+}
+CALLS_PER_STEP = {"emb_fwd": 1, "emb_bwd_sgd": 1, "interact_fwd": 1, "interact_bwd": 1, "linear_fwd": 8, "linear_bwd_data": 7,
+                  "linear_bwd_weight": 8}
+
+
+def load(path):
+    rows = list(csv.DictReader(open(path)))
+    return [(r["kernel"], int(r["calls"]), float(r["avg_value"])) for r in rows]
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    steps = 6      # bench.py --steps 4 --warmup 2 under the profiler
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 4 --warmup 2",
+           "units": "bytes per C-ABI call (average over the calls of one training step)",
+           "fetch_correction": "FETCH_SIZE x 2 (gfx950: 128-B requests counted as 64 B)", "kernels": {}}
+    fetch, write = load(f"{src}/pmc_FETCH_SIZE.csv"), load(f"{src}/pmc_WRITE_SIZE.csv")
+    for cat, pats in CATS.items():
+        f_kb = sum(c * v for k, c, v in fetch if any(p in k for p in pats)) / steps
+        w_kb = sum(c * v for k, c, v in write if any(p in k for p in pats)) / steps
+        n = CALLS_PER_STEP[cat]
+        out["kernels"][cat] = {"fetch_raw_bytes": f_kb * 1024 / n, "fetch_bytes": 2 * f_kb * 1024 / n,
+                               "write_bytes": w_kb * 1024 / n, "traffic_bytes": (2 * f_kb + w_kb) * 1024 / n,
+                               "calls_per_step": n}
+    json.dump(out, open(dst, "w"), indent=1)
+    for k, v in out["kernels"].items():
+        print("%-18s traffic %8.1f MB/call (fetch %8.1f, write %8.1f)" % (k, v["traffic_bytes"] / 1e6, v["fetch_bytes"] / 1e6, v["write_bytes"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
