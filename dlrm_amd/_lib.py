@@ -35,7 +35,7 @@ SIGNATURES = {
     "dlrm_emb_bwd_workspace_bytes": (_i64, [_i32, _pi64, _pi64]),
     "dlrm_emb_bwd_sgd": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64,
                                 _f32, _i32, _vp, _i64, _vp]),
-    "dlrm_emb_adagrad_workspace_bytes": (_i64, [_i32, _pi64, _pi64]),
+    "dlrm_emb_adagrad_workspace_bytes": (_i64, [_i32, _i32, _pi64, _pi64]),
     "dlrm_emb_bwd_rowwise_adagrad": (_i32, [_i32, _i64, _i32, _pp, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32,
                                             _vp, _i64, _f32, _f32, _vp, _i64, _vp]),
     "dlrm_interact_fwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _vp]),
@@ -50,7 +50,12 @@ SIGNATURES = {
     "dlrm_loss_workspace_bytes": (_i64, [_i64]),
     "dlrm_bce_loss": (_i32, [_i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
     "dlrm_mse_loss": (_i32, [_i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
+    "dlrm_scale_by_device_scalar": (_i32, [_i64, _vp, _vp, _vp, _vp]),
     "dlrm_sgd_dense": (_i32, [_i64, _vp, _vp, _f32, _vp]),
+    "dlrm_sgd_dense_multi": (_i32, [_i32, _pp, _pp, _pi64, _f32, _vp]),
+    "dlrm_adagrad_dense": (_i32, [_i64, _vp, _vp, _vp, _f32, _f32, _vp]),
+    "dlrm_binary_metrics_workspace_bytes": (_i64, [_i64]),
+    "dlrm_binary_metrics": (_i32, [_i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dlrm_a2a_unpack": (_i32, [_i32, _i64, _i32, C.POINTER(_i32), _vp, _vp, _i64, _vp]),
 }
 

@@ -97,6 +97,48 @@ __global__ __launch_bounds__(256) void sgd_dense_kernel(long long n4, long long 
         w[i] = __builtin_fmaf(neg_lr, g[i], w[i]);
 }
 
+// y[i] = x[i] * s[0]   (s = the upstream gradient of the scalar loss: a device scalar, no host read)
+__global__ __launch_bounds__(256) void scale_kernel(long long n, const float* __restrict__ x, const float* __restrict__ s,
+                                                    float* __restrict__ y) {
+    const float f = s[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * f;
+}
+
+// dense SGD for MANY parameter tensors in one launch (the 16 weights/biases of the two towers): pointers and sizes
+// travel by value in the kernarg segment, every workgroup owns one 4096-float chunk of one tensor.
+#define DLRM_MAX_DENSE_TENSORS 48
+constexpr int kSgdChunk = 4096;
+struct MultiSgdArgs {
+    float*       w[DLRM_MAX_DENSE_TENSORS];
+    const float* g[DLRM_MAX_DENSE_TENSORS];
+    long long    n[DLRM_MAX_DENSE_TENSORS];
+    int          blk0[DLRM_MAX_DENSE_TENSORS + 1];     // first workgroup of tensor k; blk0[count] = grid size
+    int          count;
+};
+
+__global__ __launch_bounds__(256) void sgd_dense_multi_kernel(MultiSgdArgs a, float neg_lr) {
+    int k = 0;
+    while (k + 1 < a.count && (int)blockIdx.x >= a.blk0[k + 1]) ++k;     // wave-uniform scan over <= 48 entries
+    float* __restrict__ w = a.w[k];
+    const float* __restrict__ g = a.g[k];
+    const long long n = a.n[k];
+    const long long e0 = (long long)((int)blockIdx.x - a.blk0[k]) * kSgdChunk;
+    const long long e1 = (e0 + kSgdChunk < n) ? e0 + kSgdChunk : n;
+    if (((((uintptr_t)w) | ((uintptr_t)g)) & 15u) == 0) {
+        for (long long i = e0 + 4 * threadIdx.x; i + 3 < e1; i += 4 * 256) {
+            float4 x = *(const float4*)(w + i);
+            const float4 y = *(const float4*)(g + i);
+            x.x = __builtin_fmaf(neg_lr, y.x, x.x); x.y = __builtin_fmaf(neg_lr, y.y, x.y);
+            x.z = __builtin_fmaf(neg_lr, y.z, x.z); x.w = __builtin_fmaf(neg_lr, y.w, x.w);
+            *(float4*)(w + i) = x;
+        }
+        const long long tail = e0 + ((e1 - e0) & ~3LL);                  // e0 is a multiple of 4
+        for (long long i = tail + threadIdx.x; i < e1; i += 256) w[i] = __builtin_fmaf(neg_lr, g[i], w[i]);
+    } else {
+        for (long long i = e0 + threadIdx.x; i < e1; i += 256) w[i] = __builtin_fmaf(neg_lr, g[i], w[i]);
+    }
+}
+
 struct UnpackArgs { int tables[64]; long long src_off[64]; int col_off[64]; };
 
 // recv = concat over source ranks s of [b_local][T_s][D]  ->  out[b, col_off[s]*D ...]
@@ -115,7 +157,7 @@ __global__ __launch_bounds__(256) void a2a_unpack_kernel(UnpackArgs u, int nrank
 
 }  // namespace
 
-extern "C" int dlrm_hip_abi_version(void) { return 3; }
+extern "C" int dlrm_hip_abi_version(void) { return 4; }
 
 extern "C" const char* dlrm_hip_build_info(void) {
     return "libdlrm_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " clang " __clang_version__;
@@ -174,6 +216,35 @@ extern "C" int dlrm_sgd_dense(int64_t n, float* w, const float* g, float lr, voi
     hipLaunchKernelGGL(sgd_dense_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, n4, (long long)n,
                        (float4*)w, (const float4*)g, w, g, -lr);
     DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_scale_by_device_scalar(int64_t n, const float* x, const float* scalar_dev, float* y, void* stream) {
+    if (n <= 0 || !x || !scalar_dev || !y) return DLRM_E_ARG;
+    long long nblk = (n + 255) / 256; if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (long long)n, x, scalar_dev, y);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_sgd_dense_multi(int count, float* const* w_host, const float* const* g_host, const int64_t* n_host,
+                                    float lr, void* stream) {
+    if (count <= 0 || !w_host || !g_host || !n_host) return DLRM_E_ARG;
+    for (int c0 = 0; c0 < count; c0 += DLRM_MAX_DENSE_TENSORS) {
+        MultiSgdArgs a = {};
+        const int m = (count - c0 < DLRM_MAX_DENSE_TENSORS) ? count - c0 : DLRM_MAX_DENSE_TENSORS;
+        long long blocks = 0;
+        for (int k = 0; k < m; ++k) {
+            if (!w_host[c0 + k] || !g_host[c0 + k] || n_host[c0 + k] <= 0) return DLRM_E_ARG;
+            a.w[k] = w_host[c0 + k]; a.g[k] = g_host[c0 + k]; a.n[k] = n_host[c0 + k];
+            a.blk0[k] = (int)blocks;
+            blocks += (n_host[c0 + k] + kSgdChunk - 1) / kSgdChunk;
+            if (blocks > 0x7fffffffLL) return DLRM_E_RANGE;
+        }
+        a.blk0[m] = (int)blocks; a.count = m;
+        hipLaunchKernelGGL(sgd_dense_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, -lr);
+        DLRM_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -1,0 +1,125 @@
+// sorted_common.h — pieces shared by the sort-based embedding updates (emb_sorted.hip: SGD, adagrad.hip: row-wise
+// Adagrad): vector helpers, the (table,row) key expansion kernel, and the workspace layout around rocPRIM's radix sort.
+#pragma once
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "common.h"
+
+namespace {
+
+
+template <int VEC> struct Vec;
+template <> struct Vec<4> { using T = float4; };
+template <> struct Vec<1> { using T = float; };
+
+__device__ __forceinline__ void v_zero(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void v_zero(float& a) { a = 0.f; }
+__device__ __forceinline__ void v_fma(float4& a, float w, const float4& v) {
+    a.x = __builtin_fmaf(w, v.x, a.x); a.y = __builtin_fmaf(w, v.y, a.y);
+    a.z = __builtin_fmaf(w, v.z, a.z); a.w = __builtin_fmaf(w, v.w, a.w);
+}
+__device__ __forceinline__ void v_fma(float& a, float w, const float& v) { a = __builtin_fmaf(w, v, a); }
+__device__ __forceinline__ float4 v_mul(float s, const float4& v) { return make_float4(s * v.x, s * v.y, s * v.z, s * v.w); }
+__device__ __forceinline__ float v_mul(float s, const float& v) { return s * v; }
+__device__ __forceinline__ void v_atomic_add(float* p, const float4& v) {
+    atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+__device__ __forceinline__ void v_atomic_add(float* p, const float& v) { atomicAdd(p, v); }
+
+struct SortedArgs {
+    float*       w[DLRM_MAX_TABLES_PER_LAUNCH];
+    const float* psw[DLRM_MAX_TABLES_PER_LAUNCH];
+    long long    base[DLRM_MAX_TABLES_PER_LAUNCH];   // first global lookup position of the table
+    int          slot[DLRM_MAX_TABLES_PER_LAUNCH];   // dout column block of the table
+};
+
+// (table, bag, lookup) -> key = table << row_bits | row, val = global lookup position, bag_of[pos] = bag
+template <typename IT, typename KT>
+__global__ __launch_bounds__(256) void expand_kernel(EmbArgs a, SortedArgs sa, long long B, int row_bits,
+                                                     KT* __restrict__ keys, unsigned* __restrict__ vals,
+                                                     unsigned* __restrict__ bag_of) {
+    const int t = blockIdx.y;
+    const IT* __restrict__ idx = (const IT*)a.idx[t];
+    const IT* __restrict__ off = (const IT*)a.off[t];
+    const long long nnz = a.nnz[t];
+    const long long base = sa.base[t];
+    const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const long long s = (long long)off[b];
+    const long long e = (b + 1 < B) ? (long long)off[b + 1] : nnz;
+    for (long long i = s; i < e; ++i) {
+        const long long pos = base + i;
+        keys[pos] = ((KT)t << row_bits) | (KT)(long long)idx[i];
+        vals[pos] = (unsigned)pos;
+        bag_of[pos] = (unsigned)b;
+    }
+}
+
+static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+static int bits_for(long long n) { int b = 0; while (((long long)1 << b) < n) ++b; return b < 1 ? 1 : b; }
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Layout { size_t keys_in, keys_out, vals_in, vals_out, bag_of, temp, temp_bytes, total; };
+
+template <typename KT>
+static hipError_t sort_temp_bytes(size_t L, int bits, size_t* bytes) {
+    *bytes = 0;
+    return rocprim::radix_sort_pairs<rocprim::default_config, const KT*, KT*, const unsigned*, unsigned*>(
+        nullptr, *bytes, nullptr, nullptr, nullptr, nullptr, L, 0, bits, (hipStream_t)0, false);
+}
+
+static int make_layout(size_t L, bool wide, int bits, Layout* lo) {
+    const size_t ksz = wide ? 8 : 4;
+    size_t o = 0;
+    lo->keys_in = o;  o += align256(L * ksz);
+    lo->keys_out = o; o += align256(L * ksz);
+    lo->vals_in = o;  o += align256(L * 4);
+    lo->vals_out = o; o += align256(L * 4);
+    lo->bag_of = o;   o += align256(L * 4);
+    hipError_t e = wide ? sort_temp_bytes<unsigned long long>(L, bits, &lo->temp_bytes)
+                        : sort_temp_bytes<unsigned>(L, bits, &lo->temp_bytes);
+    if (e != hipSuccess) return (int)e;
+    lo->temp = o; o += align256(lo->temp_bytes);
+    lo->total = o;
+    return 0;
+}
+
+
+// Fills the by-value kernel arguments for tables ids[0..n), expands every lookup to (key = table << row_bits | row,
+// value = global lookup position, bag_of[position] = bag) and radix-sorts the pairs by key (stable: equal rows keep
+// input order).  Results: keys_out / vals_out / bag_of inside `ws` as laid out by `lo`.
+template <typename KT>
+static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight_host, const int64_t* rows_host,
+                           const void* const* indices_host, const void* const* offsets_host, const int64_t* nnz_host,
+                           const void* const* psw_host, int idx_bits, char* ws, const Layout& lo, size_t L, int row_bits,
+                           int key_bits, hipStream_t st, SortedArgs* sa_out) {
+    EmbArgs a;
+    SortedArgs& sa = *sa_out;
+    long long base = 0;
+    for (int k = 0; k < DLRM_MAX_TABLES_PER_LAUNCH; ++k) {
+        const int t = ids[k < n ? k : 0];
+        a.w[k] = (float*)weight_host[t]; a.idx[k] = indices_host[t]; a.off[k] = offsets_host[t];
+        a.psw[k] = psw_host ? (const float*)psw_host[t] : nullptr;
+        a.nnz[k] = k < n ? nnz_host[t] : 0; a.rows[k] = rows_host[t]; a.slot[k] = t;
+        sa.w[k] = a.w[k]; sa.psw[k] = a.psw[k]; sa.slot[k] = t; sa.base[k] = base;
+        if (k < n) base += nnz_host[t];
+    }
+    KT* keys_in = (KT*)(ws + lo.keys_in);
+    KT* keys_out = (KT*)(ws + lo.keys_out);
+    unsigned* vals_in = (unsigned*)(ws + lo.vals_in);
+    unsigned* vals_out = (unsigned*)(ws + lo.vals_out);
+    unsigned* bag_of = (unsigned*)(ws + lo.bag_of);
+    dim3 grid((unsigned)((B + 255) / 256), (unsigned)n, 1), block(256);
+    if (idx_bits == 64)
+        hipLaunchKernelGGL((expand_kernel<long long, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
+    else
+        hipLaunchKernelGGL((expand_kernel<int, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
+    DLRM_LAUNCH_CHECK();
+    size_t tb = lo.temp_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(ws + lo.temp, tb, (const KT*)keys_in, keys_out, (const unsigned*)vals_in,
+                                             vals_out, L, 0, key_bits, st, false);
+    if (e != hipSuccess) return (int)e;
+    return 0;
+}
+
+}  // namespace

@@ -240,7 +240,7 @@ class BCELossFunction(Function):
     @staticmethod
     def backward(ctx, g):
         (dp,) = ctx.saved_tensors
-        return dp.view(ctx.shape) * g, None, None
+        return ops.scale_by_scalar(dp, g.reshape(1).float()).view(ctx.shape), None, None
 
 
 class MSELossFunction(Function):
@@ -254,4 +254,4 @@ class MSELossFunction(Function):
     @staticmethod
     def backward(ctx, g):
         (dp,) = ctx.saved_tensors
-        return dp.view(ctx.shape) * g, None
+        return ops.scale_by_scalar(dp, g.reshape(1).float()).view(ctx.shape), None

@@ -201,23 +201,28 @@ def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Ten
 
 
 def emb_bwd_rowwise_adagrad(weights: Sequence[torch.Tensor], states: Sequence[torch.Tensor], bags: BagBatch,
-                            dout: torch.Tensor, lr: float, eps: float,
-                            workspace: Optional[torch.Tensor] = None) -> None:
+                            dout: torch.Tensor, lr: float, eps: float) -> None:
+    """Fused EmbeddingBag backward + row-wise sparse Adagrad (optim/rwsadagrad.py:117-143), in place:
+    per touched row r:  g_r = sum of its lookups' gradients;  states[t][r] += mean(g_r^2);
+    W_t[r] -= lr * g_r / (sqrt(states[t][r]) + eps).  `lr` is the decayed clr of rwsadagrad.py:115."""
     lib = _lib.load()
     D, wp, rows = _weights_desc(weights)
     _req(dout, "dout", ndim=2)
+    if dout.size(0) != bags.B or dout.size(1) < bags.T * D or len(weights) != bags.T or len(states) != bags.T:
+        raise RuntimeError("dlrm_amd: emb_bwd_rowwise_adagrad shape mismatch")
     for s_, w in zip(states, weights):
         _req(s_, "adagrad state", ndim=1)
-        if s_.numel() != w.size(0):
-            raise RuntimeError("dlrm_amd: row-wise adagrad state must be [rows]")
+        if s_.numel() != w.size(0) or not s_.is_contiguous():
+            raise RuntimeError("dlrm_amd: row-wise adagrad state must be a contiguous [rows] tensor")
     sp = _lib.ptr_array([s_.data_ptr() for s_ in states])
-    need = lib.dlrm_emb_adagrad_workspace_bytes(bags.T, bags._nnz, rows)
-    if workspace is None or workspace.numel() * workspace.element_size() < need:
-        workspace = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dout.device)
-    rc = lib.dlrm_emb_bwd_rowwise_adagrad(bags.T, bags.B, D, wp, sp, rows, bags._idx, bags._off, bags._nnz,
-                                          bags._psw, bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout),
-                                          float(lr), float(eps), C.c_void_p(workspace.data_ptr()),
-                                          workspace.numel() * workspace.element_size(), _stream())
+    need = lib.dlrm_emb_adagrad_workspace_bytes(bags.T, D, bags._nnz, rows)
+    if need < 0:
+        raise RuntimeError("dlrm_amd: dlrm_emb_adagrad_workspace_bytes failed")
+    ws = _emb_workspace(need, dout.device)
+    with _timed("emb_bwd_adagrad"):
+        rc = lib.dlrm_emb_bwd_rowwise_adagrad(bags.T, bags.B, D, wp, sp, rows, bags._idx, bags._off, bags._nnz,
+                                              bags._psw, bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout),
+                                              float(lr), float(eps), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
     _lib.check(rc, "dlrm_emb_bwd_rowwise_adagrad")
 
 
@@ -427,6 +432,19 @@ def mse_loss(p: torch.Tensor, target: torch.Tensor, grad_scale: float, want_grad
     return loss, dp
 
 
+def scale_by_scalar(x: torch.Tensor, scalar: torch.Tensor) -> torch.Tensor:
+    """x * scalar with `scalar` a 1-element GPU tensor (read on the device)."""
+    lib = _lib.load()
+    _req(x, "x"); _req(scalar, "scalar")
+    if not x.is_contiguous() or scalar.numel() != 1:
+        raise RuntimeError("dlrm_amd: scale_by_scalar needs a contiguous tensor and a 1-element scalar")
+    y = torch.empty_like(x)
+    rc = lib.dlrm_scale_by_device_scalar(x.numel(), C.c_void_p(x.data_ptr()), C.c_void_p(scalar.data_ptr()),
+                                         C.c_void_p(y.data_ptr()), _stream())
+    _lib.check(rc, "dlrm_scale_by_device_scalar")
+    return y
+
+
 def sgd_dense(w: torch.Tensor, g: torch.Tensor, lr: float) -> None:
     lib = _lib.load()
     _req(w, "w"); _req(g, "g")
@@ -435,6 +453,70 @@ def sgd_dense(w: torch.Tensor, g: torch.Tensor, lr: float) -> None:
     with _timed("sgd_dense"):
         rc = lib.dlrm_sgd_dense(w.numel(), C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), float(lr), _stream())
     _lib.check(rc, "dlrm_sgd_dense")
+
+
+def sgd_dense_multi(ws: Sequence[torch.Tensor], gs: Sequence[torch.Tensor], lr: float) -> None:
+    """w -= lr * g for a whole list of dense parameters, one kernel launch."""
+    if not ws:
+        return
+    lib = _lib.load()
+    for w, g in zip(ws, gs):
+        _req(w, "w"); _req(g, "g")
+        if not w.is_contiguous() or not g.is_contiguous() or w.numel() != g.numel():
+            raise RuntimeError("dlrm_amd: sgd_dense_multi needs contiguous tensors of equal size")
+    with _timed("sgd_dense"):
+        rc = lib.dlrm_sgd_dense_multi(len(ws), _lib.ptr_array([w.data_ptr() for w in ws]),
+                                      _lib.ptr_array([g.data_ptr() for g in gs]), _lib.i64_array([w.numel() for w in ws]),
+                                      float(lr), _stream())
+    _lib.check(rc, "dlrm_sgd_dense_multi")
+
+
+def adagrad_dense(w: torch.Tensor, state_sum: torch.Tensor, g: torch.Tensor, lr: float, eps: float) -> None:
+    """state_sum += g*g; w -= lr * g / (sqrt(state_sum) + eps)   (optim/rwsadagrad.py:145-148)"""
+    lib = _lib.load()
+    _req(w, "w"); _req(g, "g"); _req(state_sum, "state_sum")
+    if not (w.is_contiguous() and g.is_contiguous() and state_sum.is_contiguous()) or \
+            w.numel() != g.numel() or w.numel() != state_sum.numel():
+        raise RuntimeError("dlrm_amd: adagrad_dense needs contiguous tensors of equal size")
+    rc = lib.dlrm_adagrad_dense(w.numel(), C.c_void_p(w.data_ptr()), C.c_void_p(state_sum.data_ptr()),
+                                C.c_void_p(g.data_ptr()), float(lr), float(eps), _stream())
+    _lib.check(rc, "dlrm_adagrad_dense")
+
+
+_METRIC_NAMES = ("n", "positives", "tp", "fp", "fn", "tn", "roc_auc", "ap", "round_matches")
+
+
+def binary_metrics_raw(scores: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+    """Device float64[9] = (n, positives, TP, FP, FN, TN, roc_auc, average_precision, #{rint(score) == target});
+    no host synchronisation.  Replaces the numpy / scikit-learn metrics of inference() (dlrm_s_pytorch.py:819-847)."""
+    lib = _lib.load()
+    _req(scores, "scores"); _req(targets, "targets")
+    scores, targets = scores.reshape(-1), targets.reshape(-1)
+    if not scores.is_contiguous() or not targets.is_contiguous() or scores.numel() != targets.numel() or scores.numel() == 0:
+        raise RuntimeError("dlrm_amd: binary_metrics needs non-empty contiguous scores/targets of equal size")
+    n = scores.numel()
+    need = lib.dlrm_binary_metrics_workspace_bytes(n)
+    if need < 0:
+        raise RuntimeError("dlrm_amd: dlrm_binary_metrics_workspace_bytes failed")
+    ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=scores.device)
+    out = torch.empty(9, dtype=torch.float64, device=scores.device)
+    rc = lib.dlrm_binary_metrics(n, C.c_void_p(scores.data_ptr()), C.c_void_p(targets.data_ptr()),
+                                 C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+    _lib.check(rc, "dlrm_binary_metrics")
+    return out
+
+
+def binary_metrics(scores: torch.Tensor, targets: torch.Tensor) -> dict:
+    """The validation_results dictionary of the reference's inference() (recall, precision, f1, ap, roc_auc,
+    accuracy; dlrm_s_pytorch.py:828-847) plus `round_accuracy` = its non-mlperf accuracy (:819-821).  One D2H copy."""
+    v = dict(zip(_METRIC_NAMES, binary_metrics_raw(scores, targets).tolist()))
+    tp, fp, fn, tn, n = v["tp"], v["fp"], v["fn"], v["tn"], v["n"]
+    # sklearn's zero_division="warn" convention: an undefined ratio counts as 0
+    recall = tp / (tp + fn) if tp + fn > 0 else 0.0
+    precision = tp / (tp + fp) if tp + fp > 0 else 0.0
+    f1 = 2 * tp / (2 * tp + fp + fn) if 2 * tp + fp + fn > 0 else 0.0
+    v.update(recall=recall, precision=precision, f1=f1, accuracy=(tp + tn) / n, round_accuracy=v["round_matches"] / n)
+    return v
 
 
 def a2a_unpack(recv: torch.Tensor, tables_per_rank: List[int], b_local: int, D: int, out: torch.Tensor) -> torch.Tensor:

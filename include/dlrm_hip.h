@@ -94,7 +94,7 @@ int dlrm_emb_bwd_sgd(int T, int64_t B, int D,
  *     W[r,:]  -= lr * g_r / (sqrt(state[r]) + eps)
  * workspace: device scratch of at least dlrm_emb_adagrad_workspace_bytes(...) bytes.
  */
-int64_t dlrm_emb_adagrad_workspace_bytes(int T, const int64_t* nnz_host, const int64_t* rows_host);
+int64_t dlrm_emb_adagrad_workspace_bytes(int T, int D, const int64_t* nnz_host, const int64_t* rows_host);
 int dlrm_emb_bwd_rowwise_adagrad(int T, int64_t B, int D,
                      void* const* weight_host, void* const* state_host, const int64_t* rows_host,
                      const void* const* indices_host, const void* const* offsets_host,
@@ -186,8 +186,34 @@ int dlrm_bce_loss(int64_t B, const float* p, const float* target, const float* w
 int dlrm_mse_loss(int64_t B, const float* p, const float* target,
                   float grad_scale, float* loss_out, float* dp, void* partials, void* stream);
 
+/* loss backward glue: y[i] = x[i] * scalar_dev[0] (dL/dp scaled by the upstream gradient of the scalar loss, which
+ * autograd hands over as a device scalar — read on the device, no host synchronisation) */
+int dlrm_scale_by_device_scalar(int64_t n, const float* x, const float* scalar_dev, float* y, void* stream);
+
 /* dense SGD step over a flat parameter buffer: w -= lr * g   (torch.optim.SGD, no momentum) */
 int dlrm_sgd_dense(int64_t n, float* w, const float* g, float lr, void* stream);
+/* the same step for `count` parameter tensors in ONE launch (w_host/g_host: host arrays of device pointers,
+ * n_host: element counts) — the 16 weight/bias tensors of the two MLP towers (dlrm_s_pytorch.py:1620). */
+int dlrm_sgd_dense_multi(int count, float* const* w_host, const float* const* g_host, const int64_t* n_host,
+                         float lr, void* stream);
+/* dense Adagrad step, RWSAdagrad's dense branch (optim/rwsadagrad.py:145-148):
+ *   sum += g*g;  w -= lr * g / (sqrt(sum) + eps)        (lr = the decayed clr of :115) */
+int dlrm_adagrad_dense(int64_t n, float* w, float* sum, const float* g, float lr, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Evaluation metrics of the inference pass, on the device (dlrm_s_pytorch.py:759-899: numpy accuracy :819-821,
+ * scikit-learn recall / precision / f1 / accuracy / roc_auc / average_precision :828-847).
+ *   scores, targets : device float[n]  (targets are 0/1 labels; label = target > 0.5)
+ *   out             : device double[9] = { n, positives, TP, FP, FN, TN (predicted label = rint(score), i.e.
+ *                     np.round), roc_auc (trapezoids over distinct thresholds == sklearn.metrics.roc_auc_score),
+ *                     average_precision (== sklearn.metrics.average_precision_score),
+ *                     count of rint(score) == target (the reference's A_test) }
+ *                     roc_auc / average_precision are NaN when a class is absent (sklearn raises there).
+ *   workspace       : device scratch of dlrm_binary_metrics_workspace_bytes(n) bytes, 16-byte aligned.
+ * Sums are integer or fp64 in a fixed order: deterministic. */
+int64_t dlrm_binary_metrics_workspace_bytes(int64_t n);
+int dlrm_binary_metrics(int64_t n, const float* scores, const float* targets, double* out,
+                        void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * C1 helpers for the pooled-embedding all-to-all (extend_distributed.py:389-486).  The exchange

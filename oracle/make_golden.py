@@ -279,8 +279,40 @@ def capture_distributed(name="dist2_tiny"):
     print(name, "rank losses", [[float(results[r][f"s{s}.loss"]) for s in range(cfg["steps"])] for r in range(size)])
 
 
+def capture_metrics(name="metrics_sklearn"):
+    """scores/targets -> the scikit-learn numbers inference() reports (dlrm_s_pytorch.py:828-847)."""
+    import sklearn.metrics as M
+    rng = np.random.default_rng(11)
+    out, cases = {}, []
+    def add(tag, s, t):
+        s = s.astype(np.float32); t = t.astype(np.float32)
+        out[f"{tag}.scores"], out[f"{tag}.targets"] = s, t
+        r = dict(tag=tag,
+                 recall=float(M.recall_score(y_true=t, y_pred=np.round(s), zero_division=0)),
+                 precision=float(M.precision_score(y_true=t, y_pred=np.round(s), zero_division=0)),
+                 f1=float(M.f1_score(y_true=t, y_pred=np.round(s), zero_division=0)),
+                 ap=float(M.average_precision_score(t, s)), roc_auc=float(M.roc_auc_score(t, s)),
+                 accuracy=float(M.accuracy_score(y_true=t, y_pred=np.round(s))),
+                 round_matches=int(np.sum((np.round(s, 0) == t).astype(np.uint8))))
+        cases.append(r)
+    n = 5000
+    t = np.round(rng.random(n))
+    add("informative", 1 / (1 + np.exp(-(2.0 * (t - 0.5) + rng.standard_normal(n)))), t)
+    add("random", rng.random(n), t)
+    add("heavy_ties", np.round(rng.random(n) * 10) / 10, t)                    # 11 distinct thresholds
+    add("saturated", np.clip(np.round(rng.random(n) * 3) / 2 - 0.25, 0, 1), t)   # exact 0.0 / 0.5 / 1.0 values
+    add("tiny", np.asarray([0.1, 0.4, 0.35, 0.8, 0.5, 0.5]), np.asarray([0, 0, 1, 1, 1, 0]))
+    add("imbalanced", rng.random(3000) ** 3, (rng.random(3000) < 0.03).astype(np.float64))
+    meta = dict(name=name, cases=cases, sklearn=__import__("sklearn").__version__)
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(name, [(c["tag"], round(c["roc_auc"], 4), round(c["ap"], 4)) for c in cases])
+
+
 def main(which):
     os.makedirs(OUT, exist_ok=True)
+    if which == "metrics":
+        return capture_metrics()
     ref, dp, ext = import_reference()
     if which in ("all", "train"):
         # BASELINE.json configs[0]: 3 tables x 1000 x 16, bot 13-512-16, batch 128 (top tower 128-64-1)
@@ -301,6 +333,8 @@ def main(which):
         capture_bookkeeping(ref, ext)
     if which in ("all", "dist"):
         capture_distributed()
+    if which == "all":
+        capture_metrics()
 
 
 if __name__ == "__main__":

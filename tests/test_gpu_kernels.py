@@ -287,3 +287,115 @@ def test_a2a_unpack_layout():
     out = torch.empty((bl, sum(tables) * D), device=dev())
     ops.a2a_unpack(recv, tables, bl, D, out)
     assert np.array_equal(out.cpu().numpy(), np.concatenate(chunks, axis=1))
+
+
+# ------------------------------------------------------------------------------------------ K4: row-wise Adagrad
+@pytest.mark.parametrize("D,rows,B,max_len", [(16, [3, 40, 5000], 300, 5), (128, [4, 10, 130, 100000], 700, 3),
+                                              (6, [2, 9], 97, 4), (64, [1, 3], 5000, 2), (200, [7, 300], 260, 6)])
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_emb_bwd_rowwise_adagrad_matches_oracle(D, rows, B, max_len, idx_dtype):
+    """Fused backward + row-wise sparse Adagrad vs the C oracle (pinned to optim/rwsadagrad.py by
+    tests/test_oracle_golden.py).  Tables with 1-4 rows make runs of thousands of duplicates that cross many
+    64-entry groups (edge buffers + fix-up pass); two consecutive steps exercise the accumulated state."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(1000 + D + B)
+    Ws = [rng.standard_normal((n, D)).astype(np.float32) for n in rows]
+    moms = [np.full(n, 0.01, dtype=np.float32) for n in rows]
+    dW = [to_dev(W) for W in Ws]
+    dM = [to_dev(m) for m in moms]
+    for step in range(2):
+        bags = [ragged(rng, B, n, max_len, empty_frac=0.1) for n in rows]
+        psw = [None] * len(rows)
+        psw[-1] = rng.standard_normal(bags[-1][1].shape[0]).astype(np.float32)
+        dV = (rng.standard_normal((B, len(rows) * D)) * 0.1).astype(np.float32)
+        clr, eps = 0.05 / (1 + step * 0.1), 1e-8
+        for t, (W, m, (o, i), w) in enumerate(zip(Ws, moms, bags, psw)):
+            O.emb_bwd_rowwise_adagrad(W, m, i, o, np.ascontiguousarray(dV[:, t * D:(t + 1) * D]), clr, eps, psw=w)
+        bb = ops.BagBatch([to_dev(o, idx_dtype) for o, _ in bags], [to_dev(i, idx_dtype) for _, i in bags],
+                          [None if w is None else to_dev(w) for w in psw])
+        ops.emb_bwd_rowwise_adagrad(dW, dM, bb, to_dev(dV), clr, eps)
+        torch.cuda.synchronize()
+        for t in range(len(rows)):
+            # hot rows sum thousands of duplicates: fp32 re-association (per 64 lookups) vs the sequential oracle
+            np.testing.assert_allclose(dM[t].cpu().numpy(), moms[t], rtol=2e-4, atol=1e-7, err_msg=f"mom {t} step {step}")
+            np.testing.assert_allclose(dW[t].cpu().numpy(), Ws[t], rtol=2e-4, atol=2e-5, err_msg=f"W {t} step {step}")
+
+
+def test_emb_bwd_rowwise_adagrad_is_deterministic_and_touches_only_looked_up_rows():
+    from dlrm_amd import ops
+    rng = np.random.default_rng(5)
+    D, rows, B = 32, [5, 2000], 4000
+    bags = [ragged(rng, B, n, 3) for n in rows]
+    dV = to_dev((rng.standard_normal((B, len(rows) * D)) * 0.1).astype(np.float32))
+    W0 = [rng.standard_normal((n, D)).astype(np.float32) for n in rows]
+    bb = ops.BagBatch([to_dev(o) for o, _ in bags], [to_dev(i) for _, i in bags])
+    results = []
+    for _ in range(2):
+        dW = [to_dev(W) for W in W0]
+        dM = [torch.zeros(n, device=dev()) for n in rows]
+        ops.emb_bwd_rowwise_adagrad(dW, dM, bb, dV, 0.1, 1e-8)
+        torch.cuda.synchronize()
+        results.append(([w.cpu().numpy() for w in dW], [m.cpu().numpy() for m in dM]))
+    for a, b in zip(results[0][0] + results[0][1], results[1][0] + results[1][1]):
+        assert np.array_equal(a, b)                       # fixed summation order: bit-identical run to run
+    touched = np.zeros(rows[1], dtype=bool)
+    touched[bags[1][1]] = True
+    assert np.array_equal(results[0][0][1][~touched], W0[1][~touched])
+    assert np.all(results[0][1][1][~touched] == 0)
+
+
+def test_dense_optimizer_kernels():
+    from dlrm_amd import ops
+    rng = np.random.default_rng(9)
+    sizes = [1, 3, 4, 13, 4096, 4097, 512 * 13, 1024 * 1024 + 5]
+    ws = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+    gs = [rng.standard_normal(n).astype(np.float32) for n in sizes]
+    big = torch.empty(sum(sizes) + 8 * len(sizes) + 1, device=dev())     # odd offsets: unaligned tensors too
+    dws, o = [], 1
+    for w in ws:
+        v = big[o:o + w.size]; v.copy_(torch.from_numpy(w)); dws.append(v); o += w.size + 3
+    dgs = [to_dev(g) for g in gs]
+    ops.sgd_dense_multi(dws, dgs, 0.37)
+    torch.cuda.synchronize()
+    for w, g, dw in zip(ws, gs, dws):
+        want = (w.astype(np.float64) - 0.37 * g.astype(np.float64))
+        np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+    # dense Adagrad (optim/rwsadagrad.py:145-148)
+    w, g, sm = ws[-1].copy(), gs[-1], np.abs(rng.standard_normal(sizes[-1])).astype(np.float32)
+    dw, dsum = to_dev(w), to_dev(sm)
+    ops.adagrad_dense(dw, dsum, to_dev(g), 0.05, 1e-10)
+    torch.cuda.synchronize()
+    s2 = sm.astype(np.float64) + g.astype(np.float64) ** 2
+    np.testing.assert_allclose(dsum.cpu().numpy(), s2, rtol=1e-6)
+    np.testing.assert_allclose(dw.cpu().numpy(), w - 0.05 * g / (np.sqrt(s2) + 1e-10), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ evaluation metrics
+def test_binary_metrics_match_scikit_learn_golden():
+    from conftest import load_golden
+    from dlrm_amd import ops
+    d, meta = load_golden("metrics_sklearn")
+    for case in meta["cases"]:
+        s, t = d[case["tag"] + ".scores"], d[case["tag"] + ".targets"]
+        m = ops.binary_metrics(to_dev(s), to_dev(t))
+        for k in ("recall", "precision", "f1", "ap", "roc_auc", "accuracy"):
+            assert abs(m[k] - case[k]) <= 1e-9, (case["tag"], k, m[k], case[k])
+        assert m["round_matches"] == case["round_matches"]
+        o = O.binary_metrics(s, t)
+        assert (m["tp"], m["fp"], m["fn"], m["tn"]) == (o["tp"], o["fp"], o["fn"], o["tn"])
+
+
+def test_binary_metrics_large_and_degenerate():
+    from dlrm_amd import ops
+    rng = np.random.default_rng(3)
+    n = 3_000_000
+    t = (rng.random(n) < 0.25).astype(np.float32)
+    s = (1 / (1 + np.exp(-(1.5 * (t - 0.3) + rng.standard_normal(n))))).astype(np.float32)
+    s[::7] = np.round(s[::7], 2)                       # long tie groups
+    m, o = ops.binary_metrics(to_dev(s), to_dev(t)), O.binary_metrics(s, t)
+    assert abs(m["roc_auc"] - o["roc_auc"]) < 1e-10 and abs(m["ap"] - o["ap"]) < 1e-10
+    assert m["round_matches"] == o["round_matches"] and m["positives"] == o["positives"]
+    one_class = ops.binary_metrics(to_dev(s[:100]), torch.zeros(100, device=dev()))
+    assert np.isnan(one_class["roc_auc"]) and np.isnan(one_class["ap"]) and one_class["recall"] == 0.0
+    const = ops.binary_metrics(torch.full((1000,), 0.5, device=dev()), to_dev(t[:1000]))
+    assert abs(const["roc_auc"] - 0.5) < 1e-12       # one threshold: the ROC curve is the diagonal

@@ -69,6 +69,38 @@ def _training_matches_reference_golden(name, mode):
         np.testing.assert_allclose(model.state_dict()[k].cpu().numpy(), v, rtol=1e-4, atol=5e-6, err_msg=k)
 
 
+def test_rwsadagrad_training_matches_reference_golden():
+    """3 training steps with row-wise sparse Adagrad (K4) against the live reference + optim/rwsadagrad.py: losses,
+    parameters and the row-wise optimizer state.  The reference's own RWSAdagrad class is not importable on the GPU box,
+    FusedRWSAdagrad mirrors its hyper-parameters / state layout and DLRM_Net's step pre-hook drives the fused kernel."""
+    from dlrm_amd.optim import FusedRWSAdagrad
+    d, meta = load_golden("rwsadagrad_tiny")
+    meta.setdefault("itself", False)
+    device = torch.device("cuda:0")
+    init = {k: v for k, v in params_with_prefix(d, "init").items()}
+    model = build_model(meta, init, device)
+    opt = FusedRWSAdagrad(model.parameters(), lr=meta["lr"], eps=meta["eps"])
+    for s, (X, lS_o, lS_i, T) in enumerate(golden_batches(d, meta)):
+        Z = model(torch.from_numpy(X).to(device), [torch.from_numpy(o).to(device) for o in lS_o],
+                  [torch.from_numpy(i).to(device) for i in lS_i])
+        E = model.loss_fn(Z, torch.from_numpy(T).to(device))
+        assert abs(float(E) - d["losses"][s]) <= 1e-5 * abs(d["losses"][s]), (s, float(E), d["losses"][s])
+        opt.zero_grad()
+        E.backward()
+        opt.step()
+        if s == 0:
+            for k, v in params_with_prefix(d, "after1").items():
+                if k.startswith("mom"):
+                    got = opt.state[model.emb_l[int(k[3:])].weight]["momentum"]
+                else:
+                    got = model.state_dict()[k]
+                np.testing.assert_allclose(got.cpu().numpy(), v, rtol=1e-4, atol=2e-6, err_msg=k)
+    for k, v in params_with_prefix(d, "final").items():
+        got = opt.state[model.emb_l[int(k[3:])].weight]["momentum"] if k.startswith("mom") else model.state_dict()[k]
+        np.testing.assert_allclose(got.cpu().numpy(), v, rtol=2e-4, atol=5e-6, err_msg=k)
+    assert opt.state[model.emb_l[0].weight]["step"] == 3
+
+
 def test_reference_shaped_helpers():
     """apply_emb / interact_features / apply_mlp called one by one like tools/visualize.py does"""
     d, meta = load_golden("config1_b128")

@@ -154,3 +154,14 @@ def test_torch_port_is_bit_identical_to_reference(name):
         assert loss == float(np.float32(d["losses"][s]))
     for k, v in params_with_prefix(d, "final").items():
         assert np.array_equal(m.p[k].detach().numpy(), v), k
+
+
+def test_binary_metrics_oracle_matches_scikit_learn():
+    """oracle.binary_metrics (numpy restatement) against the scikit-learn numbers the reference's inference() reports
+    (fixture generated by oracle/make_golden.py metrics)."""
+    d, meta = load_golden("metrics_sklearn")
+    for case in meta["cases"]:
+        m = O.binary_metrics(d[case["tag"] + ".scores"], d[case["tag"] + ".targets"])
+        for k in ("recall", "precision", "f1", "ap", "roc_auc", "accuracy"):
+            assert abs(m[k] - case[k]) <= 1e-12 + 1e-10 * abs(case[k]), (case["tag"], k, m[k], case[k])
+        assert m["round_matches"] == case["round_matches"]
