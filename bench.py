@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-arith", action="store_true", help="skip the extra bf16x6 measurement")
+    ap.add_argument("--graph", action="store_true",
+                    help="run the timed region as HIP-graph replays of the captured step (dlrm_amd.graph; N=1 only, implies "
+                         "--no-kernel-timers: events cannot be recorded inside a replay)")
+    ap.add_argument("--no-alt-graph", action="store_true", help="skip the extra HIP-graph replay measurement")
     ap.add_argument("--no-kernel-timers", action="store_true", help="no per-kernel HIP events in the timed region (no roofline)")
     ap.add_argument("--timer-every", type=int, default=4,
                     help="per-kernel HIP events are recorded on every n-th step of the timed region (each event pair costs "
@@ -171,7 +175,7 @@ def main():
     my_rows = ext_dist.get_my_slice(B) if N > 1 else slice(0, B)
     local_tables = list(range(len(rows)))[model.local_emb_slice] if N > 1 else list(range(len(rows)))
 
-    def step(i):
+    def eager_step(i):
         X, off, idx, T = batches[i % len(batches)]
         Z = model(X, off, idx)
         E = model.loss_fn(Z, T[my_rows])
@@ -179,6 +183,20 @@ def main():
         E.backward()
         opt.step()
         return E
+
+    graphed = None
+    if args.graph:
+        if N > 1:
+            sys.exit("ERROR: --graph is single-process only (RCCL collectives are not captured)")
+        from dlrm_amd.graph import GraphedTrainStep
+        graphed = GraphedTrainStep(model, opt)
+        args.no_kernel_timers = True
+
+    def step(i):
+        if graphed is None:
+            return eager_step(i)
+        X, off, idx, T = batches[i % len(batches)]
+        return graphed(X, off, idx, T)
 
     for i in range(args.warmup):
         step(i)
@@ -206,6 +224,7 @@ def main():
     ms = dt / args.steps * 1e3
     value = B / (dt / args.steps)
     final_loss = float(loss.detach())
+    del loss                                      # keeps no autograd graph alive past the timed region
 
     # ---- algorithmic work per launch -------------------------------
     Bl = B // N if N > 1 else B
@@ -274,6 +293,7 @@ def main():
                    "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": "sgd",
                    "loss": "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
                    "embedding_update": args.emb_update,
+                   "launch": "HIP graph replay of the captured step (dlrm_amd.graph)" if graphed is not None else "eager (one C-ABI call per kernel)",
                    "mlp_arith": ("f32: native fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.mlp_arith == "f32" else
                                  "bf16x6: fp32 operands split exactly into 3 bf16 terms in-kernel, 6 bf16 MFMA products, fp32 accumulate")},
         "final_loss": final_loss,
@@ -300,6 +320,30 @@ def main():
         result["alt_mlp_arith"] = {"mlp_arith": "bf16x6", "value": B / dta, "unit": "samples/s", "ms_per_step": dta * 1e3,
                                    "final_loss": float(loss_alt.detach()),
                                    "note": "opt-in (--mlp-arith bf16x6); parity-tested at the fp32 tolerances"}
+        del loss_alt
+    if N == 1 and graphed is None and not args.no_alt_graph:
+        # the same step captured once in a HIP graph and replayed (dlrm_amd.graph): removes the host launch path; reported
+        # beside the headline value.  Never allowed to break the headline line.
+        try:
+            from dlrm_amd.graph import GraphedTrainStep
+            gs = GraphedTrainStep(model, opt)
+            for i in range(4):                       # 2 eager warm-up calls, capture, first replays
+                X, off, idx, T = batches[i % len(batches)]
+                gs(X, off, idx, T)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                X, off, idx, T = batches[i % len(batches)]
+                loss_g = gs(X, off, idx, T)
+            torch.cuda.synchronize()
+            dtg = (time.perf_counter() - t0) / args.steps
+            result["alt_hip_graph"] = {"value": B / dtg, "unit": "samples/s", "ms_per_step": dtg * 1e3,
+                                       "final_loss": float(loss_g), "captures": gs.captures,
+                                       "note": "whole step (fwd+loss+bwd+fused updates) replayed as one HIP graph; inputs copied "
+                                               "into static buffers each step"}
+            del gs
+        except Exception as e:                       # noqa: BLE001 - diagnostic only
+            result["alt_hip_graph"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         del model, opt, batches
         torch.cuda.empty_cache()

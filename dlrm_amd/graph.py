@@ -1,0 +1,154 @@
+"""Whole-step HIP graph: forward + loss + backward + fused embedding update + dense optimizer step captured once
+and replayed with one `hipGraphLaunch` per training step.
+
+Why: at Criteo-Kaggle shapes (BASELINE.json configs[1]: B = 2048, D = 16) one step is ~70 kernel launches of a few
+microseconds each and the Python/ctypes/autograd host path (~1 ms per step, measured) is the whole step time; at
+Criteo-Terabyte shapes the GPU work (9 ms) hides the host path and replay only removes the inter-kernel gaps.
+The reference loop body (dlrm_s_pytorch.py:1574-1621) is what gets captured, unchanged in order:
+    Z = dlrm(X, lS_o, lS_i); E = loss_fn(Z, T); optimizer.zero_grad(); E.backward(); optimizer.step()
+
+Everything the C ABI enqueues is capture-safe by construction: kernels take table / tensor pointers by value in
+the kernarg segment, nothing allocates or synchronises, scratch buffers come from torch's caching allocator (graph
+private pool during capture) and rocPRIM's radix sort runs entirely on the capture stream.
+
+Constraints (checked, never silently worked around):
+  * single process (ext_dist.my_size == 1): RCCL collectives and DDP hooks are not captured;
+  * fixed shapes: every call must pass tensors of the shapes/dtypes of the first call (multi-hot batches whose number
+    of lookups varies cannot be replayed) — inputs are copied into static device buffers before each replay;
+  * learning rates are baked into kernel arguments at capture time: when a scheduler changes a param group's lr the
+    step is re-captured (correct, but a schedule that changes lr every step gains nothing from replay).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Union
+
+import torch
+
+from . import ext_dist, ops
+
+TensorOrList = Union[torch.Tensor, Sequence[torch.Tensor]]
+
+
+def _clone_struct(x: TensorOrList):
+    """Static copies; tensors that appear several times in a list (e.g. one shared offsets tensor for all tables) are
+    cloned once and aliased the same way."""
+    if isinstance(x, torch.Tensor):
+        return x.clone()
+    seen = {}
+    out = []
+    for t in x:
+        if id(t) not in seen:
+            seen[id(t)] = t.clone()
+        out.append(seen[id(t)])
+    return out
+
+
+def _copy_struct(dst: TensorOrList, src: TensorOrList) -> None:
+    if isinstance(dst, torch.Tensor):
+        if not isinstance(src, torch.Tensor) or src.shape != dst.shape or src.dtype != dst.dtype:
+            raise RuntimeError("dlrm_amd.graph: input shape/dtype differs from the captured step")
+        if src.data_ptr() != dst.data_ptr():
+            dst.copy_(src, non_blocking=True)
+        return
+    if isinstance(src, torch.Tensor) or len(src) != len(dst):
+        raise RuntimeError("dlrm_amd.graph: input structure differs from the captured step")
+    d_list, s_list, done = [], [], set()
+    for d, s_ in zip(dst, src):
+        if s_.shape != d.shape or s_.dtype != d.dtype:
+            raise RuntimeError("dlrm_amd.graph: input shape/dtype differs from the captured step "
+                               "(variable-length multi-hot batches cannot be replayed)")
+        if id(d) in done or s_.data_ptr() == d.data_ptr():
+            continue
+        done.add(id(d))
+        d_list.append(d)
+        s_list.append(s_)
+    if d_list:
+        torch._foreach_copy_(d_list, s_list, non_blocking=True)
+
+
+class GraphedTrainStep:
+    """step = GraphedTrainStep(model, optimizer);  loss = step(X, lS_o, lS_i, T)   (loss: static 0-dim device tensor)
+
+    The first `warmup` calls are ordinary eager steps (kernel attributes, workspaces and allocator pools settle); the
+    next call captures the step and every call from then on copies its inputs into the static buffers and replays.
+    `self.out` holds the predictions of the last step (static buffer)."""
+
+    def __init__(self, model, optimizer, warmup: int = 2):
+        if ext_dist.my_size > 1:
+            raise RuntimeError("dlrm_amd.graph: the whole-step HIP graph is single-process only "
+                               "(RCCL all-to-all / DDP all-reduce are not captured)")
+        self.model, self.optimizer = model, optimizer
+        self.warmup = max(int(warmup), 1)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.stream: Optional[torch.cuda.Stream] = None
+        self.static = None
+        self.loss: Optional[torch.Tensor] = None
+        self.out: Optional[torch.Tensor] = None
+        self._lrs: List[float] = []
+        self.captures = 0
+        self._eager_calls = 0
+
+    # one eager training step on the static buffers (the reference loop body)
+    def _eager(self):
+        X, lS_o, lS_i, T = self.static
+        Z = self.model(X, lS_o, lS_i)
+        E = self.model.loss_fn(Z, T)
+        # E.backward() would run the parameters' AccumulateGrad nodes; those are created once and live as long as ANY
+        # autograd graph references them (a loss tensor the caller kept from an earlier eager step is enough), on the
+        # stream of that time — which breaks stream capture.  torch.autograd.grad returns the gradients without
+        # AccumulateGrad; the embedding tables are listed so that their Function's backward (the fused-update stash)
+        # runs, and come back as None exactly like after backward().
+        params = [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad]
+        grads = torch.autograd.grad(E, params, allow_unused=True)
+        for p, g in zip(params, grads):
+            p.grad = g
+        self.optimizer.step()
+        return Z, E
+
+    def _current_lrs(self) -> List[float]:
+        return [float(g["lr"]) for g in self.optimizer.param_groups]
+
+    def _capture(self) -> None:
+        if ops.timers is not None:
+            raise RuntimeError("dlrm_amd.graph: per-kernel event timers cannot be recorded inside a graph capture")
+        dev = self.static[0].device
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        if self.graph is not None:
+            self.graph.reset()
+        self.graph = torch.cuda.CUDAGraph()
+        # backward runs on the autograd engine's thread: "relaxed" lets that thread enqueue into the capturing stream
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
+            Z, E = self._eager()
+        self.out, self.loss = Z.detach(), E.detach()
+        self._lrs = self._current_lrs()
+        self.captures += 1
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+
+    def __call__(self, X, lS_o, lS_i, T):
+        if self.static is None:
+            self.static = (X.clone(), _clone_struct(lS_o), _clone_struct(lS_i), T.clone())
+        else:
+            xs, os_, is_, ts = self.static
+            _copy_struct(xs, X)
+            _copy_struct(os_, lS_o)
+            _copy_struct(is_, lS_i)
+            _copy_struct(ts, T)
+        dev = X.device
+        if self._eager_calls < self.warmup:
+            # the first calls are ordinary eager steps, issued on the stream the capture will use so that kernel
+            # attributes, scratch workspaces and allocator pools are those the graph will see
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(device=dev)
+            self.stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self.stream):
+                Z, E = self._eager()
+            torch.cuda.current_stream(dev).wait_stream(self.stream)
+            self._eager_calls += 1
+            self.out, self.loss = Z.detach(), E.detach()
+            return self.loss
+        if self.graph is None or self._lrs != self._current_lrs():
+            self._capture()          # capture only records; the replay below executes this step
+        self.graph.replay()
+        return self.loss

@@ -216,6 +216,23 @@ int dlrm_binary_metrics(int64_t n, const float* scores, const float* targets, do
                         void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Synthetic ("random") input batches generated in HBM.  Replaces generate_dist_input_batch (uniform) and
+ * generate_random_output_batch of the reference (dlrm_data_pytorch.py:899-960, 835-846):
+ *   table t, bag b:  L = P if fixed else round(max(1, r * min(rows_t, P)));  indices = unique(round(r_j * (rows_t-1))), j < L
+ *   offsets[t][b]  = running sum of the post-unique bag lengths;  nnz_dev[t] = total lookups of table t (device int64)
+ * Uniforms come from Philox4x32-10 keyed by `seed` with counter (bag, table, draw): same distributions as the
+ * reference, different stream (numpy's MT19937 sequence is not reproduced).
+ *   offsets_host[t] : device int32/int64* [B]        indices_host[t] : device int32/int64*, capacity >= B * P
+ *   workspace       : dlrm_gen_workspace_bytes(T, B) bytes (not needed for the one-hot case P == 1 && fixed)
+ * dlrm_gen_uniform_dense fills x[n] with float32(U[0,1)) (dense features), rounded to 0/1 when round_values != 0
+ * (targets with --round-targets). */
+int64_t dlrm_gen_workspace_bytes(int T, int64_t B);
+int dlrm_gen_uniform_bags(int T, int64_t B, const int64_t* rows_host, int num_indices_per_lookup, int fixed,
+                          uint64_t seed, int idx_bits, void* const* offsets_host, void* const* indices_host,
+                          int64_t* nnz_dev, void* workspace, int64_t workspace_bytes, void* stream);
+int dlrm_gen_uniform_dense(int64_t n, float* x, int round_values, uint64_t seed, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * C1 helpers for the pooled-embedding all-to-all (extend_distributed.py:389-486).  The exchange
  * itself is RCCL (ncclSend/ncclRecv grouped) driven by the host; these kernels are only needed
  * when a caller wants the reference's tensor shapes back (tuple of [B/N, T_s*D]) as one

@@ -279,6 +279,36 @@ def capture_distributed(name="dist2_tiny"):
     print(name, "rank losses", [[float(results[r][f"s{s}.loss"]) for s in range(cfg["steps"])] for r in range(size)])
 
 
+def capture_datagen(dp, name="datagen_uniform"):
+    """The reference's own generate_dist_input_batch (uniform) run on a RECORDED stream of uniforms: pins the
+    transformation uniforms -> (offsets, indices) that oracle.bags_from_uniforms restates."""
+    class Recorder:
+        def __init__(self, seed):
+            self.rs, self.log = np.random.RandomState(seed), []
+        def random(self, k=None):
+            r = self.rs.random_sample(k)
+            self.log.append(np.atleast_1d(np.asarray(r, dtype=np.float64)).copy())
+            return r
+        def rand(self, *shape):
+            return self.rs.rand(*shape)
+    out, cases = {}, []
+    for tag, ln_emb, n, P, fixed in (("var_p10", [1000, 3, 40000000], 64, 10, False), ("fixed_p4", [7, 100000], 50, 4, True),
+                                     ("onehot", [5, 39884406], 80, 1, True), ("var_small_tables", [1, 2, 3], 40, 6, False)):
+        rec = Recorder(1234)
+        saved, dp.ra = dp.ra, rec
+        try:
+            X, lS_o, lS_i = dp.generate_dist_input_batch(3, np.asarray(ln_emb), n, P, fixed, "uniform", 0, 1, -1, 1)
+        finally:
+            dp.ra = saved
+        out[f"{tag}.uniforms"] = np.concatenate(rec.log)
+        for k in range(len(ln_emb)):
+            out[f"{tag}.off{k}"], out[f"{tag}.idx{k}"] = lS_o[k].numpy(), lS_i[k].numpy()
+        cases.append(dict(tag=tag, ln_emb=ln_emb, n=n, P=P, fixed=fixed))
+    out["meta"] = np.frombuffer(json.dumps(dict(name=name, cases=cases)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(name, [(c["tag"], int(sum(out[f"{c['tag']}.idx{k}"].size for k in range(len(c["ln_emb"]))))) for c in cases])
+
+
 def capture_metrics(name="metrics_sklearn"):
     """scores/targets -> the scikit-learn numbers inference() reports (dlrm_s_pytorch.py:828-847)."""
     import sklearn.metrics as M
@@ -331,6 +361,8 @@ def main(which):
         capture_adagrad(ref, dp)
     if which in ("all", "book"):
         capture_bookkeeping(ref, ext)
+    if which in ("all", "datagen"):
+        capture_datagen(dp)
     if which in ("all", "dist"):
         capture_distributed()
     if which == "all":

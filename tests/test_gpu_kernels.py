@@ -399,3 +399,63 @@ def test_binary_metrics_large_and_degenerate():
     assert np.isnan(one_class["roc_auc"]) and np.isnan(one_class["ap"]) and one_class["recall"] == 0.0
     const = ops.binary_metrics(torch.full((1000,), 0.5, device=dev()), to_dev(t[:1000]))
     assert abs(const["roc_auc"] - 0.5) < 1e-12       # one threshold: the ROC curve is the diagonal
+
+
+# ------------------------------------------------------------------------------------------ synthetic input generator
+@pytest.mark.parametrize("P,fixed", [(1, True), (4, True), (10, False), (37, False)])
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_datagen_bit_exact_against_oracle(P, fixed, idx_dtype):
+    """Device generator vs oracle.philox_bags / philox_dense: the integer bookkeeping (bag lengths, offsets, sorted unique
+    indices) must agree bit for bit; the transformation itself is pinned to the reference generator on CPU."""
+    from dlrm_amd.datagen import UniformBatchGenerator
+    rows = [1, 2, 3, 1000, 39884406, 7]
+    B = 777
+    gen = UniformBatchGenerator(13, rows, P, fixed, round_targets=True, seed=5, device=dev(), index_dtype=idx_dtype)
+    X, lS_o, lS_i, T = gen.batch(B, batch_no=3)
+    torch.cuda.synchronize()
+    assert np.array_equal(X.cpu().numpy().reshape(-1), O.philox_dense(B * 13, gen._seed(3, 1)))
+    assert np.array_equal(T.cpu().numpy().reshape(-1), O.philox_dense(B, gen._seed(3, 2), round_values=True))
+    for t, n in enumerate(rows):
+        off, idx = O.philox_bags(t, n, B, P, fixed, gen._seed(3, 16))
+        assert lS_o[t].dtype == idx_dtype and lS_i[t].dtype == idx_dtype
+        assert np.array_equal(lS_o[t].cpu().numpy().astype(np.int64), off), t
+        assert np.array_equal(lS_i[t].cpu().numpy().astype(np.int64), idx), t
+
+
+def test_datagen_full_batch_properties():
+    """MLPerf batch (65536) x 26 Criteo tables, reference default pooling (up to 10 lookups): size-independent
+    properties — offsets are the running sum of bag lengths, bags are sorted + unique + in range, bag lengths and
+    indices follow the reference's distributions — and the batch feeds the embedding kernel."""
+    from dlrm_amd import ops
+    from dlrm_amd.datagen import UniformBatchGenerator
+    rows = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155, 4, 976,
+            14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]
+    B = 65536
+    gen = UniformBatchGenerator(13, rows, 10, False, seed=727, device=dev())
+    X, lS_o, lS_i, T = gen.batch(B, 0)
+    X2, lS_o2, lS_i2, _ = gen.batch(B, 1)
+    assert not torch.equal(X, X2) and not torch.equal(lS_i[0][:1000], lS_i2[0][:1000])      # batches differ
+    Xr, lS_or, lS_ir, _ = gen.batch(B, 0)
+    assert torch.equal(X, Xr) and all(torch.equal(a, b) for a, b in zip(lS_i, lS_ir))        # and are reproducible
+    assert 0.49 < float(X.mean()) < 0.51 and float(X.min()) >= 0 and float(X.max()) <= 1
+    assert set(torch.unique(T).tolist()) <= {0.0, 1.0} and 0.49 < float(T.mean()) < 0.51
+    for t, n in enumerate(rows):
+        off, idx = lS_o[t], lS_i[t]
+        lens = torch.diff(torch.cat([off, torch.tensor([idx.numel()], device=off.device)]))
+        assert int(off[0]) == 0 and int(lens.min()) >= 1 and int(lens.max()) <= min(n, 10)
+        assert int(idx.min()) >= 0 and int(idx.max()) <= n - 1
+        # strictly increasing inside every bag: the only non-increasing steps are at bag starts
+        dec = (idx[1:] <= idx[:-1]).nonzero().flatten() + 1
+        starts = torch.zeros(idx.numel(), dtype=torch.bool, device=idx.device)
+        starts[off] = True
+        assert bool(starts[dec].all()), t
+        if n >= 100000:    # mean pooling of round(max(1, U*10)) is ~5.05 before duplicates are removed (rare in a large table)
+            assert 4.9 < float(lens.float().mean()) < 5.2, (t, float(lens.float().mean()))
+            assert abs(float(idx.double().mean()) / (n - 1) - 0.5) < 0.01
+    # the generated batch drives the embedding kernel (indices are in range: no fault, pooled sums are finite)
+    D = 16
+    Ws = [torch.randn(min(n, 50000), D, device=dev()) for n in rows]
+    capped = [torch.remainder(i, w.size(0)) for i, w in zip(lS_i, Ws)]
+    out = torch.empty(B, len(rows) * D, device=dev())
+    ops.emb_fwd(Ws, ops.BagBatch(lS_o, capped), out)
+    assert bool(torch.isfinite(out).all())

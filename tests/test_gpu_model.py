@@ -101,6 +101,76 @@ def test_rwsadagrad_training_matches_reference_golden():
     assert opt.state[model.emb_l[0].weight]["step"] == 3
 
 
+def test_graphed_step_equals_eager_step():
+    """The whole-step HIP graph (dlrm_amd.graph) replays exactly the kernels of the eager step: same losses, same
+    parameters, bit for bit (deterministic embedding update), over more steps than the warm-up + capture."""
+    from dlrm_amd.graph import GraphedTrainStep
+    from dlrm_amd.optim import FusedSGD
+    d, meta = load_golden("config1_b128")
+    device = torch.device("cuda:0")
+    batches = [(torch.from_numpy(X).to(device), [torch.from_numpy(o).to(device) for o in lS_o],
+                [torch.from_numpy(i).to(device) for i in lS_i], torch.from_numpy(T).to(device))
+               for X, lS_o, lS_i, T in golden_batches(d, meta)]
+    # fixed shapes are required for replay: rebuild the sparse inputs as one lookup per bag
+    B = batches[0][0].size(0)
+    fixed = []
+    for X, lS_o, lS_i, T in batches:
+        idx = [i[o.clamp(max=max(i.numel() - 1, 0))] if i.numel() else i for o, i in zip(lS_o, lS_i)]
+        off = [torch.arange(B, device=device)] * len(idx)
+        fixed.append((X, off, idx, T))
+    seq = [fixed[i % len(fixed)] for i in range(7)]
+    results = []
+    for use_graph in (False, True):
+        model = build_model(meta, params_with_prefix(d, "init"), device)
+        opt = FusedSGD(model.parameters(), lr=meta["lr"])
+        losses = []
+        if use_graph:
+            # one ordinary eager step first, its loss tensor (and with it the autograd graph and the parameters'
+            # AccumulateGrad nodes of the default stream) deliberately kept alive across the capture
+            X, off, idx, T = seq[0]
+            keep = model.loss_fn(model(X, off, idx), T)
+            opt.zero_grad()
+            keep.backward()
+            opt.step()
+            losses.append(float(keep.detach()))
+            step = GraphedTrainStep(model, opt, warmup=2)
+            for X, off, idx, T in seq[1:]:
+                losses.append(float(step(X, off, idx, T)))
+            assert step.captures == 1 and keep.grad_fn is not None
+        else:
+            for X, off, idx, T in seq:
+                E = model.loss_fn(model(X, off, idx), T)
+                opt.zero_grad()
+                E.backward()
+                opt.step()
+                losses.append(float(E.detach()))
+        results.append((losses, {k: v.clone() for k, v in model.state_dict().items()}))
+    assert results[0][0] == results[1][0], (results[0][0], results[1][0])
+    for k in results[0][1]:
+        assert torch.equal(results[0][1][k], results[1][1][k]), k
+
+
+def test_inference_metrics_on_device():
+    """dlrm_amd.evaluate.inference (forward + device-side metrics) against the oracle forward + numpy metrics."""
+    from dlrm_amd.evaluate import inference
+    d, meta = load_golden("config1_b128")
+    device = torch.device("cuda:0")
+    model = build_model(meta, params_with_prefix(d, "init"), device)
+    gb = golden_batches(d, meta)
+    batches = [(torch.from_numpy(X), [torch.from_numpy(o) for o in lS_o], [torch.from_numpy(i) for i in lS_i],
+                torch.from_numpy(T)) for X, lS_o, lS_i, T in gb]
+    m = inference(model, batches, device)
+    S = d["s0.Z"]                                  # golden predictions of the untrained model exist for batch 0 only
+    ref = O.OracleDLRM(params_with_prefix(d, "init"), sigmoid_top=meta["sigmoid_top"])
+    Zs = [ref.forward(X, lS_o, lS_i) for X, lS_o, lS_i, T in gb]
+    np.testing.assert_allclose(Zs[0], S, rtol=2e-5, atol=1e-6)
+    o = O.binary_metrics(np.concatenate(Zs), np.concatenate([T for *_, T in gb]))
+    assert m["n"] == o["n"] and m["positives"] == o["positives"]
+    # scores differ from the oracle's in the last bits: the rank statistics agree to ~1e-4, the counts almost always exactly
+    assert abs(m["roc_auc"] - o["roc_auc"]) < 2e-3 and abs(m["ap"] - o["ap"]) < 2e-3
+    assert abs(m["accuracy"] - o["accuracy"]) <= 2.0 / o["n"]
+
+
 def test_reference_shaped_helpers():
     """apply_emb / interact_features / apply_mlp called one by one like tools/visualize.py does"""
     d, meta = load_golden("config1_b128")

@@ -165,3 +165,38 @@ def test_binary_metrics_oracle_matches_scikit_learn():
         for k in ("recall", "precision", "f1", "ap", "roc_auc", "accuracy"):
             assert abs(m[k] - case[k]) <= 1e-12 + 1e-10 * abs(case[k]), (case["tag"], k, m[k], case[k])
         assert m["round_matches"] == case["round_matches"]
+
+
+def test_datagen_transformation_matches_reference_generator():
+    """oracle.bags_from_uniforms replays the uniforms the reference's generate_dist_input_batch consumed
+    (dlrm_data_pytorch.py:899-960) and must reproduce its offsets / indices bit for bit."""
+    d, meta = load_golden("datagen_uniform")
+    for case in meta["cases"]:
+        u = d[case["tag"] + ".uniforms"]
+        pos = [0]
+
+        def draw(k):
+            out = u[pos[0]:pos[0] + k]
+            pos[0] += k
+            return out
+        for k, rows in enumerate(case["ln_emb"]):
+            off, idx = O.bags_from_uniforms(draw, rows, case["n"], case["P"], case["fixed"])
+            assert np.array_equal(off, d[f"{case['tag']}.off{k}"]) and np.array_equal(idx, d[f"{case['tag']}.idx{k}"]), (case, k)
+        assert pos[0] == u.size
+
+
+def test_philox_known_answers():
+    """Philox4x32-10 known-answer vectors (Random123 kat_vectors: zero counter/key, and all-ones)."""
+    z = O.philox4x32(0, 0, 0, 0, 0)
+    assert [int(x) for x in z] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    o = O.philox4x32(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffffffffffff)
+    assert [int(x) for x in o] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    # statistical sanity of the derived streams
+    x = O.philox_dense(200001, 7)
+    assert x.dtype == np.float32 and 0.0 <= x.min() and x.max() <= 1.0 and abs(x.mean() - 0.5) < 5e-3
+    off, idx = O.philox_bags(2, 1000, 500, 10, False, 99)
+    lens = np.diff(np.r_[off, idx.size])
+    assert lens.min() >= 1 and lens.max() <= 10 and idx.min() >= 0 and idx.max() <= 999
+    for b in range(500):
+        seg = idx[off[b]:off[b] + lens[b]]
+        assert np.all(np.diff(seg) > 0)          # sorted, unique
