@@ -57,7 +57,8 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="run the timed region as HIP-graph replays of the captured step (dlrm_amd.graph; N=1 only, implies "
                          "--no-kernel-timers: events cannot be recorded inside a replay)")
-    ap.add_argument("--no-alt-graph", action="store_true", help="skip the extra HIP-graph replay measurement")
+    ap.add_argument("--alt-graph", action="store_true",
+                    help="after the timed region, also measure the same step replayed as one HIP graph (reported as alt_hip_graph)")
     ap.add_argument("--no-kernel-timers", action="store_true", help="no per-kernel HIP events in the timed region (no roofline)")
     ap.add_argument("--timer-every", type=int, default=4,
                     help="per-kernel HIP events are recorded on every n-th step of the timed region (each event pair costs "
@@ -65,6 +66,8 @@ def parse():
     ap.add_argument("--cpu-row-cap", type=int, default=1000000)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "rwsadagrad"],
+                    help="sgd: the reference default (and the headline); rwsadagrad: row-wise sparse Adagrad (K4, optim/rwsadagrad.py)")
     ap.add_argument("--mlp-arith", default=os.environ.get("DLRM_MLP_ARITH", "f32"), choices=["f32", "bf16x6"],
                     help="f32: native fp32 MFMA; bf16x6: exact 3-term bf16 split of the fp32 operands, 6 bf16 MFMA products, "
                          "fp32 accumulation (fp32 round-off class)")
@@ -72,15 +75,15 @@ def parse():
 
 
 def make_batches(n, B, rows, device, seed):
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
+    """Synthetic batches in the reference's layout (dlrm_data_pytorch.py:899-960 with one lookup per bag, as the Criteo
+    data sets have): indices and offsets as stacked [T, B] int64 tensors (row t = table t), generated on the device by
+    dlrm_amd.datagen (same distributions as the reference generator, Philox stream)."""
+    from dlrm_amd.datagen import UniformBatchGenerator
+    gen = UniformBatchGenerator(13, rows, 1, True, round_targets=True, seed=seed, device=device)
     out = []
-    for _ in range(n):
-        X = torch.rand((B, 13), generator=g, device=device)
-        idx = [torch.randint(0, r, (B,), generator=g, device=device, dtype=torch.int64) for r in rows]
-        off = torch.arange(B, device=device, dtype=torch.int64)
-        T = torch.round(torch.rand((B, 1), generator=g, device=device))
-        out.append((X, [off] * len(rows), idx, T))
+    for k in range(n):
+        X, lS_o, lS_i, T = gen.batch(B, batch_no=k)
+        out.append((X, torch.stack(lS_o), torch.stack(lS_i), T))
     return out
 
 
@@ -128,6 +131,9 @@ def load_pmc_traffic():
 
 def main():
     args = parse()
+    if os.environ.get("DLRM_BENCH_WATCHDOG"):       # debugging aid: dump every thread's Python stack after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DLRM_BENCH_WATCHDOG"]), repeat=False, exit=False)
     wl = dict(WORKLOADS[args.workload])
     if args.batch:
         wl["batch"] = args.batch
@@ -140,7 +146,7 @@ def main():
 
     import dlrm_amd
     from dlrm_amd import ext_dist, ops
-    from dlrm_amd.optim import FusedSGD
+    from dlrm_amd.optim import FusedRWSAdagrad, FusedSGD
 
     if N > 1:
         ext_dist.init_distributed(use_gpu=True, backend="nccl")   # RCCL
@@ -167,9 +173,9 @@ def main():
         groups = [{"params": [p for e in model.emb_l for p in e.parameters()], "lr": args.lr},
                   {"params": model.bot_l.parameters(), "lr": args.lr},
                   {"params": model.top_l.parameters(), "lr": args.lr}]
-        opt = FusedSGD(groups, lr=args.lr)
+        opt = FusedSGD(groups, lr=args.lr) if args.optimizer == "sgd" else FusedRWSAdagrad(groups, lr=args.lr)
     else:
-        opt = FusedSGD(model.parameters(), lr=args.lr)
+        opt = (FusedSGD if args.optimizer == "sgd" else FusedRWSAdagrad)(model.parameters(), lr=args.lr)
 
     batches = make_batches(4, B, rows, device, seed=727)     # every rank reads the whole global batch (reference :1541)
     my_rows = ext_dist.get_my_slice(B) if N > 1 else slice(0, B)
@@ -243,6 +249,7 @@ def main():
     for name, work, unit, peak, bound in (
             ("emb_fwd", emb_fwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("emb_bwd_sgd", emb_bwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
+            ("emb_bwd_adagrad", emb_bwd_bytes + Tl * B * 8, "GB/s", HBM_PEAK_GBS, "hbm"),   # + row-wise state read/write per touched row
             ("interact_fwd", inter_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("interact_bwd", 2 * inter_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("linear_fwd", fwd_fl, "TFLOP/s", FP32_MFMA_PEAK_TF, "mfma"),
@@ -266,6 +273,7 @@ def main():
     kname = {"linear_fwd": "gemm3_kernel<KC,KC> (Y = X*W^T + bias, act; LDS-DMA ring, 256x128x16 tiles)",
              "linear_bwd_data": "gemm3_kernel<KC,KS> (dX = dY*W, previous layer's act' fused in the epilogue)",
              "linear_bwd_weight": "gemm3_kernel<KS,KS> (dW = dY^T*X split over the batch + bias-grad row sums) + splitk_reduce_kernel",
+             "emb_bwd_adagrad": "expand + rocprim radix sort + adagrad_groups_kernel + adagrad_fixup_kernel",
              "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "expand + rocprim radix sort + sorted_update_kernel" if args.emb_update == "sorted" else "emb_bwd_sgd_{atomic,lds}_kernel",
              "interact_fwd": "interact_fwd_dma_kernel", "interact_bwd": "interact_bwd_dma_kernel"}
     pmc = load_pmc_traffic() if (N == 1 and args.workload == "criteo_terabyte" and not args.batch and not args.row_cap) else None
@@ -286,11 +294,12 @@ def main():
         "metric": "samples/sec (global batch) + embedding HBM GB/s, Criteo-TB config",
         "value": value, "unit": "samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic (uniform one-hot indices, uniform dense features, rounded targets; random-init parameters)",
+        "data": "synthetic (the reference's random generator distributions, one lookup per bag, produced on the device by "
+                "dlrm_amd.datagen; random-init parameters)",
         "config": {"workload": args.workload + (": MLPerf Criteo-Terabyte shapes (BASELINE.json configs[2])"
                                                 if args.workload == "criteo_terabyte" else ""),
                    "tables": len(rows), "emb_dim": D, "global_batch": B, "table_rows_total": int(sum(rows)),
-                   "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": "sgd",
+                   "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": args.optimizer,
                    "loss": "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
                    "embedding_update": args.emb_update,
                    "launch": "HIP graph replay of the captured step (dlrm_amd.graph)" if graphed is not None else "eager (one C-ABI call per kernel)",
@@ -321,7 +330,7 @@ def main():
                                    "final_loss": float(loss_alt.detach()),
                                    "note": "opt-in (--mlp-arith bf16x6); parity-tested at the fp32 tolerances"}
         del loss_alt
-    if N == 1 and graphed is None and not args.no_alt_graph:
+    if N == 1 and graphed is None and args.alt_graph:
         # the same step captured once in a HIP graph and replayed (dlrm_amd.graph): removes the host launch path; reported
         # beside the headline value.  Never allowed to break the headline line.
         try:

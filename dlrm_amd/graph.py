@@ -15,6 +15,9 @@ Constraints (checked, never silently worked around):
   * single process (ext_dist.my_size == 1): RCCL collectives and DDP hooks are not captured;
   * fixed shapes: every call must pass tensors of the shapes/dtypes of the first call (multi-hot batches whose number
     of lookups varies cannot be replayed) — inputs are copied into static device buffers before each replay;
+  * no autograd graph of an earlier eager step may still be alive at capture time (e.g. a loss tensor the caller kept):
+    the autograd engine would synchronise the capture stream with the stream those old nodes were created on, which
+    invalidates the capture.  Reduce losses to Python floats (`float(loss)`) or `del` them before the first graphed call;
   * learning rates are baked into kernel arguments at capture time: when a scheduler changes a param group's lr the
     step is re-captured (correct, but a schedule that changes lr every step gains nothing from replay).
 """
@@ -52,7 +55,7 @@ def _copy_struct(dst: TensorOrList, src: TensorOrList) -> None:
         return
     if isinstance(src, torch.Tensor) or len(src) != len(dst):
         raise RuntimeError("dlrm_amd.graph: input structure differs from the captured step")
-    d_list, s_list, done = [], [], set()
+    done = set()
     for d, s_ in zip(dst, src):
         if s_.shape != d.shape or s_.dtype != d.dtype:
             raise RuntimeError("dlrm_amd.graph: input shape/dtype differs from the captured step "
@@ -60,10 +63,10 @@ def _copy_struct(dst: TensorOrList, src: TensorOrList) -> None:
         if id(d) in done or s_.data_ptr() == d.data_ptr():
             continue
         done.add(id(d))
-        d_list.append(d)
-        s_list.append(s_)
-    if d_list:
-        torch._foreach_copy_(d_list, s_list, non_blocking=True)
+        # one copy_ per distinct tensor.  (torch._foreach_copy_ on int64 lists raised GPU memory faults on
+        # torch 2.10 + ROCm 7 at B = 65536 — profiles/r02/graph_probe.md; pass stacked [T, B] index / offset tensors to
+        # make this a single copy.)
+        d.copy_(s_, non_blocking=True)
 
 
 class GraphedTrainStep:
