@@ -25,6 +25,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Union
 
+import os as _os
+
 import torch
 
 from . import ext_dist, ops
@@ -90,6 +92,8 @@ class GraphedTrainStep:
         self._lrs: List[float] = []
         self.captures = 0
         self._eager_calls = 0
+        self._done: Optional[torch.cuda.Event] = None
+        self.serialize = _os.environ.get("DLRM_GTS_SERIALIZE", "1") == "1"
 
     # one eager training step on the static buffers (the reference loop body)
     def _eager(self):
@@ -130,6 +134,13 @@ class GraphedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(self.stream)
 
     def __call__(self, X, lS_o, lS_i, T):
+        if self._done is not None:
+            # at most ONE replay in flight: with a second hipGraphLaunch of the same executable graph queued behind a
+            # running one, the two instances were observed to overlap on ROCm 7.2 (they share every intermediate buffer:
+            # GPU memory faults at Criteo-Terabyte sizes, where the host runs ahead of the 9 ms replay —
+            # profiles/r02/graph_probe.md).  The host waits for the previous replay before it touches the static inputs.
+            self._done.synchronize()
+            self._done = None
         if self.static is None:
             self.static = (X.clone(), _clone_struct(lS_o), _clone_struct(lS_i), T.clone())
         else:
@@ -154,4 +165,7 @@ class GraphedTrainStep:
         if self.graph is None or self._lrs != self._current_lrs():
             self._capture()          # capture only records; the replay below executes this step
         self.graph.replay()
+        if self.serialize:
+            self._done = torch.cuda.Event()
+            self._done.record()
         return self.loss

@@ -93,31 +93,50 @@ class BagBatch:
             raise RuntimeError("dlrm_amd: offsets / indices table counts differ")
         self.T = T
         self.keep = []  # keep tensors alive while kernels may still read them
-        idx_ptrs, off_ptrs, nnz = [], [], []
-        dt = None
-        B = None
-        for k in range(T):
-            i_k, o_k = lS_i[k], lS_o[k]
-            if i_k.dtype not in (torch.int64, torch.int32) or o_k.dtype != i_k.dtype:
+        if isinstance(lS_i, torch.Tensor) and isinstance(lS_o, torch.Tensor) and lS_i.dim() == 2 and lS_o.dim() == 2:
+            # stacked [T, n] inputs (what the reference's collate functions build, dlrm_data_pytorch.py:686,337): the
+            # per-table pointers are plain address arithmetic — no 2*T view tensors per step on the host path
+            if lS_i.dtype not in (torch.int64, torch.int32) or lS_o.dtype != lS_i.dtype:
                 raise RuntimeError("dlrm_amd: indices/offsets must both be int64 or both int32")
-            if dt is None:
-                dt = i_k.dtype
-            elif dt != i_k.dtype:
-                raise RuntimeError("dlrm_amd: all tables must use the same index dtype")
-            if not i_k.is_cuda or not o_k.is_cuda:
+            if not lS_i.is_cuda or not lS_o.is_cuda:
                 raise RuntimeError("dlrm_amd: indices/offsets must be GPU tensors")
-            if not i_k.is_contiguous():
-                i_k = i_k.contiguous()
-            if not o_k.is_contiguous():
-                o_k = o_k.contiguous()
-            if B is None:
-                B = o_k.numel()
-            elif B != o_k.numel():
-                raise RuntimeError("dlrm_amd: every table must have the same number of bags")
-            self.keep += [i_k, o_k]
-            idx_ptrs.append(i_k.data_ptr() if i_k.numel() else 0)
-            off_ptrs.append(o_k.data_ptr())
-            nnz.append(i_k.numel())
+            if lS_i.stride(1) != 1 and lS_i.size(1) > 1:
+                lS_i = lS_i.contiguous()
+            if lS_o.stride(1) != 1 and lS_o.size(1) > 1:
+                lS_o = lS_o.contiguous()
+            self.keep += [lS_i, lS_o]
+            isz = lS_i.element_size()
+            B, n_i = lS_o.size(1), lS_i.size(1)
+            dt = lS_i.dtype
+            idx_ptrs = [lS_i.data_ptr() + k * lS_i.stride(0) * isz if n_i else 0 for k in range(T)]
+            off_ptrs = [lS_o.data_ptr() + k * lS_o.stride(0) * isz for k in range(T)]
+            nnz = [n_i] * T
+        else:
+            idx_ptrs, off_ptrs, nnz = [], [], []
+            dt = None
+            B = None
+            for k in range(T):
+                i_k, o_k = lS_i[k], lS_o[k]
+                if i_k.dtype not in (torch.int64, torch.int32) or o_k.dtype != i_k.dtype:
+                    raise RuntimeError("dlrm_amd: indices/offsets must both be int64 or both int32")
+                if dt is None:
+                    dt = i_k.dtype
+                elif dt != i_k.dtype:
+                    raise RuntimeError("dlrm_amd: all tables must use the same index dtype")
+                if not i_k.is_cuda or not o_k.is_cuda:
+                    raise RuntimeError("dlrm_amd: indices/offsets must be GPU tensors")
+                if not i_k.is_contiguous():
+                    i_k = i_k.contiguous()
+                if not o_k.is_contiguous():
+                    o_k = o_k.contiguous()
+                if B is None:
+                    B = o_k.numel()
+                elif B != o_k.numel():
+                    raise RuntimeError("dlrm_amd: every table must have the same number of bags")
+                self.keep += [i_k, o_k]
+                idx_ptrs.append(i_k.data_ptr() if i_k.numel() else 0)
+                off_ptrs.append(o_k.data_ptr())
+                nnz.append(i_k.numel())
         self.B = int(B)
         self.idx_bits = 64 if dt == torch.int64 else 32
         self.nnz = nnz

@@ -56,6 +56,33 @@ def test_emb_fwd_bit_exact(D, idx_dtype):
     assert torch.all(buf[:, :D] == -7.0) and torch.all(buf[:, D + len(rows) * D:] == -7.0)
 
 
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_emb_stacked_inputs_equal_lists(idx_dtype):
+    """Stacked [T, B] offsets/indices (the reference's collate layout) take the pointer-arithmetic path of BagBatch:
+    same results as the list form, also for a row-sliced (table-sharded) view."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(77)
+    rows, B, D = [5, 1000, 33, 70000], 333, 32
+    Ws = [to_dev(rng.standard_normal((n, D)).astype(np.float32)) for n in rows]
+    idx = np.stack([rng.integers(0, n, size=B) for n in rows]).astype(np.int64)
+    off = np.tile(np.arange(B, dtype=np.int64), (len(rows), 1))
+    want = np.concatenate([O.emb_fwd(W.cpu().numpy(), idx[t], off[t]) for t, W in enumerate(Ws)], axis=1)
+    I, Ofs = to_dev(idx, idx_dtype), to_dev(off, idx_dtype)
+    out = torch.empty(B, len(rows) * D, device=dev())
+    ops.emb_fwd(Ws, ops.BagBatch(Ofs, I), out)
+    assert np.array_equal(out.cpu().numpy(), want)
+    out2 = torch.empty(B, 2 * D, device=dev())
+    ops.emb_fwd(Ws[1:3], ops.BagBatch(Ofs[1:3], I[1:3]), out2)
+    assert np.array_equal(out2.cpu().numpy(), want[:, D:3 * D])
+    dV = to_dev(rng.standard_normal((B, len(rows) * D)).astype(np.float32))
+    W1 = [w.clone() for w in Ws]
+    W2 = [w.clone() for w in Ws]
+    ops.emb_bwd_sgd(W1, ops.BagBatch(Ofs, I), dV, 0.1, ops.UPD_DETERMINISTIC)
+    ops.emb_bwd_sgd(W2, ops.BagBatch([Ofs[t] for t in range(4)], [I[t] for t in range(4)]), dV, 0.1, ops.UPD_DETERMINISTIC)
+    for a, b in zip(W1, W2):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("D", [2, 16, 128, 200])
 def test_emb_bwd_sgd_deterministic_bit_exact(D):
     from dlrm_amd import ops
