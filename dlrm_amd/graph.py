@@ -18,6 +18,9 @@ Constraints (checked, never silently worked around):
   * no autograd graph of an earlier eager step may still be alive at capture time (e.g. a loss tensor the caller kept):
     the autograd engine would synchronise the capture stream with the stream those old nodes were created on, which
     invalidates the capture.  Reduce losses to Python floats (`float(loss)`) or `del` them before the first graphed call;
+  * KNOWN ISSUE (profiles/r02/graph_probe.md, d): at Criteo-Terabyte shapes a run of the form "5 replays, host sync, >= 8
+    replays in total" ended in a GPU memory fault on ROCm 7.2, while 24 back-to-back replays, a sync after every replay,
+    and every pattern at Criteo-Kaggle shapes are clean.  Opt-in until understood; the eager path is the default everywhere;
   * learning rates are baked into kernel arguments at capture time: when a scheduler changes a param group's lr the
     step is re-captured (correct, but a schedule that changes lr every step gains nothing from replay).
 """
@@ -32,6 +35,7 @@ import torch
 from . import ext_dist, ops
 
 TensorOrList = Union[torch.Tensor, Sequence[torch.Tensor]]
+_TRACE = _os.environ.get("DLRM_GTS_TRACE", "0") == "1"
 
 
 def _clone_struct(x: TensorOrList):
@@ -134,6 +138,9 @@ class GraphedTrainStep:
         torch.cuda.current_stream(dev).wait_stream(self.stream)
 
     def __call__(self, X, lS_o, lS_i, T):
+        if _TRACE:
+            print("[gts] call eager=%d captures=%d pending_event=%s" % (self._eager_calls, self.captures, self._done is not None),
+                  flush=True)
         if self._done is not None:
             # at most ONE replay in flight: with a second hipGraphLaunch of the same executable graph queued behind a
             # running one, the two instances were observed to overlap on ROCm 7.2 (they share every intermediate buffer:
