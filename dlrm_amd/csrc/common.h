@@ -49,3 +49,14 @@ int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_ho
                                  const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
                                  const float* dout, int64_t dout_ld, float lr, void* workspace,
                                  int64_t workspace_bytes, void* stream);
+
+// gemv.hip: the N == 1 MLP layer as HBM-streaming kernels; each returns 0 when it handled the call and
+// DLRM_GEMV_NOT_HANDLED when the shape/alignment is outside its fast path (the caller then uses the GEMM kernels).
+#define DLRM_GEMV_NOT_HANDLED (-100)
+int64_t dlrm_gemv_bwd_weight_workspace_bytes(int64_t M, int K);
+int dlrm_gemv_fwd(int64_t M, int K, const float* X, int64_t ldx, const float* w, const float* bias, int act, float* Y,
+                  int64_t ldy, hipStream_t st);
+int dlrm_gemv_bwd_data(int64_t M, int K, const float* dY, int64_t lddy, const float* w, const float* Xact, int64_t ldxa,
+                       int kind, float* dX, int64_t lddx, hipStream_t st);
+int dlrm_gemv_bwd_weight(int64_t M, int K, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,
+                         float* dbias, int accumulate, void* workspace, int64_t workspace_bytes, hipStream_t st);

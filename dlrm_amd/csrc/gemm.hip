@@ -776,6 +776,10 @@ extern "C" int dlrm_linear_fwd(int64_t M, int N, int K, const float* X, int64_t 
     if (M <= 0 || N <= 0 || K <= 0 || !X || !W || !Y) return DLRM_E_ARG;
     if (ldx < K || ldw < K || ldy < N) return DLRM_E_ARG;
     if (act < DLRM_ACT_NONE || act > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
+    if (N == 1 && gemm_path() != 2) {                // matrix-vector layer: HBM streaming, not MFMA (gemv.hip)
+        const int rc = dlrm_gemv_fwd(M, K, X, ldx, W, bias, act, Y, ldy, (hipStream_t)stream);
+        if (rc != DLRM_GEMV_NOT_HANDLED) return rc;
+    }
     GemmArgs g = {};
     g.M = M; g.N = N; g.K = K;
     g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
@@ -793,6 +797,11 @@ extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, in
     if (lddy < N || ldw < K || lddx < K) return DLRM_E_ARG;
     if (xact_kind < DLRM_ACT_NONE || xact_kind > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
     if (xact_kind != DLRM_ACT_NONE && (!Xact || ldxa < K)) return DLRM_E_ARG;
+    if (N == 1 && gemm_path() != 2) {
+        const int rc = dlrm_gemv_bwd_data(M, K, dY, lddy, W, xact_kind != DLRM_ACT_NONE ? Xact : nullptr, ldxa, xact_kind, dX,
+                                          lddx, (hipStream_t)stream);
+        if (rc != DLRM_GEMV_NOT_HANDLED) return rc;
+    }
     GemmArgs g = {};
     g.M = M; g.N = K; g.K = N;                       // output [M, K_layer], reduce over N_layer
     g.A = dY; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = lddx;
@@ -824,9 +833,13 @@ extern "C" int64_t dlrm_linear_bwd_weight_workspace_bytes(int64_t M, int N, int 
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     int splits; int64_t kchunk;
     wgrad_plan(M, N, K, &splits, &kchunk);
-    if (splits <= 1) return 0;
     const int64_t ldp = ((int64_t)K + 3) & ~(int64_t)3;
-    return (int64_t)splits * N * ldp * (int64_t)sizeof(float);
+    int64_t need = splits <= 1 ? 0 : (int64_t)splits * N * ldp * (int64_t)sizeof(float);
+    if (N == 1) {                                    // the matrix-vector path keeps per-workgroup column partials
+        const int64_t gv = dlrm_gemv_bwd_weight_workspace_bytes(M, K);
+        if (gv > need) need = gv;
+    }
+    return need;
 }
 
 extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, int64_t lddy,
@@ -836,6 +849,10 @@ extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, 
     if (M <= 0 || N <= 0 || K <= 0 || !dY || !X || !dW) return DLRM_E_ARG;
     if (lddy < N || ldx < K || lddw < K) return DLRM_E_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (N == 1 && gemm_path() != 2) {
+        const int rc = dlrm_gemv_bwd_weight(M, K, dY, lddy, X, ldx, dW, dbias, accumulate, workspace, workspace_bytes, st);
+        if (rc != DLRM_GEMV_NOT_HANDLED) return rc;
+    }
     GemmArgs g = {};
     g.M = N; g.N = K; g.K = M;                       // output [N_layer, K_layer], reduce over the batch
     g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx; g.C = dW; g.ldc = lddw;

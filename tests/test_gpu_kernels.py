@@ -274,6 +274,42 @@ def test_linear_bwd_data_fused_mask():
     np.testing.assert_allclose(db.cpu().numpy(), 1.0 + dZ.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,K,act", [(5000, 256, 2), (333, 64, 1), (70001, 1024, 0), (129, 12, 2), (64, 100, 1)])
+def test_linear_single_output_layer(M, K, act):
+    """N == 1 (the last top-MLP layer): the matrix-vector kernels (gemv.hip) for K % 4 == 0 <= 1024, the GEMM path
+    otherwise — forward, masked data gradient, weight + bias gradient with and without accumulation."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + K)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((1, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(1).astype(np.float32)
+    Xd, Wd, bd = to_dev(X), to_dev(W), to_dev(b)
+    Yd = torch.empty((M, 1), device=dev())
+    ops.linear_fwd(Xd, Wd, bd, act, Yd)
+    np.testing.assert_allclose(Yd.cpu().numpy(), O.linear_fwd(X, W, b, act), rtol=1e-5, atol=1e-5)
+    dZ = rng.standard_normal((M, 1)).astype(np.float32)
+    mask = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    dXd = torch.empty((M, K), device=dev())
+    ops.linear_bwd_data(to_dev(dZ), Wd, to_dev(mask), 1, dXd)
+    np.testing.assert_allclose(dXd.cpu().numpy(), (dZ.astype(np.float64) @ W.astype(np.float64)) * (mask > 0), rtol=1e-5, atol=1e-6)
+    ops.linear_bwd_data(to_dev(dZ), Wd, None, 0, dXd)
+    np.testing.assert_allclose(dXd.cpu().numpy(), dZ.astype(np.float64) @ W.astype(np.float64), rtol=1e-5, atol=1e-6)
+    want_dW = dZ.astype(np.float64).T @ X.astype(np.float64)
+    want_db = dZ.astype(np.float64).sum(0)
+    tol = 1e-5 * max(1.0, float(np.abs(want_dW).max())) * 10
+    dWd, dbd = torch.full((1, K), 3.0, device=dev()), torch.full((1,), 3.0, device=dev())
+    ops.linear_bwd_weight(to_dev(dZ), Xd, dWd, dbd)                       # overwrite
+    np.testing.assert_allclose(dWd.cpu().numpy(), want_dW, rtol=1e-4, atol=tol)
+    np.testing.assert_allclose(dbd.cpu().numpy(), want_db, rtol=1e-4, atol=tol)
+    first = dWd.clone()
+    ops.linear_bwd_weight(to_dev(dZ), Xd, dWd, dbd, accumulate=True)      # accumulate on top
+    np.testing.assert_allclose(dWd.cpu().numpy(), 2 * want_dW, rtol=1e-4, atol=2 * tol)
+    np.testing.assert_allclose(dbd.cpu().numpy(), 2 * want_db, rtol=1e-4, atol=2 * tol)
+    again = torch.empty((1, K), device=dev())
+    ops.linear_bwd_weight(to_dev(dZ), Xd, again, None)
+    assert torch.equal(again, first)                                     # fixed-order partial sums: deterministic
+
+
 # ------------------------------------------------------------------------------------------ loss / SGD
 @pytest.mark.parametrize("B", [1, 7, 128, 65536])
 def test_bce_and_mse(B):
