@@ -839,6 +839,10 @@ extern "C" int64_t dlrm_linear_bwd_weight_workspace_bytes(int64_t M, int N, int 
         const int64_t gv = dlrm_gemv_bwd_weight_workspace_bytes(M, K);
         if (gv > need) need = gv;
     }
+    if (K <= 16 && M >= 4096) {
+        const int64_t sk = dlrm_smallk_bwd_weight_workspace_bytes(M, N, K);
+        if (sk > need) need = sk;
+    }
     return need;
 }
 
@@ -851,6 +855,10 @@ extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, 
     hipStream_t st = (hipStream_t)stream;
     if (N == 1 && gemm_path() != 2) {
         const int rc = dlrm_gemv_bwd_weight(M, K, dY, lddy, X, ldx, dW, dbias, accumulate, workspace, workspace_bytes, st);
+        if (rc != DLRM_GEMV_NOT_HANDLED) return rc;
+    }
+    if (K <= 16 && M >= 4096 && gemm_path() != 2) {
+        const int rc = dlrm_smallk_bwd_weight(M, N, K, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, st);
         if (rc != DLRM_GEMV_NOT_HANDLED) return rc;
     }
     GemmArgs g = {};

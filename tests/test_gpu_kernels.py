@@ -310,6 +310,42 @@ def test_linear_single_output_layer(M, K, act):
     assert torch.equal(again, first)                                     # fixed-order partial sums: deterministic
 
 
+@pytest.mark.parametrize("M,N,K,act", [(5000, 512, 16, 1), (4096, 64, 8, 1), (70001, 16, 4, 0), (4100, 1024, 12, 2)])
+def test_linear_small_reduction_layer(M, N, K, act):
+    """K <= 16 and M >= 4096 (the first bottom-MLP layer at training batch sizes): the weight/bias gradient runs the
+    streaming kernel of smallk.hip (forward stays on the GEMM kernel) — both against the oracle / a float64 restatement,
+    accumulate mode, run-to-run bit identity (fixed-order partial sums), strided destination."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    Xd, Wd, bd = to_dev(X), to_dev(W), to_dev(b)
+    Yd = torch.empty((M, N), device=dev())
+    ops.linear_fwd(Xd, Wd, bd, act, Yd)
+    np.testing.assert_allclose(Yd.cpu().numpy(), O.linear_fwd(X, W, b, act), rtol=1e-5, atol=1e-5)
+    dZ = rng.standard_normal((M, N)).astype(np.float32)
+    want_dW = dZ.astype(np.float64).T @ X.astype(np.float64)
+    want_db = dZ.astype(np.float64).sum(0)
+    tol = 1e-5 * max(1.0, float(np.abs(want_dW).max())) * 10
+    dZd = to_dev(dZ)
+    dWd, dbd = torch.full((N, K), 3.0, device=dev()), torch.full((N,), 3.0, device=dev())
+    ops.linear_bwd_weight(dZd, Xd, dWd, dbd)
+    np.testing.assert_allclose(dWd.cpu().numpy(), want_dW, rtol=1e-4, atol=tol)
+    np.testing.assert_allclose(dbd.cpu().numpy(), want_db, rtol=1e-4, atol=tol)
+    first = dWd.clone()
+    ops.linear_bwd_weight(dZd, Xd, dWd, dbd, accumulate=True)
+    np.testing.assert_allclose(dWd.cpu().numpy(), 2 * want_dW, rtol=1e-4, atol=2 * tol)
+    np.testing.assert_allclose(dbd.cpu().numpy(), 2 * want_db, rtol=1e-4, atol=2 * tol)
+    again = torch.empty((N, K), device=dev())
+    ops.linear_bwd_weight(dZd, Xd, again, None)
+    assert torch.equal(again, first)
+    # strided destination (a slot of a wider buffer, like the [B, (1+T)*D] feature buffer)
+    wide = torch.full((M, N + 8), -1.0, device=dev())
+    ops.linear_fwd(Xd, Wd, bd, act, wide[:, 4:4 + N])
+    assert torch.equal(wide[:, 4:4 + N], Yd) and torch.all(wide[:, :4] == -1.0) and torch.all(wide[:, 4 + N:] == -1.0)
+
+
 # ------------------------------------------------------------------------------------------ loss / SGD
 @pytest.mark.parametrize("B", [1, 7, 128, 65536])
 def test_bce_and_mse(B):
