@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "rwsadagrad"],
                     help="sgd: the reference default (and the headline); rwsadagrad: row-wise sparse Adagrad (K4, optim/rwsadagrad.py)")
-    ap.add_argument("--mlp-arith", default=os.environ.get("DLRM_MLP_ARITH", "f32"), choices=["f32", "bf16x6"],
+    ap.add_argument("--mlp-arith", default=os.environ.get("DLRM_MLP_ARITH", "f32"), choices=["f32", "bf16x6", "bf16"],
                     help="f32: native fp32 MFMA; bf16x6: exact 3-term bf16 split of the fp32 operands, 6 bf16 MFMA products, "
                          "fp32 accumulation (fp32 round-off class)")
     return ap.parse_args()
@@ -299,7 +299,8 @@ def main():
     result = {
         "metric": "samples/sec (global batch) + embedding HBM GB/s, Criteo-TB config",
         "value": value, "unit": "samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16" if args.mlp_arith == "bf16" else "f32",
         "data": "synthetic (the reference's random generator distributions, one lookup per bag, produced on the device by "
                 "dlrm_amd.datagen; random-init parameters)",
         "config": {"workload": args.workload + (": MLPerf Criteo-Terabyte shapes (BASELINE.json configs[2])"
@@ -309,8 +310,10 @@ def main():
                    "loss": "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
                    "embedding_update": args.emb_update,
                    "launch": "HIP graph replay of the captured step (dlrm_amd.graph)" if graphed is not None else "eager (one C-ABI call per kernel)",
-                   "mlp_arith": ("f32: native fp32 MFMA (v_mfma_f32_32x32x2_f32)" if args.mlp_arith == "f32" else
-                                 "bf16x6: fp32 operands split exactly into 3 bf16 terms in-kernel, 6 bf16 MFMA products, fp32 accumulate")},
+                   "mlp_arith": {"f32": "f32: native fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                                 "bf16x6": "bf16x6: fp32 operands split exactly into 3 bf16 terms in-kernel, 6 bf16 MFMA products, fp32 accumulate",
+                                 "bf16": "bf16: MLP operands rounded to bf16 in-kernel, one bf16 MFMA per 16-k step, fp32 accumulate "
+                                         "(reduced precision: NOT the headline configuration)"}[args.mlp_arith]},
         "final_loss": final_loss,
         "kernel_timing": "HIP events on the launch stream around every C-ABI call, on %d of the %d timed steps" % (timed_steps, args.steps),
         "roofline": roof(dom) if dom else None,

@@ -343,6 +343,20 @@ __device__ __forceinline__ Split3 split3(const float (&x)[8]) {
     }
     return r;
 }
+// ---- plain bf16 operands (ARITH = 2, "bf16": BASELINE.json configs[4], "bf16 MLP on MFMA") -----------------------
+// each fp32 operand is rounded to the nearest bf16 (ties to even, the rounding torch.bfloat16 conversion uses), ONE
+// v_mfma_f32_32x32x16_bf16 per 16-k step, fp32 accumulation and fp32 results: 16x the fp32 MFMA rate, ~3 significant
+// decimal digits per operand.
+__device__ __forceinline__ unsigned bf16_rne_hi(float a) {               // bf16 bits of a in the UPPER half, lower half junk-free
+    const unsigned u = __float_as_uint(a);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+}
+__device__ __forceinline__ uintx4 round8_bf16(const float (&x)[8]) {
+    uintx4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (bf16_rne_hi(x[2 * i]) >> 16) | bf16_rne_hi(x[2 * i + 1]);
+    return r;
+}
 #define MFMA_BF16(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
 
 __device__ __forceinline__ void glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[e] = p[e * BNt];
                 }
-                sb[t] = split3(x);
+                if constexpr (ARITH == 1) sb[t] = split3(x); else sb[t].h = round8_bf16(x);
             }
             // one 32-row band of A at a time: read + split its 8 operands, then its 6 x TN products (smallest terms
             // first; the TN accumulators of the band alternate).  Measured alternatives (profiles/r01/bf16x6_variants.md):
@@ -556,10 +570,16 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
                     for (int e = 0; e < 8; ++e) x[e] = p[e * BMt];
                 }
                 if (do_rowsum) rs[tm] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-                const Split3 sa = split3(x);
 #define GEMM3_PRODUCT(BP, AP) _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA_BF16(sb[tn].BP, sa.AP, acc[tm][tn]);
-                GEMM3_PRODUCT(l, h) GEMM3_PRODUCT(h, l) GEMM3_PRODUCT(m, m)
-                GEMM3_PRODUCT(m, h) GEMM3_PRODUCT(h, m) GEMM3_PRODUCT(h, h)
+                if constexpr (ARITH == 1) {
+                    const Split3 sa = split3(x);
+                    GEMM3_PRODUCT(l, h) GEMM3_PRODUCT(h, l) GEMM3_PRODUCT(m, m)
+                    GEMM3_PRODUCT(m, h) GEMM3_PRODUCT(h, m) GEMM3_PRODUCT(h, h)
+                } else {
+                    Split3 sa;
+                    sa.h = round8_bf16(x);
+                    GEMM3_PRODUCT(h, h)
+                }
 #undef GEMM3_PRODUCT
             }
         }
@@ -723,7 +743,8 @@ static int g_mlp_arith = -1;   // DLRM_ARITH_*; -1 = not initialised (env DLRM_M
 static void arith_init() {
     if (g_mlp_arith >= 0) return;
     const char* e = getenv("DLRM_MLP_ARITH");
-    g_mlp_arith = (e && (!strcmp(e, "bf16x6") || !strcmp(e, "1"))) ? DLRM_ARITH_BF16X6 : DLRM_ARITH_F32;
+    g_mlp_arith = (e && (!strcmp(e, "bf16x6") || !strcmp(e, "1"))) ? DLRM_ARITH_BF16X6
+                : (e && (!strcmp(e, "bf16") || !strcmp(e, "2"))) ? DLRM_ARITH_BF16 : DLRM_ARITH_F32;
 }
 
 static int gemm_path() {   // env DLRM_GEMM_PATH: 0 = auto (default), 2 = force the register-staged fallback kernel
@@ -743,6 +764,8 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st) {
         const bool big = g.M >= 256 && wg256 >= 512;
         if (g_mlp_arith == DLRM_ARITH_BF16X6)
             return big ? launch_gemm3<A_KC, B_KC, 4, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 1>(g, splits, st);
+        if (g_mlp_arith == DLRM_ARITH_BF16)
+            return big ? launch_gemm3<A_KC, B_KC, 4, 2>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 2>(g, splits, st);
         return big ? launch_gemm3<A_KC, B_KC, 4, 0>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0>(g, splits, st);
     }
     g.tiles_m = (int)((g.M + BM - 1) / BM);
@@ -923,7 +946,7 @@ extern "C" int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, con
 }
 
 extern "C" int dlrm_mlp_set_arith(int arith) {
-    if (arith != DLRM_ARITH_F32 && arith != DLRM_ARITH_BF16X6) return DLRM_E_MODE;
+    if (arith != DLRM_ARITH_F32 && arith != DLRM_ARITH_BF16X6 && arith != DLRM_ARITH_BF16) return DLRM_E_MODE;
     g_mlp_arith = arith;
     return 0;
 }

@@ -299,14 +299,16 @@ def interact_bwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool,
 # ------------------------------------------------------------------------------------------------
 # MLP layers
 # ------------------------------------------------------------------------------------------------
-_ARITH_NAMES = {"f32": _lib.ARITH_F32, "bf16x6": _lib.ARITH_BF16X6}
+_ARITH_NAMES = {"f32": _lib.ARITH_F32, "bf16x6": _lib.ARITH_BF16X6, "bf16": _lib.ARITH_BF16}
 
 
 def set_mlp_arith(name: str) -> None:
     """"f32": native fp32 MFMA.  "bf16x6": fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA products,
-    fp32 accumulation (fp32 round-off class, 2.7x the matrix rate) — see include/dlrm_hip.h."""
+    fp32 accumulation (fp32 round-off class, 2.7x the matrix rate).  "bf16": operands rounded to bf16, one bf16 MFMA per
+    16-k step, fp32 accumulation — the reduced-precision "bf16 MLP" of BASELINE.json configs[4] (NOT fp32-class).
+    See include/dlrm_hip.h."""
     if name not in _ARITH_NAMES:
-        raise RuntimeError(f"dlrm_amd: unknown MLP arithmetic {name!r} (f32 | bf16x6)")
+        raise RuntimeError(f"dlrm_amd: unknown MLP arithmetic {name!r} (f32 | bf16x6 | bf16)")
     _lib.check(_lib.load().dlrm_mlp_set_arith(_ARITH_NAMES[name]), "dlrm_mlp_set_arith")
 
 

@@ -128,7 +128,7 @@ int dlrm_interact_bwd(int64_t B, int F, int D,
  * K5  MLP layer = nn.Linear + activation  (dlrm_s_pytorch.py:216,238-241,405), fp32 MFMA.
  *   Y[M,N] = act(X[M,K] · W[N,K]^T + bias[N])
  */
-/* Arithmetic of the three MLP GEMMs (process-wide; default DLRM_ARITH_F32, or env DLRM_MLP_ARITH=f32|bf16x6 read once):
+/* Arithmetic of the three MLP GEMMs (process-wide; default DLRM_ARITH_F32, or env DLRM_MLP_ARITH=f32|bf16x6|bf16 read once):
  *   DLRM_ARITH_F32    v_mfma_f32_32x32x2_f32: every product and sum in fp32 (157 TFLOP/s matrix peak).
  *   DLRM_ARITH_BF16X6 fp32 operands split EXACTLY into three bf16 terms inside the kernel (x = h + m + l), the six
  *                     products of order >= 2^-16 issued on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; dropped
@@ -136,6 +136,8 @@ int dlrm_interact_bwd(int64_t B, int F, int D,
  * Only operands that meet the fast-path preconditions (16-byte alignment, k % 16 == 0) use BF16X6; others run F32. */
 #define DLRM_ARITH_F32    0
 #define DLRM_ARITH_BF16X6 1
+#define DLRM_ARITH_BF16   2   /* operands rounded to bf16 (nearest even) in the kernel, one bf16 MFMA per 16-k step, fp32 accumulate:
+                                 the "bf16 MLP" of BASELINE.json configs[4]; NOT an fp32-class result (about 3 decimal digits per operand) */
 int dlrm_mlp_set_arith(int arith);
 int dlrm_mlp_get_arith(void);
 

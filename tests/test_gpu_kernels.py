@@ -274,6 +274,40 @@ def test_linear_bwd_data_fused_mask():
     np.testing.assert_allclose(db.cpu().numpy(), 1.0 + dZ.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 256, 512), (4096, 1024, 480), (304, 128, 256)])
+def test_linear_bf16_arithmetic(M, N, K):
+    """"bf16" MLP arithmetic (BASELINE configs[4]): equals a float64 product of the bf16-ROUNDED operands (nearest even,
+    the rounding of torch's bfloat16 conversion) up to fp32 accumulation error, for forward, data and weight gradient;
+    and differs from the fp32 result by about the bf16 operand precision — it is a different arithmetic, not a bug.
+    (Every reduction length here is a multiple of 16: other shapes run the any-shape fp32 kernel, include/dlrm_hip.h.)"""
+    from dlrm_amd import ops
+
+    def rb(a):        # round fp32 -> bf16 -> fp32 exactly like the kernel (and torch)
+        return torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy().astype(np.float64)
+    rng = np.random.default_rng(M + N + K)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    dY = rng.standard_normal((M, N)).astype(np.float32)
+    Xd, Wd, bd, dYd = to_dev(X), to_dev(W), to_dev(b), to_dev(dY)
+    Y, dX, dW, db = (torch.empty((M, N), device=dev()), torch.empty((M, K), device=dev()), torch.empty((N, K), device=dev()),
+                     torch.empty(N, device=dev()))
+    ops.set_mlp_arith("bf16")
+    try:
+        ops.linear_fwd(Xd, Wd, bd, 0, Y)
+        ops.linear_bwd_data(dYd, Wd, None, 0, dX)
+        ops.linear_bwd_weight(dYd, Xd, dW, db)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_mlp_arith("f32")
+    np.testing.assert_allclose(Y.cpu().numpy(), rb(X) @ rb(W).T + b, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(dX.cpu().numpy(), rb(dY) @ rb(W), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(dW.cpu().numpy(), rb(dY).T @ rb(X), rtol=1e-4, atol=1e-4 * np.sqrt(M))
+    np.testing.assert_allclose(db.cpu().numpy(), dY.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)   # bias grad stays fp32
+    err = np.abs(Y.cpu().numpy() - (X.astype(np.float64) @ W.astype(np.float64).T + b)).max()
+    assert 1e-4 < err < 0.1, err
+
+
 @pytest.mark.parametrize("M,K,act", [(5000, 256, 2), (333, 64, 1), (70001, 1024, 0), (129, 12, 2), (64, 100, 1)])
 def test_linear_single_output_layer(M, K, act):
     """N == 1 (the last top-MLP layer): the matrix-vector kernels (gemv.hip) for K % 4 == 0 <= 1024, the GEMM path
