@@ -59,6 +59,7 @@ SIGNATURES = {
     "dlrm_gen_workspace_bytes": (_i64, [_i32, _i64]),
     "dlrm_gen_uniform_bags": (_i32, [_i32, _i64, _pi64, _i32, _i32, C.c_uint64, _i32, _pp, _pp, _vp, _vp, _i64, _vp]),
     "dlrm_gen_uniform_dense": (_i32, [_i64, _vp, _i32, C.c_uint64, _vp]),
+    "dlrm_criteo_bin_transform": (_i32, [_i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
     "dlrm_a2a_unpack": (_i32, [_i32, _i64, _i32, C.POINTER(_i32), _vp, _vp, _i64, _vp]),
 }
 

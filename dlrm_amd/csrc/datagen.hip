@@ -199,3 +199,64 @@ extern "C" int dlrm_gen_uniform_dense(int64_t n, float* x, int round_values, uin
     DLRM_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Criteo-Terabyte binary records -> model inputs, on the device.
+// Reference replaced: CriteoBinDataset.__getitem__ + _transform_features (data_loader_terabyte.py:233-248, 74-93): one
+// record = 40 little-endian int32 = [label | 13 dense counts | 26 categorical ids]; the reference converts on the host
+// (torch.log(x_int + 1), x_cat % max_ind_range, transposes to [26, B], builds offsets arange per table).  Here the raw
+// [B, 40] block is copied to HBM once (42 % of the bytes of the converted batch) and one kernel writes every input.
+//   X[b, j]      = logf(float(raw[b, 1 + j]) + 1)                 j < 13      (fp32, like torch.log on a float tensor)
+//   idx[t, b]    = raw[b, 14 + t] mod max_ind_range (if > 0)       t < 26      (python/torch `%`: result in [0, m))
+//   off[t, b]    = b
+//   target[b]    = float(raw[b, 0])
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename IT>
+__global__ __launch_bounds__(256) void criteo_bin_transform_kernel(long long B, const int* __restrict__ raw, long long max_ind_range,
+                                                                   float* __restrict__ X, long long ldx, IT* __restrict__ idx,
+                                                                   IT* __restrict__ off, long long ld_idx,
+                                                                   float* __restrict__ target) {
+    // a workgroup owns 64 records: the 64 x 40 block goes through LDS so that both the row-major reads and the
+    // table-major (transposed) writes are coalesced
+    __shared__ int tile[64][41];
+    const long long b0 = (long long)blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * 40; e += 256) {
+        const int r = e / 40, c = e - r * 40;
+        tile[r][c] = (b0 + r < B) ? raw[(b0 + r) * 40 + c] : 0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 13; e += 256) {              // dense features, row-major output
+        const int r = e / 13, j = e - r * 13;
+        if (b0 + r < B) X[(b0 + r) * ldx + j] = logf((float)tile[r][1 + j] + 1.0f);
+    }
+    for (int e = threadIdx.x; e < 26 * 64; e += 256) {              // categorical ids, table-major output
+        const int t = e >> 6, r = e & 63;
+        if (b0 + r < B) {
+            long long v = (long long)tile[r][14 + t];
+            if (max_ind_range > 0) { v %= max_ind_range; if (v < 0) v += max_ind_range; }
+            idx[(long long)t * ld_idx + b0 + r] = (IT)v;
+            off[(long long)t * ld_idx + b0 + r] = (IT)(b0 + r);
+        }
+    }
+    if (threadIdx.x < 64 && b0 + threadIdx.x < B) target[b0 + threadIdx.x] = (float)tile[threadIdx.x][0];
+}
+
+}  // namespace
+
+extern "C" int dlrm_criteo_bin_transform(int64_t B, const int32_t* raw, int64_t max_ind_range, int idx_bits, float* X,
+                                         int64_t ldx, void* indices, void* offsets, int64_t ld_idx, float* target,
+                                         void* stream) {
+    if (B <= 0 || !raw || !X || !indices || !offsets || !target || ldx < 13 || ld_idx < B) return DLRM_E_ARG;
+    if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
+    dim3 grid((unsigned)((B + 63) / 64)), block(256);
+    if (idx_bits == 64)
+        hipLaunchKernelGGL(criteo_bin_transform_kernel<long long>, grid, block, 0, (hipStream_t)stream, (long long)B, (const int*)raw,
+                           (long long)max_ind_range, X, (long long)ldx, (long long*)indices, (long long*)offsets, (long long)ld_idx, target);
+    else
+        hipLaunchKernelGGL(criteo_bin_transform_kernel<int>, grid, block, 0, (hipStream_t)stream, (long long)B, (const int*)raw,
+                           (long long)max_ind_range, X, (long long)ldx, (int*)indices, (int*)offsets, (long long)ld_idx, target);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}

@@ -234,6 +234,13 @@ int dlrm_gen_uniform_bags(int T, int64_t B, const int64_t* rows_host, int num_in
                           int64_t* nnz_dev, void* workspace, int64_t workspace_bytes, void* stream);
 int dlrm_gen_uniform_dense(int64_t n, float* x, int round_values, uint64_t seed, void* stream);
 
+/* Criteo-Terabyte binary records -> model inputs on the device.  Replaces CriteoBinDataset.__getitem__ +
+ * _transform_features (data_loader_terabyte.py:233-248, 74-93).  raw: device int32 [B, 40] = label | 13 dense | 26 ids.
+ *   X[b, 0:13] = logf(float(dense) + 1);  indices[t*ld_idx + b] = id_t mod max_ind_range (if > 0; result in [0, m));
+ *   offsets[t*ld_idx + b] = b;  target[b] = float(label).   indices/offsets: int32 or int64 [26, ld_idx >= B]. */
+int dlrm_criteo_bin_transform(int64_t B, const int32_t* raw, int64_t max_ind_range, int idx_bits, float* X,
+                              int64_t ldx, void* indices, void* offsets, int64_t ld_idx, float* target, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * C1 helpers for the pooled-embedding all-to-all (extend_distributed.py:389-486).  The exchange
  * itself is RCCL (ncclSend/ncclRecv grouped) driven by the host; these kernels are only needed

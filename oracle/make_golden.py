@@ -309,6 +309,39 @@ def capture_datagen(dp, name="datagen_uniform"):
     print(name, [(c["tag"], int(sum(out[f"{c['tag']}.idx{k}"].size for k in range(len(c["ln_emb"]))))) for c in cases])
 
 
+def capture_criteo_bin(name="criteo_bin"):
+    """A synthetic Criteo binary file read through the reference's own CriteoBinDataset (data_loader_terabyte.py:197-251)."""
+    import tempfile
+    sys.path.insert(0, REF)
+    import data_loader_terabyte as dlt
+    rng = np.random.default_rng(3)
+    n = 1000                                                     # 3 full batches of 300 + a short one of 100
+    raw = np.empty((n, 40), dtype=np.int32)
+    raw[:, 0] = rng.integers(0, 2, n)
+    raw[:, 1:14] = (rng.pareto(1.5, (n, 13)) * 20).astype(np.int32)
+    raw[:5, 1:14] = 0
+    raw[:, 14:] = rng.integers(0, 2 ** 31 - 1, (n, 26), dtype=np.int64).astype(np.int32)
+    raw[::7, 14:] = rng.integers(0, 50, (len(raw[::7]), 26))
+    out = {"raw": raw}
+    cases = []
+    with tempfile.TemporaryDirectory() as td:
+        f, cf = os.path.join(td, "day.bin"), os.path.join(td, "counts.npz")
+        raw.tofile(f)
+        np.savez(cf, counts=np.full(26, 40000000))
+        for mir in (-1, 40000000, 1000):
+            ds = dlt.CriteoBinDataset(f, cf, batch_size=300, max_ind_range=mir)
+            assert len(ds) == 4
+            for i in range(len(ds)):
+                X, lS_o, lS_i, T = ds[i]
+                tag = f"m{mir}.b{i}"
+                out[tag + ".X"], out[tag + ".lS_o"], out[tag + ".lS_i"], out[tag + ".T"] = (X.numpy(), lS_o.numpy(), lS_i.numpy(), T.numpy())
+            cases.append(dict(max_ind_range=mir, batch_size=300, batches=len(ds)))
+            del ds
+    out["meta"] = np.frombuffer(json.dumps(dict(name=name, cases=cases, records=n)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(name, cases)
+
+
 def capture_metrics(name="metrics_sklearn"):
     """scores/targets -> the scikit-learn numbers inference() reports (dlrm_s_pytorch.py:828-847)."""
     import sklearn.metrics as M
@@ -343,6 +376,8 @@ def main(which):
     os.makedirs(OUT, exist_ok=True)
     if which == "metrics":
         return capture_metrics()
+    if which == "criteo_bin":
+        return capture_criteo_bin()
     ref, dp, ext = import_reference()
     if which in ("all", "train"):
         # BASELINE.json configs[0]: 3 tables x 1000 x 16, bot 13-512-16, batch 128 (top tower 128-64-1)
@@ -367,6 +402,7 @@ def main(which):
         capture_distributed()
     if which == "all":
         capture_metrics()
+        capture_criteo_bin()
 
 
 if __name__ == "__main__":

@@ -200,3 +200,25 @@ def test_philox_known_answers():
     for b in range(500):
         seg = idx[off[b]:off[b] + lens[b]]
         assert np.all(np.diff(seg) > 0)          # sorted, unique
+
+
+def test_criteo_bin_transform_matches_reference_dataset():
+    """oracle.criteo_bin_transform + the batch byte-range arithmetic of dlrm_amd.criteo_bin against the reference's own
+    CriteoBinDataset on a synthetic binary file (data_loader_terabyte.py:197-251): ids and offsets bit-exact, log(x+1)
+    to the last bit or one ulp (numpy vs torch log)."""
+    from dlrm_amd.criteo_bin import batch_byte_range, num_batches
+    d, meta = load_golden("criteo_bin")
+    raw = d["raw"]
+    nbytes = raw.size * 4
+    for case in meta["cases"]:
+        bs, mir = case["batch_size"], case["max_ind_range"]
+        assert num_batches(nbytes, bs) == case["batches"]
+        for i in range(case["batches"]):
+            s, e = batch_byte_range(nbytes, bs, i)
+            rows = raw.reshape(-1)[s // 4:e // 4].reshape(-1, 40)
+            X, lS_o, lS_i, T = O.criteo_bin_transform(rows, mir)
+            tag = f"m{mir}.b{i}"
+            assert np.array_equal(lS_i, d[tag + ".lS_i"]) and np.array_equal(lS_o, d[tag + ".lS_o"])
+            assert np.array_equal(T, d[tag + ".T"])
+            np.testing.assert_allclose(X, d[tag + ".X"], rtol=2e-7, atol=0)
+    assert batch_byte_range(nbytes, 300, 3) == (3 * 300 * 160, nbytes)      # the short last batch
