@@ -63,6 +63,6 @@ int dlrm_gemv_bwd_weight(int64_t M, int K, const float* dY, int64_t lddy, const 
 
 // smallk.hip: weight gradient of layers with K <= 16 (the first bottom-MLP layer: 13 dense features padded to 16)
 int64_t dlrm_smallk_bwd_weight_workspace_bytes(int64_t M, int N, int K);
-int dlrm_smallk_bwd_weight(int64_t M, int N, int K, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,
+int dlrm_smallk_bwd_weight(int64_t M, int N, int K, int K_store, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,
                            int64_t lddw, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
                            hipStream_t st);

@@ -857,7 +857,7 @@ extern "C" int64_t dlrm_linear_bwd_weight_workspace_bytes(int64_t M, int N, int 
     int splits; int64_t kchunk;
     wgrad_plan(M, N, K, &splits, &kchunk);
     const int64_t ldp = ((int64_t)K + 3) & ~(int64_t)3;
-    int64_t need = splits <= 1 ? 0 : (int64_t)splits * N * ldp * (int64_t)sizeof(float);
+    int64_t need = (int64_t)(splits < 1 ? 1 : splits) * N * ldp * (int64_t)sizeof(float);   // >= one slab: the padded-dW form needs it even unsplit
     if (N == 1) {                                    // the matrix-vector path keeps per-workgroup column partials
         const int64_t gv = dlrm_gemv_bwd_weight_workspace_bytes(M, K);
         if (gv > need) need = gv;
@@ -869,19 +869,20 @@ extern "C" int64_t dlrm_linear_bwd_weight_workspace_bytes(int64_t M, int N, int 
     return need;
 }
 
-extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, int64_t lddy,
-                                      const float* X, int64_t ldx, float* dW, int64_t lddw,
-                                      float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
-                                      void* stream) {
-    if (M <= 0 || N <= 0 || K <= 0 || !dY || !X || !dW) return DLRM_E_ARG;
-    if (lddy < N || ldx < K || lddw < K) return DLRM_E_ARG;
+// K_store <= K: dW is [N, K_store]; the columns K_store..K-1 of X are alignment padding (zeros) whose gradient is dropped
+static int linear_bwd_weight_impl(int64_t M, int N, int K, int K_store, const float* dY, int64_t lddy,
+                                  const float* X, int64_t ldx, float* dW, int64_t lddw,
+                                  float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || K_store <= 0 || K_store > K || !dY || !X || !dW) return DLRM_E_ARG;
+    if (lddy < N || ldx < K || lddw < K_store) return DLRM_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (N == 1 && gemm_path() != 2) {
+    if (N == 1 && K_store == K && gemm_path() != 2) {
         const int rc = dlrm_gemv_bwd_weight(M, K, dY, lddy, X, ldx, dW, dbias, accumulate, workspace, workspace_bytes, st);
         if (rc != DLRM_GEMV_NOT_HANDLED) return rc;
     }
     if (K <= 16 && M >= 4096 && gemm_path() != 2) {
-        const int rc = dlrm_smallk_bwd_weight(M, N, K, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, st);
+        const int rc = dlrm_smallk_bwd_weight(M, N, K, K_store, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, st);
         if (rc != DLRM_GEMV_NOT_HANDLED) return rc;
     }
     GemmArgs g = {};
@@ -900,8 +901,9 @@ extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, 
     // slower on the small-output layers: up to 128 atomic adds land on every address).
     const int64_t ldp = ((int64_t)K + 3) & ~(int64_t)3;
     const int64_t slab = (int64_t)N * ldp;
-    const bool use_ws = splits > 1 && workspace && dlrm_aligned16(workspace) &&
+    const bool use_ws = (splits > 1 || K_store < K) && workspace && dlrm_aligned16(workspace) &&
                         workspace_bytes >= (int64_t)splits * slab * (int64_t)sizeof(float);
+    if (K_store < K && !use_ws) return DLRM_E_ARG;   // a narrower dW needs the slab path (pass the queried workspace)
     if (use_ws) {
         g.C = (float*)workspace; g.ldc = ldp; g.vecC = 1; g.c_split_stride = slab; g.atomic_out = 0;
         if (dbias && !accumulate) {
@@ -910,12 +912,12 @@ extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, 
         }
         int rc = launch_gemm<false, false>(g, splits, st);
         if (rc) return rc;
-        const bool v4 = dlrm_aligned16(dW) && lddw % 4 == 0 && K % 4 == 0;
-        const long long items = (long long)N * (v4 ? K / 4 : K);
+        const bool v4 = dlrm_aligned16(dW) && lddw % 4 == 0 && K_store % 4 == 0;
+        const long long items = (long long)N * (v4 ? K_store / 4 : K_store);
         int blocks = (int)((items + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-        if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, N, K, splits, (const float*)workspace,
+        if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, N, K_store, splits, (const float*)workspace,
                                    (long long)ldp, (long long)slab, dW, (long long)lddw, accumulate ? 1 : 0);
-        else    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, N, K, splits, (const float*)workspace,
+        else    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, N, K_store, splits, (const float*)workspace,
                                    (long long)ldp, (long long)slab, dW, (long long)lddw, accumulate ? 1 : 0);
         DLRM_LAUNCH_CHECK();
         return 0;
@@ -928,6 +930,20 @@ extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, 
         if (e != hipSuccess) return (int)e;
     }
     return launch_gemm<false, false>(g, splits, st);
+}
+
+extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, int64_t lddy,
+                                      const float* X, int64_t ldx, float* dW, int64_t lddw,
+                                      float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
+                                      void* stream) {
+    return linear_bwd_weight_impl(M, N, K, K, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dlrm_linear_bwd_weight_padded(int64_t M, int N, int K, int K_store, const float* dY, int64_t lddy,
+                                             const float* X, int64_t ldx, float* dW, int64_t lddw,
+                                             float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
+                                             void* stream) {
+    return linear_bwd_weight_impl(M, N, K, K_store, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, const float* Y,

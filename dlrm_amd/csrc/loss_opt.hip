@@ -104,6 +104,18 @@ __global__ __launch_bounds__(256) void scale_kernel(long long n, const float* __
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = x[i] * f;
 }
 
+// dst[m, 0:K] = src[m, 0:K], dst[m, K:Kp] = 0: 16-byte aligned rows for operands whose width is not a multiple of 4
+// (13 dense features, 479 interaction outputs and the first-layer weights that multiply them)
+__global__ __launch_bounds__(256) void pad_cols_kernel(long long M, int K, int Kp, const float* __restrict__ src, long long lds_,
+                                                       float* __restrict__ dst, long long ldd) {
+    const long long total = M * Kp;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long m = e / Kp;
+        const int k = (int)(e - m * Kp);
+        dst[m * ldd + k] = k < K ? src[m * lds_ + k] : 0.f;
+    }
+}
+
 // dense SGD for MANY parameter tensors in one launch (the 16 weights/biases of the two towers): pointers and sizes
 // travel by value in the kernarg segment, every workgroup owns one 4096-float chunk of one tensor.
 #define DLRM_MAX_DENSE_TENSORS 48
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(256) void a2a_unpack_kernel(UnpackArgs u, int nrank
 
 }  // namespace
 
-extern "C" int dlrm_hip_abi_version(void) { return 4; }
+extern "C" int dlrm_hip_abi_version(void) { return 5; }
 
 extern "C" const char* dlrm_hip_build_info(void) {
     return "libdlrm_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " clang " __clang_version__;
@@ -223,6 +235,15 @@ extern "C" int dlrm_scale_by_device_scalar(int64_t n, const float* x, const floa
     if (n <= 0 || !x || !scalar_dev || !y) return DLRM_E_ARG;
     long long nblk = (n + 255) / 256; if (nblk > 1024) nblk = 1024;
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (long long)n, x, scalar_dev, y);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_pad_cols(int64_t M, int K, int Kp, const float* src, int64_t ld_src, float* dst, int64_t ld_dst, void* stream) {
+    if (M <= 0 || K <= 0 || Kp < K || !src || !dst || ld_src < K || ld_dst < Kp) return DLRM_E_ARG;
+    long long nblk = ((long long)M * Kp + 255) / 256; if (nblk > 4096) nblk = 4096;
+    hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (long long)M, K, Kp, src,
+                       (long long)ld_src, dst, (long long)ld_dst);
     DLRM_LAUNCH_CHECK();
     return 0;
 }

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void smallk_wgrad_partial_kernel(long long M, 
 }
 
 // stage 2: element e of [N*K | N]: fixed-order sum over the blocks' partials (4 interleaved sub-sums folded through LDS)
-__global__ __launch_bounds__(256) void smallk_wgrad_finish_kernel(int N, int K, int nblk, const float* __restrict__ part,
+__global__ __launch_bounds__(256) void smallk_wgrad_finish_kernel(int N, int K, int K_store, int nblk, const float* __restrict__ part,
                                                                   long long part_stride, float* __restrict__ dW, long long lddw,
                                                                   float* __restrict__ dbias, int accumulate) {
     __shared__ float red[4][64];
@@ -125,8 +125,10 @@ __global__ __launch_bounds__(256) void smallk_wgrad_finish_kernel(int N, int K, 
     if (q == 0 && e < total) {
         s = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
         if (e < (long long)N * K) {
-            float* o = dW + (e / K) * lddw + (e % K);
-            *o = accumulate ? *o + s : s;
+            if ((int)(e % K) < K_store) {                       // columns K_store..K-1 are alignment padding of X
+                float* o = dW + (e / K) * lddw + (e % K);
+                *o = accumulate ? *o + s : s;
+            }
         } else if (dbias) {
             float* o = dbias + (e - (long long)N * K);
             *o = accumulate ? *o + s : s;
@@ -158,7 +160,7 @@ int64_t dlrm_smallk_bwd_weight_workspace_bytes(int64_t M, int N, int K) {
     return (int64_t)nblk * stride * (int64_t)sizeof(float);
 }
 
-int dlrm_smallk_bwd_weight(int64_t M, int N, int K, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,
+int dlrm_smallk_bwd_weight(int64_t M, int N, int K, int K_store, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,
                            int64_t lddw, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
                            hipStream_t st) {
     if (!smallk_shape_ok(N, K) || !dlrm_aligned16(X) || !dlrm_aligned16(dY) || ldx % 4 || lddy % 4) return DLRM_GEMV_NOT_HANDLED;
@@ -179,7 +181,7 @@ int dlrm_smallk_bwd_weight(int64_t M, int N, int K, const float* dY, int64_t ldd
     }
     DLRM_LAUNCH_CHECK();
     const long long total = (long long)N * K + N;
-    hipLaunchKernelGGL(smallk_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, N, K, nblk,
+    hipLaunchKernelGGL(smallk_wgrad_finish_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, N, K, K_store, nblk,
                        (const float*)workspace, stride, dW, (long long)lddw, dbias, accumulate ? 1 : 0);
     DLRM_LAUNCH_CHECK();
     return 0;

@@ -84,11 +84,8 @@ class MLPFunction(Function):
             if x.size(1) != Kp:
                 if x.size(1) != K0:
                     raise RuntimeError("dlrm_amd: MLP input width %d does not match the first layer (%d)" % (x.size(1), K0))
-                xp = torch.zeros((M, Kp), dtype=torch.float32, device=x.device)
-                xp[:, :K0].copy_(x)
-                x = xp
-            W0p = torch.zeros((W0.size(0), Kp), dtype=torch.float32, device=x.device)
-            W0p[:, :K0].copy_(W0)
+                x = ops.pad_cols(x, Kp)
+            W0p = ops.pad_cols(W0, Kp)
         elif x.size(1) != K0:
             raise RuntimeError("dlrm_amd: MLP input width %d does not match the first layer (%d)" % (x.size(1), K0))
         cur = x
@@ -137,7 +134,9 @@ class MLPFunction(Function):
         for i in range(L - 1, -1, -1):
             W = params[2 * i] if not (i == 0 and W0p is not None) else W0p
             X_i = x if i == 0 else outs[i - 1]
-            dW = torch.empty_like(W)
+            # first layer on a zero-padded input: the gradient is written at the parameter's true width (the padding
+            # columns of X are dropped inside the kernel) — contiguous, no slicing / re-packing afterwards
+            dW = torch.empty_like(params[2 * i])
             db = torch.empty(W.size(0), dtype=torch.float32, device=x.device)
             if side is not None:
                 side.wait_event(main.record_event())
@@ -146,8 +145,6 @@ class MLPFunction(Function):
                 keep.append(dZ)
             else:
                 ops.linear_bwd_weight(dZ, X_i, dW, db)
-            if i == 0 and W0p is not None:
-                dW = dW[:, :params[0].size(1)]               # padding column of the weight gradient is exactly 0
             grads[2 * i], grads[2 * i + 1] = dW, db
             if i > 0:
                 dprev = alloc2d(M, W.size(1), x)

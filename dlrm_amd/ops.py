@@ -371,12 +371,14 @@ def _wgrad_workspace(need: int, device) -> Optional[torch.Tensor]:
 def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor] = None,
                       accumulate: bool = False, use_workspace: bool = True) -> torch.Tensor:
     """dW = dY^T @ X and (optionally) dbias = column sums of dY, one GEMM (+ the split-K slab reduction).
-    use_workspace=False exercises the atomic-accumulation variant (no scratch memory)."""
+    dW may be NARROWER than X (dW [N, K_store], X [M, K >= K_store]): the extra columns of X are alignment padding
+    (zeros) and their gradient is dropped.  use_workspace=False exercises the atomic-accumulation variant."""
     lib = _lib.load()
     _req(dY, "dY", ndim=2); _req(X, "X", ndim=2); _req(dW, "dW", ndim=2)
     M, N = dY.shape
     K = X.size(1)
-    if X.size(0) != M or dW.size(0) != N or dW.size(1) != K:
+    K_store = dW.size(1)
+    if X.size(0) != M or dW.size(0) != N or K_store > K:
         raise RuntimeError("dlrm_amd: linear_bwd_weight shape mismatch")
     if dbias is not None:
         _req(dbias, "dbias", ndim=1)
@@ -384,14 +386,33 @@ def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias
             raise RuntimeError("dlrm_amd: linear_bwd_weight dbias size mismatch")
     ws = _wgrad_workspace(lib.dlrm_linear_bwd_weight_workspace_bytes(M, N, K), dY.device) if use_workspace else None
     with _timed("linear_bwd_weight"):
-        rc = lib.dlrm_linear_bwd_weight(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(X.data_ptr()), _ld(X),
-                                        C.c_void_p(dW.data_ptr()), _ld(dW),
-                                        C.c_void_p(dbias.data_ptr()) if dbias is not None else None,
-                                        int(bool(accumulate)),
-                                        C.c_void_p(ws.data_ptr()) if ws is not None else None,
-                                        ws.numel() if ws is not None else 0, _stream())
+        common = (C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(X.data_ptr()), _ld(X),
+                  C.c_void_p(dW.data_ptr()), _ld(dW),
+                  C.c_void_p(dbias.data_ptr()) if dbias is not None else None,
+                  int(bool(accumulate)),
+                  C.c_void_p(ws.data_ptr()) if ws is not None else None,
+                  ws.numel() if ws is not None else 0, _stream())
+        if K_store == K:
+            rc = lib.dlrm_linear_bwd_weight(M, N, K, *common)
+        else:
+            rc = lib.dlrm_linear_bwd_weight_padded(M, N, K, K_store, *common)
     _lib.check(rc, "dlrm_linear_bwd_weight")
     return dW
+
+
+def pad_cols(src: torch.Tensor, Kp: int) -> torch.Tensor:
+    """[M, K] -> new contiguous [M, Kp] with zero columns K..Kp-1 (one kernel; replaces torch.zeros + slice copy_)."""
+    lib = _lib.load()
+    _req(src, "src", ndim=2)
+    M, K = src.shape
+    if Kp < K:
+        raise RuntimeError("dlrm_amd: pad_cols target width is smaller than the source")
+    dst = torch.empty((M, Kp), dtype=torch.float32, device=src.device)
+    if M == 0:
+        return dst
+    rc = lib.dlrm_pad_cols(M, K, Kp, C.c_void_p(src.data_ptr()), _ld(src), C.c_void_p(dst.data_ptr()), Kp, _stream())
+    _lib.check(rc, "dlrm_pad_cols")
+    return dst
 
 
 def act_bwd(dY: torch.Tensor, Y: torch.Tensor, act: int, dZ: torch.Tensor, dbias: Optional[torch.Tensor]) -> torch.Tensor:

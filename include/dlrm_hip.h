@@ -168,6 +168,16 @@ int dlrm_linear_bwd_weight(int64_t M, int N, int K,
                            float* dW, int64_t lddw, float* dbias, int accumulate,
                            void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same weight gradient when X carries alignment padding: X is [M, K] with columns K_store..K-1 zero (e.g. 13 dense
+ * features padded to 16, 479 interaction outputs padded to 480), dW is the true [N, K_store] gradient.  Needs the
+ * workspace of dlrm_linear_bwd_weight_workspace_bytes(M, N, K). */
+int dlrm_linear_bwd_weight_padded(int64_t M, int N, int K, int K_store,
+                           const float* dY, int64_t lddy, const float* X, int64_t ldx,
+                           float* dW, int64_t lddw, float* dbias, int accumulate,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+/* dst[m, 0:K] = src[m, 0:K], dst[m, K:Kp] = 0   (builds those padded operands: no ATen fill/copy on the hot path) */
+int dlrm_pad_cols(int64_t M, int K, int Kp, const float* src, int64_t ld_src, float* dst, int64_t ld_dst, void* stream);
+
 /* activation backward for a layer whose dY does not come out of dlrm_linear_bwd_data (i.e. the last
  * layer of a tower):  dZ = dY ⊙ act'(Y);  optionally dbias[N] += column sums of dZ (dbias != NULL; the
  * caller zeroes it — normally NULL because dlrm_linear_bwd_weight produces the bias gradient). */

@@ -308,6 +308,33 @@ def test_linear_bf16_arithmetic(M, N, K):
     assert 1e-4 < err < 0.1, err
 
 
+@pytest.mark.parametrize("M,N,K0", [(5000, 512, 13), (300, 64, 479), (4096, 1024, 479), (33, 8, 5), (8192, 128, 14)])
+def test_linear_weight_gradient_of_padded_input(M, N, K0):
+    """First MLP layers run on a zero-padded input (13 -> 16 dense features, 479 -> 480 interaction outputs):
+    ops.pad_cols builds the operand, dlrm_linear_bwd_weight_padded writes the gradient at the parameter's true width."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + N + K0)
+    Kp = (K0 + 3) & ~3
+    X = rng.standard_normal((M, K0)).astype(np.float32)
+    dZ = rng.standard_normal((M, N)).astype(np.float32)
+    wide = torch.full((M, K0 + 2), 9.0, device=dev())
+    wide[:, 1:1 + K0] = to_dev(X)
+    Xp = ops.pad_cols(wide[:, 1:1 + K0], Kp)                         # strided source
+    assert Xp.shape == (M, Kp) and Xp.is_contiguous()
+    assert torch.equal(Xp[:, :K0], to_dev(X)) and bool((Xp[:, K0:] == 0).all())
+    dW = torch.full((N, K0), 5.0, device=dev())
+    db = torch.full((N,), 5.0, device=dev())
+    ops.linear_bwd_weight(to_dev(dZ), Xp, dW, db)
+    want = dZ.astype(np.float64).T @ X.astype(np.float64)
+    tol = 1e-5 * max(1.0, float(np.abs(want).max())) * 10
+    np.testing.assert_allclose(dW.cpu().numpy(), want, rtol=1e-4, atol=tol)
+    np.testing.assert_allclose(db.cpu().numpy(), dZ.astype(np.float64).sum(0), rtol=1e-4, atol=tol)
+    ops.linear_bwd_weight(to_dev(dZ), Xp, dW, db, accumulate=True)
+    np.testing.assert_allclose(dW.cpu().numpy(), 2 * want, rtol=1e-4, atol=2 * tol)
+    with pytest.raises(RuntimeError):                                # the narrow form needs the slab workspace
+        ops.linear_bwd_weight(to_dev(dZ), Xp, dW, db, use_workspace=False)
+
+
 @pytest.mark.parametrize("M,K,act", [(5000, 256, 2), (333, 64, 1), (70001, 1024, 0), (129, 12, 2), (64, 100, 1)])
 def test_linear_single_output_layer(M, K, act):
     """N == 1 (the last top-MLP layer): the matrix-vector kernels (gemv.hip) for K % 4 == 0 <= 1024, the GEMM path
