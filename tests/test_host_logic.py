@@ -119,3 +119,87 @@ def test_launcher_swaps_the_hot_path_under_the_unmodified_reference_run(tmp_path
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run(base + cli + ["--nepochs=1"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_embedding_update_plan_for_sgd_and_rowwise_adagrad():
+    """The optimizer-step pre-hook's plan: SGD -> ("sgd", lr); RWSAdagrad (ours, and the reference's own class when the
+    reference checkout is present) -> clr = lr / (1 + (step-1)*lr_decay) (optim/rwsadagrad.py:113-115), row-wise state
+    created lazily in optimizer.state[p]["momentum"] with initial_accumulator_value, step counted per table."""
+    import sys
+    from dlrm_amd.dlrm_net import _embedding_update_plan
+    from dlrm_amd.optim import FusedRWSAdagrad
+    tables = [torch.nn.Parameter(torch.zeros(7, 4)), torch.nn.Parameter(torch.zeros(3, 4))]
+    dense = torch.nn.Parameter(torch.zeros(5))
+    sgd = torch.optim.SGD(tables + [dense], lr=0.25)
+    assert _embedding_update_plan(sgd, tables) == ("sgd", 0.25)
+    assert _embedding_update_plan(torch.optim.SGD([dense], lr=0.1), tables) is None      # does not own the tables
+    with pytest.raises(SystemExit):
+        _embedding_update_plan(torch.optim.SGD(tables, lr=0.1, momentum=0.9), tables)
+    with pytest.raises(SystemExit):
+        _embedding_update_plan(torch.optim.Adam(tables, lr=0.1), tables)
+    classes = [FusedRWSAdagrad]
+    if os.path.isfile(os.path.join(REFERENCE, "optim", "rwsadagrad.py")):
+        sys.path.insert(0, os.path.join(REFERENCE, "optim"))
+        import rwsadagrad
+        classes.append(rwsadagrad.RWSAdagrad)
+    for cls in classes:
+        opt = cls(tables + [dense], lr=0.5, lr_decay=0.1, initial_accumulator_value=0.25, eps=1e-7)
+        kind, clr, eps, states = _embedding_update_plan(opt, tables)
+        assert kind == "rwsadagrad" and clr == 0.5 and eps == 1e-7
+        assert [tuple(s_.shape) for s_ in states] == [(7,), (3,)] and all(float(s_[0]) == 0.25 for s_ in states)
+        assert states[0] is opt.state[tables[0]]["momentum"] and opt.state[tables[1]]["step"] == 1
+        _, clr2, _, states2 = _embedding_update_plan(opt, tables)
+        assert abs(clr2 - 0.5 / 1.1) < 1e-12 and states2[0] is states[0] and opt.state[tables[0]]["step"] == 2
+
+
+def test_fused_rwsadagrad_hyperparameter_checks():
+    from dlrm_amd.optim import FusedRWSAdagrad
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    for bad in (dict(lr=-1.0), dict(lr_decay=-0.1), dict(eps=-1e-3), dict(initial_accumulator_value=-1.0), dict(weight_decay=0.1)):
+        with pytest.raises(ValueError):
+            FusedRWSAdagrad(p, **bad)
+    opt = FusedRWSAdagrad(p, lr=0.1)
+    assert opt.state[p[0]]["step"] == 0 and opt.defaults["eps"] == 1e-10 and opt.defaults["lr_decay"] == 0.0
+
+
+def test_graph_input_helpers():
+    """Static-input bookkeeping of the whole-step HIP graph: shared tensors stay shared, stale shapes are refused."""
+    from dlrm_amd.graph import _clone_struct, _copy_struct
+    off = torch.arange(5)
+    lst = [off, off, torch.arange(5) * 2]
+    st = _clone_struct(lst)
+    assert st[0] is st[1] and st[0] is not off and torch.equal(st[2], lst[2])
+    _copy_struct(st, [off + 1, off + 1, off * 3])
+    assert torch.equal(st[0], off + 1) and torch.equal(st[2], off * 3)
+    t = _clone_struct(torch.ones(2, 3))
+    _copy_struct(t, torch.zeros(2, 3))
+    assert float(t.sum()) == 0
+    with pytest.raises(RuntimeError, match="shape"):
+        _copy_struct(t, torch.zeros(3, 3))
+    with pytest.raises(RuntimeError, match="shape"):
+        _copy_struct(st, [off, off, torch.arange(6)])
+    with pytest.raises(RuntimeError, match="structure"):
+        _copy_struct(st, [off, off])
+
+
+def test_data_front_ends_refuse_cpu_and_malformed_input(tmp_path):
+    from dlrm_amd.criteo_bin import CriteoBinBatches, batch_byte_range, num_batches
+    from dlrm_amd.datagen import UniformBatchGenerator
+    from dlrm_amd.evaluate import inference
+    with pytest.raises(RuntimeError, match="GPU"):
+        UniformBatchGenerator(13, [10, 20], device="cpu")
+    g = object.__new__(UniformBatchGenerator)
+    g.seed = 5
+    seeds = {g._seed(b, s_) for b in range(50) for s_ in (1, 2, 16, 48)}
+    assert len(seeds) == 200 and all(0 <= x < 2 ** 64 for x in seeds)
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"\0" * 161)
+    with pytest.raises(RuntimeError, match="160-byte"):
+        CriteoBinBatches(str(bad), 4)
+    ok = tmp_path / "ok.bin"
+    ok.write_bytes(b"\0" * 160 * 10)
+    with pytest.raises(RuntimeError, match="GPU"):
+        CriteoBinBatches(str(ok), 4, device="cpu")
+    assert num_batches(1600, 4) == 3 and batch_byte_range(1600, 4, 2) == (1280, 1600)
+    with pytest.raises(RuntimeError, match="no test batch"):
+        inference(None, [])
