@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--cpu-row-cap", type=int, default=1000000)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
+    ap.add_argument("--a2a-chunks", type=int, default=int(os.environ.get("DLRM_A2A_CHUNKS", "0")),
+                    help="N > 1: pipeline the pooled-embedding all-to-all in this many batch chunks; 1 = the reference schedule "
+                         "(only the bottom MLP overlaps the exchange); 0 = auto: 4 chunks at N=2 and 2 at N=4, where one rank "
+                         "moves 218 / 164 MB per direction over 1 / 3 xGMI links (tools/scaling_model.py), 1 otherwise")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "rwsadagrad"],
                     help="sgd: the reference default (and the headline); rwsadagrad: row-wise sparse Adagrad (K4, optim/rwsadagrad.py)")
     ap.add_argument("--mlp-arith", default=os.environ.get("DLRM_MLP_ARITH", "f32"), choices=["f32", "bf16x6", "bf16"],
@@ -169,6 +173,7 @@ def main():
     dlrm_amd.set_embedding_init(device)
     model = dlrm_amd.DLRM_Net(D, np.asarray(rows), np.asarray(wl["bot"]), ln_top, "dot", sigmoid_top=ln_top.size - 2,
                               loss_function="bce").to(device)
+    model.a2a_chunks = args.a2a_chunks if args.a2a_chunks > 0 else {2: 4, 4: 2}.get(N, 1)
     model.emb_update_mode = {"sorted": ops.UPD_SORTED, "atomic": ops.UPD_ATOMIC, "deterministic": ops.UPD_DETERMINISTIC}[args.emb_update]
     if N > 1:
         model.bot_l = ext_dist.DDP(model.bot_l, device_ids=[device.index])
@@ -180,6 +185,7 @@ def main():
     else:
         opt = (FusedSGD if args.optimizer == "sgd" else FusedRWSAdagrad)(model.parameters(), lr=args.lr)
 
+    model_a2a_chunks = model.a2a_chunks if N > 1 else 1
     batches = make_batches(4, B, rows, device, seed=727)     # every rank reads the whole global batch (reference :1541)
     my_rows = ext_dist.get_my_slice(B) if N > 1 else slice(0, B)
     local_tables = list(range(len(rows)))[model.local_emb_slice] if N > 1 else list(range(len(rows)))
@@ -308,7 +314,7 @@ def main():
                    "tables": len(rows), "emb_dim": D, "global_batch": B, "table_rows_total": int(sum(rows)),
                    "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": args.optimizer,
                    "loss": "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
-                   "embedding_update": args.emb_update,
+                   "embedding_update": args.emb_update, "a2a_chunks": model_a2a_chunks,
                    "launch": "HIP graph replay of the captured step (dlrm_amd.graph)" if graphed is not None else "eager (one C-ABI call per kernel)",
                    "mlp_arith": {"f32": "f32: native fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                                  "bf16x6": "bf16x6: fp32 operands split exactly into 3 bf16 terms in-kernel, 6 bf16 MFMA products, fp32 accumulate",

@@ -17,6 +17,7 @@ of the reference (nnz x D floats per table) is never written to HBM.
 """
 from __future__ import annotations
 
+import os
 import sys
 import weakref
 from typing import List, Optional, Sequence
@@ -26,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from . import ext_dist, ops
-from .functional import (BCELossFunction, EmbeddingBagsFunction, InteractFunction, MLPFunction,
+from .functional import (BCELossFunction, ChunkPackFunction, EmbeddingBagsFunction, InteractFunction, MLPFunction,
                          MSELossFunction, OutSlot)
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, BagBatch
 
@@ -159,6 +160,8 @@ class DLRM_Net(nn.Module):
         super().__init__()
         self._pending_emb: list = []
         self.emb_update_mode = ops.UPD_SORTED
+        # > 1: the pooled-embedding all-to-all of the distributed forward is pipelined in that many batch chunks (opt-in)
+        self.a2a_chunks = max(int(os.environ.get("DLRM_A2A_CHUNKS", "1")), 1)
         if m_spa is None or ln_emb is None or ln_bot is None or ln_top is None or arch_interaction_op is None:
             return  # empty shell, like the reference's guard (dlrm_s_pytorch.py:320-326)
 
@@ -323,6 +326,9 @@ class DLRM_Net(nn.Module):
             sys.exit("ERROR: corrupted model input detected in distributed_forward call")
         D = self.emb_l[0].weight.size(1)
         E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l)           # [B, T_loc*D] == packed send buffer
+        C = self.a2a_chunks
+        if C > 1 and self.arch_interaction_op == "dot" and (batch_size // ext_dist.my_size) % C == 0:
+            return self._pipelined_exchange_forward(dense_x, E, D, batch_size, C)
         req = ext_dist.alltoall([E], self.n_emb_per_rank, emb_dim=D)
         x = self.apply_mlp(dense_x, self.bot_l)                             # overlaps the exchange
         ly = list(req.wait())                                               # N x [B/N, T_s*D], read in place
@@ -331,6 +337,27 @@ class DLRM_Net(nn.Module):
         else:
             z = self.interact_features(x, ly)
         return self._clamp(self.apply_mlp(z, self.top_l))
+
+    def _pipelined_exchange_forward(self, dense_x, E, D, batch_size, C):
+        """Distributed forward with the all-to-all split into C batch chunks (opt-in, DLRM_A2A_CHUNKS / model.a2a_chunks).
+
+        The exchange moves B*T_loc*D*4*(N-1)/N bytes per rank and direction over N-1 xGMI links (218 MB over ONE link at
+        N = 2) while only the bottom MLP overlaps it in the reference schedule (dlrm_s_pytorch.py:563-568).  Here all C chunk
+        exchanges are issued up front (they queue on RCCL's stream); interaction + top MLP of chunk c run while chunks
+        c+1.. are still on the wire, and in backward the reverse exchange of chunk c overlaps the top-MLP backward of the
+        chunks before it (the autograd engine reaches them in reverse order).  Weight gradients of the C top-MLP passes are
+        summed by autograd; results equal the unchunked schedule up to fp32 summation order of those C partial gradients."""
+        N = ext_dist.my_size
+        Bc = batch_size // N // C
+        sends = ChunkPackFunction.apply(E, N, C)
+        reqs = [ext_dist.alltoall([sends[c]], self.n_emb_per_rank, emb_dim=D) for c in range(C)]
+        x = self.apply_mlp(dense_x, self.bot_l)                                 # overlaps the first exchange
+        outs = []
+        for c in range(C):
+            ly = list(reqs[c].wait())                                           # N x [Bc, T_s*D]
+            z = InteractFunction.apply(D, bool(self.arch_interaction_itself), True, x[c * Bc:(c + 1) * Bc], *ly)
+            outs.append(self.apply_mlp(z, self.top_l))
+        return self._clamp(torch.cat(outs, dim=0))
 
 
 def _is_rwsadagrad(optimizer) -> bool:

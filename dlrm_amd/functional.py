@@ -224,6 +224,33 @@ class InteractFunction(Function):
         return (None, None, None, *dblocks)
 
 
+class ChunkPackFunction(Function):
+    """Re-orders the rows of the pooled-embedding send buffer for a PIPELINED all-to-all.
+
+    `E` is [B, W] in global-batch order (rank r's samples are rows r*Bl .. (r+1)*Bl, Bl = B/N).  Chunk c of the pipeline
+    holds, for every destination rank r, the c-th sub-slice (Bc = Bl/C rows) of r's samples; the function returns C tensors
+    [N*Bc, W] (views of one [C, N, Bc, W] buffer), each of which is a complete, smaller all-to-all send buffer.  Backward
+    scatters the C gradient buffers back to global-batch order for the fused embedding update."""
+
+    @staticmethod
+    def forward(ctx, E, N, C):
+        B, W = E.shape
+        Bc = B // (N * C)
+        if Bc * N * C != B:
+            raise RuntimeError("dlrm_amd: batch %d does not split into %d ranks x %d chunks" % (B, N, C))
+        packed = _rowmajor(E).reshape(N, C, Bc, W).permute(1, 0, 2, 3).contiguous()
+        ctx.dims = (N, C, Bc, W)
+        return tuple(packed[c].view(N * Bc, W) for c in range(C))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        N, C, Bc, W = ctx.dims
+        dE = torch.empty((N, C, Bc, W), dtype=grads[0].dtype, device=grads[0].device)
+        for c, g in enumerate(grads):
+            dE[:, c].copy_(g.reshape(N, Bc, W))
+        return dE.view(N * C * Bc, W), None, None
+
+
 class BCELossFunction(Function):
     """BCELoss(reduction='mean'); loss and dL/dp are produced by one kernel pass."""
 

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, size, port, q):
+def _worker(rank, size, port, q, chunks=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK="0")
     import dlrm_amd
     from dlrm_amd import ext_dist, ops
@@ -43,6 +43,7 @@ def _worker(rank, size, port, q):
             p.copy_(torch.from_numpy(init[f"top_l.{name}"]))
     model = model.to(dev)
     model.emb_update_mode = ops.UPD_DETERMINISTIC
+    model.a2a_chunks = chunks                # > 1: pipelined all-to-all (DLRM_Net._pipelined_exchange_forward)
     model.bot_l = ext_dist.DDP(model.bot_l, device_ids=[0])
     model.top_l = ext_dist.DDP(model.top_l, device_ids=[0])
     opt = torch.optim.SGD([{"params": [p for e in model.emb_l for p in e.parameters()], "lr": meta["lr"]},
@@ -71,13 +72,14 @@ def _worker(rank, size, port, q):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_training_matches_reference_two_rank_run():
+@pytest.mark.parametrize("chunks", [1, 2], ids=["single-exchange", "pipelined-2-chunks"])
+def test_two_rank_training_matches_reference_two_rank_run(chunks):
     d, meta = load_golden("dist2_tiny")
     size = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, size, port, q)) for r in range(size)]
+    procs = [ctx.Process(target=_worker, args=(r, size, port, q, chunks)) for r in range(size)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=600) for _ in range(size))

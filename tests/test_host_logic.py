@@ -203,3 +203,22 @@ def test_data_front_ends_refuse_cpu_and_malformed_input(tmp_path):
     assert num_batches(1600, 4) == 3 and batch_byte_range(1600, 4, 2) == (1280, 1600)
     with pytest.raises(RuntimeError, match="no test batch"):
         inference(None, [])
+
+
+def test_chunk_pack_permutation_and_gradient():
+    """Row bookkeeping of the pipelined all-to-all (functional.ChunkPackFunction): chunk c holds, per destination rank r,
+    rows r*Bl + c*Bc .. of the global batch; backward routes every gradient row back to its global position."""
+    from dlrm_amd.functional import ChunkPackFunction
+    N, C, Bc, W = 3, 4, 2, 5
+    B = N * C * Bc
+    E = torch.arange(B * W, dtype=torch.float32).view(B, W).requires_grad_()
+    outs = ChunkPackFunction.apply(E, N, C)
+    assert len(outs) == C and all(o.shape == (N * Bc, W) and o.is_contiguous() for o in outs)
+    for c in range(C):
+        for r in range(N):
+            assert torch.equal(outs[c][r * Bc:(r + 1) * Bc], E.detach()[r * C * Bc + c * Bc:r * C * Bc + (c + 1) * Bc])
+    sum((o * (i + 1)).sum() for i, o in enumerate(outs)).backward()
+    want = torch.tensor([(b % (C * Bc)) // Bc + 1.0 for b in range(B)]).view(B, 1).expand(B, W)
+    assert torch.equal(E.grad, want)
+    with pytest.raises(RuntimeError, match="split"):
+        ChunkPackFunction.apply(torch.zeros(10, 2), 3, 2)
