@@ -74,7 +74,7 @@ def sd_np(model, prefix):
 
 
 def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, lr, loss, itself=False,
-                     num_idx=10, fixed=False, seed=123, round_targets=True):
+                     num_idx=10, fixed=False, seed=123, round_targets=True, compact=False):
     ln_emb = np.asarray(ln_emb)
     ln_bot = np.asarray(ln_bot)
     F = ln_emb.size + 1
@@ -104,7 +104,7 @@ def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, l
             out["s0.top0_weight_grad"] = model.top_l[0].weight.grad.numpy().copy()
             out["s0.bot0_bias_grad"] = model.bot_l[0].bias.grad.numpy().copy()
         opt.step()
-        if s == 0:
+        if s == 0 and not compact:
             out.update(sd_np(model, "after1"))
     out.update(sd_np(model, "final"))
     out["losses"] = np.asarray(losses, dtype=np.float64)
@@ -392,6 +392,13 @@ def main(which):
         # multi-hot with many duplicates across bags (hot rows)
         capture_training(ref, dp, "multihot_hotrows", 8, [3, 4, 100], [9, 8], [8, 1], B=64, steps=2, lr=0.3, loss="bce",
                          num_idx=8)
+    if which in ("all", "kaggle"):
+        # BASELINE.json configs[1]: Criteo-Kaggle shapes — 26 tables, D = 16, bot 13-512-256-64-16, top 512-256-1
+        # (bench/dlrm_s_criteo_kaggle.sh:24), batch 2048, one lookup per bag; table rows capped at 600 to keep the fixture small
+        kaggle_rows = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306,
+                       10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+        capture_training(ref, dp, "kaggle_b2048", 16, [min(n, 600) for n in kaggle_rows], [13, 512, 256, 64, 16], [512, 256, 1],
+                         B=2048, steps=2, lr=0.1, loss="bce", num_idx=1, fixed=True, compact=True)
     if which in ("all", "adagrad"):
         capture_adagrad(ref, dp)
     if which in ("all", "book"):

@@ -9,7 +9,8 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-FIXTURES = ["config1_b128", "cli_default_mse", "self_interact_d12", "multihot_hotrows"]
+# kaggle_b2048 = BASELINE.json configs[1] shapes (26 tables, D = 16, bot 13-512-256-64-16, top 512-256-1, batch 2048; rows capped)
+FIXTURES = ["config1_b128", "cli_default_mse", "self_interact_d12", "multihot_hotrows", "kaggle_b2048"]
 
 
 def build_model(meta, init, device, deterministic=True, mode=None):

@@ -10,7 +10,7 @@ import pytest
 from conftest import GOLDEN, golden_batches, load_golden, params_with_prefix
 from oracle import oracle as O
 
-TRAIN_FIXTURES = ["config1_b128", "cli_default_mse", "self_interact_d12", "multihot_hotrows"]
+TRAIN_FIXTURES = ["config1_b128", "cli_default_mse", "self_interact_d12", "multihot_hotrows", "kaggle_b2048"]
 
 
 @pytest.mark.parametrize("name", TRAIN_FIXTURES)
