@@ -135,9 +135,6 @@ def load_pmc_traffic():
 
 def main():
     args = parse()
-    if os.environ.get("DLRM_BENCH_GC") == "off":      # debugging aid
-        import gc
-        gc.disable()
     if os.environ.get("DLRM_BENCH_WATCHDOG"):       # debugging aid: dump every thread's Python stack after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DLRM_BENCH_WATCHDOG"]), repeat=False, exit=False)
@@ -217,10 +214,7 @@ def main():
         step(i)
     if N > 1:
         torch.distributed.barrier()
-    if os.environ.get("DLRM_BENCH_SYNC") == "stream":   # debugging aid (profiles/r02/graph_probe.md, issue d)
-        torch.cuda.current_stream().synchronize()
-    else:
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
     ops.timers = None if args.no_kernel_timers else ops.KernelTimers()
     t0 = time.perf_counter()
     timed_steps = 0
