@@ -96,7 +96,7 @@ class GraphedTrainStep:
         self._lrs: List[float] = []
         self.captures = 0
         self._eager_calls = 0
-        self._done: Optional[torch.cuda.Event] = None
+        self._replayed = False
         self.serialize = _os.environ.get("DLRM_GTS_SERIALIZE", "1") == "1"
 
     # one eager training step on the static buffers (the reference loop body)
@@ -141,13 +141,16 @@ class GraphedTrainStep:
         if _TRACE:
             print("[gts] call eager=%d captures=%d pending_event=%s" % (self._eager_calls, self.captures, self._done is not None),
                   flush=True)
-        if self._done is not None:
-            # at most ONE replay in flight: with a second hipGraphLaunch of the same executable graph queued behind a
-            # running one, the two instances were observed to overlap on ROCm 7.2 (they share every intermediate buffer:
-            # GPU memory faults at Criteo-Terabyte sizes, where the host runs ahead of the 9 ms replay —
-            # profiles/r02/graph_probe.md).  The host waits for the previous replay before it touches the static inputs.
-            self._done.synchronize()
-            self._done = None
+        if self._replayed:
+            # at most ONE replay in flight, and a full stream synchronisation between replays.  Two launches of the same
+            # executable graph queued behind each other overlapped on ROCm 7.2 (they share every intermediate buffer), and
+            # event waits alone were not enough once the application synchronised the stream somewhere in between
+            # (profiles/r02/graph_probe.md, b and d): the pattern that was clean in every probe is "synchronise the stream
+            # after every replay", so that is what happens here before the static inputs are touched again.  At
+            # Criteo-Terabyte sizes the GPU is the bottleneck (the wait costs one launch latency per step); at launch-bound
+            # sizes the replay has finished long before the host gets here.
+            torch.cuda.current_stream(X.device).synchronize()
+            self._replayed = False
         if self.static is None:
             self.static = (X.clone(), _clone_struct(lS_o), _clone_struct(lS_i), T.clone())
         else:
@@ -172,7 +175,5 @@ class GraphedTrainStep:
         if self.graph is None or self._lrs != self._current_lrs():
             self._capture()          # capture only records; the replay below executes this step
         self.graph.replay()
-        if self.serialize:
-            self._done = torch.cuda.Event()
-            self._done.record()
+        self._replayed = self.serialize
         return self.loss
