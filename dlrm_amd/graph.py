@@ -139,7 +139,7 @@ class GraphedTrainStep:
 
     def __call__(self, X, lS_o, lS_i, T):
         if _TRACE:
-            print("[gts] call eager=%d captures=%d pending_event=%s" % (self._eager_calls, self.captures, self._done is not None),
+            print("[gts] call eager=%d captures=%d replay_in_flight=%s" % (self._eager_calls, self.captures, self._replayed),
                   flush=True)
         if self._replayed:
             # at most ONE replay in flight, and a full stream synchronisation between replays.  Two launches of the same
