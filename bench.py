@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--row-cap", type=int, default=0, help="cap table rows (debug / small-memory runs)")
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true",
+                    help="skip the pre-run check of this exact configuration against the golden fixture of the live reference")
     ap.add_argument("--no-alt-arith", action="store_true", help="skip the extra bf16x6 measurement")
     ap.add_argument("--graph", action="store_true",
                     help="run the timed region as HIP-graph replays of the captured step (dlrm_amd.graph; N=1 only, implies "
@@ -122,6 +124,25 @@ def cpu_baseline(wl, args):
                       f"(oracle/torch_port.py: the reference's torch CPU operator calls, {torch.get_num_threads()} threads)"}
 
 
+def parity_check(args, device):
+    """Before anything is timed: the bench configuration (stacked [T, B] inputs, sorted fused update, FusedSGD, the GEMM /
+    interaction kernels these shapes select, the requested MLP arithmetic) trained for 3 steps on the full-batch golden
+    fixture of the live reference (tests/golden/terabyte_b65536.npz: B = 65536, 26 tables, D = 128, rows capped at 2000;
+    oracle/make_golden.py capture_terabyte).  north_star bar: fp32 loss within 1e-5 relative at every step."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_tb
+    mode = {"sorted": 2, "atomic": 0, "deterministic": 1}[args.emb_update]
+    try:
+        rel = golden_tb.run_on_gpu(device, arith=args.mlp_arith, mode=mode, check=True)
+        return {"fixture": "tests/golden/terabyte_b65536.npz (3 training steps of the live reference at B=65536, T=26, D=128, "
+                           "towers 13-512-256-128 / 479-1024-1024-512-256-1, lr 1.0, rows capped at 2000)",
+                "rel_err": max(rel), "rel_err_per_step": rel, "bar": 1e-5, "pass": bool(max(rel) <= 1e-5),
+                "also_checked": "predictions rtol 2e-5, 3 step-0 gradients rtol 2e-4, final MLP parameters and table rows/column sums rtol 1e-4",
+                "mlp_arith": args.mlp_arith, "embedding_update": args.emb_update}
+    except AssertionError as e:
+        return {"fixture": "tests/golden/terabyte_b65536.npz", "pass": False, "error": str(e)[:400]}
+
+
 def load_pmc_traffic():
     """Latest committed profiles/rNN/pmc_traffic.json (tools/gpu_pmc_traffic.sh + tools/pmc_to_json.py), or None."""
     import glob
@@ -161,7 +182,6 @@ def main():
     torch.cuda.set_device(device)
     rank = max(ext_dist.my_rank, 0)
 
-    ops.set_mlp_arith(args.mlp_arith)
     rows, D, B = wl["rows"], wl["D"], wl["batch"]
     nf = len(rows) + 1
     ln_top = np.asarray([D + nf * (nf - 1) // 2] + wl["top"])
@@ -170,6 +190,7 @@ def main():
     dlrm_amd.set_embedding_init(device)
     model = dlrm_amd.DLRM_Net(D, np.asarray(rows), np.asarray(wl["bot"]), ln_top, "dot", sigmoid_top=ln_top.size - 2,
                               loss_function="bce").to(device)
+    model.set_mlp_arith(args.mlp_arith)
     model.a2a_chunks = args.a2a_chunks if args.a2a_chunks > 0 else {2: 4, 4: 2}.get(N, 1)
     model.emb_update_mode = {"sorted": ops.UPD_SORTED, "atomic": ops.UPD_ATOMIC, "deterministic": ops.UPD_DETERMINISTIC}[args.emb_update]
     if N > 1:
@@ -182,6 +203,10 @@ def main():
     else:
         opt = (FusedSGD if args.optimizer == "sgd" else FusedRWSAdagrad)(model.parameters(), lr=args.lr)
 
+    parity = None
+    if N == 1 and args.workload == "criteo_terabyte" and not args.no_parity_check:
+        parity = parity_check(args, device)
+        torch.cuda.empty_cache()
     model_a2a_chunks = model.a2a_chunks if N > 1 else 1
     batches = make_batches(4, B, rows, device, seed=727)     # every rank reads the whole global batch (reference :1541)
     my_rows = ext_dist.get_my_slice(B) if N > 1 else slice(0, B)
@@ -315,6 +340,7 @@ def main():
                                  "bf16": "bf16: MLP operands rounded to bf16 in-kernel, one bf16 MFMA per 16-k step, fp32 accumulate "
                                          "(reduced precision: NOT the headline configuration)"}[args.mlp_arith]},
         "final_loss": final_loss,
+        "parity_check": parity,
         "kernel_timing": "HIP events on the launch stream around every C-ABI call, on %d of the %d timed steps" % (timed_steps, args.steps),
         "roofline": roof(dom) if dom else None,
         "roofline_embedding": roof("emb_fwd") if "emb_fwd" in kernels else None,
@@ -325,7 +351,7 @@ def main():
     if N == 1 and args.mlp_arith == "f32" and not args.no_alt_arith:
         # the same step with the opt-in bf16x6 MLP arithmetic (fp32 round-off class, see include/dlrm_hip.h): reported
         # beside the headline value, never instead of it
-        ops.set_mlp_arith("bf16x6")
+        model.set_mlp_arith("bf16x6")
         for i in range(2):
             step(i)
         torch.cuda.synchronize()
@@ -334,7 +360,7 @@ def main():
             loss_alt = step(i)
         torch.cuda.synchronize()
         dta = (time.perf_counter() - t0) / args.steps
-        ops.set_mlp_arith("f32")
+        model.set_mlp_arith("f32")
         result["alt_mlp_arith"] = {"mlp_arith": "bf16x6", "value": B / dta, "unit": "samples/s", "ms_per_step": dta * 1e3,
                                    "final_loss": float(loss_alt.detach()),
                                    "note": "opt-in (--mlp-arith bf16x6); parity-tested at the fp32 tolerances"}

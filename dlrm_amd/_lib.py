@@ -7,6 +7,7 @@ and cannot be built, or a call returns non-zero, a RuntimeError is raised.
 from __future__ import annotations
 
 import ctypes as C
+import fcntl
 import os
 import subprocess
 import threading
@@ -31,26 +32,25 @@ SIGNATURES = {
     "dlrm_hip_abi_version": (_i32, []),
     "dlrm_hip_build_info": (C.c_char_p, []),
     "dlrm_hip_device_info": (_i32, [_i32, C.POINTER(_i32), C.POINTER(_i32), _pi64, C.c_char_p, _i32]),
-    "dlrm_emb_fwd": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64, _vp]),
+    "dlrm_emb_fwd": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64, _vp, _vp]),
     "dlrm_emb_bwd_workspace_bytes": (_i64, [_i32, _pi64, _pi64]),
     "dlrm_emb_bwd_sgd": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64,
-                                _f32, _i32, _vp, _i64, _vp]),
+                                _f32, _i32, _vp, _i64, _vp, _vp]),
+    "dlrm_emb_bwd_coo": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _i32, _vp, _i64, _pp, _vp]),
     "dlrm_emb_adagrad_workspace_bytes": (_i64, [_i32, _i32, _pi64, _pi64]),
     "dlrm_emb_bwd_rowwise_adagrad": (_i32, [_i32, _i64, _i32, _pp, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32,
-                                            _vp, _i64, _f32, _f32, _vp, _i64, _vp]),
+                                            _vp, _i64, _f32, _f32, _vp, _i64, _vp, _vp]),
     "dlrm_interact_fwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _vp]),
     "dlrm_interact_bwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _pp, _pi64, _vp]),
-    "dlrm_mlp_set_arith": (_i32, [_i32]),
-    "dlrm_mlp_get_arith": (_i32, []),
-    "dlrm_linear_fwd": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
-    "dlrm_linear_bwd_data": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "dlrm_linear_fwd": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "dlrm_linear_bwd_data": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),
     "dlrm_linear_bwd_weight_workspace_bytes": (_i64, [_i64, _i32, _i32]),
-    "dlrm_linear_bwd_weight": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
-    "dlrm_linear_bwd_weight_padded": (_i32, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
+    "dlrm_linear_bwd_weight": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "dlrm_linear_bwd_weight_padded": (_i32, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
     "dlrm_pad_cols": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_act_bwd": (_i32, [_i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     "dlrm_loss_workspace_bytes": (_i64, [_i64]),
-    "dlrm_bce_loss": (_i32, [_i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
+    "dlrm_bce_loss": (_i32, [_i64, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "dlrm_mse_loss": (_i32, [_i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
     "dlrm_scale_by_device_scalar": (_i32, [_i64, _vp, _vp, _vp, _vp]),
     "dlrm_sgd_dense": (_i32, [_i64, _vp, _vp, _f32, _vp]),
@@ -62,7 +62,11 @@ SIGNATURES = {
     "dlrm_gen_uniform_bags": (_i32, [_i32, _i64, _pi64, _i32, _i32, C.c_uint64, _i32, _pp, _pp, _vp, _vp, _i64, _vp]),
     "dlrm_gen_uniform_dense": (_i32, [_i64, _vp, _i32, C.c_uint64, _vp]),
     "dlrm_criteo_bin_transform": (_i32, [_i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
-    "dlrm_a2a_unpack": (_i32, [_i32, _i64, _i32, C.POINTER(_i32), _vp, _vp, _i64, _vp]),
+    "dlrm_copy_blocks": (_i32, [_i64, _i32, _pp, _pi64, _pp, _pi64, C.POINTER(_i32), _vp]),
+    "dlrm_bce_elementwise": (_i32, [_i64, _vp, _vp, _vp, _vp]),
+    "dlrm_bce_elementwise_bwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp]),
+    "dlrm_clamp": (_i32, [_i64, _vp, _f32, _f32, _vp, _vp]),
+    "dlrm_clamp_bwd": (_i32, [_i64, _vp, _f32, _f32, _vp, _vp, _vp]),
 }
 
 _ERR = {-1: "DLRM_E_ARG (null pointer / bad size)", -2: "DLRM_E_ALIGN", -3: "DLRM_E_RANGE (compiled limit exceeded)",
@@ -70,14 +74,23 @@ _ERR = {-1: "DLRM_E_ARG (null pointer / bad size)", -2: "DLRM_E_ALIGN", -3: "DLR
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile libdlrm_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    if force:
-        subprocess.run(["make", "-C", CSRC, "clean"], check=False, capture_output=not verbose)
-    r = subprocess.run(["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("building libdlrm_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
-    if verbose:
-        print(r.stdout[-2000:])
+    """Compile libdlrm_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    Safe to call from several processes at once (`torchrun --nproc-per-node 8` on a fresh checkout): the build is
+    serialised by an exclusive flock on csrc/.build.lock, and the Makefile links to a temporary name that is renamed
+    over the target, so no process can ever dlopen a half-written library."""
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if force:
+                subprocess.run(["make", "-C", CSRC, "clean"], check=False, capture_output=not verbose)
+            r = subprocess.run(["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("building libdlrm_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+            if verbose:
+                print(r.stdout[-2000:])
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB_PATH
 
 
@@ -85,10 +98,9 @@ def _sources_newer_than_lib() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    for f in os.listdir(CSRC):
-        if f.endswith((".hip", ".h")) and os.path.getmtime(os.path.join(CSRC, f)) > t:
-            return True
-    return False
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) or f == "Makefile"]
+    files.append(os.path.join(_HERE, "..", "include", "dlrm_hip.h"))
+    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in files)
 
 
 def load():
@@ -101,7 +113,7 @@ def load():
             return _lib
         if _sources_newer_than_lib():
             if os.path.exists("/opt/rocm/bin/hipcc"):
-                build()
+                build()          # cross-process safe; a rank that lost the race finds everything up to date
             elif not os.path.exists(LIB_PATH):
                 raise RuntimeError(
                     "libdlrm_hip.so is missing and hipcc is not available; the HIP extension is required "

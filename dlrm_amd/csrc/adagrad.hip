@@ -122,16 +122,18 @@ __global__ __launch_bounds__(256) void adagrad_groups_kernel(SortedArgs sa, Adag
             k[j] = live[j] ? keys[c0 + j] : run_key;
             const unsigned pos = live[j] ? vals[c0 + j] : 0u;
             const int t = (int)(k[j] >> row_bits);
-            const unsigned bag = live[j] ? bag_of[pos] : 0u;
+            unsigned bag = live[j] ? bag_of[pos] : 0u;
+            const bool dead = bag == DLRM_DEAD_BAG;            // out-of-range lookup (expand_kernel): zero gradient
+            if (dead) bag = 0u;
             const float* psw = sa.psw[t];
-            weighted[j] = live[j] && psw != nullptr;
+            weighted[j] = live[j] && psw != nullptr && !dead;
             sc[j] = weighted[j] ? psw[(long long)pos - sa.base[t]] : 1.f;
             const float* grow = dout + (long long)bag * dout_ld + (long long)sa.slot[t] * D;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int col = (c * LPB + lig) * VEC;
                 v_zero(gr[j][c]);
-                if (live[j] && col < D) gr[j][c] = *(const VT*)(grow + col);
+                if (live[j] && !dead && col < D) gr[j][c] = *(const VT*)(grow + col);
             }
         }
 #pragma unroll
@@ -240,10 +242,10 @@ static int run_adagrad(int n, const int* ids, int64_t B, int D, void* const* wei
                        const int64_t* rows_host, const void* const* indices_host, const void* const* offsets_host,
                        const int64_t* nnz_host, const void* const* psw_host, int idx_bits, const float* dout, int64_t dout_ld,
                        float clr, float eps, char* ws, const AdaLayout& lo, size_t L, int row_bits, int key_bits, bool vec_ok,
-                       hipStream_t st) {
+                       hipStream_t st, int64_t* err) {
     SortedArgs sa;
     int rc = expand_and_sort<KT>(n, ids, B, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host, idx_bits, ws,
-                                 lo.sort, L, row_bits, key_bits, st, &sa);
+                                 lo.sort, L, row_bits, key_bits, st, &sa, err);
     if (rc) return rc;
     AdagradArgs aa;
     for (int k = 0; k < DLRM_MAX_TABLES_PER_LAUNCH; ++k) aa.state[k] = (float*)state_host[ids[k < n ? k : 0]];
@@ -315,7 +317,7 @@ extern "C" int dlrm_emb_bwd_rowwise_adagrad(int T, int64_t B, int D, void* const
                                             const void* const* indices_host, const void* const* offsets_host,
                                             const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
                                             const float* dout, int64_t dout_ld, float lr, float eps,
-                                            void* workspace, int64_t workspace_bytes, void* stream) {
+                                            void* workspace, int64_t workspace_bytes, int64_t* err, void* stream) {
     if (T <= 0 || B <= 0 || D <= 0 || !weight_host || !state_host || !rows_host || !indices_host || !offsets_host || !nnz_host ||
         !dout || dout_ld < (int64_t)T * D)
         return DLRM_E_ARG;
@@ -348,10 +350,10 @@ extern "C" int dlrm_emb_bwd_rowwise_adagrad(int T, int64_t B, int D, void* const
         }
         rc = wide ? run_adagrad<unsigned long long>(n, ids, B, D, weight_host, state_host, rows_host, indices_host, offsets_host,
                                                     nnz_host, psw_host, idx_bits, dout, dout_ld, lr, eps, (char*)workspace, lo, L,
-                                                    row_bits, key_bits, vec_ok, st)
+                                                    row_bits, key_bits, vec_ok, st, err)
                   : run_adagrad<unsigned>(n, ids, B, D, weight_host, state_host, rows_host, indices_host, offsets_host, nnz_host,
                                           psw_host, idx_bits, dout, dout_ld, lr, eps, (char*)workspace, lo, L, row_bits, key_bits,
-                                          vec_ok, st);
+                                          vec_ok, st, err);
         if (rc) return rc;
     }
     return 0;

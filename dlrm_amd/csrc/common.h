@@ -22,6 +22,9 @@
         }                                                                    \
     } while (0)
 
+#define DLRM_MAX_DEVICES 64
+static inline int dlrm_current_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < DLRM_MAX_DEVICES) ? d : 0; }
+
 static inline bool dlrm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 __device__ __forceinline__ float dlrm_wave_sum(float v) {
@@ -41,14 +44,25 @@ struct EmbArgs {
     long long   nnz[DLRM_MAX_TABLES_PER_LAUNCH];
     long long   rows[DLRM_MAX_TABLES_PER_LAUNCH];
     int         slot[DLRM_MAX_TABLES_PER_LAUNCH];  // feature slot (column block) of the table in out/dout
+    long long*  err;                               // device-visible int64[4] out-of-range report (nullable), see dlrm_hip.h
 };
+
+// Out-of-range index: the lookup is SKIPPED (never read or written out of bounds) and, when the caller passed an error
+// block, reported as {1, table, index, rows}.  Plain stores: concurrent reporters race benignly (any one bad index wins).
+__device__ __forceinline__ void dlrm_report_bad_index(long long* err, int table, long long idx, long long rows) {
+    if (err) { volatile long long* e = err; e[1] = table; e[2] = idx; e[3] = rows; e[0] = 1; }
+}
+__device__ __forceinline__ bool dlrm_index_ok(long long idx, long long rows) {
+    return (unsigned long long)idx < (unsigned long long)rows;
+}
+#define DLRM_DEAD_BAG 0xFFFFFFFFu   // bag_of[] marker of a skipped (out-of-range) lookup in the sorted update paths
 
 // emb_sorted.hip: sort-based fused backward + SGD (mode DLRM_UPD_SORTED of dlrm_emb_bwd_sgd)
 int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_host, const int64_t* rows_host,
                                  const void* const* indices_host, const void* const* offsets_host,
                                  const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
                                  const float* dout, int64_t dout_ld, float lr, void* workspace,
-                                 int64_t workspace_bytes, void* stream);
+                                 int64_t workspace_bytes, int64_t* err, void* stream);
 
 // gemv.hip: the N == 1 MLP layer as HBM-streaming kernels; each returns 0 when it handled the call and
 // DLRM_GEMV_NOT_HANDLED when the shape/alignment is outside its fast path (the caller then uses the GEMM kernels).

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs a, long long B, in
     const IT* __restrict__ off = (const IT*)a.off[t];
     const float* __restrict__ psw = a.psw[t];
     const long long nnz = a.nnz[t];
+    const long long rows = a.rows[t];
 
     constexpr int GPB = 256 / LPB;  // groups (bags in flight) per workgroup
     const int g = threadIdx.x / LPB;
@@ -83,14 +84,18 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs a, long long B, in
         for (int c = 0; c < NCH; ++c) v_zero(acc[u][c]);
 
     // ---- phase 1: first row of every bag, all loads in flight together --------------------
+    // an out-of-range index contributes nothing and is reported (the reference raises on it)
     long long r0[U];
     float w0[U];
+    bool ok0[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        r0[u] = 0; w0[u] = 1.f;
+        r0[u] = 0; w0[u] = 1.f; ok0[u] = false;
         if (s[u] < e[u]) {
             r0[u] = (long long)idx[s[u]];
             if (psw) w0[u] = psw[s[u]];
+            ok0[u] = dlrm_index_ok(r0[u], rows);
+            if (!ok0[u]) dlrm_report_bad_index(a.err, a.slot[t], r0[u], rows);
         }
     }
     VT v0[U][NCH];
@@ -100,11 +105,11 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs a, long long B, in
         for (int c = 0; c < NCH; ++c) {
             const int col = (c * LPB + lig) * VEC;
             v_zero(v0[u][c]);
-            if (s[u] < e[u] && col < D) v0[u][c] = *(const VT*)(W + r0[u] * D + col);
+            if (ok0[u] && col < D) v0[u][c] = *(const VT*)(W + r0[u] * D + col);
         }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        if (s[u] < e[u]) {
+        if (ok0[u]) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) v_fma(acc[u][c], w0[u], v0[u][c]);
         }
@@ -116,24 +121,33 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs a, long long B, in
         const long long end = e[u];
         for (; i + 4 <= end; i += 4) {
             long long r[4]; float w[4]; VT v[4][NCH];
+            bool ok[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { r[k] = (long long)idx[i + k]; w[k] = psw ? psw[i + k] : 1.f; }
+            for (int k = 0; k < 4; ++k) {
+                r[k] = (long long)idx[i + k]; w[k] = psw ? psw[i + k] : 1.f;
+                ok[k] = dlrm_index_ok(r[k], rows);
+                if (!ok[k]) dlrm_report_bad_index(a.err, a.slot[t], r[k], rows);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     const int col = (c * LPB + lig) * VEC;
                     v_zero(v[k][c]);
-                    if (col < D) v[k][c] = *(const VT*)(W + r[k] * D + col);
+                    if (ok[k] && col < D) v[k][c] = *(const VT*)(W + r[k] * D + col);
                 }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k) {
+                if (ok[k]) {
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) v_fma(acc[u][c], w[k], v[k][c]);
+                    for (int c = 0; c < NCH; ++c) v_fma(acc[u][c], w[k], v[k][c]);
+                }
+            }
         }
         for (; i < end; ++i) {
             const long long r = (long long)idx[i];
             const float w = psw ? psw[i] : 1.f;
+            if (!dlrm_index_ok(r, rows)) { dlrm_report_bad_index(a.err, a.slot[t], r, rows); continue; }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int col = (c * LPB + lig) * VEC;
@@ -209,6 +223,7 @@ __global__ __launch_bounds__(256) void emb_bwd_sgd_atomic_kernel(EmbArgs a, long
         for (long long i = s[u]; i < e[u]; ++i) {
             const long long r = (i == s[u]) ? r0[u] : (long long)idx[i];
             const float w = psw ? psw[i] : 1.f;
+            if (!dlrm_index_ok(r, a.rows[t])) { dlrm_report_bad_index(a.err, a.slot[t], r, a.rows[t]); continue; }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int col = (c * LPB + lig) * VEC;
@@ -256,6 +271,7 @@ __global__ __launch_bounds__(256) void emb_bwd_sgd_lds_kernel(EmbArgs a, long lo
         const long long e = (b + 1 < B) ? (long long)off[b + 1] : nnz;
         for (long long i = s; i < e; ++i) {
             const long long r = (long long)idx[i];
+            if (!dlrm_index_ok(r, a.rows[t])) { dlrm_report_bad_index(a.err, a.slot[t], r, a.rows[t]); continue; }
             atomicAdd(&lds_acc[r * D + d], psw ? psw[i] * gneg : gneg);
         }
     }
@@ -292,6 +308,7 @@ __global__ __launch_bounds__(256) void emb_bwd_sgd_det_kernel(EmbArgs a, long lo
         const long long e = (b + 1 < B) ? (long long)off[b + 1] : nnz;
         for (long long i = s; i < e; ++i) {
             const long long r = (long long)idx[i];
+            if (!dlrm_index_ok(r, a.rows[t])) { dlrm_report_bad_index(a.err, a.slot[t], r, a.rows[t]); continue; }
             if (r % NG != G) continue;  // wave-uniform
             const float w = psw ? psw[i] : 1.f;
             for (int d = lane; d < D; d += 64) {
@@ -301,6 +318,34 @@ __global__ __launch_bounds__(256) void emb_bwd_sgd_det_kernel(EmbArgs a, long lo
                 *p = __builtin_fmaf(neg_lr, gval, *p);
             }
         }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// backward WITHOUT the fused update: the reference's sparse COO gradient, materialised.
+//   values_t[i, :] = psw_t[i] * dout[bag(i), t*D:(t+1)*D]      for every lookup i of table t, in input order
+// (indices of the COO tensor are the lookup indices verbatim, uncoalesced — what EmbeddingBagBackward returns,
+// dlrm_s_pytorch.py:1613).  Escape hatch for optimizers the fused kernels do not implement: 2R extra bytes per lookup.
+// -------------------------------------------------------------------------------------------
+struct CooArgs { float* values[DLRM_MAX_TABLES_PER_LAUNCH]; };
+
+template <typename IT>
+__global__ __launch_bounds__(256) void emb_bwd_coo_kernel(EmbArgs a, CooArgs ca, long long B, int D,
+                                                          const float* __restrict__ dout, long long dout_ld) {
+    const int t = blockIdx.y;
+    const IT* __restrict__ off = (const IT*)a.off[t];
+    const float* __restrict__ psw = a.psw[t];
+    float* __restrict__ values = ca.values[t];
+    const long long nnz = a.nnz[t];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long b = (long long)blockIdx.x * 4 + wave;          // one wavefront per bag
+    if (b >= B) return;
+    const long long s = (long long)off[b];
+    const long long e = (b + 1 < B) ? (long long)off[b + 1] : nnz;
+    const float* g = dout + b * dout_ld + (long long)a.slot[t] * D;
+    for (int d = lane; d < D; d += 64) {
+        const float gv = g[d];
+        for (long long i = s; i < e; ++i) values[i * D + d] = psw ? gv * psw[i] : gv;
     }
 }
 
@@ -367,7 +412,8 @@ static int check_common(int T, int64_t B, int D, const void* const* weight_host,
 
 static void fill_args(EmbArgs& a, const int* ids, int n, void* const* weight_host, const int64_t* rows_host,
                       const void* const* indices_host, const void* const* offsets_host,
-                      const int64_t* nnz_host, const void* const* psw_host) {
+                      const int64_t* nnz_host, const void* const* psw_host, int64_t* err) {
+    a.err = (long long*)err;
     for (int k = 0; k < DLRM_MAX_TABLES_PER_LAUNCH; ++k) {
         const int t = ids[k < n ? k : 0];
         a.w[k] = (float*)weight_host[t];
@@ -386,7 +432,7 @@ extern "C" int dlrm_emb_fwd(int T, int64_t B, int D, const void* const* weight_h
                             const int64_t* rows_host, const void* const* indices_host,
                             const void* const* offsets_host, const int64_t* nnz_host,
                             const void* const* psw_host, int idx_bits, float* out, int64_t out_ld,
-                            void* stream) {
+                            int64_t* err, void* stream) {
     int rc = check_common(T, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host, idx_bits);
     if (rc) return rc;
     if (!out || out_ld < (int64_t)T * D) return DLRM_E_ARG;
@@ -405,7 +451,7 @@ extern "C" int dlrm_emb_fwd(int T, int64_t B, int D, const void* const* weight_h
         int ids[DLRM_MAX_TABLES_PER_LAUNCH];
         for (int k = 0; k < n; ++k) ids[k] = t0 + k;
         EmbArgs a;
-        fill_args(a, ids, n, (void* const*)weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host);
+        fill_args(a, ids, n, (void* const*)weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host, err);
         dim3 grid((unsigned)((B + bags_per_block - 1) / bags_per_block), (unsigned)n, 1), block(256, 1, 1);
         if (idx_bits == 64) EMB_DISPATCH_SHAPE(emb_fwd_kernel, long long, a, (long long)B, D, out, (long long)out_ld);
         else                EMB_DISPATCH_SHAPE(emb_fwd_kernel, int, a, (long long)B, D, out, (long long)out_ld);
@@ -419,7 +465,7 @@ extern "C" int dlrm_emb_bwd_sgd(int T, int64_t B, int D, void* const* weight_hos
                                 const void* const* offsets_host, const int64_t* nnz_host,
                                 const void* const* psw_host, int idx_bits, const float* dout,
                                 int64_t dout_ld, float lr, int mode, void* workspace,
-                                int64_t workspace_bytes, void* stream) {
+                                int64_t workspace_bytes, int64_t* err, void* stream) {
     int rc = check_common(T, B, D, (const void* const*)weight_host, rows_host, indices_host, offsets_host,
                           nnz_host, idx_bits);
     if (rc) return rc;
@@ -427,7 +473,7 @@ extern "C" int dlrm_emb_bwd_sgd(int T, int64_t B, int D, void* const* weight_hos
     if (mode != DLRM_UPD_ATOMIC && mode != DLRM_UPD_DETERMINISTIC && mode != DLRM_UPD_SORTED) return DLRM_E_MODE;
     if (mode == DLRM_UPD_SORTED)
         return dlrm_emb_bwd_sgd_sorted_impl(T, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host,
-                                            psw_host, idx_bits, dout, dout_ld, lr, workspace, workspace_bytes, stream);
+                                            psw_host, idx_bits, dout, dout_ld, lr, workspace, workspace_bytes, err, stream);
     hipStream_t st = (hipStream_t)stream;
     const float neg_lr = -lr;
     dim3 block(256, 1, 1);
@@ -438,7 +484,7 @@ extern "C" int dlrm_emb_bwd_sgd(int T, int64_t B, int D, void* const* weight_hos
             int ids[DLRM_MAX_TABLES_PER_LAUNCH];
             for (int k = 0; k < n; ++k) ids[k] = t0 + k;
             EmbArgs a;
-            fill_args(a, ids, n, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host);
+            fill_args(a, ids, n, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host, err);
             dim3 grid(64, (unsigned)n, 1);
             if (idx_bits == 64)
                 hipLaunchKernelGGL(emb_bwd_sgd_det_kernel<long long>, grid, block, 0, st, a, (long long)B, D, dout, (long long)dout_ld, neg_lr);
@@ -473,7 +519,7 @@ extern "C" int dlrm_emb_bwd_sgd(int T, int64_t B, int D, void* const* weight_hos
             }
             if (n == 0) break;
             EmbArgs a;
-            fill_args(a, ids, n, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host);
+            fill_args(a, ids, n, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host, err);
             if (cls == 1) {
                 const size_t lds = (size_t)(max_rows * D * 4);
                 // enough bags per workgroup to amortise the flush, enough workgroups to fill the chip
@@ -491,6 +537,30 @@ extern "C" int dlrm_emb_bwd_sgd(int T, int64_t B, int D, void* const* weight_hos
             }
             DLRM_LAUNCH_CHECK();
         }
+    }
+    return 0;
+}
+
+extern "C" int dlrm_emb_bwd_coo(int T, int64_t B, int D, const void* const* offsets_host, const int64_t* nnz_host,
+                                const void* const* psw_host, int idx_bits, const float* dout, int64_t dout_ld,
+                                void* const* values_host, void* stream) {
+    if (T <= 0 || B <= 0 || D <= 0 || !offsets_host || !nnz_host || !values_host || !dout || dout_ld < (int64_t)T * D) return DLRM_E_ARG;
+    if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
+    hipStream_t st = (hipStream_t)stream;
+    for (int t0 = 0; t0 < T; t0 += DLRM_MAX_TABLES_PER_LAUNCH) {
+        const int n = (T - t0 < DLRM_MAX_TABLES_PER_LAUNCH) ? T - t0 : DLRM_MAX_TABLES_PER_LAUNCH;
+        EmbArgs a = {};
+        CooArgs ca = {};
+        for (int k = 0; k < DLRM_MAX_TABLES_PER_LAUNCH; ++k) {
+            const int t = t0 + (k < n ? k : 0);
+            if (!offsets_host[t] || nnz_host[t] < 0 || (nnz_host[t] > 0 && !values_host[t])) return DLRM_E_ARG;
+            a.off[k] = offsets_host[t]; a.psw[k] = psw_host ? (const float*)psw_host[t] : nullptr;
+            a.nnz[k] = nnz_host[t]; a.slot[k] = t; ca.values[k] = (float*)values_host[t];
+        }
+        dim3 grid((unsigned)((B + 3) / 4), (unsigned)n, 1), block(256, 1, 1);
+        if (idx_bits == 64) hipLaunchKernelGGL(emb_bwd_coo_kernel<long long>, grid, block, 0, st, a, ca, (long long)B, D, dout, (long long)dout_ld);
+        else                hipLaunchKernelGGL(emb_bwd_coo_kernel<int>, grid, block, 0, st, a, ca, (long long)B, D, dout, (long long)dout_ld);
+        DLRM_LAUNCH_CHECK();
     }
     return 0;
 }

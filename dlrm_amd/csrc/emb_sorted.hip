@@ -98,9 +98,11 @@ __global__ __launch_bounds__(256) void sorted_update_kernel(SortedArgs sa, long 
         for (int j = 0; j < C; ++j) {
             const int t = live[j] ? (int)(k[j] >> row_bits) : 0;
             const long long row = live[j] ? (long long)(k[j] & row_mask) : 0;
-            const unsigned bag = live[j] ? bag_of[pos[j]] : 0u;
+            unsigned bag = live[j] ? bag_of[pos[j]] : 0u;
+            const bool dead = bag == DLRM_DEAD_BAG;            // out-of-range lookup (expand_kernel): zero gradient
+            if (dead) bag = 0u;
             const float* psw = (const float*)s_psw[t];
-            sc[j] = (live[j] && psw) ? neg_lr * psw[(long long)pos[j] - s_base[t]] : neg_lr;
+            sc[j] = dead ? 0.f : ((live[j] && psw) ? neg_lr * psw[(long long)pos[j] - s_base[t]] : neg_lr);
             wrow[j] = (float*)s_w[t] + row * D;
             // a run needs atomics iff it began before this group or continues into the next one
             atom[j] = (it == 0 && j == 0 && has_prev && k[j] == prev_key) || (has_end && k[j] == end_key);
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void sorted_update_kernel(SortedArgs sa, long 
                 const int col = (c * LPB + lig) * VEC;
                 v_zero(gr[j][c]); v_zero(wr[j][c]);
                 if (live[j] && col < D) {
-                    gr[j][c] = *(const VT*)(grow + col);
+                    if (!dead) gr[j][c] = *(const VT*)(grow + col);
                     if (starts[j] && !atom[j]) wr[j][c] = *(const VT*)(wrow[j] + col);
                 }
             }
@@ -137,10 +139,11 @@ template <typename KT>
 static int run_sorted(int n, const int* ids, int64_t B, int D, void* const* weight_host, const int64_t* rows_host,
                       const void* const* indices_host, const void* const* offsets_host, const int64_t* nnz_host,
                       const void* const* psw_host, int idx_bits, const float* dout, int64_t dout_ld, float neg_lr,
-                      char* ws, const Layout& lo, size_t L, int row_bits, int key_bits, bool vec_ok, hipStream_t st) {
+                      char* ws, const Layout& lo, size_t L, int row_bits, int key_bits, bool vec_ok, hipStream_t st,
+                      int64_t* err) {
     SortedArgs sa;
     int rc0 = expand_and_sort<KT>(n, ids, B, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host, idx_bits,
-                                  ws, lo, L, row_bits, key_bits, st, &sa);
+                                  ws, lo, L, row_bits, key_bits, st, &sa, err);
     if (rc0) return rc0;
     const KT* keys_out = (const KT*)(ws + lo.keys_out);
     const unsigned* vals_out = (const unsigned*)(ws + lo.vals_out);
@@ -198,7 +201,7 @@ int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_ho
                                  const void* const* indices_host, const void* const* offsets_host,
                                  const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
                                  const float* dout, int64_t dout_ld, float lr, void* workspace,
-                                 int64_t workspace_bytes, void* stream) {
+                                 int64_t workspace_bytes, int64_t* err, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     bool vec_ok = dlrm_aligned16(dout) && (dout_ld % 4 == 0);
     for (int t = 0; t < T; ++t) vec_ok = vec_ok && dlrm_aligned16(weight_host[t]);
@@ -227,9 +230,9 @@ int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_ho
         }
         rc = wide ? run_sorted<unsigned long long>(n, ids, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host,
                                                    psw_host, idx_bits, dout, dout_ld, -lr, (char*)workspace, lo, L, row_bits,
-                                                   key_bits, vec_ok, st)
+                                                   key_bits, vec_ok, st, err)
                   : run_sorted<unsigned>(n, ids, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host,
-                                         idx_bits, dout, dout_ld, -lr, (char*)workspace, lo, L, row_bits, key_bits, vec_ok, st);
+                                         idx_bits, dout, dout_ld, -lr, (char*)workspace, lo, L, row_bits, key_bits, vec_ok, st, err);
         if (rc) return rc;
     }
     return 0;

@@ -727,24 +727,16 @@ static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     g.tiles_n = (int)((g.N + BNt - 1) / BNt);
     g.debug = 0;
     const size_t lds = (size_t)NSTAGE3 * (BMt + BNt) * BK3 * 4;     // 72 KiB (TM=4) / 48 KiB (TM=2)
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[DLRM_MAX_DEVICES] = {};      // the attribute is per (function, device)
+    const int dev = dlrm_current_device();
+    if (!attr_done[dev]) {
         (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+        attr_done[dev] = true;
     }
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), block(256);
     hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM>), grid, block, lds, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
-}
-
-static int g_mlp_arith = -1;   // DLRM_ARITH_*; -1 = not initialised (env DLRM_MLP_ARITH=f32|bf16x6, default f32)
-
-static void arith_init() {
-    if (g_mlp_arith >= 0) return;
-    const char* e = getenv("DLRM_MLP_ARITH");
-    g_mlp_arith = (e && (!strcmp(e, "bf16x6") || !strcmp(e, "1"))) ? DLRM_ARITH_BF16X6
-                : (e && (!strcmp(e, "bf16") || !strcmp(e, "2"))) ? DLRM_ARITH_BF16 : DLRM_ARITH_F32;
 }
 
 static int gemm_path() {   // env DLRM_GEMM_PATH: 0 = auto (default), 2 = force the register-staged fallback kernel
@@ -754,17 +746,16 @@ static int gemm_path() {   // env DLRM_GEMM_PATH: 0 = auto (default), 2 = force 
 }
 
 template <bool A_KC, bool B_KC>
-static int launch_gemm(GemmArgs& g, int splits, hipStream_t st) {
+static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith) {
     // fast path preconditions: 16-byte vector access to both operands, every k-slice a multiple of 16
-    arith_init();
     const bool k16 = (g.K % BK3 == 0) && (g.kchunk % BK3 == 0);
     if (gemm_path() != 2 && g.vecA && g.vecB && k16 && g.lda % 4 == 0 && g.ldb % 4 == 0) {
         // 256-row tiles when they still give every CU two workgroups, else 128-row tiles
         const long long wg256 = ((g.M + 255) / 256) * ((g.N + 127) / 128) * splits;
         const bool big = g.M >= 256 && wg256 >= 512;
-        if (g_mlp_arith == DLRM_ARITH_BF16X6)
+        if (arith == DLRM_ARITH_BF16X6)
             return big ? launch_gemm3<A_KC, B_KC, 4, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 1>(g, splits, st);
-        if (g_mlp_arith == DLRM_ARITH_BF16)
+        if (arith == DLRM_ARITH_BF16)
             return big ? launch_gemm3<A_KC, B_KC, 4, 2>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 2>(g, splits, st);
         return big ? launch_gemm3<A_KC, B_KC, 4, 0>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0>(g, splits, st);
     }
@@ -774,10 +765,11 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st) {
     if (dbg < 0) { const char* e = getenv("DLRM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
     g.debug = dbg;
     const size_t lds = 2 * 2 * TILE_F * sizeof(float);   // 73,728 B: two workgroups per CU
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[DLRM_MAX_DEVICES] = {};
+    const int dev = dlrm_current_device();
+    if (!attr_done[dev]) {
         (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<A_KC, B_KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+        attr_done[dev] = true;
     }
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), block(256);
     hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC>), grid, block, lds, st, g);
@@ -785,6 +777,7 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st) {
     return 0;
 }
 
+static bool arith_ok(int a) { return a == DLRM_ARITH_F32 || a == DLRM_ARITH_BF16X6 || a == DLRM_ARITH_BF16; }
 static int vec_ok_kc(const float* p, long long ld, long long kext) { return dlrm_aligned16(p) && ld % 4 == 0 && kext % 4 == 0; }
 // k-strided operand: a 16-byte load may run past the logical column extent as long as it stays inside the
 // row pitch (ld % 4 == 0 guarantees that); the extra columns only feed output rows/columns >= M/N, which
@@ -795,8 +788,9 @@ static int vec_ok_ks(const float* p, long long ld, long long cext) { (void)cext;
 
 extern "C" int dlrm_linear_fwd(int64_t M, int N, int K, const float* X, int64_t ldx, const float* W,
                                int64_t ldw, const float* bias, int act, float* Y, int64_t ldy,
-                               void* stream) {
+                               int arith, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !X || !W || !Y) return DLRM_E_ARG;
+    if (!arith_ok(arith)) return DLRM_E_MODE;
     if (ldx < K || ldw < K || ldy < N) return DLRM_E_ARG;
     if (act < DLRM_ACT_NONE || act > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
     if (N == 1 && gemm_path() != 2) {                // matrix-vector layer: HBM streaming, not MFMA (gemv.hip)
@@ -810,13 +804,14 @@ extern "C" int dlrm_linear_fwd(int64_t M, int N, int K, const float* X, int64_t 
     g.vecC = dlrm_aligned16(Y) && ldy % 4 == 0;
     g.kchunk = ((K + BK - 1) / BK) * BK;
     g.bias = bias; g.act = act;
-    return launch_gemm<true, true>(g, 1, (hipStream_t)stream);
+    return launch_gemm<true, true>(g, 1, (hipStream_t)stream, arith);
 }
 
 extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, int64_t lddy,
                                     const float* W, int64_t ldw, const float* Xact, int64_t ldxa,
-                                    int xact_kind, float* dX, int64_t lddx, void* stream) {
+                                    int xact_kind, float* dX, int64_t lddx, int arith, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !dY || !W || !dX) return DLRM_E_ARG;
+    if (!arith_ok(arith)) return DLRM_E_MODE;
     if (lddy < N || ldw < K || lddx < K) return DLRM_E_ARG;
     if (xact_kind < DLRM_ACT_NONE || xact_kind > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
     if (xact_kind != DLRM_ACT_NONE && (!Xact || ldxa < K)) return DLRM_E_ARG;
@@ -836,7 +831,7 @@ extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, in
         g.mask = Xact; g.ldmask = ldxa; g.mask_act = xact_kind;
         g.vecC = g.vecC && dlrm_aligned16(Xact) && ldxa % 4 == 0;
     }
-    return launch_gemm<true, false>(g, 1, (hipStream_t)stream);
+    return launch_gemm<true, false>(g, 1, (hipStream_t)stream, arith);
 }
 
 static void wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* kchunk_out) {
@@ -873,7 +868,8 @@ extern "C" int64_t dlrm_linear_bwd_weight_workspace_bytes(int64_t M, int N, int 
 static int linear_bwd_weight_impl(int64_t M, int N, int K, int K_store, const float* dY, int64_t lddy,
                                   const float* X, int64_t ldx, float* dW, int64_t lddw,
                                   float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
-                                  void* stream) {
+                                  int arith, void* stream) {
+    if (!arith_ok(arith)) return DLRM_E_MODE;
     if (M <= 0 || N <= 0 || K <= 0 || K_store <= 0 || K_store > K || !dY || !X || !dW) return DLRM_E_ARG;
     if (lddy < N || ldx < K || lddw < K_store) return DLRM_E_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -910,7 +906,7 @@ static int linear_bwd_weight_impl(int64_t M, int N, int K, int K_store, const fl
             hipError_t e = hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), st);
             if (e != hipSuccess) return (int)e;
         }
-        int rc = launch_gemm<false, false>(g, splits, st);
+        int rc = launch_gemm<false, false>(g, splits, st, arith);
         if (rc) return rc;
         const bool v4 = dlrm_aligned16(dW) && lddw % 4 == 0 && K_store % 4 == 0;
         const long long items = (long long)N * (v4 ? K_store / 4 : K_store);
@@ -929,21 +925,21 @@ static int linear_bwd_weight_impl(int64_t M, int N, int K, int K_store, const fl
         if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
-    return launch_gemm<false, false>(g, splits, st);
+    return launch_gemm<false, false>(g, splits, st, arith);
 }
 
 extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, int64_t lddy,
                                       const float* X, int64_t ldx, float* dW, int64_t lddw,
                                       float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
-                                      void* stream) {
-    return linear_bwd_weight_impl(M, N, K, K, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, stream);
+                                      int arith, void* stream) {
+    return linear_bwd_weight_impl(M, N, K, K, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, arith, stream);
 }
 
 extern "C" int dlrm_linear_bwd_weight_padded(int64_t M, int N, int K, int K_store, const float* dY, int64_t lddy,
                                              const float* X, int64_t ldx, float* dW, int64_t lddw,
                                              float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
-                                             void* stream) {
-    return linear_bwd_weight_impl(M, N, K, K_store, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, stream);
+                                             int arith, void* stream) {
+    return linear_bwd_weight_impl(M, N, K, K_store, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, arith, stream);
 }
 
 extern "C" int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, const float* Y,
@@ -960,11 +956,3 @@ extern "C" int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, con
     DLRM_LAUNCH_CHECK();
     return 0;
 }
-
-extern "C" int dlrm_mlp_set_arith(int arith) {
-    if (arith != DLRM_ARITH_F32 && arith != DLRM_ARITH_BF16X6 && arith != DLRM_ARITH_BF16) return DLRM_E_MODE;
-    g_mlp_arith = arith;
-    return 0;
-}
-
-extern "C" int dlrm_mlp_get_arith(void) { arith_init(); return g_mlp_arith; }

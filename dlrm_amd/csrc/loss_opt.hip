@@ -1,4 +1,4 @@
-// loss_opt.hip — loss (forward + gradient in one pass), dense SGD, a2a unpack, introspection.
+// loss_opt.hip — loss (forward + gradient in one pass), dense SGD, strided block copies, clamp, introspection.
 //
 // Reference call sites replaced:
 //   torch.nn.BCELoss(reduction="mean") / MSELoss via loss_fn_wrap   dlrm_s_pytorch.py:386-393,148-156
@@ -14,7 +14,7 @@ constexpr int kLossPerThread = 4;
 // BCE per torch: log terms clamped at -100; grad = w*(p-t)/max((1-p)*p, 1e-12)/B
 __global__ __launch_bounds__(kLossBlock) void bce_kernel(long long B, const float* __restrict__ p,
                                                          const float* __restrict__ t,
-                                                         const float* __restrict__ w, float gscale,
+                                                         const float* __restrict__ w, float w_neg, float w_pos, float gscale,
                                                          float* __restrict__ dp, float* __restrict__ partials) {
     __shared__ float red[kLossBlock / 64];
     float local = 0.f;
@@ -23,7 +23,9 @@ __global__ __launch_bounds__(kLossBlock) void bce_kernel(long long B, const floa
     for (int k = 0; k < kLossPerThread; ++k) {
         const long long i = base + k;
         if (i < B) {
-            const float pi = p[i], ti = t[i], wi = w ? w[i] : 1.f;
+            const float pi = p[i], ti = t[i];
+            // class weight = loss_ws[target.long()] of the reference's wbce path (truncation: only t >= 1 selects w_pos)
+            const float wi = (w ? w[i] : 1.f) * (ti >= 1.f ? w_pos : w_neg);
             const float lp = fmaxf(logf(pi), -100.f);
             const float l1p = fmaxf(log1pf(-pi), -100.f);
             local += wi * -(ti * lp + (1.f - ti) * l1p);
@@ -151,25 +153,71 @@ __global__ __launch_bounds__(256) void sgd_dense_multi_kernel(MultiSgdArgs a, fl
     }
 }
 
-struct UnpackArgs { int tables[64]; long long src_off[64]; int col_off[64]; };
+// strided block copy: dst_k[m, 0:w_k] = src_k[m, 0:w_k] for nblk (pointer, row stride) pairs — torch.cat / torch.split along
+// dim 1 without ATen: the "cat" interaction (dlrm_s_pytorch.py:505-507) and the re-layout of all-to-all receive
+// buffers (extend_distributed.py:446-465) in both directions.
+#define DLRM_MAX_COPY_BLOCKS 64
+struct CopyBlocksArgs {
+    const float* src[DLRM_MAX_COPY_BLOCKS]; long long src_ld[DLRM_MAX_COPY_BLOCKS];
+    float*       dst[DLRM_MAX_COPY_BLOCKS]; long long dst_ld[DLRM_MAX_COPY_BLOCKS];
+    int          width[DLRM_MAX_COPY_BLOCKS];
+};
 
-// recv = concat over source ranks s of [b_local][T_s][D]  ->  out[b, col_off[s]*D ...]
-__global__ __launch_bounds__(256) void a2a_unpack_kernel(UnpackArgs u, int nranks, long long b_local, int D,
-                                                         const float* __restrict__ recv, float* __restrict__ out,
-                                                         long long out_ld) {
-    const int s = blockIdx.y;
-    const long long row_len = (long long)u.tables[s] * D;
-    const long long total = b_local * row_len;
-    const float* src = recv + u.src_off[s];
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const long long b = e / row_len, c = e - b * row_len;
-        out[b * out_ld + (long long)u.col_off[s] * D + c] = src[e];
+__global__ __launch_bounds__(256) void copy_blocks_kernel(CopyBlocksArgs a, long long M) {
+    const int k = blockIdx.y;
+    const int w = a.width[k];
+    const float* __restrict__ src = a.src[k];
+    float* __restrict__ dst = a.dst[k];
+    const long long sld = a.src_ld[k], dld = a.dst_ld[k];
+    const bool v4 = (w % 4 == 0) && (sld % 4 == 0) && (dld % 4 == 0) && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15u) == 0;
+    if (v4) {
+        const int w4 = w / 4;
+        const long long total = M * w4;
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+            const long long m = e / w4; const int c = (int)(e - m * w4) * 4;
+            *(float4*)(dst + m * dld + c) = *(const float4*)(src + m * sld + c);
+        }
+    } else {
+        const long long total = M * w;
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+            const long long m = e / w; const int c = (int)(e - m * w);
+            dst[m * dld + c] = src[m * sld + c];
+        }
+    }
+}
+
+// BCELoss(reduction="none") — the per-sample loss `wbce` needs (dlrm_s_pytorch.py:388-391, 150-156) — and its backward
+__global__ __launch_bounds__(256) void bce_elementwise_kernel(long long n, const float* __restrict__ p, const float* __restrict__ t,
+                                                              float* __restrict__ loss) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float pi = p[i], ti = t[i];
+        loss[i] = -(ti * fmaxf(logf(pi), -100.f) + (1.f - ti) * fmaxf(log1pf(-pi), -100.f));
+    }
+}
+__global__ __launch_bounds__(256) void bce_elementwise_bwd_kernel(long long n, const float* __restrict__ p, const float* __restrict__ t,
+                                                                  const float* __restrict__ dloss, float* __restrict__ dp) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float pi = p[i];
+        dp[i] = dloss[i] * (pi - t[i]) / fmaxf((1.f - pi) * pi, 1e-12f);
+    }
+}
+// torch.clamp(x, lo, hi) of the predictions (--loss-threshold, dlrm_s_pytorch.py:580-583,607-610) and its backward
+// (gradient passes where lo <= x <= hi, torch's clamp_backward mask)
+__global__ __launch_bounds__(256) void clamp_kernel(long long n, const float* __restrict__ x, float lo, float hi, float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = fminf(fmaxf(x[i], lo), hi);
+}
+__global__ __launch_bounds__(256) void clamp_bwd_kernel(long long n, const float* __restrict__ x, float lo, float hi,
+                                                        const float* __restrict__ dy, float* __restrict__ dx) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = x[i];
+        dx[i] = (v >= lo && v <= hi) ? dy[i] : 0.f;
     }
 }
 
 }  // namespace
 
-extern "C" int dlrm_hip_abi_version(void) { return 5; }
+extern "C" int dlrm_hip_abi_version(void) { return 6; }
 
 extern "C" const char* dlrm_hip_build_info(void) {
     return "libdlrm_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " clang " __clang_version__;
@@ -192,13 +240,13 @@ extern "C" int64_t dlrm_loss_workspace_bytes(int64_t B) {
     return ((B + per_block - 1) / per_block) * (int64_t)sizeof(float);
 }
 
-extern "C" int dlrm_bce_loss(int64_t B, const float* p, const float* target, const float* weights,
+extern "C" int dlrm_bce_loss(int64_t B, const float* p, const float* target, const float* weights, float w_neg, float w_pos,
                              float grad_scale, float* loss_out, float* dp, void* partials, void* stream) {
     if (B <= 0 || !p || !target || !loss_out || !partials) return DLRM_E_ARG;
     const int64_t per_block = (int64_t)kLossBlock * kLossPerThread;
     const int nblk = (int)((B + per_block - 1) / per_block);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bce_kernel, dim3(nblk), dim3(kLossBlock), 0, st, (long long)B, p, target, weights,
+    hipLaunchKernelGGL(bce_kernel, dim3(nblk), dim3(kLossBlock), 0, st, (long long)B, p, target, weights, w_neg, w_pos,
                        grad_scale / (float)B, dp, (float*)partials);
     DLRM_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, nblk, (const float*)partials, 1.0 / (double)B, loss_out);
@@ -269,18 +317,53 @@ extern "C" int dlrm_sgd_dense_multi(int count, float* const* w_host, const float
     return 0;
 }
 
-extern "C" int dlrm_a2a_unpack(int nranks, int64_t b_local, int D, const int* tables_per_rank_host,
-                               const float* recv, float* out, int64_t out_ld, void* stream) {
-    if (nranks <= 0 || nranks > 64 || b_local <= 0 || D <= 0 || !tables_per_rank_host || !recv || !out) return DLRM_E_ARG;
-    UnpackArgs u = {};
-    long long off = 0; int col = 0;
-    for (int s = 0; s < nranks; ++s) {
-        u.tables[s] = tables_per_rank_host[s]; u.src_off[s] = off; u.col_off[s] = col;
-        off += b_local * (long long)tables_per_rank_host[s] * D; col += tables_per_rank_host[s];
+extern "C" int dlrm_copy_blocks(int64_t M, int nblk, const void* const* src_host, const int64_t* src_ld_host,
+                                void* const* dst_host, const int64_t* dst_ld_host, const int* width_host, void* stream) {
+    if (M <= 0 || nblk <= 0 || !src_host || !src_ld_host || !dst_host || !dst_ld_host || !width_host) return DLRM_E_ARG;
+    for (int k0 = 0; k0 < nblk; k0 += DLRM_MAX_COPY_BLOCKS) {
+        const int n = (nblk - k0 < DLRM_MAX_COPY_BLOCKS) ? nblk - k0 : DLRM_MAX_COPY_BLOCKS;
+        CopyBlocksArgs a = {};
+        long long widest = 1;
+        for (int k = 0; k < n; ++k) {
+            const int w = width_host[k0 + k];
+            if (!src_host[k0 + k] || !dst_host[k0 + k] || w <= 0 || src_ld_host[k0 + k] < w || dst_ld_host[k0 + k] < w) return DLRM_E_ARG;
+            a.src[k] = (const float*)src_host[k0 + k]; a.src_ld[k] = src_ld_host[k0 + k];
+            a.dst[k] = (float*)dst_host[k0 + k]; a.dst_ld[k] = dst_ld_host[k0 + k]; a.width[k] = w;
+            if (w > widest) widest = w;
+        }
+        long long nblkx = (M * widest / 4 + 255) / 256; if (nblkx < 1) nblkx = 1; if (nblkx > 1024) nblkx = 1024;
+        hipLaunchKernelGGL(copy_blocks_kernel, dim3((unsigned)nblkx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, a, (long long)M);
+        DLRM_LAUNCH_CHECK();
     }
-    if (out_ld < (int64_t)col * D) return DLRM_E_ARG;
-    hipLaunchKernelGGL(a2a_unpack_kernel, dim3(256, (unsigned)nranks), dim3(256), 0, (hipStream_t)stream, u, nranks,
-                       (long long)b_local, D, recv, out, (long long)out_ld);
+    return 0;
+}
+
+static inline unsigned ew_blocks(int64_t n) { long long b = (n + 255) / 256; if (b > 2048) b = 2048; if (b < 1) b = 1; return (unsigned)b; }
+
+extern "C" int dlrm_bce_elementwise(int64_t n, const float* p, const float* target, float* loss, void* stream) {
+    if (n <= 0 || !p || !target || !loss) return DLRM_E_ARG;
+    hipLaunchKernelGGL(bce_elementwise_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (long long)n, p, target, loss);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_bce_elementwise_bwd(int64_t n, const float* p, const float* target, const float* dloss, float* dp, void* stream) {
+    if (n <= 0 || !p || !target || !dloss || !dp) return DLRM_E_ARG;
+    hipLaunchKernelGGL(bce_elementwise_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (long long)n, p, target, dloss, dp);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_clamp(int64_t n, const float* x, float lo, float hi, float* y, void* stream) {
+    if (n <= 0 || !x || !y || !(lo <= hi)) return DLRM_E_ARG;
+    hipLaunchKernelGGL(clamp_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (long long)n, x, lo, hi, y);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_clamp_bwd(int64_t n, const float* x, float lo, float hi, const float* dy, float* dx, void* stream) {
+    if (n <= 0 || !x || !dy || !dx || !(lo <= hi)) return DLRM_E_ARG;
+    hipLaunchKernelGGL(clamp_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (long long)n, x, lo, hi, dy, dx);
     DLRM_LAUNCH_CHECK();
     return 0;
 }

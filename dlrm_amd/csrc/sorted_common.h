@@ -49,9 +49,17 @@ __global__ __launch_bounds__(256) void expand_kernel(EmbArgs a, SortedArgs sa, l
     const long long e = (b + 1 < B) ? (long long)off[b + 1] : nnz;
     for (long long i = s; i < e; ++i) {
         const long long pos = base + i;
-        keys[pos] = ((KT)t << row_bits) | (KT)(long long)idx[i];
+        long long r = (long long)idx[i];
+        unsigned bag = (unsigned)b;
+        if (!dlrm_index_ok(r, a.rows[t])) {
+            // skipped lookup: it sorts into row 0 of its table with a zero gradient (DLRM_DEAD_BAG) and is reported —
+            // an index >= 2^row_bits would otherwise spill into the table bits of the key
+            dlrm_report_bad_index(a.err, a.slot[t], r, a.rows[t]);
+            r = 0; bag = DLRM_DEAD_BAG;
+        }
+        keys[pos] = ((KT)t << row_bits) | (KT)r;
         vals[pos] = (unsigned)pos;
-        bag_of[pos] = (unsigned)b;
+        bag_of[pos] = bag;
     }
 }
 
@@ -92,8 +100,9 @@ template <typename KT>
 static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight_host, const int64_t* rows_host,
                            const void* const* indices_host, const void* const* offsets_host, const int64_t* nnz_host,
                            const void* const* psw_host, int idx_bits, char* ws, const Layout& lo, size_t L, int row_bits,
-                           int key_bits, hipStream_t st, SortedArgs* sa_out) {
+                           int key_bits, hipStream_t st, SortedArgs* sa_out, int64_t* err) {
     EmbArgs a;
+    a.err = (long long*)err;
     SortedArgs& sa = *sa_out;
     long long base = 0;
     for (int k = 0; k < DLRM_MAX_TABLES_PER_LAUNCH; ++k) {

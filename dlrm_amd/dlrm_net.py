@@ -27,8 +27,8 @@ import torch
 import torch.nn as nn
 
 from . import ext_dist, ops
-from .functional import (BCELossFunction, ChunkPackFunction, EmbeddingBagsFunction, InteractFunction, MLPFunction,
-                         MSELossFunction, OutSlot)
+from .functional import (BCEElementwiseFunction, BCELossFunction, CatFunction, ChunkPackFunction, ClampFunction,
+                         EmbeddingBagsFunction, InteractFunction, MLPFunction, MSELossFunction, OutSlot)
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, BagBatch
 
 
@@ -46,7 +46,12 @@ def set_embedding_init(device=None) -> None:
 class FusedMLP(nn.Sequential):
     """nn.Sequential of Linear / ReLU / Sigmoid children (same child names -> same state_dict keys as
     the reference tower) whose forward runs the whole tower through the fused GEMM kernels.
-    Being an nn.Module it can be wrapped by DistributedDataParallel exactly like the reference's."""
+    Being an nn.Module it can be wrapped by DistributedDataParallel exactly like the reference's.
+
+    `arith` ("f32" default | "bf16x6" | "bf16", see ops.arith_code) is the arithmetic of this tower's GEMMs; it is a
+    property of the module and is handed to every C-ABI call — there is no process-wide switch."""
+
+    arith = os.environ.get("DLRM_MLP_ARITH", "f32")
 
     def _layers(self):
         mods = list(self.children())
@@ -67,7 +72,7 @@ class FusedMLP(nn.Sequential):
 
     def forward(self, x, out_slot: Optional[OutSlot] = None):
         params, acts = self._layers()
-        return MLPFunction.apply(x, acts, out_slot, *params)
+        return MLPFunction.apply(x, acts, out_slot, ops.arith_code(self.arith), *params)
 
 
 class FusedBCELoss(nn.Module):
@@ -75,6 +80,14 @@ class FusedBCELoss(nn.Module):
 
     def forward(self, p, target):
         return BCELossFunction.apply(p, target, None)
+
+
+class FusedBCELossNone(nn.Module):
+    """BCELoss(reduction="none") by the elementwise loss kernel: what `loss_fn` is under --loss-function=wbce, where the
+    reference's loss_fn_wrap multiplies it by loss_ws[T] and takes the mean (dlrm_s_pytorch.py:150-156)."""
+
+    def forward(self, p, target):
+        return BCEElementwiseFunction.apply(p, target)
 
 
 class FusedMSELoss(nn.Module):
@@ -160,6 +173,9 @@ class DLRM_Net(nn.Module):
         super().__init__()
         self._pending_emb: list = []
         self.emb_update_mode = ops.UPD_SORTED
+        # False (or env DLRM_FUSED_EMB_UPDATE=0): backward materialises the reference's sparse COO gradient into
+        # `emb.weight.grad` (dlrm_emb_bwd_coo) and ANY torch optimizer consumes it, exactly like the reference
+        self.fused_emb_update = os.environ.get("DLRM_FUSED_EMB_UPDATE", "1") != "0"
         # > 1: the pooled-embedding all-to-all of the distributed forward is pipelined in that many batch chunks (opt-in)
         self.a2a_chunks = max(int(os.environ.get("DLRM_A2A_CHUNKS", "1")), 1)
         if m_spa is None or ln_emb is None or ln_bot is None or ln_top is None or arch_interaction_op is None:
@@ -216,10 +232,16 @@ class DLRM_Net(nn.Module):
             import __main__ as _m  # the reference reads the CLI global `args.loss_weights` (:391)
             lw = getattr(getattr(_m, "args", None), "loss_weights", "1.0-1.0")
             self.loss_ws = torch.tensor(np.fromstring(lw, dtype=float, sep="-"))
-            self.loss_fn = torch.nn.BCELoss(reduction="none")
+            self.loss_fn = FusedBCELossNone()
         else:
             sys.exit("ERROR: --loss-function=" + str(loss_function) + " is not supported")
         EmbeddingUpdateHook.register(self)
+
+    def set_mlp_arith(self, name: str) -> None:
+        """Arithmetic of both towers' GEMMs (FusedMLP.arith): "f32" | "bf16x6" | "bf16"."""
+        ops.arith_code(name)
+        for tower in (self.bot_l, self.top_l):
+            getattr(tower, "module", tower).arith = name        # DDP-wrapped towers keep the FusedMLP in .module
 
     # ---------------------------------------------------------------- operators
     def apply_mlp(self, x, layers, out_slot: Optional[OutSlot] = None):
@@ -249,12 +271,18 @@ class DLRM_Net(nn.Module):
         D = emb_l[0].weight.size(1)
         return list(packed.split(D, dim=1))
 
+    def weighted_bce(self, Z, T):
+        """The whole wbce loss of the reference's loss_fn_wrap (mean of loss_ws[T.long()] * BCE(Z, T), dlrm_s_pytorch.py:
+        150-156) in ONE fused kernel pass — for loops that call the model directly instead of through loss_fn_wrap."""
+        ws = self.loss_ws.tolist()
+        return BCELossFunction.apply(Z, T, None, (ws[0], ws[1] if len(ws) > 1 else ws[0]))
+
     def interact_features(self, x, ly):
         if self.arch_interaction_op == "dot":
             D = x.size(1)
             return InteractFunction.apply(D, bool(self.arch_interaction_itself), False, x, *ly)
         if self.arch_interaction_op == "cat":
-            return torch.cat([x] + list(ly), dim=1)
+            return CatFunction.apply(None, x, *ly)
         sys.exit("ERROR: --arch-interaction-op=" + str(self.arch_interaction_op) + " is not supported")
 
     def quantize_embedding(self, bits):
@@ -262,7 +290,24 @@ class DLRM_Net(nn.Module):
 
     # ---------------------------------------------------------------- fused sparse update
     def _stash_embedding_grad(self, weights, bags, dout):
+        if not self.fused_emb_update:
+            self._materialize_coo_grads(weights, bags, dout)
+            return
         self._pending_emb.append((weights, bags, dout))
+        if len(self._pending_emb) == 65:
+            print("WARNING: dlrm_amd: 65 embedding gradients are parked and no optimizer that owns the tables has stepped; "
+                  "every backward() keeps its [B, T*D] gradient buffer alive until then", file=sys.stderr)
+
+    @staticmethod
+    def _materialize_coo_grads(weights, bags, dout):
+        """emb.weight.grad (+)= the reference's sparse COO gradient: indices = the lookup indices verbatim (uncoalesced),
+        values = dout[bag(i)] * psw[i] (EmbeddingBagBackward, dlrm_s_pytorch.py:1613)."""
+        D = weights[0].size(1)
+        values = ops.emb_bwd_coo(bags, dout, D)
+        for k, (w, v) in enumerate(zip(weights, values)):
+            idx = ops.bag_index_tensor(bags, k).reshape(1, -1).long()
+            g = torch.sparse_coo_tensor(idx, v, size=tuple(w.shape), check_invariants=False)
+            w.grad = g if w.grad is None else w.grad + g
 
     def apply_pending_embedding_updates(self, optimizer=None, lr: Optional[float] = None) -> None:
         """Launch the fused backward+update for every stashed embedding gradient: sparse SGD for torch.optim.SGD,
@@ -272,9 +317,11 @@ class DLRM_Net(nn.Module):
             if lr is not None:
                 ops.emb_bwd_sgd(weights, bags, dout, lr, self.emb_update_mode)
                 continue
-            plan = _embedding_update_plan(optimizer, weights)
+            plan = _embedding_update_plan(optimizer, weights, count=sum(1 for p_ in pending if p_[0] is weights))
             if plan is None:
                 self._pending_emb.append((weights, bags, dout))   # another optimizer owns these tables
+            elif plan[0] == "coo":
+                self._materialize_coo_grads(weights, bags, dout)  # the optimizer's own step consumes .grad right after this hook
             elif plan[0] == "sgd":
                 ops.emb_bwd_sgd(weights, bags, dout, plan[1], self.emb_update_mode)
             else:
@@ -289,25 +336,28 @@ class DLRM_Net(nn.Module):
 
     def _clamp(self, p):
         if 0.0 < self.loss_threshold < 1.0:
-            return torch.clamp(p, min=self.loss_threshold, max=(1.0 - self.loss_threshold))
+            return ClampFunction.apply(p, float(self.loss_threshold), float(1.0 - self.loss_threshold))
         return p
 
     def sequential_forward(self, dense_x, lS_o, lS_i):
         """bottom MLP -> embeddings -> interaction -> top MLP (dlrm_s_pytorch.py:587-612), with the
         bottom tower and the embedding kernel writing directly into the [B, (1+T)*D] feature buffer."""
-        if self.arch_interaction_op != "dot":
-            x = self.apply_mlp(dense_x, self.bot_l)
-            ly = self.apply_emb(lS_o, lS_i, self.emb_l, self.v_W_l)
-            return self._clamp(self.apply_mlp(self.interact_features(x, ly), self.top_l))
+        if self.arch_interaction_op not in ("dot", "cat"):
+            sys.exit("ERROR: --arch-interaction-op=" + str(self.arch_interaction_op) + " is not supported")
+        ops.check_index_errors()          # host memory read, no synchronisation: bad indices of earlier steps surface here
         B = dense_x.size(0)
         T = len(self.emb_l)
         D = self.emb_l[0].weight.size(1)
-        feat = torch.empty((B, (1 + T) * D), dtype=torch.float32, device=dense_x.device)
-        x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :D]))
-        if x.size(1) != D:
-            sys.exit("ERROR: bottom MLP output (%d) and embedding dimension (%d) differ" % (x.size(1), D))
-        E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l, out_slot=OutSlot(feat[:, D:]))
-        z = InteractFunction.apply(D, bool(self.arch_interaction_itself), True, x, E)   # [B, round4(width)], zero padded
+        n_out = self.bot_l[-2].out_features if isinstance(self.bot_l[-2], nn.Linear) else D
+        if self.arch_interaction_op == "dot" and n_out != D:
+            sys.exit("ERROR: bottom MLP output (%d) and embedding dimension (%d) differ" % (n_out, D))
+        feat = torch.empty((B, n_out + T * D), dtype=torch.float32, device=dense_x.device)
+        x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :n_out]))
+        E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l, out_slot=OutSlot(feat[:, n_out:]))
+        if self.arch_interaction_op == "cat":
+            z = CatFunction.apply(OutSlot(feat), x, E)      # the feature buffer IS cat([x] + ly, 1): nothing is copied
+        else:
+            z = InteractFunction.apply(D, bool(self.arch_interaction_itself), True, x, E)   # [B, round4(width)], zero padded
         return self._clamp(self.apply_mlp(z, self.top_l))
 
     def distributed_forward(self, dense_x, lS_o, lS_i):
@@ -319,6 +369,7 @@ class DLRM_Net(nn.Module):
             sys.exit("ERROR: batch_size (%d) must be larger than number of ranks (%d)" % (batch_size, ext_dist.my_size))
         if batch_size % ext_dist.my_size != 0:
             sys.exit("ERROR: batch_size %d can not split across %d ranks evenly" % (batch_size, ext_dist.my_size))
+        ops.check_index_errors()
         dense_x = dense_x[ext_dist.get_my_slice(batch_size)]
         lS_o = lS_o[self.local_emb_slice]
         lS_i = lS_i[self.local_emb_slice]
@@ -368,11 +419,13 @@ def _is_rwsadagrad(optimizer) -> bool:
         all(k in d for k in ("lr", "lr_decay", "eps", "initial_accumulator_value"))
 
 
-def _embedding_update_plan(optimizer, weights):
+def _embedding_update_plan(optimizer, weights, count=1):
     """None if `optimizer` does not own the tables; ("sgd", lr) for torch.optim.SGD; ("rwsadagrad", clr, eps, states)
     for RWSAdagrad — `states` are the per-table row-wise accumulators kept in optimizer.state[p]["momentum"] exactly
     where the reference keeps them (created lazily with initial_accumulator_value, rwsadagrad.py:89-95), the step count
-    in state[p]["step"] (clr = lr / (1 + (step-1)*lr_decay), :113-115)."""
+    in state[p]["step"] (clr = lr / (1 + (step-1)*lr_decay), :113-115); ("coo",) for every other optimizer (and SGD with
+    momentum / weight decay): the sparse COO gradient is materialised and the optimizer's own step consumes it, as in
+    the reference.  `count` = parked backward passes of these tables (gradient accumulation)."""
     if optimizer is None:
         return None
     owner = {}
@@ -385,6 +438,11 @@ def _embedding_update_plan(optimizer, weights):
     if any(g is None for g in groups):
         sys.exit("ERROR: optimizer holds only some of the embedding tables")
     if _is_rwsadagrad(optimizer):
+        if count > 1:
+            # the reference coalesces the ACCUMULATED gradient and applies one non-linear update / one step increment;
+            # several separate fused updates would not equal that
+            sys.exit("ERROR: gradient accumulation (more than one backward per optimizer step) with the fused row-wise "
+                     "Adagrad update is not supported; set model.fused_emb_update = False (DLRM_FUSED_EMB_UPDATE=0)")
         clrs, states = [], []
         for w, g in zip(weights, groups):
             if g.get("weight_decay", 0) != 0:
@@ -400,11 +458,10 @@ def _embedding_update_plan(optimizer, weights):
             sys.exit("ERROR: embedding tables in param groups with different learning rates are not supported")
         return ("rwsadagrad", clrs[0], float(groups[0]["eps"]), states)
     if not isinstance(optimizer, torch.optim.SGD):
-        sys.exit("ERROR: the fused embedding update implements torch.optim.SGD and RWSAdagrad; got %s"
-                 % type(optimizer).__name__)
+        return ("coo",)
     for g in groups:
         if g.get("momentum", 0) != 0 or g.get("weight_decay", 0) != 0 or g.get("nesterov", False) or g.get("maximize", False):
-            sys.exit("ERROR: fused sparse SGD supports momentum=0, weight_decay=0 only (as sparse gradients do)")
+            return ("coo",)
     lrs = [float(g["lr"]) for g in groups]
     if len(set(lrs)) != 1:
         sys.exit("ERROR: embedding tables in param groups with different learning rates are not supported")

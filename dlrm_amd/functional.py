@@ -62,7 +62,8 @@ class OutSlot:
 class MLPFunction(Function):
     """nn.Sequential(Linear, act, Linear, act, ...) as one chain of fused GEMM(+bias+act) kernels.
 
-    forward(x, acts, out_slot, W0, b0, W1, b1, ...) -> activated output of the last layer.
+    forward(x, acts, out_slot, arith, W0, b0, W1, b1, ...) -> activated output of the last layer (`arith`: the MLP
+    arithmetic of every GEMM of the tower, forward and backward — a per-call argument of the C ABI).
     Reference: DLRM_Net.create_mlp / apply_mlp (dlrm_s_pytorch.py:208-246, 399-405).
 
     Input widths that are not a multiple of 4 floats (13 dense features, 479 interaction outputs) would
@@ -72,8 +73,9 @@ class MLPFunction(Function):
     `x` is made (cheap: it only happens for the narrow dense-feature input)."""
 
     @staticmethod
-    def forward(ctx, x, acts, out_slot, *params):
+    def forward(ctx, x, acts, out_slot, arith, *params):
         x = _rowmajor(x)
+        ctx.arith = arith
         L = len(acts)
         M = x.size(0)
         W0 = params[0]
@@ -99,7 +101,7 @@ class MLPFunction(Function):
                 y = out_slot.get()
             else:
                 y = alloc2d(M, N, x)
-            ops.linear_fwd(cur, W, b, acts[i], y)
+            ops.linear_fwd(cur, W, b, acts[i], y, arith)
             outs.append(y)
             cur = y
         ctx.acts = acts
@@ -109,7 +111,7 @@ class MLPFunction(Function):
 
     @staticmethod
     def backward(ctx, dY):
-        acts = ctx.acts
+        acts, arith = ctx.acts, ctx.arith
         L = len(acts)
         saved = ctx.saved_tensors
         x = saved[0]
@@ -141,25 +143,25 @@ class MLPFunction(Function):
             if side is not None:
                 side.wait_event(main.record_event())
                 with torch.cuda.stream(side):
-                    ops.linear_bwd_weight(dZ, X_i, dW, db)  # dW and db (row sums of dZ^T) in one GEMM
+                    ops.linear_bwd_weight(dZ, X_i, dW, db, arith=arith)  # dW and db (row sums of dZ^T) in one GEMM
                 keep.append(dZ)
             else:
-                ops.linear_bwd_weight(dZ, X_i, dW, db)
+                ops.linear_bwd_weight(dZ, X_i, dW, db, arith=arith)
             grads[2 * i], grads[2 * i + 1] = dW, db
             if i > 0:
                 dprev = alloc2d(M, W.size(1), x)
                 # dgrad GEMM with the previous layer's activation derivative fused into the epilogue
-                ops.linear_bwd_data(dZ, W, X_i, acts[i - 1], dprev)
+                ops.linear_bwd_data(dZ, W, X_i, acts[i - 1], dprev, arith)
                 dZ = dprev
             elif ctx.needs_input_grad[0]:
                 dX = alloc2d(M, W.size(1), x)
-                ops.linear_bwd_data(dZ, W, None, ACT_NONE, dX)
+                ops.linear_bwd_data(dZ, W, None, ACT_NONE, dX, arith)
                 if dX.size(1) != ctx.in_width:
                     dX = dX[:, :ctx.in_width]
         if side is not None:
             main.wait_stream(side)
             del keep
-        return (dX, None, None, *grads)
+        return (dX, None, None, None, *grads)
 
 
 class EmbeddingBagsFunction(Function):
@@ -251,12 +253,63 @@ class ChunkPackFunction(Function):
         return dE.view(N * C * Bc, W), None, None
 
 
-class BCELossFunction(Function):
-    """BCELoss(reduction='mean'); loss and dL/dp are produced by one kernel pass."""
+class CatFunction(Function):
+    """R = torch.cat(blocks, dim=1) — the "cat" interaction (dlrm_s_pytorch.py:505-507).
+
+    forward(shared, block0, block1, ...): `shared` is None (R is allocated and filled by ONE strided-copy launch), or an
+    OutSlot over a buffer in which the blocks ALREADY sit side by side in order (the [B, (1+T)*D] feature buffer the
+    bottom tower and the embedding kernel wrote into): then R is that buffer and nothing is copied.  Backward hands out
+    column views of dR (consumers take row strides)."""
 
     @staticmethod
-    def forward(ctx, p, target, weights):
-        loss, dp = ops.bce_loss(p.contiguous(), target.contiguous(), weights, 1.0, want_grad=True)
+    def forward(ctx, shared, *blocks):
+        ctx.widths = [b.size(1) for b in blocks]
+        if shared is not None:
+            R = shared.get()
+            if R.size(1) != sum(ctx.widths):
+                raise RuntimeError("dlrm_amd: CatFunction shared buffer width mismatch")
+            return R
+        blocks = [_rowmajor(b) for b in blocks]
+        R = alloc2d(blocks[0].size(0), sum(ctx.widths), blocks[0])
+        dsts, o = [], 0
+        for w in ctx.widths:
+            dsts.append(R[:, o:o + w])
+            o += w
+        ops.copy_blocks(blocks, dsts)
+        return R
+
+    @staticmethod
+    def backward(ctx, dR):
+        outs, o = [], 0
+        for w in ctx.widths:
+            outs.append(dR[:, o:o + w])
+            o += w
+        return (None, *outs)
+
+
+class ClampFunction(Function):
+    """torch.clamp(p, lo, hi) of the predictions (--loss-threshold, dlrm_s_pytorch.py:580-583,607-610)."""
+
+    @staticmethod
+    def forward(ctx, p, lo, hi):
+        p = p.contiguous()
+        ctx.save_for_backward(p)
+        ctx.lo, ctx.hi = lo, hi
+        return ops.clamp(p, lo, hi)
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        return ops.clamp_bwd(p, ctx.lo, ctx.hi, g), None, None
+
+
+class BCELossFunction(Function):
+    """BCELoss(reduction='mean'); loss and dL/dp are produced by one kernel pass.  class_weights = (w_neg, w_pos) turns it
+    into the reference's weighted BCE (mean of loss_ws[T.long()] * bce, loss_fn_wrap dlrm_s_pytorch.py:150-156)."""
+
+    @staticmethod
+    def forward(ctx, p, target, weights, class_weights=(1.0, 1.0)):
+        loss, dp = ops.bce_loss(p.contiguous(), target.contiguous(), weights, 1.0, want_grad=True, class_weights=class_weights)
         ctx.save_for_backward(dp)
         ctx.shape = p.shape
         return loss.reshape(())
@@ -264,7 +317,23 @@ class BCELossFunction(Function):
     @staticmethod
     def backward(ctx, g):
         (dp,) = ctx.saved_tensors
-        return ops.scale_by_scalar(dp, g.reshape(1).float()).view(ctx.shape), None, None
+        return ops.scale_by_scalar(dp, g.reshape(1).float()).view(ctx.shape), None, None, None
+
+
+class BCEElementwiseFunction(Function):
+    """BCELoss(reduction='none'): the per-sample loss the reference's wbce path multiplies by class weights and averages
+    in loss_fn_wrap (dlrm_s_pytorch.py:388-391, 150-156)."""
+
+    @staticmethod
+    def forward(ctx, p, target):
+        p, target = p.contiguous(), target.contiguous()
+        ctx.save_for_backward(p, target)
+        return ops.bce_elementwise(p, target)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, target = ctx.saved_tensors
+        return ops.bce_elementwise_bwd(p, target, g.to(torch.float32)), None
 
 
 class MSELossFunction(Function):

@@ -16,7 +16,13 @@ from . import _lib
 from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED  # noqa: F401
 
 
-def _stream() -> C.c_void_p:
+def _stream(t: Optional[torch.Tensor] = None) -> C.c_void_p:
+    """torch's current stream of the device the kernels will run on.  HIP launches go to the CURRENT device, so an operand
+    that lives on another device (a model on cuda:1 in a process that never called torch.cuda.set_device(1)) is refused
+    loudly instead of launching device-0 kernels on device-1 pointers."""
+    if t is not None and t.is_cuda and t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"dlrm_amd: operand on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device(...) (one process per GPU) before using the model")
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -79,6 +85,39 @@ def _ld(t: torch.Tensor) -> int:
 
 
 # ------------------------------------------------------------------------------------------------
+# out-of-range embedding indices
+# ------------------------------------------------------------------------------------------------
+_err_blocks = {}   # device index -> pinned host int64[4] the embedding kernels report into (include/dlrm_hip.h, `err`)
+
+
+def _err_block(device: torch.device) -> torch.Tensor:
+    """Pinned host memory is device-visible under HIP's unified addressing: the kernels store {1, table, index, rows}
+    straight into it when they meet an index outside [0, rows), and the host polls it WITHOUT synchronising."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    blk = _err_blocks.get(key)
+    if blk is None:
+        blk = torch.zeros(4, dtype=torch.int64).pin_memory()
+        _err_blocks[key] = blk
+    return blk
+
+
+def check_index_errors(device=None, sync: bool = False) -> None:
+    """Raise IndexError if an embedding kernel that has FINISHED met an out-of-range index (the lookup was skipped on the
+    device; the reference's EmbeddingBag raises at the call).  sync=True first waits for the device, which makes the
+    check exact for everything enqueued so far; without it the check costs one host memory read (DLRM_Net.forward does
+    that at every step, so bad data is reported at most one step late)."""
+    if sync and torch.cuda.is_available():
+        torch.cuda.synchronize(device)
+    for key, blk in _err_blocks.items():
+        if device is not None and torch.device(device).index not in (None, key):
+            continue
+        if int(blk[0]) != 0:
+            _, t, idx, rows = blk.tolist()
+            blk.zero_()
+            raise IndexError(f"dlrm_amd: embedding index out of range: table {t}, index {idx}, rows {rows} (cuda:{key})")
+
+
+# ------------------------------------------------------------------------------------------------
 # embedding bags
 # ------------------------------------------------------------------------------------------------
 class BagBatch:
@@ -111,10 +150,12 @@ class BagBatch:
             idx_ptrs = [lS_i.data_ptr() + k * lS_i.stride(0) * isz if n_i else 0 for k in range(T)]
             off_ptrs = [lS_o.data_ptr() + k * lS_o.stride(0) * isz for k in range(T)]
             nnz = [n_i] * T
+            self._idx_src = lS_i
         else:
             idx_ptrs, off_ptrs, nnz = [], [], []
             dt = None
             B = None
+            self._idx_src = []
             for k in range(T):
                 i_k, o_k = lS_i[k], lS_o[k]
                 if i_k.dtype not in (torch.int64, torch.int32) or o_k.dtype != i_k.dtype:
@@ -134,6 +175,7 @@ class BagBatch:
                 elif B != o_k.numel():
                     raise RuntimeError("dlrm_amd: every table must have the same number of bags")
                 self.keep += [i_k, o_k]
+                self._idx_src.append(i_k)
                 idx_ptrs.append(i_k.data_ptr() if i_k.numel() else 0)
                 off_ptrs.append(o_k.data_ptr())
                 nnz.append(i_k.numel())
@@ -159,6 +201,11 @@ class BagBatch:
             self._psw = _lib.ptr_array(ptrs)
 
 
+def bag_index_tensor(bags: "BagBatch", k: int) -> torch.Tensor:
+    """the 1-D index tensor of table k as it was passed in (the COO gradient's indices, verbatim)"""
+    return bags._idx_src[k]
+
+
 def _weights_desc(weights: Sequence[torch.Tensor]):
     D = None
     for w in weights:
@@ -181,7 +228,8 @@ def emb_fwd(weights: Sequence[torch.Tensor], bags: BagBatch, out: torch.Tensor) 
         raise RuntimeError("dlrm_amd: emb_fwd shape mismatch")
     with _timed("emb_fwd"):
         rc = lib.dlrm_emb_fwd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
-                              bags.idx_bits, C.c_void_p(out.data_ptr()), _ld(out), _stream())
+                              bags.idx_bits, C.c_void_p(out.data_ptr()), _ld(out),
+                              C.c_void_p(_err_block(out.device).data_ptr()), _stream(out))
     _lib.check(rc, "dlrm_emb_fwd")
     return out
 
@@ -215,7 +263,7 @@ def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Ten
     with _timed("emb_bwd_sgd"):
         rc = lib.dlrm_emb_bwd_sgd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
                                   bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout), float(lr), int(mode),
-                                  ws_ptr, ws_bytes, _stream())
+                                  ws_ptr, ws_bytes, C.c_void_p(_err_block(dout.device).data_ptr()), _stream(dout))
     _lib.check(rc, "dlrm_emb_bwd_sgd")
 
 
@@ -241,8 +289,25 @@ def emb_bwd_rowwise_adagrad(weights: Sequence[torch.Tensor], states: Sequence[to
     with _timed("emb_bwd_adagrad"):
         rc = lib.dlrm_emb_bwd_rowwise_adagrad(bags.T, bags.B, D, wp, sp, rows, bags._idx, bags._off, bags._nnz,
                                               bags._psw, bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout),
-                                              float(lr), float(eps), C.c_void_p(ws.data_ptr()), ws.numel(), _stream())
+                                              float(lr), float(eps), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                              C.c_void_p(_err_block(dout.device).data_ptr()), _stream(dout))
     _lib.check(rc, "dlrm_emb_bwd_rowwise_adagrad")
+
+
+def emb_bwd_coo(bags: BagBatch, dout: torch.Tensor, D: int) -> List[torch.Tensor]:
+    """The reference's EmbeddingBag backward WITHOUT the fused update: per table the [nnz_t, D] value block of the sparse
+    COO gradient (values[i] = psw[i] * dout[bag(i), t*D:(t+1)*D]; its indices are the lookup indices verbatim)."""
+    lib = _lib.load()
+    _req(dout, "dout", ndim=2)
+    if dout.size(0) != bags.B or dout.size(1) < bags.T * D:
+        raise RuntimeError("dlrm_amd: emb_bwd_coo shape mismatch")
+    values = [torch.empty((n, D), dtype=torch.float32, device=dout.device) for n in bags.nnz]
+    with _timed("emb_bwd_coo"):
+        rc = lib.dlrm_emb_bwd_coo(bags.T, bags.B, D, bags._off, bags._nnz, bags._psw, bags.idx_bits,
+                                  C.c_void_p(dout.data_ptr()), _ld(dout),
+                                  _lib.ptr_array([v.data_ptr() if v.numel() else 0 for v in values]), _stream())
+    _lib.check(rc, "dlrm_emb_bwd_coo")
+    return values
 
 
 # ------------------------------------------------------------------------------------------------
@@ -275,7 +340,7 @@ def interact_fwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool,
         raise RuntimeError("dlrm_amd: interact_fwd output shape mismatch")
     with _timed("interact_fwd"):
         rc = lib.dlrm_interact_fwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(bool(self_interaction)),
-                                   C.c_void_p(R.data_ptr()), _ld(R), _stream())
+                                   C.c_void_p(R.data_ptr()), _ld(R), _stream(R))
     _lib.check(rc, "dlrm_interact_fwd")
     return R
 
@@ -292,32 +357,31 @@ def interact_bwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool,
     with _timed("interact_bwd"):
         rc = lib.dlrm_interact_bwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(bool(self_interaction)),
                                    C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
-                                   _stream())
+                                   _stream(dR))
     _lib.check(rc, "dlrm_interact_bwd")
 
 
 # ------------------------------------------------------------------------------------------------
 # MLP layers
 # ------------------------------------------------------------------------------------------------
-_ARITH_NAMES = {"f32": _lib.ARITH_F32, "bf16x6": _lib.ARITH_BF16X6, "bf16": _lib.ARITH_BF16}
+ARITH_NAMES = {"f32": _lib.ARITH_F32, "bf16x6": _lib.ARITH_BF16X6, "bf16": _lib.ARITH_BF16}
 
 
-def set_mlp_arith(name: str) -> None:
-    """"f32": native fp32 MFMA.  "bf16x6": fp32 operands split exactly into 3 bf16 terms, 6 bf16 MFMA products,
-    fp32 accumulation (fp32 round-off class, 2.7x the matrix rate).  "bf16": operands rounded to bf16, one bf16 MFMA per
-    16-k step, fp32 accumulation — the reduced-precision "bf16 MLP" of BASELINE.json configs[4] (NOT fp32-class).
-    See include/dlrm_hip.h."""
-    if name not in _ARITH_NAMES:
-        raise RuntimeError(f"dlrm_amd: unknown MLP arithmetic {name!r} (f32 | bf16x6 | bf16)")
-    _lib.check(_lib.load().dlrm_mlp_set_arith(_ARITH_NAMES[name]), "dlrm_mlp_set_arith")
+def arith_code(arith) -> int:
+    """MLP arithmetic as the C ABI's per-call argument.  "f32": native fp32 MFMA.  "bf16x6": fp32 operands split exactly into
+    3 bf16 terms, 6 bf16 MFMA products, fp32 accumulation (fp32 round-off class, 2.7x the matrix rate).  "bf16": operands
+    rounded to bf16, one bf16 MFMA per 16-k step, fp32 accumulation — the reduced-precision "bf16 MLP" of BASELINE.json
+    configs[4] (NOT fp32-class).  There is no process-wide switch: the arithmetic belongs to the module (FusedMLP.arith)
+    and travels with every call.  See include/dlrm_hip.h."""
+    if isinstance(arith, int) and arith in ARITH_NAMES.values():
+        return arith
+    if arith not in ARITH_NAMES:
+        raise RuntimeError(f"dlrm_amd: unknown MLP arithmetic {arith!r} (f32 | bf16x6 | bf16)")
+    return ARITH_NAMES[arith]
 
 
-def get_mlp_arith() -> str:
-    v = _lib.load().dlrm_mlp_get_arith()
-    return {b: a for a, b in _ARITH_NAMES.items()}[v]
-
-
-def linear_fwd(X: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], act: int, Y: torch.Tensor) -> torch.Tensor:
+def linear_fwd(X: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], act: int, Y: torch.Tensor,
+               arith=_lib.ARITH_F32) -> torch.Tensor:
     lib = _lib.load()
     _req(X, "X", ndim=2); _req(W, "W", ndim=2); _req(Y, "Y", ndim=2)
     M, K = X.shape
@@ -329,13 +393,13 @@ def linear_fwd(X: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], a
     with _timed("linear_fwd"):
         rc = lib.dlrm_linear_fwd(M, N, K, C.c_void_p(X.data_ptr()), _ld(X), C.c_void_p(W.data_ptr()), _ld(W),
                                  C.c_void_p(bias.data_ptr()) if bias is not None else None, int(act),
-                                 C.c_void_p(Y.data_ptr()), _ld(Y), _stream())
+                                 C.c_void_p(Y.data_ptr()), _ld(Y), arith_code(arith), _stream(Y))
     _lib.check(rc, "dlrm_linear_fwd")
     return Y
 
 
 def linear_bwd_data(dY: torch.Tensor, W: torch.Tensor, Xact: Optional[torch.Tensor], xact_kind: int,
-                    dX: torch.Tensor) -> torch.Tensor:
+                    dX: torch.Tensor, arith=_lib.ARITH_F32) -> torch.Tensor:
     """dX = (dY @ W) * act'(Xact)   (Xact None -> no mask)"""
     lib = _lib.load()
     _req(dY, "dY", ndim=2); _req(W, "W", ndim=2); _req(dX, "dX", ndim=2)
@@ -349,7 +413,7 @@ def linear_bwd_data(dY: torch.Tensor, W: torch.Tensor, Xact: Optional[torch.Tens
         rc = lib.dlrm_linear_bwd_data(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(W.data_ptr()), _ld(W),
                                       C.c_void_p(Xact.data_ptr()) if Xact is not None else None,
                                       _ld(Xact) if Xact is not None else 0, int(xact_kind if Xact is not None else ACT_NONE),
-                                      C.c_void_p(dX.data_ptr()), _ld(dX), _stream())
+                                      C.c_void_p(dX.data_ptr()), _ld(dX), arith_code(arith), _stream(dX))
     _lib.check(rc, "dlrm_linear_bwd_data")
     return dX
 
@@ -369,7 +433,7 @@ def _wgrad_workspace(need: int, device) -> Optional[torch.Tensor]:
 
 
 def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor] = None,
-                      accumulate: bool = False, use_workspace: bool = True) -> torch.Tensor:
+                      accumulate: bool = False, use_workspace: bool = True, arith=_lib.ARITH_F32) -> torch.Tensor:
     """dW = dY^T @ X and (optionally) dbias = column sums of dY, one GEMM (+ the split-K slab reduction).
     dW may be NARROWER than X (dW [N, K_store], X [M, K >= K_store]): the extra columns of X are alignment padding
     (zeros) and their gradient is dropped.  use_workspace=False exercises the atomic-accumulation variant."""
@@ -391,7 +455,7 @@ def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias
                   C.c_void_p(dbias.data_ptr()) if dbias is not None else None,
                   int(bool(accumulate)),
                   C.c_void_p(ws.data_ptr()) if ws is not None else None,
-                  ws.numel() if ws is not None else 0, _stream())
+                  ws.numel() if ws is not None else 0, arith_code(arith), _stream(dW))
         if K_store == K:
             rc = lib.dlrm_linear_bwd_weight(M, N, K, *common)
         else:
@@ -436,8 +500,9 @@ def _loss_ws(B: int, device) -> torch.Tensor:
 
 
 def bce_loss(p: torch.Tensor, target: torch.Tensor, weights: Optional[torch.Tensor], grad_scale: float,
-             want_grad: bool):
-    """returns (loss[1], dp or None); p/target are [B] or [B,1] contiguous."""
+             want_grad: bool, class_weights=(1.0, 1.0)):
+    """returns (loss[1], dp or None); p/target are [B] or [B,1] contiguous.  class_weights = (w_neg, w_pos): the wbce
+    weights `loss_ws[T.long()]` of the reference applied inside the kernel."""
     lib = _lib.load()
     _req(p, "p"); _req(target, "target")
     if not p.is_contiguous() or not target.is_contiguous() or p.numel() != target.numel():
@@ -451,7 +516,8 @@ def bce_loss(p: torch.Tensor, target: torch.Tensor, weights: Optional[torch.Tens
         weights = weights.contiguous()
     with _timed("bce_loss"):
         rc = lib.dlrm_bce_loss(B, C.c_void_p(p.data_ptr()), C.c_void_p(target.data_ptr()),
-                               C.c_void_p(weights.data_ptr()) if weights is not None else None, float(grad_scale),
+                               C.c_void_p(weights.data_ptr()) if weights is not None else None,
+                               float(class_weights[0]), float(class_weights[1]), float(grad_scale),
                                C.c_void_p(loss.data_ptr()), C.c_void_p(dp.data_ptr()) if dp is not None else None,
                                C.c_void_p(ws.data_ptr()), _stream())
     _lib.check(rc, "dlrm_bce_loss")
@@ -561,14 +627,68 @@ def binary_metrics(scores: torch.Tensor, targets: torch.Tensor) -> dict:
     return v
 
 
-def a2a_unpack(recv: torch.Tensor, tables_per_rank: List[int], b_local: int, D: int, out: torch.Tensor) -> torch.Tensor:
+def copy_blocks(srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor]) -> None:
+    """dsts[k][:, :] = srcs[k][:, :] for [M, w_k] row-major views with arbitrary row strides, one launch: torch.cat / split
+    along dim 1 without ATen (the "cat" interaction and its backward)."""
     lib = _lib.load()
-    _req(recv, "recv"); _req(out, "out", ndim=2)
-    arr = (C.c_int * len(tables_per_rank))(*tables_per_rank)
-    rc = lib.dlrm_a2a_unpack(len(tables_per_rank), b_local, D, arr, C.c_void_p(recv.data_ptr()),
-                             C.c_void_p(out.data_ptr()), _ld(out), _stream())
-    _lib.check(rc, "dlrm_a2a_unpack")
-    return out
+    if len(srcs) != len(dsts) or not srcs:
+        raise RuntimeError("dlrm_amd: copy_blocks needs equally many sources and destinations")
+    M = srcs[0].size(0)
+    for a_, b_ in zip(srcs, dsts):
+        _req(a_, "src", ndim=2); _req(b_, "dst", ndim=2)
+        if a_.shape != b_.shape or a_.size(0) != M:
+            raise RuntimeError("dlrm_amd: copy_blocks shape mismatch")
+    if M == 0:
+        return
+    widths = (C.c_int * len(srcs))(*[int(a_.size(1)) for a_ in srcs])
+    rc = lib.dlrm_copy_blocks(M, len(srcs), _lib.ptr_array([a_.data_ptr() for a_ in srcs]), _lib.i64_array([_ld(a_) for a_ in srcs]),
+                              _lib.ptr_array([b_.data_ptr() for b_ in dsts]), _lib.i64_array([_ld(b_) for b_ in dsts]),
+                              widths, _stream())
+    _lib.check(rc, "dlrm_copy_blocks")
+
+
+def bce_elementwise(p: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _req(p, "p"); _req(target, "target")
+    if not p.is_contiguous() or not target.is_contiguous() or p.numel() != target.numel():
+        raise RuntimeError("dlrm_amd: bce_elementwise needs contiguous p/target of equal size")
+    loss = torch.empty_like(p)
+    rc = lib.dlrm_bce_elementwise(p.numel(), C.c_void_p(p.data_ptr()), C.c_void_p(target.data_ptr()),
+                                  C.c_void_p(loss.data_ptr()), _stream())
+    _lib.check(rc, "dlrm_bce_elementwise")
+    return loss
+
+
+def bce_elementwise_bwd(p: torch.Tensor, target: torch.Tensor, dloss: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _req(dloss, "dloss")
+    dloss = dloss.contiguous()
+    dp = torch.empty_like(p)
+    rc = lib.dlrm_bce_elementwise_bwd(p.numel(), C.c_void_p(p.data_ptr()), C.c_void_p(target.data_ptr()),
+                                      C.c_void_p(dloss.data_ptr()), C.c_void_p(dp.data_ptr()), _stream())
+    _lib.check(rc, "dlrm_bce_elementwise_bwd")
+    return dp
+
+
+def clamp(x: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
+    lib = _lib.load()
+    _req(x, "x")
+    if not x.is_contiguous():
+        raise RuntimeError("dlrm_amd: clamp needs a contiguous tensor")
+    y = torch.empty_like(x)
+    _lib.check(lib.dlrm_clamp(x.numel(), C.c_void_p(x.data_ptr()), float(lo), float(hi), C.c_void_p(y.data_ptr()), _stream()),
+               "dlrm_clamp")
+    return y
+
+
+def clamp_bwd(x: torch.Tensor, lo: float, hi: float, dy: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    _req(dy, "dy")
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    _lib.check(lib.dlrm_clamp_bwd(x.numel(), C.c_void_p(x.data_ptr()), float(lo), float(hi), C.c_void_p(dy.data_ptr()),
+                                  C.c_void_p(dx.data_ptr()), _stream()), "dlrm_clamp_bwd")
+    return dx
 
 
 def device_info(device: int = 0) -> dict:

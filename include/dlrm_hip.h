@@ -14,6 +14,13 @@
  *   - `*_host` arguments are HOST arrays (of device pointers or sizes) read during the call.
  *   - `stream` is a hipStream_t (NULL = default stream).  Nothing allocates, nothing
  *     synchronises; work is enqueued on `stream` and the call returns.
+ *   - no process-wide mutable state: every mode (MLP arithmetic, update mode, error block) is a
+ *     per-call argument, so two models / threads / streams in one process never interact.
+ *   - `err` (embedding entry points): NULL, or a DEVICE-VISIBLE int64[4] block (device memory, or pinned
+ *     host memory the caller can poll without synchronising).  An embedding index outside [0, rows_t)
+ *     is never dereferenced: the lookup is skipped (contributes zero / updates nothing) and, when
+ *     err != NULL, reported as err = {1, table, index, rows_t}.  The reference raises on such an
+ *     index (torch's EmbeddingBag bounds check); the Python host raises from the block.
  */
 #ifndef DLRM_HIP_H
 #define DLRM_HIP_H
@@ -61,13 +68,13 @@ int         dlrm_hip_device_info(int device, int* cu_count, int* lds_bytes,
  *   out             : device float*, row b at out + b*out_ld, table t at column t*D
  *                     (out_ld = T*D gives the torch.cat(ly,1) layout; out_ld = (T+1)*D with
  *                      out = feat + D writes straight into the [B, 1+T, D] interaction buffer)
- * Empty bags produce zeros.  Indices are NOT range-checked on the device.
+ * Empty bags produce zeros.  Out-of-range indices are skipped and reported through `err` (see conventions).
  */
 int dlrm_emb_fwd(int T, int64_t B, int D,
                  const void* const* weight_host, const int64_t* rows_host,
                  const void* const* indices_host, const void* const* offsets_host,
                  const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
-                 float* out, int64_t out_ld, void* stream);
+                 float* out, int64_t out_ld, int64_t* err, void* stream);
 
 /* K2+K3  fused EmbeddingBag backward + sparse SGD step, all tables, no gradient materialised.
  * Replaces: autograd `EmbeddingBagBackward` (sparse COO grad) followed by
@@ -85,7 +92,17 @@ int dlrm_emb_bwd_sgd(int T, int64_t B, int D,
                      const void* const* indices_host, const void* const* offsets_host,
                      const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
                      const float* dout, int64_t dout_ld, float lr, int mode,
-                     void* workspace, int64_t workspace_bytes, void* stream);
+                     void* workspace, int64_t workspace_bytes, int64_t* err, void* stream);
+
+/* K2 alone: the reference's sparse COO gradient, materialised (escape hatch: `--fused-emb-update=0`, or any
+ * optimizer the fused kernels do not implement, e.g. torch.optim.Adagrad / the reference's --optimizer=adagrad).
+ * Replaces: autograd EmbeddingBagBackward (dlrm_s_pytorch.py:1613).
+ *   values_host[t] : device float* [nnz_host[t], D];  values_t[i,:] = psw_t[i] * dout[bag(i), t*D:(t+1)*D]
+ * The COO indices are indices_host[t] verbatim (uncoalesced, input order) — the caller wraps both into
+ * torch.sparse_coo_tensor and hands it to the optimizer as `.grad`. */
+int dlrm_emb_bwd_coo(int T, int64_t B, int D, const void* const* offsets_host, const int64_t* nnz_host,
+                     const void* const* psw_host, int idx_bits, const float* dout, int64_t dout_ld,
+                     void* const* values_host, void* stream);
 
 /* K4  fused EmbeddingBag backward + row-wise sparse Adagrad (optim/rwsadagrad.py:117-143).
  *   per table, per UNIQUE row r touched this step (duplicates summed first, in input order):
@@ -100,7 +117,7 @@ int dlrm_emb_bwd_rowwise_adagrad(int T, int64_t B, int D,
                      const void* const* indices_host, const void* const* offsets_host,
                      const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
                      const float* dout, int64_t dout_ld, float lr, float eps,
-                     void* workspace, int64_t workspace_bytes, void* stream);
+                     void* workspace, int64_t workspace_bytes, int64_t* err, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K6  dot interaction forward.
@@ -128,7 +145,7 @@ int dlrm_interact_bwd(int64_t B, int F, int D,
  * K5  MLP layer = nn.Linear + activation  (dlrm_s_pytorch.py:216,238-241,405), fp32 MFMA.
  *   Y[M,N] = act(X[M,K] · W[N,K]^T + bias[N])
  */
-/* Arithmetic of the three MLP GEMMs (process-wide; default DLRM_ARITH_F32, or env DLRM_MLP_ARITH=f32|bf16x6|bf16 read once):
+/* Arithmetic of the three MLP GEMMs — the `arith` argument of every dlrm_linear_* call (per call: no global switch):
  *   DLRM_ARITH_F32    v_mfma_f32_32x32x2_f32: every product and sum in fp32 (157 TFLOP/s matrix peak).
  *   DLRM_ARITH_BF16X6 fp32 operands split EXACTLY into three bf16 terms inside the kernel (x = h + m + l), the six
  *                     products of order >= 2^-16 issued on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; dropped
@@ -138,12 +155,10 @@ int dlrm_interact_bwd(int64_t B, int F, int D,
 #define DLRM_ARITH_BF16X6 1
 #define DLRM_ARITH_BF16   2   /* operands rounded to bf16 (nearest even) in the kernel, one bf16 MFMA per 16-k step, fp32 accumulate:
                                  the "bf16 MLP" of BASELINE.json configs[4]; NOT an fp32-class result (about 3 decimal digits per operand) */
-int dlrm_mlp_set_arith(int arith);
-int dlrm_mlp_get_arith(void);
 
 int dlrm_linear_fwd(int64_t M, int N, int K,
                     const float* X, int64_t ldx, const float* W, int64_t ldw,
-                    const float* bias, int act, float* Y, int64_t ldy, void* stream);
+                    const float* bias, int act, float* Y, int64_t ldy, int arith, void* stream);
 
 /* data gradient with the PREVIOUS layer's activation backward fused into the epilogue:
  *   dX[M,K] = (dY[M,N] · W[N,K]) ⊙ act'(Xact[M,K])        (Xact = this layer's input = previous
@@ -153,7 +168,7 @@ int dlrm_linear_fwd(int64_t M, int N, int K,
 int dlrm_linear_bwd_data(int64_t M, int N, int K,
                          const float* dY, int64_t lddy, const float* W, int64_t ldw,
                          const float* Xact, int64_t ldxa, int xact_kind,
-                         float* dX, int64_t lddx, void* stream);
+                         float* dX, int64_t lddx, int arith, void* stream);
 
 /* weight AND bias gradient:  dW[N,K] (+)= dY[M,N]^T · X[M,K],  dbias[N] (+)= column sums of dY
  * (reduction over the batch, split over workgroups; the bias gradient is taken from the dY fragments
@@ -166,7 +181,7 @@ int64_t dlrm_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K);
 int dlrm_linear_bwd_weight(int64_t M, int N, int K,
                            const float* dY, int64_t lddy, const float* X, int64_t ldx,
                            float* dW, int64_t lddw, float* dbias, int accumulate,
-                           void* workspace, int64_t workspace_bytes, void* stream);
+                           void* workspace, int64_t workspace_bytes, int arith, void* stream);
 
 /* The same weight gradient when X carries alignment padding: X is [M, K] with columns K_store..K-1 zero (e.g. 13 dense
  * features padded to 16, 479 interaction outputs padded to 480), dW is the true [N, K_store] gradient.  Needs the
@@ -174,7 +189,7 @@ int dlrm_linear_bwd_weight(int64_t M, int N, int K,
 int dlrm_linear_bwd_weight_padded(int64_t M, int N, int K, int K_store,
                            const float* dY, int64_t lddy, const float* X, int64_t ldx,
                            float* dW, int64_t lddw, float* dbias, int accumulate,
-                           void* workspace, int64_t workspace_bytes, void* stream);
+                           void* workspace, int64_t workspace_bytes, int arith, void* stream);
 /* dst[m, 0:K] = src[m, 0:K], dst[m, K:Kp] = 0   (builds those padded operands: no ATen fill/copy on the hot path) */
 int dlrm_pad_cols(int64_t M, int K, int Kp, const float* src, int64_t ld_src, float* dst, int64_t ld_dst, void* stream);
 
@@ -188,11 +203,13 @@ int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, const float* Y
  * K7  BCELoss(reduction="mean") forward + backward (dlrm_s_pytorch.py:386-393,148-156).
  *   loss = -mean_b w_b*(t_b*max(log p_b,-100) + (1-t_b)*max(log(1-p_b),-100))
  *   dp_b = w_b*(p_b - t_b) / max(p_b*(1-p_b), 1e-12) / B * grad_scale       (torch's formulas)
- * weights may be NULL (w_b = 1).  loss_out: device float[1].  dp may be NULL (forward only).
+ *   w_b  = weights[b] (1 if weights == NULL) * (t_b >= 1 ? w_pos : w_neg)
+ * w_neg / w_pos are the two class weights of --loss-function=wbce (`loss_ws[T.long()]`, loss_fn_wrap :150-156: the
+ * whole weighted mean in one pass); pass 1, 1 for plain BCE.  loss_out: device float[1].  dp may be NULL (forward only).
  * partials: device scratch, >= dlrm_loss_workspace_bytes(B) bytes.
  */
 int64_t dlrm_loss_workspace_bytes(int64_t B);
-int dlrm_bce_loss(int64_t B, const float* p, const float* target, const float* weights,
+int dlrm_bce_loss(int64_t B, const float* p, const float* target, const float* weights, float w_neg, float w_pos,
                   float grad_scale, float* loss_out, float* dp, void* partials, void* stream);
 /* MSELoss(mean): loss = mean((p-t)^2), dp = 2(p-t)/B*grad_scale */
 int dlrm_mse_loss(int64_t B, const float* p, const float* target,
@@ -252,13 +269,25 @@ int dlrm_criteo_bin_transform(int64_t B, const int32_t* raw, int64_t max_ind_ran
                               int64_t ldx, void* indices, void* offsets, int64_t ld_idx, float* target, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * C1 helpers for the pooled-embedding all-to-all (extend_distributed.py:389-486).  The exchange
- * itself is RCCL (ncclSend/ncclRecv grouped) driven by the host; these kernels are only needed
- * when a caller wants the reference's tensor shapes back (tuple of [B/N, T_s*D]) as one
- * [B/N, T*D] matrix; the native path lets dlrm_interact_* read the receive buffer in place. */
-int dlrm_a2a_unpack(int nranks, int64_t b_local, int D, const int* tables_per_rank_host,
-                    const float* recv, float* out /* [b_local, T*D] */, int64_t out_ld,
-                    void* stream);
+ * Strided block copy = torch.cat / torch.split along dim 1 without ATen:
+ *   for k < nblk:  dst_host[k][m*dst_ld_host[k] + c] = src_host[k][m*src_ld_host[k] + c],  m < M, c < width_host[k]
+ * Uses: the "cat" interaction R = cat([x] + ly, 1) (dlrm_s_pytorch.py:505-507) when the features do not already sit
+ * in one buffer (distributed mode: the all-to-all receive blocks, extend_distributed.py:446-465), and its backward
+ * (the same call with the roles swapped).  The dot interaction never needs it: dlrm_interact_* read the receive
+ * buffer in place through their {ptr, stride} tables. */
+int dlrm_copy_blocks(int64_t M, int nblk, const void* const* src_host, const int64_t* src_ld_host,
+                     void* const* dst_host, const int64_t* dst_ld_host, const int* width_host, void* stream);
+
+/* BCELoss(reduction="none") forward / backward — the per-sample loss the reference's `wbce` path weights and averages
+ * (dlrm_s_pytorch.py:388-391, loss_fn_wrap :150-156).  loss[i] = -(t*max(log p,-100) + (1-t)*max(log(1-p),-100));
+ * dp[i] = dloss[i] * (p-t) / max(p*(1-p), 1e-12).  (dlrm_bce_loss with `weights` is the fully fused weighted mean.) */
+int dlrm_bce_elementwise(int64_t n, const float* p, const float* target, float* loss, void* stream);
+int dlrm_bce_elementwise_bwd(int64_t n, const float* p, const float* target, const float* dloss, float* dp, void* stream);
+
+/* torch.clamp(p, lo, hi) of the predictions and its backward (--loss-threshold, dlrm_s_pytorch.py:580-583, 607-610):
+ * y = min(max(x, lo), hi);  dx = dy where lo <= x <= hi, else 0. */
+int dlrm_clamp(int64_t n, const float* x, float lo, float hi, float* y, void* stream);
+int dlrm_clamp_bwd(int64_t n, const float* x, float lo, float hi, const float* dy, float* dx, void* stream);
 
 #ifdef __cplusplus
 }

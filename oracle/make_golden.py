@@ -74,16 +74,23 @@ def sd_np(model, prefix):
 
 
 def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, lr, loss, itself=False,
-                     num_idx=10, fixed=False, seed=123, round_targets=True, compact=False):
+                     num_idx=10, fixed=False, seed=123, round_targets=True, compact=False, interaction="dot",
+                     loss_threshold=0.0, loss_weights=None):
     ln_emb = np.asarray(ln_emb)
     ln_bot = np.asarray(ln_bot)
     F = ln_emb.size + 1
-    num_int = (F * (F + 1)) // 2 + ln_bot[-1] if itself else (F * (F - 1)) // 2 + ln_bot[-1]
+    if interaction == "cat":
+        num_int = F * ln_bot[-1]
+    else:
+        num_int = (F * (F + 1)) // 2 + ln_bot[-1] if itself else (F * (F - 1)) // 2 + ln_bot[-1]
     ln_top = np.asarray([num_int] + list(top_tail))
     np.random.seed(seed)
     torch.manual_seed(seed)
-    model = ref.DLRM_Net(m_spa, ln_emb, ln_bot, ln_top, arch_interaction_op="dot", arch_interaction_itself=itself,
-                         sigmoid_bot=-1, sigmoid_top=ln_top.size - 2, loss_function=loss)
+    if loss == "wbce":          # the reference reads the CLI global `args.loss_weights` (dlrm_s_pytorch.py:391)
+        ref.args = types.SimpleNamespace(loss_weights=loss_weights, loss_function="wbce")
+    model = ref.DLRM_Net(m_spa, ln_emb, ln_bot, ln_top, arch_interaction_op=interaction, arch_interaction_itself=itself,
+                         sigmoid_bot=-1, sigmoid_top=ln_top.size - 2, loss_function=loss, loss_threshold=loss_threshold)
+    ref.dlrm = model            # loss_fn_wrap uses the module globals `dlrm` and `args` (:148-156)
     out = {}
     out.update(sd_np(model, "init"))
     batches = [gen_batch(dp, int(ln_bot[0]), ln_emb, B, num_idx, fixed, round_targets) for _ in range(steps)]
@@ -92,7 +99,7 @@ def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, l
     losses = []
     for s, (X, lS_o, lS_i, T) in enumerate(batches):
         Z = model(X, lS_o, lS_i)
-        E = model.loss_fn(Z, T)
+        E = ref.loss_fn_wrap(Z, T, False, "cpu") if loss == "wbce" else model.loss_fn(Z, T)
         out[f"s{s}.Z"] = Z.detach().numpy().copy()
         losses.append(float(E.detach().numpy()))
         opt.zero_grad()
@@ -110,6 +117,8 @@ def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, l
     out["losses"] = np.asarray(losses, dtype=np.float64)
     meta = dict(name=name, m_spa=int(m_spa), ln_emb=ln_emb.tolist(), ln_bot=ln_bot.tolist(), ln_top=ln_top.tolist(),
                 B=B, steps=steps, lr=lr, loss=loss, itself=bool(itself), sigmoid_top=int(ln_top.size - 2),
+                interaction=interaction, loss_threshold=float(loss_threshold),
+                loss_ws=None if loss_weights is None else [float(x) for x in loss_weights.split("-")],
                 torch=torch.__version__, reference="facebookresearch/dlrm @ /root/reference (2025-10-03)")
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
@@ -372,6 +381,100 @@ def capture_metrics(name="metrics_sklearn"):
     print(name, [(c["tag"], round(c["roc_auc"], 4), round(c["ap"], 4)) for c in cases])
 
 
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] at FULL batch: the configuration bench.py's headline number is quoted on
+# ---------------------------------------------------------------------------------------------
+CRITEO_TB_ROWS = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155,
+                  4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]     # tools/visualize.py:1195-1223
+
+
+def _sha(a):
+    import hashlib
+    a = np.ascontiguousarray(a)
+    return hashlib.sha256(a.tobytes()).hexdigest()[:32]
+
+
+def capture_terabyte(ref, dp, name="terabyte_b65536", row_cap=2000, B=65536, steps=3, lr=1.0, seed=123):
+    """MLPerf Criteo-Terabyte shapes (bench/run_and_time.sh:17): 26 tables, D = 128, bot 13-512-256-128, top
+    479-1024-1024-512-256-1, one lookup per bag, batch 65536, lr 1.0, table rows capped at `row_cap` (the 96 GB tables do
+    not fit the host).  The reference's DLRM_Net, data generator and training-loop body run for `steps` steps.
+
+    Kept small: initial parameters and input batches are NOT stored — both are pure functions of numpy's legacy global
+    RandomState (frozen stream), so the fixture holds the seed, the generator state after model construction and SHA-256
+    digests of every array the reference actually used; tests/golden_tb.py regenerates them (vectorised restatement of
+    dlrm_data_pytorch.py:899-960,835-846) and checks the digests.  Stored: losses, predictions of every step, final MLP
+    parameters, the first/last 48 rows of every final table, a few step-0 gradients."""
+    import time
+    ln_emb = np.asarray([min(n, row_cap) for n in CRITEO_TB_ROWS])
+    ln_bot = np.asarray([13, 512, 256, 128])
+    m_spa = 128
+    F = ln_emb.size + 1
+    ln_top = np.asarray([F * (F - 1) // 2 + m_spa, 1024, 1024, 512, 256, 1])
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    model = ref.DLRM_Net(m_spa, ln_emb, ln_bot, ln_top, arch_interaction_op="dot", arch_interaction_itself=False,
+                         sigmoid_bot=-1, sigmoid_top=ln_top.size - 2, loss_function="bce")
+    out, digests = {}, {}
+    for k, v in model.state_dict().items():
+        digests[f"init.{k}"] = _sha(v.detach().numpy())
+    st = np.random.get_state()
+    assert st[0] == "MT19937"
+    out["rng_after_init.keys"] = np.asarray(st[1], dtype=np.uint32)
+    out["rng_after_init.pos_gauss"] = np.asarray([st[2], st[3]], dtype=np.int64)
+    out["rng_after_init.cached"] = np.asarray([st[4]], dtype=np.float64)
+    t0 = time.time()
+    batches = [gen_batch(dp, 13, ln_emb, B, 1, True, True) for _ in range(steps)]
+    print(f"{name}: reference generator {time.time() - t0:.0f} s")
+    for s, (X, lS_o, lS_i, T) in enumerate(batches):
+        digests[f"s{s}.X"] = _sha(X.numpy())
+        digests[f"s{s}.T"] = _sha(T.numpy())
+        digests[f"s{s}.idx"] = _sha(np.stack([i.numpy().astype(np.int64) for i in lS_i]))
+        digests[f"s{s}.off"] = _sha(np.stack([o.numpy().astype(np.int64) for o in lS_o]))
+    opt = torch.optim.SGD(model.parameters(), lr=lr)
+    losses = []
+    t0 = time.time()
+    for s, (X, lS_o, lS_i, T) in enumerate(batches):
+        Z = model(X, lS_o, lS_i)
+        E = model.loss_fn(Z, T)
+        out[f"s{s}.Z"] = Z.detach().numpy().copy()
+        losses.append(float(E.detach().numpy()))
+        opt.zero_grad()
+        E.backward()
+        if s == 0:
+            out["s0.bot0_bias_grad"] = model.bot_l[0].bias.grad.numpy().copy()
+            out["s0.top8_weight_grad"] = model.top_l[8].weight.grad.numpy().copy()
+            out["s0.top0_bias_grad"] = model.top_l[0].bias.grad.numpy().copy()
+            g = model.emb_l[5].weight.grad.coalesce()       # the 3-row table: every row hit ~21845 times
+            out["s0.emb5_cgrad_values"] = g._values().numpy().copy()
+        opt.step()
+    print(f"{name}: reference training {time.time() - t0:.0f} s")
+    for k, v in model.state_dict().items():
+        v = v.detach().numpy()
+        if k.startswith("emb_l."):
+            out[f"final_head.{k}"] = v[:48].copy()
+            out[f"final_tail.{k}"] = v[-48:].copy()
+            out[f"final_colsum.{k}"] = v.astype(np.float64).sum(0)
+        else:
+            out[f"final.{k}"] = v.copy()
+    out["losses"] = np.asarray(losses, dtype=np.float64)
+    meta = dict(name=name, m_spa=m_spa, ln_emb=ln_emb.tolist(), ln_bot=ln_bot.tolist(), ln_top=ln_top.tolist(), B=B,
+                steps=steps, lr=lr, loss="bce", itself=False, sigmoid_top=int(ln_top.size - 2), seed=seed, row_cap=row_cap,
+                num_idx=1, fixed=True, digests=digests, torch=torch.__version__, numpy=np.__version__,
+                reference="facebookresearch/dlrm @ /root/reference (bench/run_and_time.sh:17 shapes)")
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(f"{name}: losses {losses}")
+    # the vectorised regeneration must reproduce what the reference used, bit for bit
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    import golden_tb
+    fx = golden_tb.load(name)
+    for s, (X, lS_o, lS_i, T) in enumerate(batches):
+        assert np.array_equal(fx.batches[s][0], X.numpy()) and np.array_equal(fx.batches[s][3], T.numpy())
+        assert np.array_equal(fx.batches[s][2], np.stack([i.numpy() for i in lS_i]))
+    print(f"{name}: regeneration verified")
+
+
 def main(which):
     os.makedirs(OUT, exist_ok=True)
     if which == "metrics":
@@ -392,6 +495,11 @@ def main(which):
         # multi-hot with many duplicates across bags (hot rows)
         capture_training(ref, dp, "multihot_hotrows", 8, [3, 4, 100], [9, 8], [8, 1], B=64, steps=2, lr=0.3, loss="bce",
                          num_idx=8)
+    if which in ("all", "train", "options"):
+        # the remaining --arch-* / loss options in one run: "cat" interaction (dlrm_s_pytorch.py:505-507), --loss-threshold
+        # clamp (:607-610), --loss-function=wbce with --loss-weights (:388-391, loss_fn_wrap :150-156), multi-hot bags
+        capture_training(ref, dp, "cat_wbce_clamp", 8, [30, 5, 200, 11], [7, 24, 8], [16, 1], B=96, steps=3, lr=0.3, loss="wbce",
+                         num_idx=4, interaction="cat", loss_threshold=0.45, loss_weights="0.3-1.7", round_targets=True)
     if which in ("all", "kaggle"):
         # BASELINE.json configs[1]: Criteo-Kaggle shapes — 26 tables, D = 16, bot 13-512-256-64-16, top 512-256-1
         # (bench/dlrm_s_criteo_kaggle.sh:24), batch 2048, one lookup per bag; table rows capped at 600 to keep the fixture small
@@ -399,6 +507,8 @@ def main(which):
                        10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
         capture_training(ref, dp, "kaggle_b2048", 16, [min(n, 600) for n in kaggle_rows], [13, 512, 256, 64, 16], [512, 256, 1],
                          B=2048, steps=2, lr=0.1, loss="bce", num_idx=1, fixed=True, compact=True)
+    if which in ("all", "terabyte"):
+        capture_terabyte(ref, dp)
     if which in ("all", "adagrad"):
         capture_adagrad(ref, dp)
     if which in ("all", "book"):

@@ -21,7 +21,10 @@ import torch.nn.functional as F
 
 class TorchPortDLRM:
     def __init__(self, params: Dict[str, torch.Tensor], sigmoid_top: int, self_interaction: bool = False,
-                 loss: str = "bce", lr: float = 0.1):
+                 loss: str = "bce", lr: float = 0.1, interaction: str = "dot", loss_threshold: float = 0.0, loss_ws=None):
+        # cat interaction :505-507, --loss-threshold clamp :607-610, wbce :388-391 + loss_fn_wrap :150-156
+        self.interaction, self.loss_threshold = interaction, float(loss_threshold)
+        self.loss_ws = None if loss_ws is None else torch.as_tensor(loss_ws, dtype=torch.float64)
         self.p = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
         self.T = sum(1 for k in self.p if k.startswith("emb_l."))
         self.nbot = sum(1 for k in self.p if k.startswith("bot_l.") and k.endswith(".weight"))
@@ -41,6 +44,9 @@ class TorchPortDLRM:
         ly = [F.embedding_bag(lS_i[k], self.p[f"emb_l.{k}.weight"], lS_o[k], mode="sum", sparse=True)
               for k in range(self.T)]
         B, D = x.shape
+        if self.interaction == "cat":
+            p = self._tower(torch.cat([x] + ly, dim=1), "top_l", self.ntop, self.sigmoid_top)
+            return self._clamp(p)
         Tm = torch.cat([x] + ly, dim=1).view(B, -1, D)
         Z = torch.bmm(Tm, Tm.transpose(1, 2))
         if self._pairs is None:
@@ -49,11 +55,19 @@ class TorchPortDLRM:
             self._pairs = (torch.tensor([i for i in range(nf) for _ in range(i + off)]),
                            torch.tensor([j for i in range(nf) for j in range(i + off)]))
         R = torch.cat([x, Z[:, self._pairs[0], self._pairs[1]]], dim=1)
-        return self._tower(R, "top_l", self.ntop, self.sigmoid_top)
+        return self._clamp(self._tower(R, "top_l", self.ntop, self.sigmoid_top))
+
+    def _clamp(self, p):
+        if 0.0 < self.loss_threshold < 1.0:
+            return torch.clamp(p, min=self.loss_threshold, max=1.0 - self.loss_threshold)
+        return p
 
     def train_step(self, X, lS_o, lS_i, target):
         Z = self.forward(X, lS_o, lS_i)
-        E = F.binary_cross_entropy(Z, target) if self.loss == "bce" else F.mse_loss(Z, target)
+        if self.loss == "wbce":
+            E = (self.loss_ws[target.view(-1).long()].view_as(target) * F.binary_cross_entropy(Z, target, reduction="none")).mean()
+        else:
+            E = F.binary_cross_entropy(Z, target) if self.loss == "bce" else F.mse_loss(Z, target)
         self.opt.zero_grad()
         E.backward()
         self.opt.step()

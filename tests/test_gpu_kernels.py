@@ -201,15 +201,10 @@ def test_interact_fwd_bwd(F, D, itself, B):
 def test_linear_fwd_bwd(M, N, K, act, arith):
     """both MLP arithmetics against the float64 oracle at the SAME fp32-class tolerances: "bf16x6" (exact 3-term bf16
     split of the fp32 operands, 6 bf16 MFMA products, fp32 accumulation) must not be distinguishable from fp32 MFMA"""
-    from dlrm_amd import ops
-    ops.set_mlp_arith(arith)
-    try:
-        _linear_fwd_bwd(M, N, K, act)
-    finally:
-        ops.set_mlp_arith("f32")
+    _linear_fwd_bwd(M, N, K, act, arith)
 
 
-def _linear_fwd_bwd(M, N, K, act):
+def _linear_fwd_bwd(M, N, K, act, arith):
     from dlrm_amd import ops
     rng = np.random.default_rng(M + N + K)
     # asymmetric, non-identity data so that a transposed fragment cannot pass
@@ -222,7 +217,7 @@ def _linear_fwd_bwd(M, N, K, act):
     Xd.copy_(to_dev(X))
     Wd, bd = to_dev(W), to_dev(b)
     Yd = torch.empty((M, N), device=dev())
-    ops.linear_fwd(Xd, Wd, bd, act, Yd)
+    ops.linear_fwd(Xd, Wd, bd, act, Yd, arith)
     torch.cuda.synchronize()
     np.testing.assert_allclose(Yd.cpu().numpy(), Y, rtol=1e-5, atol=1e-5)
 
@@ -234,11 +229,11 @@ def _linear_fwd_bwd(M, N, K, act):
     ops.act_bwd(to_dev(dY), Yd, act, dZd, None)
     dWd = torch.empty((N, K), device=dev())
     dbd = torch.full((N,), 7.0, device=dev())          # overwritten, not accumulated
-    ops.linear_bwd_weight(dZd, Xd, dWd, dbd)
+    ops.linear_bwd_weight(dZd, Xd, dWd, dbd, arith=arith)
     dWa = torch.empty((N, K), device=dev())             # same GEMM, k-slices accumulated with atomics (no workspace)
-    ops.linear_bwd_weight(dZd, Xd, dWa, None, use_workspace=False)
+    ops.linear_bwd_weight(dZd, Xd, dWa, None, use_workspace=False, arith=arith)
     dXd = torch.empty((M, ldx), device=dev())[:, :K]
-    ops.linear_bwd_data(dZd, Wd, None, 0, dXd)
+    ops.linear_bwd_data(dZd, Wd, None, 0, dXd, arith)
     torch.cuda.synchronize()
     scale = max(1.0, float(np.abs(dW).max()))
     np.testing.assert_allclose(dbd.cpu().numpy(), db, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(db).max())))
@@ -292,14 +287,10 @@ def test_linear_bf16_arithmetic(M, N, K):
     Xd, Wd, bd, dYd = to_dev(X), to_dev(W), to_dev(b), to_dev(dY)
     Y, dX, dW, db = (torch.empty((M, N), device=dev()), torch.empty((M, K), device=dev()), torch.empty((N, K), device=dev()),
                      torch.empty(N, device=dev()))
-    ops.set_mlp_arith("bf16")
-    try:
-        ops.linear_fwd(Xd, Wd, bd, 0, Y)
-        ops.linear_bwd_data(dYd, Wd, None, 0, dX)
-        ops.linear_bwd_weight(dYd, Xd, dW, db)
-        torch.cuda.synchronize()
-    finally:
-        ops.set_mlp_arith("f32")
+    ops.linear_fwd(Xd, Wd, bd, 0, Y, "bf16")
+    ops.linear_bwd_data(dYd, Wd, None, 0, dX, "bf16")
+    ops.linear_bwd_weight(dYd, Xd, dW, db, arith="bf16")
+    torch.cuda.synchronize()
     np.testing.assert_allclose(Y.cpu().numpy(), rb(X) @ rb(W).T + b, rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(dX.cpu().numpy(), rb(dY) @ rb(W), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(dW.cpu().numpy(), rb(dY).T @ rb(X), rtol=1e-4, atol=1e-4 * np.sqrt(M))
@@ -346,7 +337,7 @@ def test_linear_single_output_layer(M, K, act):
     b = rng.standard_normal(1).astype(np.float32)
     Xd, Wd, bd = to_dev(X), to_dev(W), to_dev(b)
     Yd = torch.empty((M, 1), device=dev())
-    ops.linear_fwd(Xd, Wd, bd, act, Yd)
+    ops.linear_fwd(Xd, Wd, bd, act, Yd, arith)
     np.testing.assert_allclose(Yd.cpu().numpy(), O.linear_fwd(X, W, b, act), rtol=1e-5, atol=1e-5)
     dZ = rng.standard_normal((M, 1)).astype(np.float32)
     mask = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
@@ -383,7 +374,7 @@ def test_linear_small_reduction_layer(M, N, K, act):
     b = rng.standard_normal(N).astype(np.float32)
     Xd, Wd, bd = to_dev(X), to_dev(W), to_dev(b)
     Yd = torch.empty((M, N), device=dev())
-    ops.linear_fwd(Xd, Wd, bd, act, Yd)
+    ops.linear_fwd(Xd, Wd, bd, act, Yd, arith)
     np.testing.assert_allclose(Yd.cpu().numpy(), O.linear_fwd(X, W, b, act), rtol=1e-5, atol=1e-5)
     dZ = rng.standard_normal((M, N)).astype(np.float32)
     want_dW = dZ.astype(np.float64).T @ X.astype(np.float64)
@@ -391,7 +382,7 @@ def test_linear_small_reduction_layer(M, N, K, act):
     tol = 1e-5 * max(1.0, float(np.abs(want_dW).max())) * 10
     dZd = to_dev(dZ)
     dWd, dbd = torch.full((N, K), 3.0, device=dev()), torch.full((N,), 3.0, device=dev())
-    ops.linear_bwd_weight(dZd, Xd, dWd, dbd)
+    ops.linear_bwd_weight(dZd, Xd, dWd, dbd, arith=arith)
     np.testing.assert_allclose(dWd.cpu().numpy(), want_dW, rtol=1e-4, atol=tol)
     np.testing.assert_allclose(dbd.cpu().numpy(), want_db, rtol=1e-4, atol=tol)
     first = dWd.clone()
@@ -438,15 +429,102 @@ def test_sgd_dense():
         np.testing.assert_allclose(wd.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
 
 
-def test_a2a_unpack_layout():
+def test_copy_blocks_is_cat_and_split():
+    """dlrm_copy_blocks: torch.cat / split along dim 1 over strided views, e.g. the all-to-all receive blocks
+    [b_local, T_s*D] of every source rank -> one [b_local, T*D] matrix (the "cat" interaction in distributed mode)."""
     from dlrm_amd import ops
     rng = np.random.default_rng(3)
-    tables, bl, D = [2, 1, 3], 5, 4
-    chunks = [rng.standard_normal((bl, t * D)).astype(np.float32) for t in tables]
-    recv = to_dev(np.concatenate([c.reshape(-1) for c in chunks]))
-    out = torch.empty((bl, sum(tables) * D), device=dev())
-    ops.a2a_unpack(recv, tables, bl, D, out)
-    assert np.array_equal(out.cpu().numpy(), np.concatenate(chunks, axis=1))
+    for widths, M in (([8, 4, 12], 5), ([3, 5, 1], 33), ([128] * 5, 1000)):
+        chunks = [rng.standard_normal((M, w)).astype(np.float32) for w in widths]
+        srcs = [to_dev(c) for c in chunks]
+        out = torch.full((M, sum(widths) + 4), -7.0, device=dev())
+        dsts, o = [], 0
+        for w in widths:
+            dsts.append(out[:, o:o + w]); o += w
+        ops.copy_blocks(srcs, dsts)
+        assert np.array_equal(out[:, :o].cpu().numpy(), np.concatenate(chunks, axis=1)) and bool(torch.all(out[:, o:] == -7.0))
+        back = [torch.empty((M, w), device=dev()) for w in widths]
+        ops.copy_blocks(dsts, back)                      # the split direction
+        for bk, c in zip(back, chunks):
+            assert np.array_equal(bk.cpu().numpy(), c)
+
+
+@pytest.mark.parametrize("idx_dtype", [torch.int64, torch.int32])
+def test_out_of_range_index_is_skipped_and_reported(idx_dtype):
+    """An index outside [0, rows) — the reference's EmbeddingBag raises on it — must never be dereferenced: forward
+    treats the lookup as absent, every update mode leaves all tables untouched by it (the sorted path must not let it spill
+    into another table's key bits), and the host raises IndexError from the pinned error block."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(9)
+    D, rows, B = 16, [5, 64, 7], 40
+    Ws = [rng.standard_normal((n, D)).astype(np.float32) for n in rows]
+    idx = [rng.integers(0, n, size=B) for n in rows]
+    bad = [i.copy() for i in idx]
+    bad[0][3] = 5                      # == rows
+    bad[1][17] = 1 << 20               # far beyond 2^row_bits
+    bad[2][0] = -1 if idx_dtype == torch.int64 else 2 ** 31 - 1
+    off = [np.arange(B)] * 3
+    dout = rng.standard_normal((B, 3 * D)).astype(np.float32)
+
+    def run(indices, fn):
+        Wd = [to_dev(w.copy()) for w in Ws]
+        bags = ops.BagBatch([to_dev(o).to(idx_dtype) for o in off], [to_dev(i).to(idx_dtype) for i in indices])
+        fn(Wd, bags)
+        torch.cuda.synchronize()
+        return Wd
+
+    ops.check_index_errors(sync=True)   # clean slate
+    # forward: bad lookups pool to zero, the others are unaffected
+    out = torch.empty((B, 3 * D), device=dev())
+    run(bad, lambda Wd, bags: ops.emb_fwd(Wd, bags, out))
+    with pytest.raises(IndexError, match="out of range"):
+        ops.check_index_errors(sync=True)
+    ops.check_index_errors(sync=True)   # the block was reset by the raise
+    want = np.concatenate([Ws[t][idx[t]] for t in range(3)], axis=1)
+    want[3, 0:D] = 0; want[17, D:2 * D] = 0; want[0, 2 * D:3 * D] = 0
+    assert np.array_equal(out.cpu().numpy(), want)
+    # updates: identical to the update with the bad lookups REMOVED (their gradient rows zeroed), in every mode
+    dz = dout.copy()
+    dz[3, 0:D] = 0; dz[17, D:2 * D] = 0; dz[0, 2 * D:3 * D] = 0
+    for mode in (ops.UPD_SORTED, ops.UPD_ATOMIC, ops.UPD_DETERMINISTIC):
+        got = run(bad, lambda Wd, bags: ops.emb_bwd_sgd(Wd, bags, to_dev(dout), 0.5, mode))
+        with pytest.raises(IndexError):
+            ops.check_index_errors(sync=True)
+        ref = run(idx, lambda Wd, bags: ops.emb_bwd_sgd(Wd, bags, to_dev(dz), 0.5, mode))
+        ops.check_index_errors(sync=True)
+        for g, r in zip(got, ref):
+            np.testing.assert_allclose(g.cpu().numpy(), r.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    st = [torch.zeros(n, device=dev()) for n in rows]
+    got = run(bad, lambda Wd, bags: ops.emb_bwd_rowwise_adagrad(Wd, st, bags, to_dev(dout), 0.1, 1e-8))
+    with pytest.raises(IndexError):
+        ops.check_index_errors(sync=True)
+    st2 = [torch.zeros(n, device=dev()) for n in rows]
+    ref = run(idx, lambda Wd, bags: ops.emb_bwd_rowwise_adagrad(Wd, st2, bags, to_dev(dz), 0.1, 1e-8))
+    for g, r in zip(got + st, ref + st2):
+        np.testing.assert_allclose(g.cpu().numpy(), r.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_emb_bwd_coo_is_the_reference_sparse_gradient():
+    """dlrm_emb_bwd_coo: values[i] = psw[i] * dout[bag(i)] per lookup in input order (EmbeddingBagBackward's COO values,
+    dlrm_s_pytorch.py:1613) — ragged, empty and weighted bags — and, through torch.sparse_coo_tensor + torch.optim.SGD,
+    the bit-exact reference update."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(21)
+    D, rows, B = 12, [9, 300], 50
+    lens = [rng.integers(0, 5, size=B) for _ in rows]
+    off = [np.concatenate([[0], np.cumsum(l)[:-1]]) for l in lens]
+    idx = [rng.integers(0, n, size=int(l.sum())) for n, l in zip(rows, lens)]
+    psw = [rng.standard_normal(i.size).astype(np.float32) for i in idx]
+    dout = rng.standard_normal((B, 2 * D)).astype(np.float32)
+    for weights in (None, psw):
+        bags = ops.BagBatch([to_dev(o) for o in off], [to_dev(i) for i in idx], None if weights is None else [to_dev(w) for w in weights])
+        vals = ops.emb_bwd_coo(bags, to_dev(dout), D)
+        for t in range(2):
+            bag_of = np.repeat(np.arange(B), lens[t])
+            want = dout[bag_of, t * D:(t + 1) * D]
+            if weights is not None:
+                want = want * weights[t][:, None]
+            assert np.array_equal(vals[t].cpu().numpy(), want.astype(np.float32)), t
 
 
 # ------------------------------------------------------------------------------------------ K4: row-wise Adagrad

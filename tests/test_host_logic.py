@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.dlrm_hip_abi_version() == 5
+    assert lib.dlrm_hip_abi_version() == 6
     assert b"gfx950" in lib.dlrm_hip_build_info()
 
 
@@ -133,10 +133,12 @@ def test_embedding_update_plan_for_sgd_and_rowwise_adagrad():
     sgd = torch.optim.SGD(tables + [dense], lr=0.25)
     assert _embedding_update_plan(sgd, tables) == ("sgd", 0.25)
     assert _embedding_update_plan(torch.optim.SGD([dense], lr=0.1), tables) is None      # does not own the tables
-    with pytest.raises(SystemExit):
-        _embedding_update_plan(torch.optim.SGD(tables, lr=0.1, momentum=0.9), tables)
-    with pytest.raises(SystemExit):
-        _embedding_update_plan(torch.optim.Adam(tables, lr=0.1), tables)
+    # optimizers the fused kernels do not implement take the reference's own route: the sparse COO gradient is
+    # materialised (dlrm_emb_bwd_coo) and the optimizer's step consumes it
+    assert _embedding_update_plan(torch.optim.SGD(tables, lr=0.1, momentum=0.9), tables) == ("coo",)
+    assert _embedding_update_plan(torch.optim.Adagrad(tables, lr=0.1), tables) == ("coo",)
+    with pytest.raises(SystemExit):          # gradient accumulation + the non-linear fused row-wise update: refused, not approximated
+        _embedding_update_plan(FusedRWSAdagrad(tables, lr=0.1), tables, count=2)
     classes = [FusedRWSAdagrad]
     if os.path.isfile(os.path.join(REFERENCE, "optim", "rwsadagrad.py")):
         sys.path.insert(0, os.path.join(REFERENCE, "optim"))

@@ -39,10 +39,10 @@ def gemm(shapes):
         dW = torch.empty(N, K, device=DEV)
         db = torch.zeros(N, device=DEV)
         fl = 2.0 * M * N * K
-        t_f = timeit(lambda: ops.linear_fwd(X, W, b, 1, Y))
-        t_d = timeit(lambda: ops.linear_bwd_data(dY, W, X, 1, dX))
-        t_d0 = timeit(lambda: ops.linear_bwd_data(dY, W, None, 0, dX))
-        t_w = timeit(lambda: ops.linear_bwd_weight(dY, X, dW, db))
+        t_f = timeit(lambda: ops.linear_fwd(X, W, b, 1, Y, ARITH))
+        t_d = timeit(lambda: ops.linear_bwd_data(dY, W, X, 1, dX, ARITH))
+        t_d0 = timeit(lambda: ops.linear_bwd_data(dY, W, None, 0, dX, ARITH))
+        t_w = timeit(lambda: ops.linear_bwd_weight(dY, X, dW, db, arith=ARITH))
         r = dict(M=M, N=N, K=K, fwd_us=t_f * 1e3, fwd_tf=fl / t_f / 1e9, dgrad_us=t_d * 1e3, dgrad_tf=fl / t_d / 1e9,
                  dgrad_plain_us=t_d0 * 1e3, dgrad_plain_tf=fl / t_d0 / 1e9, wgrad_us=t_w * 1e3, wgrad_tf=fl / t_w / 1e9)
         out.append(r)
@@ -109,12 +109,15 @@ def emb_classes(B=65536, D=128):
         del Ws, idx, dout
 
 
+ARITH = "f32"
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["gemm", "gemm_big", "emb", "emb_classes", "all"])
     ap.add_argument("--arith", default="f32")
     a = ap.parse_args()
-    ops.set_mlp_arith(a.arith)
+    ARITH = a.arith
     B = 65536
     layer_shapes = [(B, 512, 16), (B, 256, 512), (B, 128, 256), (B, 1024, 480), (B, 1024, 1024), (B, 512, 1024), (B, 256, 512), (B, 1, 256)]
     if a.what in ("gemm", "all"):
