@@ -41,6 +41,9 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MFMA_PEAK_TF = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+# what MI355X_MICROARCH.md MEASURES as achievable on the box (float4 device copy; back-to-back fp32 MFMA): reported beside spec
+MEASURED_HBM_GBS = 6290.0
+MEASURED_FP32_MFMA_TF = 155.0
 
 
 def parse():
@@ -143,14 +146,37 @@ def parity_check(args, device):
         return {"fixture": "tests/golden/terabyte_b65536.npz", "pass": False, "error": str(e)[:400]}
 
 
+# kernel category -> the sources its kernels are compiled from: PMC traffic measured on an older version of ANY of them is stale
+KERNEL_SOURCES = {
+    "emb_fwd": ["emb.hip", "common.h"],
+    "emb_bwd_sgd": ["emb_sorted.hip", "sorted_common.h", "common.h"],
+    "emb_bwd_adagrad": ["adagrad.hip", "sorted_common.h", "common.h"],
+    "interact_fwd": ["interact.hip", "common.h"], "interact_bwd": ["interact.hip", "common.h"],
+    "linear_fwd": ["gemm.hip", "gemv.hip", "common.h"], "linear_bwd_data": ["gemm.hip", "gemv.hip", "common.h"],
+    "linear_bwd_weight": ["gemm.hip", "gemv.hip", "smallk.hip", "common.h"],
+}
+
+
+def source_hashes():
+    import hashlib
+    csrc = os.path.join(ROOT, "dlrm_amd", "csrc")
+    return {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16]
+            for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h"))}
+
+
 def load_pmc_traffic():
-    """Latest committed profiles/rNN/pmc_traffic.json (tools/gpu_pmc_traffic.sh + tools/pmc_to_json.py), or None."""
+    """Latest committed profiles/rNN/pmc_traffic.json (tools/gpu_pmc_traffic.sh + tools/pmc_to_json.py), or None.  The file
+    is stamped with the SHA-256 of every kernel source it was measured on; a category whose sources have changed since
+    gets `stale = True` and bench.py reports `traffic: null` for it instead of a number that no longer describes HEAD."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")))
     if not files:
         return None
     d = json.load(open(files[-1]))
     d["_file"] = os.path.relpath(files[-1], ROOT)
+    now, then = source_hashes(), d.get("sources")
+    for cat, k in d["kernels"].items():
+        k["stale"] = then is None or any(now.get(f) != then.get(f) for f in KERNEL_SOURCES.get(cat, list(now)))
     return d
 
 
@@ -294,7 +320,8 @@ def main():
         ach = work / (per_step_ms * 1e-3) / scale
         kernels[name] = {"ms_per_step": per_step_ms, "launches_per_step": k["calls"] / max(timed_steps, 1),
                          "avg_launch_ms": k["avg_ms"], "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                         "frac": ach / peak, "algorithmic_work_per_step": work}
+                         "frac": ach / peak, "frac_of_measured_peak": ach / (MEASURED_HBM_GBS if unit == "GB/s" else MEASURED_FP32_MFMA_TF),
+                         "algorithmic_work_per_step": work}
     for name in ("act_bwd", "bce_loss", "sgd_dense"):
         if name in ksum:
             kernels[name] = {"ms_per_step": ksum[name]["total_ms"] / max(timed_steps, 1),
@@ -312,13 +339,20 @@ def main():
     def roof(n):
         k = kernels[n]
         t = pmc["kernels"].get(n) if pmc else None
+        stale = bool(t and t.get("stale"))
+        if stale:
+            note = "stale: %s was measured on an older version of this kernel's sources (re-run tools/gpu_pmc_traffic.sh)" % pmc["_file"]
+        elif t and k["unit"] == "GB/s":
+            note = ("HBM bytes per call from rocprofv3 PMC passes of this workload (%s; FETCH_SIZE x2 gfx950 correction + "
+                    "WRITE_SIZE; source hashes match HEAD), algorithmic bytes per call = %d" %
+                    (pmc["_file"], k["algorithmic_work_per_step"] // max(int(round(k["launches_per_step"])), 1)))
+        else:
+            note = ("HBM bytes per call from rocprofv3 PMC passes (%s; source hashes match HEAD)" % pmc["_file"]) if t else None
+        measured_peak = MEASURED_HBM_GBS if k["unit"] == "GB/s" else MEASURED_FP32_MFMA_TF
         return {"kernel": kname.get(n, n), "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
                 "unit": k["unit"], "frac": k["frac"],
-                "traffic": t["traffic_bytes"] if t else None,
-                "traffic_note": ("HBM bytes per call from rocprofv3 PMC passes of this workload (%s; FETCH_SIZE x2 gfx950 "
-                                 "correction + WRITE_SIZE), algorithmic bytes per call = %d" %
-                                 (pmc["_file"], k["algorithmic_work_per_step"] // max(int(round(k["launches_per_step"])), 1)))
-                if t and k["unit"] == "GB/s" else (("HBM bytes per call from rocprofv3 PMC passes (%s)" % pmc["_file"]) if t else None),
+                "frac_of_measured_peak": k["achieved"] / measured_peak, "measured_peak": measured_peak,
+                "traffic": t["traffic_bytes"] if (t and not stale) else None, "traffic_note": note,
                 "avg_launch_ms": k["avg_launch_ms"], "ms_per_step": k["ms_per_step"]}
 
     result = {

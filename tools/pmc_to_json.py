@@ -33,6 +33,16 @@ def main():
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 4 --warmup 2",
            "units": "bytes per C-ABI call (average over the calls of one training step)",
            "fetch_correction": "FETCH_SIZE x 2 (gfx950: 128-B requests counted as 64 B)", "kernels": {}}
+    # stamp: SHA-256 of every kernel source the counters were collected on (bench.py refuses a stale file per category) + commit
+    import hashlib, os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "dlrm_amd", "csrc")
+    out["sources"] = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()[:16]
+                      for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h"))}
+    try:
+        out["git_head"] = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        out["git_head"] = None
     fetch, write = load(f"{src}/pmc_FETCH_SIZE.csv"), load(f"{src}/pmc_WRITE_SIZE.csv")
     for cat, pats in CATS.items():
         f_kb = sum(c * v for k, c, v in fetch if any(p in k for p in pats)) / steps
