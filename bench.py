@@ -71,10 +71,17 @@ def parse():
     ap.add_argument("--cpu-row-cap", type=int, default=1000000)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
-    ap.add_argument("--a2a-chunks", type=int, default=int(os.environ.get("DLRM_A2A_CHUNKS", "0")),
-                    help="N > 1: pipeline the pooled-embedding all-to-all in this many batch chunks; 1 = the reference schedule "
-                         "(only the bottom MLP overlaps the exchange); 0 = auto: 4 chunks at N=2 and 2 at N=4, where one rank "
-                         "moves 218 / 164 MB per direction over 1 / 3 xGMI links (tools/scaling_model.py), 1 otherwise")
+    ap.add_argument("--a2a-chunks", type=int, default=int(os.environ.get("DLRM_A2A_CHUNKS", "1")),
+                    help="N > 1: schedule of the HEADLINE measurement. 1 (default) = the reference schedule: one all-to-all per "
+                         "direction, only the bottom MLP overlaps it (dlrm_s_pytorch.py:563-568); C > 1 = the exchange pipelined in "
+                         "C batch chunks.  Whatever is chosen here, the other schedule is measured in the same process and reported "
+                         "as alt_a2a_pipelined / alt_a2a_reference")
+    ap.add_argument("--alt-a2a-chunks", type=int, default=0,
+                    help="chunk count of the alternative (pipelined) schedule; 0 = auto: 4 at N=2, 2 at N=4 and N=8")
+    ap.add_argument("--hang-timeout", type=int, default=int(os.environ.get("DLRM_BENCH_HANG_TIMEOUT", "240")),
+                    help="N > 1: seconds the rendezvous + RCCL capability probe + first step, and later each measurement phase, "
+                         "may take before every thread's stack is dumped and the process exits with code 3 (a hung collective "
+                         "must fail loudly, not sit until the driver kills the job)")
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "rwsadagrad"],
                     help="sgd: the reference default (and the headline); rwsadagrad: row-wise sparse Adagrad (K4, optim/rwsadagrad.py)")
     ap.add_argument("--mlp-arith", default=os.environ.get("DLRM_MLP_ARITH", "f32"), choices=["f32", "bf16x6", "bf16"],
@@ -199,7 +206,17 @@ def main():
     from dlrm_amd import ext_dist, ops
     from dlrm_amd.optim import FusedRWSAdagrad, FusedSGD
 
+    import faulthandler
+
+    def watchdog(seconds, what):
+        """(re-)arm the hang watchdog: after `seconds` all Python stacks go to stderr and the process exits (code 3)"""
+        faulthandler.cancel_dump_traceback_later()
+        if N > 1 and seconds > 0:
+            print(f"[bench rank {os.environ.get('RANK', '0')}] watchdog {seconds}s: {what}", file=sys.stderr, flush=True)
+            faulthandler.dump_traceback_later(seconds, repeat=False, exit=True)
+
     if N > 1:
+        watchdog(args.hang_timeout, "rendezvous + RCCL all_to_all capability probe")
         ext_dist.init_distributed(use_gpu=True, backend="nccl")   # RCCL
         device = torch.device("cuda", ext_dist.my_local_rank)
     else:
@@ -217,7 +234,7 @@ def main():
     model = dlrm_amd.DLRM_Net(D, np.asarray(rows), np.asarray(wl["bot"]), ln_top, "dot", sigmoid_top=ln_top.size - 2,
                               loss_function="bce").to(device)
     model.set_mlp_arith(args.mlp_arith)
-    model.a2a_chunks = args.a2a_chunks if args.a2a_chunks > 0 else {2: 4, 4: 2}.get(N, 1)
+    model.a2a_chunks = max(args.a2a_chunks, 1) if N > 1 else 1
     model.emb_update_mode = {"sorted": ops.UPD_SORTED, "atomic": ops.UPD_ATOMIC, "deterministic": ops.UPD_DETERMINISTIC}[args.emb_update]
     if N > 1:
         model.bot_l = ext_dist.DDP(model.bot_l, device_ids=[device.index])
@@ -261,8 +278,22 @@ def main():
         X, off, idx, T = batches[i % len(batches)]
         return graphed(X, off, idx, T)
 
+    dist_info = None
+    if N > 1:
+        # what the process group really is: rank count as RCCL sees it and one DISTINCT physical GPU per rank
+        uuid = str(getattr(torch.cuda.get_device_properties(device), "uuid", "cuda:%d" % device.index))
+        uuids = [None] * N
+        torch.distributed.all_gather_object(uuids, uuid)
+        dist_info = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
+                     "distinct_gpus": len(set(uuids)), "tables_per_rank": list(model.n_emb_per_rank) if model.n_emb_per_rank else None}
+        if len(set(uuids)) != N:
+            sys.exit("ERROR: %d ranks share %d GPUs; one process per GPU is required" % (N, len(set(uuids))))
+        watchdog(args.hang_timeout, "first training step (RCCL all-to-all + DDP all-reduce for the first time)")
     for i in range(args.warmup):
         step(i)
+        if i == 0 and N > 1:
+            torch.cuda.synchronize()
+            watchdog(args.hang_timeout + 20 * (args.warmup + args.steps), "warm-up + timed region")
     if N > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -422,6 +453,66 @@ def main():
             del gs
         except Exception as e:                       # noqa: BLE001 - diagnostic only
             result["alt_hip_graph"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    if N > 1:
+        # ---- the OTHER exchange schedule, same process, same model: never instead of the headline ------------------------
+        alt_c = 1 if model_a2a_chunks > 1 else (args.alt_a2a_chunks or {2: 4, 4: 2, 8: 2}.get(N, 2))
+        if alt_c == 1 or (B // N) % alt_c == 0:
+            watchdog(args.hang_timeout + 20 * args.steps, "alternative all-to-all schedule (%d chunk(s))" % alt_c)
+            model.a2a_chunks = alt_c
+            for i in range(2):
+                step(i)
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                loss_alt = step(i)
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
+            tt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dta = float(tt.item()) / args.steps
+            result["alt_a2a_pipelined" if alt_c > 1 else "alt_a2a_reference"] = {
+                "a2a_chunks": alt_c, "value": B / dta, "unit": "samples/s", "ms_per_step": dta * 1e3, "final_loss": float(loss_alt.detach()),
+                "note": ("pooled-embedding all-to-all pipelined in %d batch chunks (DLRM_Net._pipelined_exchange_forward)" % alt_c)
+                        if alt_c > 1 else "the reference schedule: one all-to-all per direction, bottom MLP overlapping it"}
+            del loss_alt
+            model.a2a_chunks = model_a2a_chunks
+        # ---- the collectives alone, at the step's exact sizes, HIP events on the stream they are enqueued on ---------------
+        watchdog(args.hang_timeout, "collective micro-measurements")
+        Tl_, D_ = len(local_tables), D
+        splits = model.n_emb_per_rank or [Tl_] * N
+        send = torch.empty(B * Tl_ * D_, device=device)
+        recv = torch.empty((B // N) * sum(splits) * D_, device=device)
+        send_counts = [(B // N) * Tl_ * D_] * N
+        recv_counts = [(B // N) * t * D_ for t in splits]
+        flat = torch.empty(sum(p.numel() for p in model.bot_l.parameters()) + sum(p.numel() for p in model.top_l.parameters()), device=device)
+
+        def timed(fn, iters=10):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([a.elapsed_time(b) / iters], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return float(t.item())
+        a2a_f = timed(lambda: torch.distributed.all_to_all_single(recv, send, recv_counts, send_counts))
+        a2a_b = timed(lambda: torch.distributed.all_to_all_single(send, recv, send_counts, recv_counts))
+        ar = timed(lambda: torch.distributed.all_reduce(flat))
+        off_node = send.numel() * 4 * (N - 1) / N
+        result["collectives"] = {
+            "a2a_fwd_ms": a2a_f, "a2a_bwd_ms": a2a_b, "allreduce_ms": ar, "timing": "HIP events, max over ranks, 10 back-to-back calls",
+            "a2a_send_bytes_per_rank": send.numel() * 4, "a2a_bytes_leaving_rank": off_node,
+            "a2a_fwd_gbps_per_rank": off_node / (a2a_f * 1e-3) / 1e9, "allreduce_bytes": flat.numel() * 4,
+            "in_step": "2 all-to-alls (forward + backward) + 1 bucketed DDP all-reduce per step"}
+        result["distributed"] = dist_info
+        faulthandler.cancel_dump_traceback_later()
+        del send, recv, flat
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         del model, opt, batches
         torch.cuda.empty_cache()

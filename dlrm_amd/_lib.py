@@ -62,6 +62,8 @@ SIGNATURES = {
     "dlrm_gen_uniform_bags": (_i32, [_i32, _i64, _pi64, _i32, _i32, C.c_uint64, _i32, _pp, _pp, _vp, _vp, _i64, _vp]),
     "dlrm_gen_uniform_dense": (_i32, [_i64, _vp, _i32, C.c_uint64, _vp]),
     "dlrm_criteo_bin_transform": (_i32, [_i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "dlrm_multihot_gen_table": (_i32, [_i32, _i64, _i32, _i32, C.c_uint64, _vp, _vp]),
+    "dlrm_multihot_expand": (_i32, [_i32, _i64, _vp, _i32, _pp, _pi64, C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp]),
     "dlrm_copy_blocks": (_i32, [_i64, _i32, _pp, _pi64, _pp, _pi64, C.POINTER(_i32), _vp]),
     "dlrm_bce_elementwise": (_i32, [_i64, _vp, _vp, _vp, _vp]),
     "dlrm_bce_elementwise_bwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp]),

@@ -269,6 +269,23 @@ int dlrm_criteo_bin_transform(int64_t B, const int32_t* raw, int64_t max_ind_ran
                               int64_t ldx, void* indices, void* offsets, int64_t ld_idx, float* target, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * MLPerf-v2 multi-hot synthetic inputs (BASELINE.json configs[4]).  Replaces the reference's `Multihot`
+ * (torchrec_dlrm/multi_hot.py:80-159), which expands every batch on the host CPU.
+ * dlrm_multihot_gen_table: lookup table M [rows, hot] int32 in HBM; column 0 = the row id, columns 1.. = uniform
+ *   randint(0, rows) (dist 0) or int32(pareto(0.25)) % rows (dist 1) (:86-104) from Philox4x32-10 (counter (row, column,
+ *   table_id), key seed): the reference's distributions, a different stream than numpy's seed-0 MT19937.
+ * dlrm_multihot_expand (:129-159, :115-127): ids = device int32/int64 [T, B] 1-hot ids, key(table)-major as in the KJT
+ *   `_values` the reference reshapes (:135);  values[vbase_t + b*hot_t + j] = M_t[ids[t, b], j] with vbase_t = B * sum_{k<t} hot_k
+ *   (== torch.cat of the per-table F.embedding results);  offsets_global [T*B + 1] int64 = the reference's cumulative
+ *   offsets (nullable);  offsets_local [T, B] int32 = b * hot_t, the per-table bag starts dlrm_emb_* take together with
+ *   indices_host[t] = values + vbase_t (nullable).  An id outside [0, rows_t) is reported through `err` (the reference's
+ *   F.embedding raises) and expanded as id 0. */
+int dlrm_multihot_gen_table(int table_id, int64_t rows, int hot, int dist, uint64_t seed, int32_t* table_out, void* stream);
+int dlrm_multihot_expand(int T, int64_t B, const void* ids, int idx_bits, const void* const* tables_host,
+                         const int64_t* rows_host, const int* hot_host, int32_t* values, int64_t* offsets_global,
+                         int32_t* offsets_local, int64_t* err, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Strided block copy = torch.cat / torch.split along dim 1 without ATen:
  *   for k < nblk:  dst_host[k][m*dst_ld_host[k] + c] = src_host[k][m*src_ld_host[k] + c],  m < M, c < width_host[k]
  * Uses: the "cat" interaction R = cat([x] + ly, 1) (dlrm_s_pytorch.py:505-507) when the features do not already sit

@@ -246,12 +246,12 @@ def _dist_worker(rank, size, port, full_init, batches, cfg, q):
     torch.distributed.destroy_process_group()
 
 
-def capture_distributed(name="dist2_tiny"):
+def capture_distributed(name="dist2_tiny", size=2, ln_emb=(30, 20, 10), B=8, top_mid=8, port=29631):
     import torch.multiprocessing as mp
     ref, dp, ext = import_reference()
-    cfg = dict(m_spa=4, ln_emb=[30, 20, 10], ln_bot=[5, 8, 4], lr=0.5, B=8, steps=2)
-    F = 4
-    cfg["ln_top"] = [F * (F - 1) // 2 + 4, 8, 1]
+    cfg = dict(m_spa=4, ln_emb=list(ln_emb), ln_bot=[5, 8, 4], lr=0.5, B=B, steps=2)
+    F = len(ln_emb) + 1
+    cfg["ln_top"] = [F * (F - 1) // 2 + 4, top_mid, 1]
     np.random.seed(11)
     torch.manual_seed(11)
     full = ref.DLRM_Net(cfg["m_spa"], np.asarray(cfg["ln_emb"]), np.asarray(cfg["ln_bot"]), np.asarray(cfg["ln_top"]),
@@ -272,7 +272,6 @@ def capture_distributed(name="dist2_tiny"):
     out.update(sd_np(full, "single.final"))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    size, port = 2, 29631
     procs = [ctx.Process(target=_dist_worker, args=(r, size, port, full_init, batches, cfg, q)) for r in range(size)]
     for p in procs:
         p.start()
@@ -475,12 +474,67 @@ def capture_terabyte(ref, dp, name="terabyte_b65536", row_cap=2000, B=65536, ste
     print(f"{name}: regeneration verified")
 
 
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[4] inputs: the reference's Multihot class (torchrec_dlrm/multi_hot.py:27-175)
+# ---------------------------------------------------------------------------------------------
+def import_multihot():
+    """torchrec is not installed: stub the two names multi_hot.py imports (`Batch`, `KeyedJaggedTensor.from_offsets_sync`)
+    — containers only, none of the arithmetic under test lives in them."""
+    tr = types.ModuleType("torchrec"); ds = types.ModuleType("torchrec.datasets"); ut = types.ModuleType("torchrec.datasets.utils")
+    sp = types.ModuleType("torchrec.sparse"); jt = types.ModuleType("torchrec.sparse.jagged_tensor")
+
+    class Batch:
+        def __init__(self, dense_features, sparse_features, labels):
+            self.dense_features, self.sparse_features, self.labels = dense_features, sparse_features, labels
+
+    class KeyedJaggedTensor:
+        def __init__(self, keys, values, offsets):
+            self._keys, self._values, self._offsets = keys, values, offsets
+
+        @classmethod
+        def from_offsets_sync(cls, keys, values, offsets):
+            return cls(keys, values, offsets)
+    ut.Batch, jt.KeyedJaggedTensor = Batch, KeyedJaggedTensor
+    sys.modules.update({"torchrec": tr, "torchrec.datasets": ds, "torchrec.datasets.utils": ut, "torchrec.sparse": sp,
+                        "torchrec.sparse.jagged_tensor": jt})
+    sys.path.insert(0, os.path.join(REF, "torchrec_dlrm"))
+    import multi_hot
+    return multi_hot, Batch, KeyedJaggedTensor
+
+
+def capture_multihot(name="multihot_tables"):
+    """The reference's own Multihot: seed-0 lookup tables (uniform and pareto), 1-hot -> multi-hot expansion and the
+    cumulative offsets, on small tables (the MLPerf sizes 3,2,1,...,100,27,... need 24 GB of lookup tables)."""
+    multi_hot, Batch, KJT = import_multihot()
+    out, cases = {}, []
+    for tag, dist, sizes, n_emb, B, B2 in (("uniform", "uniform", [3, 2, 1, 6, 1, 12], [50, 7, 3, 1000, 10, 40000], 32, 20),
+                                           ("pareto", "pareto", [4, 1, 9], [100, 5, 3000], 16, 16)):
+        mh = multi_hot.Multihot(sizes, n_emb, B, collect_freqs_stats=False, dist_type=dist)
+        for k, t in enumerate(mh.multi_hot_tables_l):
+            out[f"{tag}.table{k}"] = t.numpy().copy()
+        rng = np.random.default_rng(5)
+        for b_ in sorted({B, B2}):
+            ids = np.stack([rng.integers(0, n, size=b_) for n in n_emb]).astype(np.int64)      # [T, b] 1-hot ids, key-major
+            kjt = KJT([f"cat_{k}" for k in range(len(n_emb))], torch.from_numpy(ids.reshape(-1)), None)
+            nb = mh.convert_to_multi_hot(Batch(torch.zeros(b_, 13), kjt, torch.zeros(b_)))
+            out[f"{tag}.b{b_}.ids"] = ids
+            out[f"{tag}.b{b_}.values"] = nb.sparse_features._values.numpy().copy()
+            out[f"{tag}.b{b_}.offsets"] = nb.sparse_features._offsets.numpy().copy()
+            assert nb.sparse_features._values.dtype == torch.int32
+        cases.append(dict(tag=tag, dist=dist, sizes=sizes, n_emb=n_emb, batches=sorted({B, B2})))
+    out["meta"] = np.frombuffer(json.dumps(dict(name=name, cases=cases, numpy=np.__version__)).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(name, [(c["tag"], [int(out[f"{c['tag']}.b{b}.values"].size) for b in c["batches"]]) for c in cases])
+
+
 def main(which):
     os.makedirs(OUT, exist_ok=True)
     if which == "metrics":
         return capture_metrics()
     if which == "criteo_bin":
         return capture_criteo_bin()
+    if which == "multihot":
+        return capture_multihot()
     ref, dp, ext = import_reference()
     if which in ("all", "train"):
         # BASELINE.json configs[0]: 3 tables x 1000 x 16, bot 13-512-16, batch 128 (top tower 128-64-1)
@@ -517,7 +571,11 @@ def main(which):
         capture_datagen(dp)
     if which in ("all", "dist"):
         capture_distributed()
+    if which in ("all", "dist8"):
+        # the real Criteo split: 26 tables over 8 ranks -> [4,4,3,3,3,3,3,3] (extend_distributed.py:47-62), B = 64 -> 8 per rank
+        capture_distributed("dist8_t26", size=8, ln_emb=[5 + (7 * k) % 23 for k in range(26)], B=64, top_mid=16, port=29641)
     if which == "all":
+        capture_multihot()
         capture_metrics()
         capture_criteo_bin()
 

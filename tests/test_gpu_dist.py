@@ -23,11 +23,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, size, port, q, chunks=1):
+def _worker(rank, size, port, q, chunks=1, fixture="dist2_tiny"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK="0")
     import dlrm_amd
     from dlrm_amd import ext_dist, ops
-    d, meta = load_golden("dist2_tiny")
+    d, meta = load_golden(fixture)
     ext_dist.init_distributed(rank=rank, local_rank=0, size=size, use_gpu=True, backend="gloo")
     dev = torch.device("cuda:0")
     np.random.seed(3)
@@ -72,14 +72,18 @@ def _worker(rank, size, port, q, chunks=1):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("chunks", [1, 2], ids=["single-exchange", "pipelined-2-chunks"])
-def test_two_rank_training_matches_reference_two_rank_run(chunks):
-    d, meta = load_golden("dist2_tiny")
-    size = 2
+@pytest.mark.parametrize("fixture,chunks", [("dist2_tiny", 1), ("dist2_tiny", 2), ("dist8_t26", 1), ("dist8_t26", 2)],
+                         ids=["2ranks-single-exchange", "2ranks-pipelined-2-chunks", "8ranks-26tables-single-exchange",
+                              "8ranks-26tables-pipelined-2-chunks"])
+def test_multi_rank_training_matches_reference_multi_rank_run(fixture, chunks):
+    """dist8_t26: the real Criteo partition — 26 tables over 8 ranks ([4,4,3,3,3,3,3,3]), B = 64 (8 per rank) — through
+    DLRM_Net.distributed_forward, ext_dist.alltoall() and DDP, against the reference's own 8-rank run."""
+    d, meta = load_golden(fixture)
+    size = meta["size"]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, size, port, q, chunks)) for r in range(size)]
+    procs = [ctx.Process(target=_worker, args=(r, size, port, q, chunks, fixture)) for r in range(size)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=600) for _ in range(size))

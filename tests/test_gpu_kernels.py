@@ -331,6 +331,7 @@ def test_linear_single_output_layer(M, K, act):
     """N == 1 (the last top-MLP layer): the matrix-vector kernels (gemv.hip) for K % 4 == 0 <= 1024, the GEMM path
     otherwise — forward, masked data gradient, weight + bias gradient with and without accumulation."""
     from dlrm_amd import ops
+    arith = "f32"
     rng = np.random.default_rng(M + K)
     X = rng.standard_normal((M, K)).astype(np.float32)
     W = (rng.standard_normal((1, K)) / np.sqrt(K)).astype(np.float32)
@@ -368,6 +369,7 @@ def test_linear_small_reduction_layer(M, N, K, act):
     streaming kernel of smallk.hip (forward stays on the GEMM kernel) — both against the oracle / a float64 restatement,
     accumulate mode, run-to-run bit identity (fixed-order partial sums), strided destination."""
     from dlrm_amd import ops
+    arith = "f32"
     rng = np.random.default_rng(M + N + K)
     X = rng.standard_normal((M, K)).astype(np.float32)
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
@@ -525,6 +527,75 @@ def test_emb_bwd_coo_is_the_reference_sparse_gradient():
             if weights is not None:
                 want = want * weights[t][:, None]
             assert np.array_equal(vals[t].cpu().numpy(), want.astype(np.float32)), t
+
+
+# ------------------------------------------------------------------------------------------ config 5 inputs: Multihot
+@pytest.mark.parametrize("id_dtype", [torch.int64, torch.int32])
+def test_multihot_expand_matches_reference_class(id_dtype):
+    """dlrm_multihot_expand with the REFERENCE's lookup tables uploaded: values (int32, table-major KJT layout), cumulative
+    offsets (int64) — bit-exact against the outputs of torchrec_dlrm/multi_hot.py's own class (fixture multihot_tables.npz),
+    for the constructor's batch size and a different one; local offsets = b * h_t; pooled embeddings through the views
+    handed to the model equal the oracle's EmbeddingBag of the reference's values."""
+    from conftest import load_golden
+    from dlrm_amd import ops
+    from dlrm_amd.multihot import Multihot
+    d, meta = load_golden("multihot_tables")
+    for c in meta["cases"]:
+        tabs = [d[f"{c['tag']}.table{k}"] for k in range(len(c["sizes"]))]
+        mh = Multihot.from_host_tables(tabs, c["batches"][-1], device=dev())
+        assert mh.lookups_per_sample == sum(c["sizes"])
+        for b in c["batches"]:
+            ids = to_dev(d[f"{c['tag']}.b{b}.ids"]).to(id_dtype)
+            values, off_g, off_l = mh.expand(ids)
+            torch.cuda.synchronize()
+            assert values.dtype == torch.int32 and np.array_equal(values.cpu().numpy(), d[f"{c['tag']}.b{b}.values"])
+            assert off_g.dtype == torch.int64 and np.array_equal(off_g.cpu().numpy(), d[f"{c['tag']}.b{b}.offsets"])
+            for t, h in enumerate(c["sizes"]):
+                assert np.array_equal(off_l[t].cpu().numpy(), np.arange(b) * h)
+            # straight into the embedding kernel (int32 indices, h_t lookups per bag)
+            D = 8
+            rng = np.random.default_rng(1)
+            Ws = [rng.standard_normal((n, D)).astype(np.float32) for n in c["n_emb"]]
+            lS_o, lS_i = mh.to_model_inputs(ids)
+            out = torch.empty((b, len(Ws) * D), device=dev())
+            ops.emb_fwd([to_dev(w) for w in Ws], ops.BagBatch(lS_o, lS_i), out)
+            ref_v, ref_o = d[f"{c['tag']}.b{b}.values"], d[f"{c['tag']}.b{b}.offsets"]
+            for t in range(len(Ws)):
+                lo, hi = ref_o[t * b], ref_o[(t + 1) * b]
+                want = O.emb_fwd(Ws[t], ref_v[lo:hi].astype(np.int64), (ref_o[t * b:(t + 1) * b] - lo).astype(np.int64))
+                assert np.array_equal(out[:, t * D:(t + 1) * D].cpu().numpy(), want), (c["tag"], b, t)
+    ops.check_index_errors(sync=True)
+    # an id outside the table is reported (F.embedding raises in the reference) and never dereferenced
+    bad = to_dev(d["uniform.b32.ids"]).to(id_dtype).clone()
+    bad[2, 5] = 3                                                     # table 2 has 3 rows
+    c0 = meta["cases"][0]
+    mh = Multihot.from_host_tables([d[f"uniform.table{k}"] for k in range(len(c0["sizes"]))], 32, device=dev())
+    mh.expand(bad)
+    with pytest.raises(IndexError, match="table 2"):
+        ops.check_index_errors(sync=True)
+
+
+def test_multihot_generated_tables_match_philox_oracle():
+    """dlrm_multihot_gen_table == oracle.philox_multihot_table: column 0 the id, uniform columns bit-exact (integer
+    multiply-shift of a Philox word), pareto columns equal up to the last-bit differences of exp/log1p between the device
+    and numpy (the value is a huge heavy-tailed double truncated to int32) and both with the reference's distribution."""
+    from dlrm_amd.multihot import Multihot
+    sizes, n_emb = [3, 1, 12, 5], [1000, 7, 50000, 3]
+    mh = Multihot(sizes, n_emb, 16, dist_type="uniform", device=dev(), seed=99)
+    for t, (h, n) in enumerate(zip(sizes, n_emb)):
+        got = mh.multi_hot_tables_l[t].cpu().numpy()
+        assert got.dtype == np.int32 and np.array_equal(got, O.philox_multihot_table(t, n, h, 0, 99)), t
+        assert got.min() >= 0 and got.max() < n
+    big = mh.multi_hot_tables_l[2].cpu().numpy()[:, 1:].reshape(-1)
+    assert abs(big.mean() / 50000 - 0.5) < 5e-3                       # uniform on [0, n)
+    mp_ = Multihot(sizes, n_emb, 16, dist_type="pareto", device=dev(), seed=5)
+    for t, (h, n) in enumerate(zip(sizes, n_emb)):
+        got = mp_.multi_hot_tables_l[t].cpu().numpy()
+        want = O.philox_multihot_table(t, n, h, 1, 5)
+        assert got.min() >= 0 and got.max() < n and np.array_equal(got[:, 0], np.arange(n))
+        assert np.mean(got != want) < 1e-4, (t, np.mean(got != want))
+    with pytest.raises(ValueError):
+        Multihot(sizes, n_emb, 16, dist_type="zipf", device=dev())
 
 
 # ------------------------------------------------------------------------------------------ K4: row-wise Adagrad

@@ -287,9 +287,11 @@ def test_coo_escape_hatch_runs_any_torch_optimizer(route):
     # (2) torch.optim.Adagrad
     model = build_model(meta, init, device)
     model.fused_emb_update = (route == "auto")
-    opt = torch.optim.Adagrad(model.parameters(), lr=0.05)
+    # initial_accumulator_value > 0: from a zero accumulator the first Adagrad step is lr * sign(g), which turns the
+    # rounding noise of a near-zero gradient element into a full-size difference — not a property of the gradient route
+    opt = torch.optim.Adagrad(model.parameters(), lr=0.05, initial_accumulator_value=0.1)
     ref = TorchPortDLRM({k: torch.from_numpy(v) for k, v in init.items()}, meta["sigmoid_top"], meta["itself"], meta["loss"], 0.05)
-    ref.opt = torch.optim.Adagrad(list(ref.p.values()), lr=0.05)
+    ref.opt = torch.optim.Adagrad(list(ref.p.values()), lr=0.05, initial_accumulator_value=0.1)
     for s, (X, lS_o, lS_i, T) in enumerate(golden_batches(d, meta)):
         Z = model(torch.from_numpy(X).to(device), [torch.from_numpy(o).to(device) for o in lS_o],
                   [torch.from_numpy(i).to(device) for i in lS_i])

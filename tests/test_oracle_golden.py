@@ -255,3 +255,20 @@ def test_terabyte_full_batch_fixture_regenerates_and_oracle_reproduces_it():
     for k, v in params_with_prefix(d, "final_head").items():
         np.testing.assert_allclose(m.p[k].detach().numpy()[:48], v, rtol=1e-5, atol=1e-7, err_msg=k)
         np.testing.assert_allclose(m.p[k].detach().numpy()[-48:], d["final_tail." + k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def test_multihot_restatement_matches_reference_class():
+    """oracle.multihot_tables / multihot_expand against the reference's own Multihot class (torchrec_dlrm/multi_hot.py:
+    80-159; fixture multihot_tables.npz): seed-0 lookup tables for "uniform" and "pareto", expanded values (int32,
+    table-major) and cumulative offsets (int64) for the constructor's batch size and for a different one."""
+    d, meta = load_golden("multihot_tables")
+    for c in meta["cases"]:
+        tabs = O.multihot_tables(c["sizes"], c["n_emb"], c["dist"])
+        for k, t in enumerate(tabs):
+            assert t.dtype == np.int32 and np.array_equal(t, d[f"{c['tag']}.table{k}"]), (c["tag"], k)
+            assert np.array_equal(t[:, 0], np.arange(c["n_emb"][k]))               # column 0 is the 1-hot id itself
+        for b in c["batches"]:
+            v, o = O.multihot_expand(d[f"{c['tag']}.b{b}.ids"], tabs)
+            assert v.dtype == np.int32 and np.array_equal(v, d[f"{c['tag']}.b{b}.values"])
+            assert o.dtype == np.int64 and np.array_equal(o, d[f"{c['tag']}.b{b}.offsets"])
+            assert o[-1] == b * sum(c["sizes"])
