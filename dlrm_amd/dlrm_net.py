@@ -29,6 +29,7 @@ import torch.nn as nn
 from . import ext_dist, ops
 from .functional import (BCEElementwiseFunction, BCELossFunction, CatFunction, ChunkPackFunction, ClampFunction,
                          EmbeddingBagsFunction, InteractFunction, MLPFunction, MSELossFunction, OutSlot)
+from .functional import _side_stream
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, BagBatch
 
 
@@ -106,19 +107,38 @@ class EmbeddingUpdateHook:
 
     _models: "weakref.WeakSet" = weakref.WeakSet()
     _handle = None
+    _post = None
 
     @classmethod
     def register(cls, model: "DLRM_Net") -> None:
         cls._models.add(model)
         if cls._handle is None:
-            from torch.optim.optimizer import register_optimizer_step_pre_hook
+            from torch.optim.optimizer import register_optimizer_step_post_hook, register_optimizer_step_pre_hook
             cls._handle = register_optimizer_step_pre_hook(cls._pre_step)
+            cls._post = register_optimizer_step_post_hook(cls._post_step)
 
     @staticmethod
     def _pre_step(optimizer, args, kwargs):
         for model in list(EmbeddingUpdateHook._models):
             if model._pending_emb:
                 model.apply_pending_embedding_updates(optimizer)
+            elif model.overlap_streams and model._bound_optimizer is None and model._owned_by(optimizer):
+                model._bound_optimizer = weakref.ref(optimizer)
+
+    @staticmethod
+    def _post_step(optimizer, args, kwargs):
+        # overlap mode: the embedding update runs on the side stream; once optimizer.step() has returned, everything the
+        # caller enqueues on ITS stream (state_dict reads, evaluation, the next forward) is ordered after it
+        for model in list(EmbeddingUpdateHook._models):
+            model._join_side_stream()
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 class DLRM_Net(nn.Module):
@@ -176,6 +196,14 @@ class DLRM_Net(nn.Module):
         # False (or env DLRM_FUSED_EMB_UPDATE=0): backward materialises the reference's sparse COO gradient into
         # `emb.weight.grad` (dlrm_emb_bwd_coo) and ANY torch optimizer consumes it, exactly like the reference
         self.fused_emb_update = os.environ.get("DLRM_FUSED_EMB_UPDATE", "1") != "0"
+        # True (or env DLRM_OVERLAP=1): the HBM-bound embedding kernels run on a second HIP stream beside the MFMA-bound MLP
+        # GEMMs they do not depend on — forward: the pooled lookups beside the bottom MLP (the reference's own overlap idea,
+        # dlrm_s_pytorch.py:563-568); backward: the fused sparse update beside the bottom-MLP backward and the dense
+        # optimizer step.  Same kernels, same arithmetic, same results; optimizer.step() returns with the caller's stream
+        # ordered after the update.
+        self.overlap_streams = os.environ.get("DLRM_OVERLAP", "0") == "1"
+        self._bound_optimizer = None        # weakref to the optimizer that owns the tables (learnt at its first step)
+        self._side_keep: list = []          # tensors the side stream still reads (released at the join)
         # > 1: the pooled-embedding all-to-all of the distributed forward is pipelined in that many batch chunks (opt-in)
         self.a2a_chunks = max(int(os.environ.get("DLRM_A2A_CHUNKS", "1")), 1)
         if m_spa is None or ln_emb is None or ln_bot is None or ln_top is None or arch_interaction_op is None:
@@ -289,10 +317,35 @@ class DLRM_Net(nn.Module):
         sys.exit("ERROR: quantized embeddings are a CPU-only inference option of the reference")
 
     # ---------------------------------------------------------------- fused sparse update
+    def _owned_by(self, optimizer) -> bool:
+        mine = {id(e.weight) for e in self.emb_l}
+        return any(id(p) in mine for g in optimizer.param_groups for p in g["params"])
+
+    def _join_side_stream(self) -> None:
+        if self._side_keep:
+            dev = self._side_keep[0].device
+            torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
+            self._side_keep = []
+
     def _stash_embedding_grad(self, weights, bags, dout):
         if not self.fused_emb_update:
             self._materialize_coo_grads(weights, bags, dout)
             return
+        opt = self._bound_optimizer() if (self.overlap_streams and self._bound_optimizer is not None) else None
+        if opt is not None and not self._pending_emb:
+            # overlap mode, optimizer known from its earlier steps: the sparse SGD update is launched NOW — this backward
+            # node runs on the side stream its forward ran on, so the update overlaps the bottom-MLP backward that autograd
+            # runs next on the main stream — with the learning rate the optimizer holds at this moment (the reference reads
+            # it at step(), a few microseconds later in the same loop body: dlrm_s_pytorch.py:1611-1621)
+            plan = _embedding_update_plan(opt, weights)
+            if plan is not None and plan[0] == "sgd":
+                cur, side = torch.cuda.current_stream(dout.device), _side_stream(dout.device)
+                if cur != side:                      # (distributed forward: the lookups ran on the main stream)
+                    side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ops.emb_bwd_sgd(weights, bags, dout, plan[1], self.emb_update_mode)
+                self._side_keep += [dout] + bags.keep
+                return
         self._pending_emb.append((weights, bags, dout))
         if len(self._pending_emb) == 65:
             print("WARNING: dlrm_amd: 65 embedding gradients are parked and no optimizer that owns the tables has stepped; "
@@ -313,6 +366,19 @@ class DLRM_Net(nn.Module):
         """Launch the fused backward+update for every stashed embedding gradient: sparse SGD for torch.optim.SGD,
         row-wise sparse Adagrad for RWSAdagrad (the reference's optim/rwsadagrad.py or dlrm_amd.optim.FusedRWSAdagrad)."""
         pending, self._pending_emb = self._pending_emb, []
+        side = None
+        if self.overlap_streams and pending and pending[0][2].is_cuda:
+            # launched from the step pre-hook: on the side stream, beside the dense optimizer step (joined in the post-hook)
+            dev = pending[0][2].device
+            side = _side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            self._side_keep += [p_[2] for p_ in pending]
+            if optimizer is not None and self._bound_optimizer is None and self._owned_by(optimizer):
+                self._bound_optimizer = weakref.ref(optimizer)
+        with torch.cuda.stream(side) if side is not None else _NullCtx():
+            self._apply_pending(pending, optimizer, lr)
+
+    def _apply_pending(self, pending, optimizer, lr):
         for weights, bags, dout in pending:
             if lr is not None:
                 ops.emb_bwd_sgd(weights, bags, dout, lr, self.emb_update_mode)
@@ -352,8 +418,18 @@ class DLRM_Net(nn.Module):
         if self.arch_interaction_op == "dot" and n_out != D:
             sys.exit("ERROR: bottom MLP output (%d) and embedding dimension (%d) differ" % (n_out, D))
         feat = torch.empty((B, n_out + T * D), dtype=torch.float32, device=dense_x.device)
-        x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :n_out]))
-        E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l, out_slot=OutSlot(feat[:, n_out:]))
+        if self.overlap_streams and dense_x.is_cuda:
+            # pooled lookups (HBM-bound) on the side stream beside the bottom-MLP GEMMs (MFMA-bound): they only meet at the
+            # interaction.  The side stream first waits for everything already enqueued (inputs, the previous update).
+            main, side = torch.cuda.current_stream(dense_x.device), _side_stream(dense_x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l, out_slot=OutSlot(feat[:, n_out:]))
+            x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :n_out]))
+            main.wait_stream(side)
+        else:
+            x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :n_out]))
+            E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l, out_slot=OutSlot(feat[:, n_out:]))
         if self.arch_interaction_op == "cat":
             z = CatFunction.apply(OutSlot(feat), x, E)      # the feature buffer IS cat([x] + ly, 1): nothing is copied
         else:

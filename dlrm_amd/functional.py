@@ -39,8 +39,9 @@ def _round4(n: int) -> int:
 
 
 def alloc2d(M: int, N: int, like: torch.Tensor, zero: bool = False) -> torch.Tensor:
-    """[M, N] view of an [M, round_up(N, 4)] buffer: every row starts 16-byte aligned."""
-    ldn = _round4(N)
+    """[M, N] view of an [M, round_up(N, 4)] buffer: every row starts 16-byte aligned.  A single column stays [M, 1]
+    contiguous (the matrix-vector kernels take any pitch, and the loss kernel reads the predictions in place)."""
+    ldn = 1 if N == 1 else _round4(N)
     buf = (torch.zeros if zero else torch.empty)((M, ldn), dtype=torch.float32, device=like.device)
     return buf if ldn == N else buf[:, :N]
 

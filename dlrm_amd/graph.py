@@ -87,6 +87,9 @@ class GraphedTrainStep:
             raise RuntimeError("dlrm_amd.graph: the whole-step HIP graph is single-process only "
                                "(RCCL all-to-all / DDP all-reduce are not captured)")
         self.model, self.optimizer = model, optimizer
+        # the captured step is single-stream: a replayed graph has no launch gaps to hide, and the side-stream overlap
+        # of the eager path (DLRM_Net.overlap_streams) would put cross-stream joins into the capture
+        model.overlap_streams = False
         self.warmup = max(int(warmup), 1)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.stream: Optional[torch.cuda.Stream] = None
