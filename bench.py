@@ -35,9 +35,17 @@ CRITEO_TB_ROWS = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 385329
 # Criteo-Kaggle table sizes, tools/visualize.py:1123-1152
 CRITEO_KAGGLE_ROWS = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306,
                       10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+# MLPerf-v2 (torchrec_dlrm) table sizes and multi-hot sizes, torchrec_dlrm/README.MD:45,159 — 204.18 M rows, 214 lookups/sample
+MLPERF_V2_ROWS = [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 40000000, 3067956, 405282, 10, 2209, 11938, 155, 4,
+                  976, 14, 40000000, 40000000, 40000000, 590152, 12973, 108, 36]
+MLPERF_V2_HOT = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
 WORKLOADS = {
     "criteo_terabyte": dict(rows=CRITEO_TB_ROWS, D=128, bot=[13, 512, 256, 128], top=[1024, 1024, 512, 256, 1], batch=65536),
     "criteo_kaggle": dict(rows=CRITEO_KAGGLE_ROWS, D=16, bot=[13, 512, 256, 64, 16], top=[512, 256, 1], batch=2048),
+    # BASELINE.json configs[4] (first slice: inputs + embedding path + row-wise Adagrad; dot interaction, dlrm_s towers):
+    # int32 multi-hot indices expanded on the device by dlrm_amd.multihot.Multihot (torchrec_dlrm/multi_hot.py semantics)
+    "mlperf_v2_multihot": dict(rows=MLPERF_V2_ROWS, hot=MLPERF_V2_HOT, D=128, bot=[13, 512, 256, 128],
+                               top=[1024, 1024, 512, 256, 1], batch=65536),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MFMA_PEAK_TF = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
@@ -94,17 +102,36 @@ def parse():
     return ap.parse_args()
 
 
-def make_batches(n, B, rows, device, seed):
+def make_batches(n, B, rows, device, seed, hot=None):
     """Synthetic batches in the reference's layout (dlrm_data_pytorch.py:899-960 with one lookup per bag, as the Criteo
     data sets have): indices and offsets as stacked [T, B] int64 tensors (row t = table t), generated on the device by
-    dlrm_amd.datagen (same distributions as the reference generator, Philox stream)."""
+    dlrm_amd.datagen (same distributions as the reference generator, Philox stream).
+    hot = per-table multi-hot sizes (MLPerf-v2): the 1-hot ids are expanded on the device through HBM-resident lookup
+    tables (dlrm_amd.multihot.Multihot = torchrec_dlrm/multi_hot.py:80-159) into int32 bags of hot[t] ids; returns the
+    per-batch expansion time as well (HIP events)."""
     from dlrm_amd.datagen import UniformBatchGenerator
-    gen = UniformBatchGenerator(13, rows, 1, True, round_targets=True, seed=seed, device=device)
+    gen = UniformBatchGenerator(13, rows, 1, True, round_targets=True, seed=seed, device=device,
+                                index_dtype=torch.int32 if hot else torch.int64)
+    mh, expand_ms = None, []
+    if hot:
+        from dlrm_amd.multihot import Multihot
+        mh = Multihot(hot, rows, B, dist_type="uniform", device=device, seed=0)
     out = []
     for k in range(n):
         X, lS_o, lS_i, T = gen.batch(B, batch_no=k)
-        out.append((X, torch.stack(lS_o), torch.stack(lS_i), T))
-    return out
+        if mh is None:
+            out.append((X, torch.stack(lS_o), torch.stack(lS_i), T))
+        else:
+            ids = torch.stack(lS_i)
+            mh.to_model_inputs(ids)                                       # warm
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            off, idx = mh.to_model_inputs(ids)
+            b.record()
+            torch.cuda.synchronize()
+            expand_ms.append(a.elapsed_time(b))
+            out.append((X, off, idx, T))
+    return (out, expand_ms) if hot else out
 
 
 def cpu_baseline(wl, args):
@@ -197,6 +224,15 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DLRM_BENCH_WATCHDOG"]), repeat=False, exit=False)
     wl = dict(WORKLOADS[args.workload])
+    if args.workload == "mlperf_v2_multihot":
+        # the reference's configuration for this benchmark: Adagrad lr 0.005 eps 1e-8 (torchrec_dlrm/README.MD:177-194), bf16 MLP
+        if "--optimizer" not in " ".join(sys.argv):
+            args.optimizer = "rwsadagrad"
+        if "--lr" not in " ".join(sys.argv):
+            args.lr = 0.005
+        if "--mlp-arith" not in " ".join(sys.argv) and "DLRM_MLP_ARITH" not in os.environ:
+            args.mlp_arith = "bf16"
+        args.no_cpu_baseline = True      # the CPU baseline leg times the headline workload only
     if args.batch:
         wl["batch"] = args.batch
     if args.row_cap:
@@ -230,6 +266,9 @@ def main():
     rank = max(ext_dist.my_rank, 0)
 
     rows, D, B = wl["rows"], wl["D"], wl["batch"]
+    hot_cfg = wl.get("hot")
+    if hot_cfg and args.row_cap:
+        wl["hot"] = hot_cfg = [min(h, r) for h, r in zip(hot_cfg, wl["rows"])]
     nf = len(rows) + 1
     ln_top = np.asarray([D + nf * (nf - 1) // 2] + wl["top"])
     np.random.seed(123)          # identical MLP parameters on every rank
@@ -249,14 +288,23 @@ def main():
                   {"params": model.top_l.parameters(), "lr": args.lr}]
         opt = FusedSGD(groups, lr=args.lr) if args.optimizer == "sgd" else FusedRWSAdagrad(groups, lr=args.lr)
     else:
-        opt = (FusedSGD if args.optimizer == "sgd" else FusedRWSAdagrad)(model.parameters(), lr=args.lr)
+        opt = FusedSGD(model.parameters(), lr=args.lr) if args.optimizer == "sgd" else \
+            FusedRWSAdagrad(model.parameters(), lr=args.lr, eps=1e-8 if hot_cfg else 1e-10)
 
     parity = None
     if N == 1 and args.workload == "criteo_terabyte" and not args.no_parity_check:
         parity = parity_check(args, device)
         torch.cuda.empty_cache()
     model_a2a_chunks = model.a2a_chunks if N > 1 else 1
-    batches = make_batches(4, B, rows, device, seed=727)     # every rank reads the whole global batch (reference :1541)
+    hot = wl.get("hot")
+    expand_ms = None
+    if hot:
+        if N > 1:
+            sys.exit("ERROR: --workload mlperf_v2_multihot is single-GPU in this round (the 100-hot 40 M-row table needs row-wise "
+                     "sharding to balance, SURVEY §8 f-3)")
+        batches, expand_ms = make_batches(4, B, rows, device, seed=727, hot=hot)
+    else:
+        batches = make_batches(4, B, rows, device, seed=727)     # every rank reads the whole global batch (reference :1541)
     my_rows = ext_dist.get_my_slice(B) if N > 1 else slice(0, B)
     local_tables = list(range(len(rows)))[model.local_emb_slice] if N > 1 else list(range(len(rows)))
 
@@ -331,8 +379,11 @@ def main():
     Bl = B // N if N > 1 else B
     R = 4 * D
     Tl = len(local_tables)
-    emb_fwd_bytes = Tl * B * (R + 8 + R + 8)            # one-hot: row read + index + pooled row write + offset
-    emb_bwd_bytes = Tl * B * (3 * R + 8)                # dV row read + W row read + W row write + index
+    hots = [hot[t] for t in local_tables] if hot else [1] * Tl
+    isz = 4 if hot else 8                               # int32 multi-hot ids (torchrec KJT) / int64 (dlrm_s)
+    L = sum(hots)                                       # lookups per sample over the local tables
+    emb_fwd_bytes = B * (L * (R + isz) + Tl * (R + isz))    # per lookup: row read + index; per bag: pooled row write + offset
+    emb_bwd_bytes = B * L * (3 * R + isz)               # per lookup: dV row read + W row read + W row write + index
     bot, top = list(wl["bot"]), list(ln_top)
     fwd_fl = sum(2.0 * Bl * a * b for ln in (bot, top) for a, b in zip(ln[:-1], ln[1:]))
     wgrad_fl = fwd_fl
@@ -344,7 +395,7 @@ def main():
     for name, work, unit, peak, bound in (
             ("emb_fwd", emb_fwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("emb_bwd_sgd", emb_bwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
-            ("emb_bwd_adagrad", emb_bwd_bytes + Tl * B * 8, "GB/s", HBM_PEAK_GBS, "hbm"),   # + row-wise state read/write per touched row
+            ("emb_bwd_adagrad", emb_bwd_bytes + L * B * 8, "GB/s", HBM_PEAK_GBS, "hbm"),    # + row-wise state read/write per touched row
             ("interact_fwd", inter_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("interact_bwd", 2 * inter_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("linear_fwd", fwd_fl, "TFLOP/s", FP32_MFMA_PEAK_TF, "mfma"),
@@ -373,6 +424,14 @@ def main():
              "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "expand + rocprim radix sort + sorted_update_kernel" if args.emb_update == "sorted" else "emb_bwd_sgd_{atomic,lds}_kernel",
              "interact_fwd": "interact_fwd_dma_kernel", "interact_bwd": "interact_bwd_dma_kernel"}
     pmc = load_pmc_traffic() if (N == 1 and args.workload == "criteo_terabyte" and not args.batch and not args.row_cap) else None
+    if hot:
+        result_extra = {"multihot": {"lookups_per_sample": L, "index_dtype": "int32", "lookup_table_bytes": int(sum(4 * r * h for r, h in zip(rows, hot))),
+                                     "expand_ms_per_batch": sum(expand_ms) / len(expand_ms),
+                                     "expand_gbps": 8.0 * L * B / (sum(expand_ms) / len(expand_ms) * 1e-3) / 1e9,
+                                     "note": "1-hot -> multi-hot expansion on the device (dlrm_multihot_expand, 8 B per produced id); done "
+                                             "by the data pipeline outside the training step, as in the reference (multi_hot.py)"}}
+    else:
+        result_extra = {}
 
     def roof(n):
         k = kernels[n]
@@ -400,8 +459,9 @@ def main():
         "dtype": "bf16" if args.mlp_arith == "bf16" else "f32",
         "data": "synthetic (the reference's random generator distributions, one lookup per bag, produced on the device by "
                 "dlrm_amd.datagen; random-init parameters)",
-        "config": {"workload": args.workload + (": MLPerf Criteo-Terabyte shapes (BASELINE.json configs[2])"
-                                                if args.workload == "criteo_terabyte" else ""),
+        "config": {"workload": args.workload + {"criteo_terabyte": ": MLPerf Criteo-Terabyte shapes (BASELINE.json configs[2])",
+                                                "mlperf_v2_multihot": ": MLPerf-v2 multi-hot synthetic inputs, 214 lookups/sample (BASELINE.json "
+                                                                      "configs[4], first slice: dlrm_s towers + dot interaction) — NOT the headline"}.get(args.workload, ""),
                    "tables": len(rows), "emb_dim": D, "global_batch": B, "table_rows_total": int(sum(rows)),
                    "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": args.optimizer,
                    "loss": "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
@@ -423,6 +483,7 @@ def main():
                                "bwd_sgd": kernels.get("emb_bwd_sgd", {}).get("achieved")},
         "kernels": kernels,
     }
+    result.update(result_extra)
     if N == 1 and args.mlp_arith == "f32" and not args.no_alt_arith:
         # the same step with the opt-in bf16x6 MLP arithmetic (fp32 round-off class, see include/dlrm_hip.h): reported
         # beside the headline value, never instead of it

@@ -42,8 +42,9 @@ SIGNATURES = {
                                             _vp, _i64, _f32, _f32, _vp, _i64, _vp, _vp]),
     "dlrm_interact_fwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _vp]),
     "dlrm_interact_bwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _pp, _pi64, _vp]),
-    "dlrm_linear_fwd": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
-    "dlrm_linear_bwd_data": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _vp]),
+    "dlrm_relu_bits_bytes": (_i64, [_i64, _i32]),
+    "dlrm_linear_fwd": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i32, _vp]),
+    "dlrm_linear_bwd_data": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "dlrm_linear_bwd_weight_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "dlrm_linear_bwd_weight": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
     "dlrm_linear_bwd_weight_padded": (_i32, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),

@@ -53,6 +53,11 @@ struct GemmArgs {
     long long c_split_stride;      // elements between the C slabs of consecutive k-slices (split-K partials in a workspace), else 0
     int tiles_m, tiles_n;
     int debug;                     // tuning aid (env DLRM_GEMM_DEBUG): 1 skip global loads in the k-loop, 2 skip LDS refill + barrier, 4 skip epilogue
+    // ReLU sign bits, one bit per output element (see dlrm_relu_bits_bytes in dlrm_hip.h for the layout): written by the
+    // forward epilogue (bits_out), consumed by the dgrad epilogue of the NEXT layer instead of its fp32 act' mask (bits_in)
+    unsigned long long* bits_out;
+    const unsigned long long* bits_in;
+    long long bits_nblk;           // 64-column blocks per row band = ceil(N / 64)
 };
 
 template <bool KC>
@@ -470,8 +475,17 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     const int c4 = (lane & 15) * 4;
     const long long nb = n0 + wn * 64 + c4;
     const bool full_n = nb + 3 < g.N;
-    const bool mask_pf = MASKED && g.mask != nullptr && g.vecC && full_n;
+    const bool use_bits = MASKED && g.bits_in != nullptr;
+    const bool mask_pf = MASKED && !use_bits && g.mask != nullptr && g.vecC && full_n;
     float4 mk[2][8];
+    // bit form of the same mask: lane L < 32 holds word L of the band's 32 x u64 block (256 B per 32 x 64 band instead of 8 KB)
+    unsigned long long mkb[2] = {0ull, 0ull};
+    auto bits_fetch = [&](int band, unsigned long long& dst) {
+        const long long mb = (m0 + wm * 32 * TM + band * 32) >> 5;
+        const long long nbk = (n0 + wn * 64) >> 6;
+        const long long last_band = (g.M - 1) >> 5;
+        dst = (nbk < g.bits_nblk) ? g.bits_in[((mb < last_band ? mb : last_band) * g.bits_nblk + nbk) * 32 + (lane & 31)] : 0ull;
+    };
     auto mask_fetch = [&](int band, float4 (&dst)[8]) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -486,14 +500,17 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     unsigned cur = 0, nxt = 2 * STAGE;     // byte offsets of the stage being read / being refilled
     const char* ldsb = (const char*)lds;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();   // my share of tile kt has landed
-        __builtin_amdgcn_s_barrier();      // everyone's share has; everyone is done reading stage `nxt`
-        if (kt + 2 < nk) GEMM3_ISSUE(nxt);
+        if (!(g.debug & 2)) {
+            if (kt + 1 < nk) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();   // my share of tile kt has landed
+            __builtin_amdgcn_s_barrier();      // everyone's share has; everyone is done reading stage `nxt`
+        }
+        if (kt + 2 < nk && !(g.debug & 1)) GEMM3_ISSUE(nxt);
         if constexpr (MASKED) {
             // no DMA is issued after tile nk-1's (at kt == nk-3), so these loads sit behind every DMA in the in-order
             // vmcnt queue and the counted wait of kt == nk-2 (which leaves TM+TN newer operations in flight) and the
             // final vmcnt(0) stay correct
             if (mask_pf && kt + 2 == nk) mask_fetch(0, mk[0]);
+            if (use_bits && kt + 2 == nk) bits_fetch(0, mkb[0]);
         }
         if constexpr (ARITH == 0) {
 #pragma unroll
@@ -587,7 +604,19 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         nxt = (nxt == 2 * STAGE) ? 0 : nxt + STAGE;
     }
 #undef GEMM3_ISSUE
+    wait_vmcnt<0>();
     __syncthreads();                       // all fragment reads done: the ring becomes epilogue staging
+    if (g.debug & 4) {                     // tuning aid: no epilogue (keeps the accumulators live)
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_ += acc[i][j][r];
+        if (s_ == 123.456f) g.C[0] = s_;
+        return;
+    }
 
     if (do_rowsum) {
 #pragma unroll
@@ -610,10 +639,15 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         if (nb + 2 < g.N) bv.z = g.bias[nb + 2];
         if (nb + 3 < g.N) bv.w = g.bias[nb + 3];
     }
-    if constexpr (MASKED) { if (mask_pf && nk < 2) mask_fetch(0, mk[0]); }
+    if constexpr (MASKED) { if (mask_pf && nk < 2) mask_fetch(0, mk[0]); if (use_bits && nk < 2) bits_fetch(0, mkb[0]); }
+    const bool write_bits = A_KC && B_KC && g.bits_out != nullptr;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        if constexpr (MASKED) { if (mask_pf && tm + 1 < TM) mask_fetch(tm + 1, mk[(tm + 1) & 1]); }
+        if constexpr (MASKED) {
+            if (mask_pf && tm + 1 < TM) mask_fetch(tm + 1, mk[(tm + 1) & 1]);
+            if (use_bits && tm + 1 < TM) bits_fetch(tm + 1, mkb[(tm + 1) & 1]);
+        }
+        unsigned long long myword = 0ull;          // forward: lane L < 32 collects word L of this band's sign-bit block
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -625,14 +659,39 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + (lane >> 4);
             const long long m = m0 + wm * 32 * TM + tm * 32 + row;
-            if (m >= g.M || nb >= g.N) continue;
+            const bool live = m < g.M && nb < g.N;
             float4 v = *(const float4*)__builtin_assume_aligned(S + row * EPI_LD + c4, 16);
             v.x = act_apply(v.x + bv.x, g.act); v.y = act_apply(v.y + bv.y, g.act);
             v.z = act_apply(v.z + bv.z, g.act); v.w = act_apply(v.w + bv.w, g.act);
+            if constexpr (A_KC && B_KC) {
+                if (write_bits) {       // wave-uniform: bit `lane` of word it*4 + c  <=>  element (row it*4 + lane/16, column 4*(lane%16) + c) > 0
+                    const unsigned long long b0 = __ballot(live && v.x > 0.f), b1 = __ballot(live && nb + 1 < g.N && v.y > 0.f);
+                    const unsigned long long b2 = __ballot(live && nb + 2 < g.N && v.z > 0.f), b3 = __ballot(live && nb + 3 < g.N && v.w > 0.f);
+                    const int w_ = l31 - 4 * it;
+                    if (w_ == 0) myword = b0; else if (w_ == 1) myword = b1; else if (w_ == 2) myword = b2; else if (w_ == 3) myword = b3;
+                }
+            }
+            if (!live) continue;
             float* c = g.C + (long long)blockIdx.z * g.c_split_stride + m * g.ldc + nb;
+            if constexpr (MASKED) {
+                if (use_bits) {         // ReLU derivative from the sign bits the forward pass stored
+                    const unsigned long long wv = mkb[tm & 1];
+                    const unsigned lo = (unsigned)wv, hi = (unsigned)(wv >> 32);
+                    const int sh = lane & 31;
+                    unsigned long long w0 = ((unsigned long long)__builtin_amdgcn_readlane(hi, it * 4 + 0) << 32) | __builtin_amdgcn_readlane(lo, it * 4 + 0);
+                    unsigned long long w1 = ((unsigned long long)__builtin_amdgcn_readlane(hi, it * 4 + 1) << 32) | __builtin_amdgcn_readlane(lo, it * 4 + 1);
+                    unsigned long long w2 = ((unsigned long long)__builtin_amdgcn_readlane(hi, it * 4 + 2) << 32) | __builtin_amdgcn_readlane(lo, it * 4 + 2);
+                    unsigned long long w3 = ((unsigned long long)__builtin_amdgcn_readlane(hi, it * 4 + 3) << 32) | __builtin_amdgcn_readlane(lo, it * 4 + 3);
+                    (void)sh;
+                    if (!((w0 >> lane) & 1ull)) v.x = 0.f;
+                    if (!((w1 >> lane) & 1ull)) v.y = 0.f;
+                    if (!((w2 >> lane) & 1ull)) v.z = 0.f;
+                    if (!((w3 >> lane) & 1ull)) v.w = 0.f;
+                }
+            }
             if (g.vecC && full_n) {
                 if constexpr (MASKED) {
-                    if (g.mask) {
+                    if (g.mask && !use_bits) {
                         const float4 y = mk[tm & 1][it];
                         v.x = act_grad(v.x, y.x, g.mask_act); v.y = act_grad(v.y, y.y, g.mask_act);
                         v.z = act_grad(v.z, y.z, g.mask_act); v.w = act_grad(v.w, y.w, g.mask_act);
@@ -646,10 +705,16 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
                 for (int x = 0; x < 4; ++x) {
                     if (nb + x < g.N) {
                         float o = e[x];
-                        if (g.mask) o = act_grad(o, g.mask[m * g.ldmask + nb + x], g.mask_act);
+                        if (g.mask && !use_bits) o = act_grad(o, g.mask[m * g.ldmask + nb + x], g.mask_act);
                         if (g.atomic_out) atomicAdd(c + x, o); else c[x] = o;
                     }
                 }
+            }
+        }
+        if constexpr (A_KC && B_KC) {
+            if (write_bits && lane < 32) {
+                const long long mb = (m0 + wm * 32 * TM + tm * 32) >> 5, nbk = (n0 + wn * 64) >> 6;
+                if (mb <= ((g.M - 1) >> 5) && nbk < g.bits_nblk) g.bits_out[(mb * g.bits_nblk + nbk) * 32 + lane] = myword;
             }
         }
     }
@@ -717,6 +782,21 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(long long M, int N, const 
     }
 }
 
+// fallback producer of the ReLU sign-bit blocks (shapes the LDS-DMA kernel does not take): one thread per 64-bit word
+__global__ __launch_bounds__(256) void relu_bits_kernel(long long M, int N, const float* __restrict__ Y, long long ldy,
+                                                        unsigned long long* __restrict__ bits, long long nblk, long long words) {
+    for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < words; w += (long long)gridDim.x * 256) {
+        const int sub = (int)(w & 31), it = sub >> 2, c = sub & 3;
+        const long long blk = w >> 5, mb = blk / nblk, nbk = blk - mb * nblk;
+        unsigned long long v = 0ull;
+        for (int l = 0; l < 64; ++l) {
+            const long long m = mb * 32 + it * 4 + (l >> 4), n = nbk * 64 + (l & 15) * 4 + c;
+            if (m < M && n < N && Y[m * ldy + n] > 0.f) v |= 1ull << l;
+        }
+        bits[w] = v;
+    }
+}
+
 static int pow2ceil_i(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
 template <bool A_KC, bool B_KC, int TM, int ARITH>
@@ -725,7 +805,11 @@ static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     constexpr int BMt = 64 * TM, BNt = 128;
     g.tiles_m = (int)((g.M + BMt - 1) / BMt);
     g.tiles_n = (int)((g.N + BNt - 1) / BNt);
-    g.debug = 0;
+    {   // tuning aid (env DLRM_GEMM_DEBUG): 1 no DMA refill in the k-loop, 2 no wait + barrier, 4 no epilogue — WRONG results, timing only
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("DLRM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
+        g.debug = dbg;
+    }
     const size_t lds = (size_t)NSTAGE3 * (BMt + BNt) * BK3 * 4;     // 72 KiB (TM=4) / 48 KiB (TM=2)
     static bool attr_done[DLRM_MAX_DEVICES] = {};      // the attribute is per (function, device)
     const int dev = dlrm_current_device();
@@ -746,19 +830,22 @@ static int gemm_path() {   // env DLRM_GEMM_PATH: 0 = auto (default), 2 = force 
 }
 
 template <bool A_KC, bool B_KC>
-static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith) {
+static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool* fast = nullptr) {
+    if (fast) *fast = false;
     // fast path preconditions: 16-byte vector access to both operands, every k-slice a multiple of 16
     const bool k16 = (g.K % BK3 == 0) && (g.kchunk % BK3 == 0);
     if (gemm_path() != 2 && g.vecA && g.vecB && k16 && g.lda % 4 == 0 && g.ldb % 4 == 0) {
         // 256-row tiles when they still give every CU two workgroups, else 128-row tiles
         const long long wg256 = ((g.M + 255) / 256) * ((g.N + 127) / 128) * splits;
         const bool big = g.M >= 256 && wg256 >= 512;
+        if (fast) *fast = true;
         if (arith == DLRM_ARITH_BF16X6)
             return big ? launch_gemm3<A_KC, B_KC, 4, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 1>(g, splits, st);
         if (arith == DLRM_ARITH_BF16)
             return big ? launch_gemm3<A_KC, B_KC, 4, 2>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 2>(g, splits, st);
         return big ? launch_gemm3<A_KC, B_KC, 4, 0>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0>(g, splits, st);
     }
+    g.bits_in = nullptr; g.bits_out = nullptr;       // the any-shape kernel neither reads nor writes sign bits
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (int)((g.N + BN - 1) / BN);
     static int dbg = -1;
@@ -786,16 +873,26 @@ static int vec_ok_ks(const float* p, long long ld, long long cext) { (void)cext;
 
 }  // namespace
 
+static int relu_bits_from(int64_t M, int N, const float* Y, int64_t ldy, uint64_t* bits, hipStream_t st) {
+    const long long nblk = ((long long)N + 63) / 64, words = ((M + 31) / 32) * nblk * 32;
+    long long nb = (words + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(relu_bits_kernel, dim3((unsigned)nb), dim3(256), 0, st, (long long)M, N, Y, (long long)ldy,
+                       (unsigned long long*)bits, nblk, words);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dlrm_linear_fwd(int64_t M, int N, int K, const float* X, int64_t ldx, const float* W,
                                int64_t ldw, const float* bias, int act, float* Y, int64_t ldy,
-                               int arith, void* stream) {
+                               uint64_t* relu_bits, int arith, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !X || !W || !Y) return DLRM_E_ARG;
     if (!arith_ok(arith)) return DLRM_E_MODE;
+    if (relu_bits && act != DLRM_ACT_RELU) return DLRM_E_MODE;
     if (ldx < K || ldw < K || ldy < N) return DLRM_E_ARG;
     if (act < DLRM_ACT_NONE || act > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
     if (N == 1 && gemm_path() != 2) {                // matrix-vector layer: HBM streaming, not MFMA (gemv.hip)
         const int rc = dlrm_gemv_fwd(M, K, X, ldx, W, bias, act, Y, ldy, (hipStream_t)stream);
-        if (rc != DLRM_GEMV_NOT_HANDLED) return rc;
+        if (rc != DLRM_GEMV_NOT_HANDLED) return (rc == 0 && relu_bits) ? relu_bits_from(M, N, Y, ldy, relu_bits, (hipStream_t)stream) : rc;
     }
     GemmArgs g = {};
     g.M = M; g.N = N; g.K = K;
@@ -804,12 +901,21 @@ extern "C" int dlrm_linear_fwd(int64_t M, int N, int K, const float* X, int64_t 
     g.vecC = dlrm_aligned16(Y) && ldy % 4 == 0;
     g.kchunk = ((K + BK - 1) / BK) * BK;
     g.bias = bias; g.act = act;
-    return launch_gemm<true, true>(g, 1, (hipStream_t)stream, arith);
+    g.bits_out = (unsigned long long*)relu_bits; g.bits_nblk = ((long long)N + 63) / 64;
+    bool fast = false;
+    const int rc = launch_gemm<true, true>(g, 1, (hipStream_t)stream, arith, &fast);
+    if (rc == 0 && relu_bits && !fast) return relu_bits_from(M, N, Y, ldy, relu_bits, (hipStream_t)stream);
+    return rc;
+}
+
+extern "C" int64_t dlrm_relu_bits_bytes(int64_t M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return ((M + 31) / 32) * (((int64_t)N + 63) / 64) * 32 * 8;
 }
 
 extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, int64_t lddy,
                                     const float* W, int64_t ldw, const float* Xact, int64_t ldxa,
-                                    int xact_kind, float* dX, int64_t lddx, int arith, void* stream) {
+                                    int xact_kind, const uint64_t* relu_bits, float* dX, int64_t lddx, int arith, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !dY || !W || !dX) return DLRM_E_ARG;
     if (!arith_ok(arith)) return DLRM_E_MODE;
     if (lddy < N || ldw < K || lddx < K) return DLRM_E_ARG;
@@ -829,7 +935,11 @@ extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, in
     g.act = DLRM_ACT_NONE;
     if (xact_kind != DLRM_ACT_NONE) {
         g.mask = Xact; g.ldmask = ldxa; g.mask_act = xact_kind;
-        g.vecC = g.vecC && dlrm_aligned16(Xact) && ldxa % 4 == 0;
+        if (relu_bits && xact_kind == DLRM_ACT_RELU) {       // sign bits written by the forward pass: no fp32 mask read (fast path only)
+            g.bits_in = (const unsigned long long*)relu_bits; g.bits_nblk = ((long long)K + 63) / 64;
+        } else {
+            g.vecC = g.vecC && dlrm_aligned16(Xact) && ldxa % 4 == 0;
+        }
     }
     return launch_gemm<true, false>(g, 1, (hipStream_t)stream, arith);
 }

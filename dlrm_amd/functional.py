@@ -92,7 +92,8 @@ class MLPFunction(Function):
         elif x.size(1) != K0:
             raise RuntimeError("dlrm_amd: MLP input width %d does not match the first layer (%d)" % (x.size(1), K0))
         cur = x
-        outs = []
+        need_bits = any(ctx.needs_input_grad)          # a forward that will be differentiated (Function.forward itself runs grad-free)
+        outs, bits = [], []
         for i in range(L):
             W, b = params[2 * i], params[2 * i + 1]
             if i == 0 and W0p is not None:
@@ -102,9 +103,14 @@ class MLPFunction(Function):
                 y = out_slot.get()
             else:
                 y = alloc2d(M, N, x)
-            ops.linear_fwd(cur, W, b, acts[i], y, arith)
+            # hidden ReLU layers also store their sign bits (1 bit per element): the data-gradient GEMM of the NEXT layer reads
+            # those instead of this fp32 activation for its fused ReLU derivative
+            rb = ops.relu_bits_alloc(M, N, x.device) if (i < L - 1 and acts[i] == ACT_RELU and need_bits) else None
+            ops.linear_fwd(cur, W, b, acts[i], y, arith, relu_bits=rb)
             outs.append(y)
+            bits.append(rb)
             cur = y
+        ctx.bits = bits
         ctx.acts = acts
         ctx.padded = W0p is not None
         ctx.save_for_backward(x, *params, *outs, *([W0p] if W0p is not None else []))
@@ -152,7 +158,7 @@ class MLPFunction(Function):
             if i > 0:
                 dprev = alloc2d(M, W.size(1), x)
                 # dgrad GEMM with the previous layer's activation derivative fused into the epilogue
-                ops.linear_bwd_data(dZ, W, X_i, acts[i - 1], dprev, arith)
+                ops.linear_bwd_data(dZ, W, X_i, acts[i - 1], dprev, arith, relu_bits=ctx.bits[i - 1])
                 dZ = dprev
             elif ctx.needs_input_grad[0]:
                 dX = alloc2d(M, W.size(1), x)

@@ -380,8 +380,13 @@ def arith_code(arith) -> int:
     return ARITH_NAMES[arith]
 
 
+def relu_bits_alloc(M: int, N: int, device) -> torch.Tensor:
+    """buffer for the ReLU sign bits of an [M, N] activation (one bit per element, include/dlrm_hip.h)"""
+    return torch.empty(_lib.load().dlrm_relu_bits_bytes(M, N) // 8, dtype=torch.int64, device=device)
+
+
 def linear_fwd(X: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], act: int, Y: torch.Tensor,
-               arith=_lib.ARITH_F32) -> torch.Tensor:
+               arith=_lib.ARITH_F32, relu_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
     _req(X, "X", ndim=2); _req(W, "W", ndim=2); _req(Y, "Y", ndim=2)
     M, K = X.shape
@@ -393,14 +398,15 @@ def linear_fwd(X: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], a
     with _timed("linear_fwd"):
         rc = lib.dlrm_linear_fwd(M, N, K, C.c_void_p(X.data_ptr()), _ld(X), C.c_void_p(W.data_ptr()), _ld(W),
                                  C.c_void_p(bias.data_ptr()) if bias is not None else None, int(act),
-                                 C.c_void_p(Y.data_ptr()), _ld(Y), arith_code(arith), _stream(Y))
+                                 C.c_void_p(Y.data_ptr()), _ld(Y),
+                                 C.c_void_p(relu_bits.data_ptr()) if relu_bits is not None else None, arith_code(arith), _stream(Y))
     _lib.check(rc, "dlrm_linear_fwd")
     return Y
 
 
 def linear_bwd_data(dY: torch.Tensor, W: torch.Tensor, Xact: Optional[torch.Tensor], xact_kind: int,
-                    dX: torch.Tensor, arith=_lib.ARITH_F32) -> torch.Tensor:
-    """dX = (dY @ W) * act'(Xact)   (Xact None -> no mask)"""
+                    dX: torch.Tensor, arith=_lib.ARITH_F32, relu_bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dX = (dY @ W) * act'(Xact)   (Xact None -> no mask; relu_bits = the sign bits linear_fwd stored for Xact)"""
     lib = _lib.load()
     _req(dY, "dY", ndim=2); _req(W, "W", ndim=2); _req(dX, "dX", ndim=2)
     M, N = dY.shape
@@ -413,6 +419,7 @@ def linear_bwd_data(dY: torch.Tensor, W: torch.Tensor, Xact: Optional[torch.Tens
         rc = lib.dlrm_linear_bwd_data(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(W.data_ptr()), _ld(W),
                                       C.c_void_p(Xact.data_ptr()) if Xact is not None else None,
                                       _ld(Xact) if Xact is not None else 0, int(xact_kind if Xact is not None else ACT_NONE),
+                                      C.c_void_p(relu_bits.data_ptr()) if (relu_bits is not None and Xact is not None) else None,
                                       C.c_void_p(dX.data_ptr()), _ld(dX), arith_code(arith), _stream(dX))
     _lib.check(rc, "dlrm_linear_bwd_data")
     return dX

@@ -156,18 +156,27 @@ int dlrm_interact_bwd(int64_t B, int F, int D,
 #define DLRM_ARITH_BF16   2   /* operands rounded to bf16 (nearest even) in the kernel, one bf16 MFMA per 16-k step, fp32 accumulate:
                                  the "bf16 MLP" of BASELINE.json configs[4]; NOT an fp32-class result (about 3 decimal digits per operand) */
 
+/* relu_bits (nullable; act must be DLRM_ACT_RELU): device buffer of dlrm_relu_bits_bytes(M, N) bytes that receives one SIGN BIT
+ * per output element (Y > 0) — the ReLU derivative the backward pass needs, 32x smaller than re-reading Y.  Layout: the
+ * matrix is cut into 32-row x 64-column blocks, block (mb, nb) owns the 32 consecutive uint64 words starting at
+ * (mb * ceil(N/64) + nb) * 32; bit l of word it*4 + c is element (row 32*mb + 4*it + l/16, column 64*nb + 4*(l%16) + c)
+ * (the lane geometry of the GEMM epilogues, so a wave reads/writes its block with one 8-byte access per lane). */
+int64_t dlrm_relu_bits_bytes(int64_t M, int N);
 int dlrm_linear_fwd(int64_t M, int N, int K,
                     const float* X, int64_t ldx, const float* W, int64_t ldw,
-                    const float* bias, int act, float* Y, int64_t ldy, int arith, void* stream);
+                    const float* bias, int act, float* Y, int64_t ldy, uint64_t* relu_bits, int arith, void* stream);
 
 /* data gradient with the PREVIOUS layer's activation backward fused into the epilogue:
  *   dX[M,K] = (dY[M,N] · W[N,K]) ⊙ act'(Xact[M,K])        (Xact = this layer's input = previous
  *                                                           layer's activated output; xact_kind
  *                                                           ACT_NONE -> no mask, Xact may be NULL)
+ * relu_bits (nullable, xact_kind == DLRM_ACT_RELU): the sign bits of Xact [M, K] that dlrm_linear_fwd of the previous layer
+ * wrote; the epilogue then reads 256 B per 32 x 64 block instead of 8 KB of fp32 activations (Xact must still be passed:
+ * shapes outside the fast path fall back to it).
  */
 int dlrm_linear_bwd_data(int64_t M, int N, int K,
                          const float* dY, int64_t lddy, const float* W, int64_t ldw,
-                         const float* Xact, int64_t ldxa, int xact_kind,
+                         const float* Xact, int64_t ldxa, int xact_kind, const uint64_t* relu_bits,
                          float* dX, int64_t lddx, int arith, void* stream);
 
 /* weight AND bias gradient:  dW[N,K] (+)= dY[M,N]^T · X[M,K],  dbias[N] (+)= column sums of dY

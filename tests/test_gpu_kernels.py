@@ -242,6 +242,43 @@ def _linear_fwd_bwd(M, N, K, act, arith):
     np.testing.assert_allclose(dXd.cpu().numpy(), dX, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("M,N,K,Nn", [(65536, 512, 256, 128), (1000, 256, 64, 96), (4100, 200, 48, 64), (333, 130, 36, 16), (4096, 1, 256, 32)])
+def test_relu_sign_bits_replace_the_fp32_mask(M, N, K, Nn):
+    """dlrm_linear_fwd(relu_bits=...) stores one sign bit per output element in the documented 32 x 64-block layout (fast
+    LDS-DMA kernel, any-shape fallback and the N = 1 matrix-vector path alike); dlrm_linear_bwd_data fed with those bits
+    instead of the fp32 activation produces the IDENTICAL data gradient."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + N)
+    X = to_dev(rng.standard_normal((M, K)).astype(np.float32))
+    W = to_dev((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = to_dev(rng.standard_normal(N).astype(np.float32))
+    Y = torch.empty((M, N), device=dev())
+    bits = ops.relu_bits_alloc(M, N, dev())
+    bits.fill_(-1)
+    ops.linear_fwd(X, W, b, 1, Y, relu_bits=bits)
+    torch.cuda.synchronize()
+    y = Y.cpu().numpy() > 0
+    nblk = (N + 63) // 64
+    words = bits.cpu().numpy().view(np.uint64).reshape(-1, nblk, 8, 4)          # [row band, column block, it, c]
+    mp, npad = ((M + 31) // 32) * 32, nblk * 64
+    yp = np.zeros((mp, npad), dtype=bool)
+    yp[:M, :N] = y
+    # element (32*mb + 4*it + l//16, 64*nb + 4*(l%16) + c) <-> bit l of word [mb, nb, it, c]
+    e = yp.reshape(mp // 32, 8, 4, nblk, 16, 4)                                  # [mb, it, l//16, nb, l%16, c]
+    e = e.transpose(0, 3, 1, 5, 2, 4).reshape(mp // 32, nblk, 8, 4, 64)          # [mb, nb, it, c, l]
+    want = (e.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(-1).astype(np.uint64)
+    assert np.array_equal(words, want)
+    # consumer: the next layer (N -> Nn) back-propagates into this activation
+    W2 = to_dev((rng.standard_normal((Nn, N)) / np.sqrt(N)).astype(np.float32))
+    dZ = to_dev(rng.standard_normal((M, Nn)).astype(np.float32))
+    d_float = torch.empty((M, N), device=dev())
+    d_bits = torch.empty((M, N), device=dev())
+    ops.linear_bwd_data(dZ, W2, Y, 1, d_float)
+    ops.linear_bwd_data(dZ, W2, Y, 1, d_bits, relu_bits=bits)
+    assert torch.equal(d_float, d_bits)
+    assert bool(torch.all(d_bits[~(Y > 0)] == 0))
+
+
 def test_linear_bwd_data_fused_mask():
     """dgrad epilogue: previous layer's ReLU mask fused in (aligned and unaligned leading dimensions)"""
     from dlrm_amd import ops
