@@ -48,6 +48,7 @@ struct GemmArgs {
     int act;                       // DLRM_ACT_* applied to the result
     const float* mask; long long ldmask; int mask_act;   // result *= act'(mask[m,n])   (nullable)
     float* rowsumA;                // [M] += row sums of the A operand over this k-slice (wgrad: bias gradient)  (nullable)
+    long long rowsum_split_stride; // > 0: k-slice z STORES its row sums at rowsumA + z * stride (summed later in a fixed order); 0: atomicAdd into rowsumA
     int vecC;                      // 16-byte accesses to C (and mask) are legal
     int atomic_out;                // 1: atomicAdd into C instead of store
     long long c_split_stride;      // elements between the C slabs of consecutive k-slices (split-K partials in a workspace), else 0
@@ -55,8 +56,8 @@ struct GemmArgs {
     int debug;                     // tuning aid (env DLRM_GEMM_DEBUG): 1 skip global loads in the k-loop, 2 skip LDS refill + barrier, 4 skip epilogue
     // ReLU sign bits, one bit per output element (see dlrm_relu_bits_bytes in dlrm_hip.h for the layout): written by the
     // forward epilogue (bits_out), consumed by the dgrad epilogue of the NEXT layer instead of its fp32 act' mask (bits_in)
-    unsigned long long* bits_out;
-    const unsigned long long* bits_in;
+    unsigned* bits_out;
+    const unsigned* bits_in;
     long long bits_nblk;           // 64-column blocks per row band = ceil(N / 64)
 };
 
@@ -234,7 +235,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         for (int t = 0; t < 2; ++t) {
             const float v = rs[t] + __shfl_xor(rs[t], 32, 64);   // the two half-waves hold different k of the same row
             const long long m = m0 + wm * 64 + t * 32 + (lane & 31);
-            if (lane < 32 && m < g.M) atomicAdd(g.rowsumA + m, v);
+            if (lane < 32 && m < g.M) {
+                if (g.rowsum_split_stride) g.rowsumA[(long long)blockIdx.z * g.rowsum_split_stride + m] = v;
+                else atomicAdd(g.rowsumA + m, v);
+            }
         }
     }
 
@@ -478,13 +482,13 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     const bool use_bits = MASKED && g.bits_in != nullptr;
     const bool mask_pf = MASKED && !use_bits && g.mask != nullptr && g.vecC && full_n;
     float4 mk[2][8];
-    // bit form of the same mask: lane L < 32 holds word L of the band's 32 x u64 block (256 B per 32 x 64 band instead of 8 KB)
-    unsigned long long mkb[2] = {0ull, 0ull};
-    auto bits_fetch = [&](int band, unsigned long long& dst) {
+    // bit form of the same mask: every lane holds ITS 32 sign bits of the band (one dword: 256 B per 32 x 64 band instead of 8 KB)
+    unsigned mkb[2] = {0u, 0u};
+    auto bits_fetch = [&](int band, unsigned& dst) {
         const long long mb = (m0 + wm * 32 * TM + band * 32) >> 5;
         const long long nbk = (n0 + wn * 64) >> 6;
         const long long last_band = (g.M - 1) >> 5;
-        dst = (nbk < g.bits_nblk) ? g.bits_in[((mb < last_band ? mb : last_band) * g.bits_nblk + nbk) * 32 + (lane & 31)] : 0ull;
+        dst = (nbk < g.bits_nblk) ? g.bits_in[((mb < last_band ? mb : last_band) * g.bits_nblk + nbk) * 64 + lane] : 0u;
     };
     auto mask_fetch = [&](int band, float4 (&dst)[8]) {
 #pragma unroll
@@ -623,7 +627,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         for (int t = 0; t < TM; ++t) {
             const float v = rs[t] + __shfl_xor(rs[t], 32, 64);
             const long long m = m0 + wm * 32 * TM + t * 32 + l31;
-            if (lane < 32 && m < g.M) atomicAdd(g.rowsumA + m, v);
+            if (lane < 32 && m < g.M) {
+                if (g.rowsum_split_stride) g.rowsumA[(long long)blockIdx.z * g.rowsum_split_stride + m] = v;
+                else atomicAdd(g.rowsumA + m, v);
+            }
         }
     }
 
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             if (mask_pf && tm + 1 < TM) mask_fetch(tm + 1, mk[(tm + 1) & 1]);
             if (use_bits && tm + 1 < TM) bits_fetch(tm + 1, mkb[(tm + 1) & 1]);
         }
-        unsigned long long myword = 0ull;          // forward: lane L < 32 collects word L of this band's sign-bit block
+        unsigned myword = 0u;                      // forward: this lane's 32 sign bits of the band, shifted in one element at a time
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -664,29 +671,23 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             v.x = act_apply(v.x + bv.x, g.act); v.y = act_apply(v.y + bv.y, g.act);
             v.z = act_apply(v.z + bv.z, g.act); v.w = act_apply(v.w + bv.w, g.act);
             if constexpr (A_KC && B_KC) {
-                if (write_bits) {       // wave-uniform: bit `lane` of word it*4 + c  <=>  element (row it*4 + lane/16, column 4*(lane%16) + c) > 0
-                    const unsigned long long b0 = __ballot(live && v.x > 0.f), b1 = __ballot(live && nb + 1 < g.N && v.y > 0.f);
-                    const unsigned long long b2 = __ballot(live && nb + 2 < g.N && v.z > 0.f), b3 = __ballot(live && nb + 3 < g.N && v.w > 0.f);
-                    const int w_ = l31 - 4 * it;
-                    if (w_ == 0) myword = b0; else if (w_ == 1) myword = b1; else if (w_ == 2) myword = b2; else if (w_ == 3) myword = b3;
+                if (write_bits) {       // word = 2*word + (v > 0): compare into VCC, add-with-carry — two VALU instructions per element
+                    asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                 "v_cmp_lt_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                 "v_cmp_lt_f32 vcc, 0, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                 "v_cmp_lt_f32 vcc, 0, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                 : "+v"(myword) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "vcc");
                 }
             }
             if (!live) continue;
             float* c = g.C + (long long)blockIdx.z * g.c_split_stride + m * g.ldc + nb;
             if constexpr (MASKED) {
-                if (use_bits) {         // ReLU derivative from the sign bits the forward pass stored
-                    const unsigned long long wv = mkb[tm & 1];
-                    const unsigned lo = (unsigned)wv, hi = (unsigned)(wv >> 32);
-                    const int sh = lane & 31;
-                    unsigned long long w0 = ((unsigned long long)__builtin_amdgcn_readlane(hi, it * 4 + 0) << 32) | __builtin_amdgcn_readlane(lo, it * 4 + 0);
-                    unsigned long long w1 = ((unsigned long long)__builtin_amdgcn_readlane(hi, it * 4 + 1) << 32) | __builtin_amdgcn_readlane(lo, it * 4 + 1);
-                    unsigned long long w2 = ((unsigned long long)__builtin_amdgcn_readlane(hi, it * 4 + 2) << 32) | __builtin_amdgcn_readlane(lo, it * 4 + 2);
-                    unsigned long long w3 = ((unsigned long long)__builtin_amdgcn_readlane(hi, it * 4 + 3) << 32) | __builtin_amdgcn_readlane(lo, it * 4 + 3);
-                    (void)sh;
-                    if (!((w0 >> lane) & 1ull)) v.x = 0.f;
-                    if (!((w1 >> lane) & 1ull)) v.y = 0.f;
-                    if (!((w2 >> lane) & 1ull)) v.z = 0.f;
-                    if (!((w3 >> lane) & 1ull)) v.w = 0.f;
+                if (use_bits) {         // ReLU derivative from the sign bits the forward pass stored: element it*4 + c sits at bit 31 - (it*4 + c)
+                    const unsigned wv = mkb[tm & 1];
+                    if (!((wv >> (31 - (it * 4 + 0))) & 1u)) v.x = 0.f;
+                    if (!((wv >> (31 - (it * 4 + 1))) & 1u)) v.y = 0.f;
+                    if (!((wv >> (31 - (it * 4 + 2))) & 1u)) v.z = 0.f;
+                    if (!((wv >> (31 - (it * 4 + 3))) & 1u)) v.w = 0.f;
                 }
             }
             if (g.vecC && full_n) {
@@ -712,9 +713,9 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             }
         }
         if constexpr (A_KC && B_KC) {
-            if (write_bits && lane < 32) {
+            if (write_bits) {
                 const long long mb = (m0 + wm * 32 * TM + tm * 32) >> 5, nbk = (n0 + wn * 64) >> 6;
-                if (mb <= ((g.M - 1) >> 5) && nbk < g.bits_nblk) g.bits_out[(mb * g.bits_nblk + nbk) * 32 + lane] = myword;
+                if (mb <= ((g.M - 1) >> 5) && nbk < g.bits_nblk) g.bits_out[(mb * g.bits_nblk + nbk) * 64 + lane] = myword;
             }
         }
     }
@@ -726,7 +727,16 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
 template <int VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int N, int K, int splits, const float* __restrict__ part,
                                                             long long ldp, long long slab, float* __restrict__ dW,
-                                                            long long lddw, int accumulate) {
+                                                            long long lddw, int accumulate, const float* __restrict__ rs_part,
+                                                            float* __restrict__ dbias) {
+    // bias gradient: the k-slices' row sums of dY^T, summed in slice order (deterministic; no zero-fill, no atomics)
+    if (rs_part && blockIdx.x == 0) {
+        for (int n = threadIdx.x; n < N; n += 256) {
+            float a = accumulate ? dbias[n] : 0.f;
+            for (int s_ = 0; s_ < splits; ++s_) a += rs_part[(long long)s_ * N + n];
+            dbias[n] = a;
+        }
+    }
     const int kq = (K + VEC - 1) / VEC;
     const long long total = (long long)N * kq;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
@@ -784,14 +794,14 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(long long M, int N, const 
 
 // fallback producer of the ReLU sign-bit blocks (shapes the LDS-DMA kernel does not take): one thread per 64-bit word
 __global__ __launch_bounds__(256) void relu_bits_kernel(long long M, int N, const float* __restrict__ Y, long long ldy,
-                                                        unsigned long long* __restrict__ bits, long long nblk, long long words) {
+                                                        unsigned* __restrict__ bits, long long nblk, long long words) {
     for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < words; w += (long long)gridDim.x * 256) {
-        const int sub = (int)(w & 31), it = sub >> 2, c = sub & 3;
-        const long long blk = w >> 5, mb = blk / nblk, nbk = blk - mb * nblk;
-        unsigned long long v = 0ull;
-        for (int l = 0; l < 64; ++l) {
-            const long long m = mb * 32 + it * 4 + (l >> 4), n = nbk * 64 + (l & 15) * 4 + c;
-            if (m < M && n < N && Y[m * ldy + n] > 0.f) v |= 1ull << l;
+        const int l = (int)(w & 63);
+        const long long blk = w >> 6, mb = blk / nblk, nbk = blk - mb * nblk;
+        unsigned v = 0u;
+        for (int e = 0; e < 32; ++e) {       // element e = it*4 + c of lane l
+            const long long m = mb * 32 + (e >> 2) * 4 + (l >> 4), n = nbk * 64 + (l & 15) * 4 + (e & 3);
+            v = (v << 1) | ((m < M && n < N && Y[m * ldy + n] > 0.f) ? 1u : 0u);
         }
         bits[w] = v;
     }
@@ -874,10 +884,10 @@ static int vec_ok_ks(const float* p, long long ld, long long cext) { (void)cext;
 }  // namespace
 
 static int relu_bits_from(int64_t M, int N, const float* Y, int64_t ldy, uint64_t* bits, hipStream_t st) {
-    const long long nblk = ((long long)N + 63) / 64, words = ((M + 31) / 32) * nblk * 32;
+    const long long nblk = ((long long)N + 63) / 64, words = ((M + 31) / 32) * nblk * 64;
     long long nb = (words + 255) / 256; if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(relu_bits_kernel, dim3((unsigned)nb), dim3(256), 0, st, (long long)M, N, Y, (long long)ldy,
-                       (unsigned long long*)bits, nblk, words);
+                       (unsigned*)bits, nblk, words);
     DLRM_LAUNCH_CHECK();
     return 0;
 }
@@ -901,7 +911,7 @@ extern "C" int dlrm_linear_fwd(int64_t M, int N, int K, const float* X, int64_t 
     g.vecC = dlrm_aligned16(Y) && ldy % 4 == 0;
     g.kchunk = ((K + BK - 1) / BK) * BK;
     g.bias = bias; g.act = act;
-    g.bits_out = (unsigned long long*)relu_bits; g.bits_nblk = ((long long)N + 63) / 64;
+    g.bits_out = (unsigned*)relu_bits; g.bits_nblk = ((long long)N + 63) / 64;
     bool fast = false;
     const int rc = launch_gemm<true, true>(g, 1, (hipStream_t)stream, arith, &fast);
     if (rc == 0 && relu_bits && !fast) return relu_bits_from(M, N, Y, ldy, relu_bits, (hipStream_t)stream);
@@ -936,7 +946,7 @@ extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, in
     if (xact_kind != DLRM_ACT_NONE) {
         g.mask = Xact; g.ldmask = ldxa; g.mask_act = xact_kind;
         if (relu_bits && xact_kind == DLRM_ACT_RELU) {       // sign bits written by the forward pass: no fp32 mask read (fast path only)
-            g.bits_in = (const unsigned long long*)relu_bits; g.bits_nblk = ((long long)K + 63) / 64;
+            g.bits_in = (const unsigned*)relu_bits; g.bits_nblk = ((long long)K + 63) / 64;
         } else {
             g.vecC = g.vecC && dlrm_aligned16(Xact) && ldxa % 4 == 0;
         }
@@ -962,7 +972,7 @@ extern "C" int64_t dlrm_linear_bwd_weight_workspace_bytes(int64_t M, int N, int 
     int splits; int64_t kchunk;
     wgrad_plan(M, N, K, &splits, &kchunk);
     const int64_t ldp = ((int64_t)K + 3) & ~(int64_t)3;
-    int64_t need = (int64_t)(splits < 1 ? 1 : splits) * N * ldp * (int64_t)sizeof(float);   // >= one slab: the padded-dW form needs it even unsplit
+    int64_t need = (int64_t)(splits < 1 ? 1 : splits) * N * (ldp + 1) * (int64_t)sizeof(float);   // >= one slab (the padded-dW form needs it even unsplit) + the k-slices' bias-gradient row sums
     if (N == 1) {                                    // the matrix-vector path keeps per-workgroup column partials
         const int64_t gv = dlrm_gemv_bwd_weight_workspace_bytes(M, K);
         if (gv > need) need = gv;
@@ -1008,23 +1018,21 @@ static int linear_bwd_weight_impl(int64_t M, int N, int K, int K_store, const fl
     const int64_t ldp = ((int64_t)K + 3) & ~(int64_t)3;
     const int64_t slab = (int64_t)N * ldp;
     const bool use_ws = (splits > 1 || K_store < K) && workspace && dlrm_aligned16(workspace) &&
-                        workspace_bytes >= (int64_t)splits * slab * (int64_t)sizeof(float);
+                        workspace_bytes >= (int64_t)splits * (slab + N) * (int64_t)sizeof(float);
     if (K_store < K && !use_ws) return DLRM_E_ARG;   // a narrower dW needs the slab path (pass the queried workspace)
     if (use_ws) {
         g.C = (float*)workspace; g.ldc = ldp; g.vecC = 1; g.c_split_stride = slab; g.atomic_out = 0;
-        if (dbias && !accumulate) {
-            hipError_t e = hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), st);
-            if (e != hipSuccess) return (int)e;
-        }
+        float* rs_part = dbias ? (float*)workspace + (int64_t)splits * slab : nullptr;
+        if (dbias) { g.rowsumA = rs_part; g.rowsum_split_stride = N; }
         int rc = launch_gemm<false, false>(g, splits, st, arith);
         if (rc) return rc;
         const bool v4 = dlrm_aligned16(dW) && lddw % 4 == 0 && K_store % 4 == 0;
         const long long items = (long long)N * (v4 ? K_store / 4 : K_store);
         int blocks = (int)((items + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
         if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, N, K_store, splits, (const float*)workspace,
-                                   (long long)ldp, (long long)slab, dW, (long long)lddw, accumulate ? 1 : 0);
+                                   (long long)ldp, (long long)slab, dW, (long long)lddw, accumulate ? 1 : 0, (const float*)rs_part, dbias);
         else    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, N, K_store, splits, (const float*)workspace,
-                                   (long long)ldp, (long long)slab, dW, (long long)lddw, accumulate ? 1 : 0);
+                                   (long long)ldp, (long long)slab, dW, (long long)lddw, accumulate ? 1 : 0, (const float*)rs_part, dbias);
         DLRM_LAUNCH_CHECK();
         return 0;
     }

@@ -23,6 +23,9 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
 # Measured on MI355X (profiles/r01, g02): 11.83 ms/step with the overlap vs 11.30 ms without — two chip-filling GEMMs
 # sharing the CUs thrash each other's L2 panels — so it is OFF by default.
 OVERLAP_WGRAD = os.environ.get("DLRM_OVERLAP_WGRAD", "0") == "1"
+# hidden ReLU layers store 1 sign bit per activation for the next layer's data-gradient epilogue (DLRM_RELU_BITS=0: the
+# epilogue re-reads the fp32 activation instead)
+RELU_BITS = os.environ.get("DLRM_RELU_BITS", "1") == "1"
 _side_streams = {}
 
 
@@ -92,7 +95,7 @@ class MLPFunction(Function):
         elif x.size(1) != K0:
             raise RuntimeError("dlrm_amd: MLP input width %d does not match the first layer (%d)" % (x.size(1), K0))
         cur = x
-        need_bits = any(ctx.needs_input_grad)          # a forward that will be differentiated (Function.forward itself runs grad-free)
+        need_bits = RELU_BITS and any(ctx.needs_input_grad)          # a forward that will be differentiated (Function.forward itself runs grad-free)
         outs, bits = [], []
         for i in range(L):
             W, b = params[2 * i], params[2 * i + 1]

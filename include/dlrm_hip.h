@@ -158,9 +158,10 @@ int dlrm_interact_bwd(int64_t B, int F, int D,
 
 /* relu_bits (nullable; act must be DLRM_ACT_RELU): device buffer of dlrm_relu_bits_bytes(M, N) bytes that receives one SIGN BIT
  * per output element (Y > 0) — the ReLU derivative the backward pass needs, 32x smaller than re-reading Y.  Layout: the
- * matrix is cut into 32-row x 64-column blocks, block (mb, nb) owns the 32 consecutive uint64 words starting at
- * (mb * ceil(N/64) + nb) * 32; bit l of word it*4 + c is element (row 32*mb + 4*it + l/16, column 64*nb + 4*(l%16) + c)
- * (the lane geometry of the GEMM epilogues, so a wave reads/writes its block with one 8-byte access per lane). */
+ * matrix is cut into 32-row x 64-column blocks, block (mb, nb) owns the 64 consecutive uint32 words starting at
+ * (mb * ceil(N/64) + nb) * 64; bit 31 - (4*it + c) of word l is element (row 32*mb + 4*it + l/16, column 64*nb + 4*(l%16) + c),
+ * it < 8, c < 4 (the lane geometry of the GEMM epilogues: lane l of a wave owns word l, shifts its 32 signs in with one
+ * compare + add-with-carry each, and the block moves as ONE coalesced 4-byte access per lane). */
 int64_t dlrm_relu_bits_bytes(int64_t M, int N);
 int dlrm_linear_fwd(int64_t M, int N, int K,
                     const float* X, int64_t ldx, const float* W, int64_t ldw,

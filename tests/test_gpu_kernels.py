@@ -259,15 +259,19 @@ def test_relu_sign_bits_replace_the_fp32_mask(M, N, K, Nn):
     torch.cuda.synchronize()
     y = Y.cpu().numpy() > 0
     nblk = (N + 63) // 64
-    words = bits.cpu().numpy().view(np.uint64).reshape(-1, nblk, 8, 4)          # [row band, column block, it, c]
+    words = bits.cpu().numpy().view(np.uint32).reshape(-1, nblk, 64)             # [row band, column block, lane]
     mp, npad = ((M + 31) // 32) * 32, nblk * 64
     yp = np.zeros((mp, npad), dtype=bool)
     yp[:M, :N] = y
-    # element (32*mb + 4*it + l//16, 64*nb + 4*(l%16) + c) <-> bit l of word [mb, nb, it, c]
+    # element (32*mb + 4*it + l//16, 64*nb + 4*(l%16) + c) <-> bit 31 - (4*it + c) of word [mb, nb, l]
     e = yp.reshape(mp // 32, 8, 4, nblk, 16, 4)                                  # [mb, it, l//16, nb, l%16, c]
-    e = e.transpose(0, 3, 1, 5, 2, 4).reshape(mp // 32, nblk, 8, 4, 64)          # [mb, nb, it, c, l]
-    want = (e.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(-1).astype(np.uint64)
-    assert np.array_equal(words, want)
+    e = e.transpose(0, 3, 2, 4, 1, 5).reshape(mp // 32, nblk, 64, 32)            # [mb, nb, l, 4*it + c]
+    want = (e.astype(np.uint64) << (31 - np.arange(32, dtype=np.uint64))).sum(-1).astype(np.uint32)
+    valid = np.zeros((mp, npad), dtype=bool)
+    valid[:M, :N] = True                                                         # bits of elements outside the matrix are unspecified
+    vm = valid.reshape(mp // 32, 8, 4, nblk, 16, 4).transpose(0, 3, 2, 4, 1, 5).reshape(mp // 32, nblk, 64, 32)
+    vmask = (vm.astype(np.uint64) << (31 - np.arange(32, dtype=np.uint64))).sum(-1).astype(np.uint32)
+    assert np.array_equal(words & vmask, want)
     # consumer: the next layer (N -> Nn) back-propagates into this activation
     W2 = to_dev((rng.standard_normal((Nn, N)) / np.sqrt(N)).astype(np.float32))
     dZ = to_dev(rng.standard_normal((M, Nn)).astype(np.float32))

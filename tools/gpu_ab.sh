@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B inside ONE box (box-to-box spread is +-3 %): alternate bench runs of env settings "A" and "B" ($2, $3), 2 rounds each
+OUT=gpurun_out/${1:-ab}; mkdir -p $OUT
+run() { tag=$1; shift; env "$@" timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-alt-arith --no-parity-check $BENCH_FLAGS > $OUT/$tag.json 2> $OUT/$tag.err
+  python - <<PY
+import json
+try:
+    d=json.load(open("$OUT/$tag.json")); print("%-8s ms %.3f | " % ("$tag", d["ms_per_step"]) + "  ".join("%s %.3f" % (k[:14], v["ms_per_step"]) for k, v in d["kernels"].items() if v["ms_per_step"] > 0.05))
+except Exception as e: print("$tag no json", e)
+PY
+}
+for r in 1 2; do run A$r $2; run B$r $3; done
