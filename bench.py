@@ -67,6 +67,10 @@ def parse():
                     help="single-stream schedule: by default the HBM-bound embedding kernels (pooled lookups; fused sparse update) "
                          "run on a second HIP stream beside the MFMA-bound bottom-MLP GEMMs they do not depend on "
                          "(DLRM_Net.overlap_streams)")
+    ap.add_argument("--fuse", action="store_true",
+                    help="N = 1, one lookup per bag, D = 128: the interaction kernels fetch the embedding rows themselves and the "
+                         "pooled-embedding buffer never exists (DLRM_Net.fuse_emb_interact; bit-identical results, measured slower "
+                         "than the two kernels in round 3: opt-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the pre-run check of this exact configuration against the golden fixture of the live reference")
@@ -174,7 +178,8 @@ def parity_check(args, device):
     import golden_tb
     mode = {"sorted": 2, "atomic": 0, "deterministic": 1}[args.emb_update]
     try:
-        rel = golden_tb.run_on_gpu(device, arith=args.mlp_arith, mode=mode, check=True, overlap=not args.no_overlap)
+        rel = golden_tb.run_on_gpu(device, arith=args.mlp_arith, mode=mode, check=True, overlap=not args.no_overlap,
+                                   fuse=bool(args.fuse))
         return {"fixture": "tests/golden/terabyte_b65536.npz (3 training steps of the live reference at B=65536, T=26, D=128, "
                            "towers 13-512-256-128 / 479-1024-1024-512-256-1, lr 1.0, rows capped at 2000)",
                 "rel_err": max(rel), "rel_err_per_step": rel, "bar": 1e-5, "pass": bool(max(rel) <= 1e-5),
@@ -278,6 +283,7 @@ def main():
                               loss_function="bce").to(device)
     model.set_mlp_arith(args.mlp_arith)
     model.overlap_streams = not args.no_overlap
+    model.fuse_emb_interact = bool(args.fuse)
     model.a2a_chunks = max(args.a2a_chunks, 1) if N > 1 else 1
     model.emb_update_mode = {"sorted": ops.UPD_SORTED, "atomic": ops.UPD_ATOMIC, "deterministic": ops.UPD_DETERMINISTIC}[args.emb_update]
     if N > 1:
@@ -390,12 +396,18 @@ def main():
     dgrad_fl = fwd_fl - 2.0 * Bl * bot[0] * bot[1]      # the first bottom layer needs no data gradient
     F = nf
     inter_bytes = Bl * (F * D * 4 + (D + F * (F - 1) // 2) * 4)
+    # fused lookups + interaction (one lookup per bag): forward reads T rows + indices + bag starts + x, writes R; backward reads the
+    # same plus dR and writes the (1 + T) gradient rows
+    gi_fwd_bytes = B * (Tl * (R + 2 * isz) + D * 4 + (D + F * (F - 1) // 2) * 4)
+    gi_bwd_bytes = B * (Tl * (R + 2 * isz) + D * 4 + (D + F * (F - 1) // 2) * 4 + (1 + Tl) * R)
 
     kernels = {}
     for name, work, unit, peak, bound in (
             ("emb_fwd", emb_fwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("emb_bwd_sgd", emb_bwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("emb_bwd_adagrad", emb_bwd_bytes + L * B * 8, "GB/s", HBM_PEAK_GBS, "hbm"),    # + row-wise state read/write per touched row
+            ("emb_interact_fwd", gi_fwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
+            ("emb_interact_bwd", gi_bwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("interact_fwd", inter_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("interact_bwd", 2 * inter_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("linear_fwd", fwd_fl, "TFLOP/s", FP32_MFMA_PEAK_TF, "mfma"),
@@ -422,7 +434,9 @@ def main():
              "linear_bwd_weight": "gemm3_kernel<KS,KS> (dW = dY^T*X split over the batch + bias-grad row sums) + splitk_reduce_kernel",
              "emb_bwd_adagrad": "expand + rocprim radix sort + adagrad_groups_kernel + adagrad_fixup_kernel",
              "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "expand + rocprim radix sort + sorted_update_kernel" if args.emb_update == "sorted" else "emb_bwd_sgd_{atomic,lds}_kernel",
-             "interact_fwd": "interact_fwd_dma_kernel", "interact_bwd": "interact_bwd_dma_kernel"}
+             "interact_fwd": "interact_fwd_dma_kernel", "interact_bwd": "interact_bwd_dma_kernel",
+             "emb_interact_fwd": "interact_fwd_dma_kernel<gather>: one-hot embedding lookups fetched by the interaction kernel (K1 + K6 fused)",
+             "emb_interact_bwd": "interact_bwd_dma_kernel<gather>"}
     pmc = load_pmc_traffic() if (N == 1 and args.workload == "criteo_terabyte" and not args.batch and not args.row_cap) else None
     if hot:
         result_extra = {"multihot": {"lookups_per_sample": L, "index_dtype": "int32", "lookup_table_bytes": int(sum(4 * r * h for r, h in zip(rows, hot))),
@@ -466,6 +480,8 @@ def main():
                    "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": args.optimizer,
                    "loss": "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
                    "embedding_update": args.emb_update, "a2a_chunks": model_a2a_chunks,
+                   "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "
+                                             "(no pooled-embedding buffer)") if (args.fuse and N == 1 and not hot) else "two kernels (dlrm_emb_fwd, dlrm_interact_*)",
                    "streams": ("single stream" if (args.no_overlap or graphed is not None) else
                                "2 HIP streams: embedding lookups / fused sparse update on a side stream beside the bottom-MLP GEMMs "
                                "(per-kernel event times then overlap: their sum exceeds the step time)"),
@@ -484,6 +500,31 @@ def main():
         "kernels": kernels,
     }
     result.update(result_extra)
+    if N == 1 and "emb_fwd" not in kernels:
+        # fused forward: no separate embedding kernel ran inside the step.  BASELINE.json's second metric is the embedding kernel's
+        # HBM rate, so the stand-alone dlrm_emb_fwd (what the unfused / multi-hot / distributed paths launch) is measured here.
+        from dlrm_amd.ops import BagBatch, emb_fwd
+        X0, off0, idx0, _ = batches[0]
+        bags0 = BagBatch(off0, idx0)
+        out0 = torch.empty((B, len(rows) * D), dtype=torch.float32, device=device)
+        ws0 = [e.weight for e in model.emb_l]
+        for _ in range(2):
+            emb_fwd(ws0, bags0, out0)
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        for _ in range(5):
+            emb_fwd(ws0, bags0, out0)
+        eb.record()
+        torch.cuda.synchronize()
+        ems = ea.elapsed_time(eb) / 5
+        ach = emb_fwd_bytes / (ems * 1e-3) / 1e9
+        result["embedding_kernel_standalone"] = {"kernel": "emb_fwd_kernel (dlrm_emb_fwd, all tables in one launch), measured outside the step: "
+                                                           "the step itself runs the lookups inside the interaction kernels",
+                                                 "ms": ems, "achieved": ach, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS,
+                                                 "frac_of_measured_peak": ach / MEASURED_HBM_GBS, "algorithmic_bytes": emb_fwd_bytes}
+        result["embedding_hbm_gbps"]["fwd"] = ach
+        result["embedding_hbm_gbps"]["fwd_fused_with_interaction"] = kernels.get("emb_interact_fwd", {}).get("achieved")
+        del out0
     if N == 1 and args.mlp_arith == "f32" and not args.no_alt_arith:
         # the same step with the opt-in bf16x6 MLP arithmetic (fp32 round-off class, see include/dlrm_hip.h): reported
         # beside the headline value, never instead of it

@@ -42,6 +42,9 @@ SIGNATURES = {
                                             _vp, _i64, _f32, _f32, _vp, _i64, _vp, _vp]),
     "dlrm_interact_fwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _vp]),
     "dlrm_interact_bwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _pp, _pi64, _vp]),
+    "dlrm_interact_gather_ok": (_i32, [_i32, _i32]),
+    "dlrm_interact_fwd_gather": (_i32, [_i64, _i32, _i32, _pp, _pi64, _pp, _pp, _pi64, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "dlrm_interact_bwd_gather": (_i32, [_i64, _i32, _i32, _pp, _pi64, _pp, _pp, _pi64, _i32, _i32, _vp, _i64, _pp, _pi64, _vp, _vp]),
     "dlrm_relu_bits_bytes": (_i64, [_i64, _i32]),
     "dlrm_linear_fwd": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i32, _vp]),
     "dlrm_linear_bwd_data": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),

@@ -33,6 +33,29 @@ struct FeatArgs {
     long long    ld[DLRM_MAX_FEATURES];
 };
 
+// "gather" mode of the D = 128 kernels: a feature whose idx[f] != NULL is NOT a [B, D] matrix but a one-hot EmbeddingBag —
+// row b of the feature is table row idx[f][b] (p[f] = table base, ld[f] = D).  The pooled-embedding buffer between
+// dlrm_emb_fwd and the interaction (a 852 MB write + 852 MB read at Criteo-Terabyte shapes) then never exists.
+// MEASURED (profiles/r03/ceilings.md): bit-identical, but SLOWER than the two kernels — forward 0.64 ms vs 0.30 + 0.24, backward
+// 0.87 vs 0.38: one sample per wave in flight is enough for the plain interaction (13.8 KB contiguous per sample) and far too
+// little for 26 random 512-byte rows out of 96 GB (DRAM row + TLB misses; dlrm_emb_fwd hides them with 8 waves per SIMD x 4 bags).
+// Opt-in (DLRM_Net.fuse_emb_interact) until the gather gets a deeper software pipeline.
+struct GatherArgs {
+    const void* idx[DLRM_MAX_FEATURES];     // NULL: plain feature matrix
+    const void* off[DLRM_MAX_FEATURES];     // bag starts of that table: verified to be 0, 1, 2, ... (one lookup per bag)
+    long long   rows[DLRM_MAX_FEATURES];
+    long long*  err;
+    int         idx_bits;
+};
+
+__device__ __forceinline__ void gather_to_lds(const GatherArgs& ga, long long* tq, long long* to, long long* tr, int F) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int f = 0; f < DLRM_MAX_FEATURES; ++f) {
+        if (tid == f && f < F) { tq[f] = (long long)ga.idx[f]; to[f] = (long long)ga.off[f]; tr[f] = ga.rows[f]; }
+    }
+}
+
 // copy the kernarg pointer table into LDS with compile-time kernarg offsets (a lane-indexed read
 // of a by-value struct would otherwise be demoted to scratch memory)
 __device__ __forceinline__ void table_to_lds(const FeatArgs& fa, long long* tp, long long* tl, int F) {
@@ -300,18 +323,90 @@ __device__ __forceinline__ void dma_issue(DmaPlan& pl, unsigned lds_img) {
     }
 }
 
-template <int NI>       // NI = ceil(F / 2)
-__global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, long long B, int F, int self,
+// gather mode: per lane and DMA chunk, the byte address of "row selector 0" and the byte stride per selector; the selector
+// of sample b is b itself for a plain feature and idx[f][b] for a gathered one
+template <int NI>
+struct GatherPlan {
+    const char* base[NI];
+    unsigned stride[NI];
+    bool on[NI];
+};
+
+template <int NI>
+__device__ __forceinline__ void gather_plan_init(GatherPlan<NI>& gp, const long long* tp, const long long* tl, int F, int lane) {
+#pragma unroll
+    for (int c = 0; c < NI; ++c) {
+        const int row = 2 * c + (lane >> 5);
+        const int quad = (lane & 31) ^ (row & 15);
+        gp.on[c] = row < F;
+        const int rr = gp.on[c] ? row : 0;
+        gp.base[c] = (const char*)tp[rr] + 16 * quad;
+        gp.stride[c] = (unsigned)(tl[rr] * 4);
+    }
+}
+
+// row selectors of sample b for this lane's chunks: ONLY the loads (index + bag start; wave-half-uniform addresses, served as
+// broadcasts) — nothing here may consume them, or the compiler's wait would also drain the DMA issued just before
+template <int NI>
+__device__ __forceinline__ void gather_fetch(long long (&sel)[NI], long long (&chk)[NI], const long long* tq, const long long* to,
+                                             int F, int lane, long long b, int idx_bits) {
+    // unconditional loads (plain features carry a valid dummy index pointer, see fill_gather); 32-bit values are kept as raw
+    // zero-extended bits — sign extension would be a USE of the loaded register and stall right here
+    typedef __attribute__((address_space(1))) long long gll;
+    typedef __attribute__((address_space(1))) unsigned guint;
+    if (idx_bits == 64) {
+#pragma unroll
+        for (int c = 0; c < NI; ++c) {
+            const int row = 2 * c + (lane >> 5), rr = row < F ? row : 0;
+            sel[c] = ((const gll*)tq[rr])[b]; chk[c] = ((const gll*)to[rr])[b];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NI; ++c) {
+            const int row = 2 * c + (lane >> 5), rr = row < F ? row : 0;
+            sel[c] = (long long)((const guint*)tq[rr])[b]; chk[c] = (long long)((const guint*)to[rr])[b];
+        }
+    }
+}
+
+// issue the DMA of sample b from its (by now loaded) selectors.  Verifies the one-hot layout (bag start of b == b) and the index
+// range; a violation is reported and row 0 is read instead.
+template <int NI>
+__device__ __forceinline__ void gather_issue(const GatherPlan<NI>& gp, const long long (&sel)[NI], const long long (&chk)[NI],
+                                             const long long* tr, int lane, long long b, int idx_bits, long long* err,
+                                             unsigned lds_img) {
+#pragma unroll
+    for (int c = 0; c < NI; ++c) {
+        if (!gp.on[c]) continue;
+        const int row = 2 * c + (lane >> 5);
+        const long long rows = tr[row];                          // < 0: plain feature (selector = the sample number)
+        long long id = b;
+        if (rows >= 0) {
+            id = idx_bits == 64 ? sel[c] : (long long)(int)sel[c];
+            const long long o = idx_bits == 64 ? chk[c] : (long long)(int)chk[c];
+            if (o != b) dlrm_report_bad_index(err, row - 1, -(o + 1), -1);               // not a one-lookup-per-bag batch (rows = -1 marks it)
+            if (!dlrm_index_ok(id, rows)) { dlrm_report_bad_index(err, row - 1, id, rows); id = 0; }
+        }
+        glds16_v(gp.base[c] + id * (long long)gp.stride[c], lds_img + c * 1024);
+    }
+}
+
+template <int NI, bool GATHER>       // NI = ceil(F / 2)
+__global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, GatherArgs ga, long long B, int F, int self,
                                                                float* __restrict__ R, long long ldr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     long long* tp = (long long*)lds;
     long long* tl = tp + DLRM_MAX_FEATURES;
-    char* img0 = (char*)(tl + DLRM_MAX_FEATURES) + (size_t)wave * 2 * IDMA_IMG;
+    long long* tq = tl + DLRM_MAX_FEATURES;                 // gather mode only (the LDS is reserved either way)
+    long long* to = tq + DLRM_MAX_FEATURES;
+    long long* tr = to + DLRM_MAX_FEATURES;
+    char* img0 = (char*)(tr + DLRM_MAX_FEATURES) + (size_t)wave * 2 * IDMA_IMG;
     const unsigned img0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)img0;
 
     table_to_lds(fa, tp, tl, F);
+    if constexpr (GATHER) gather_to_lds(ga, tq, to, tr, F);
     for (int e = lane; e < 2 * IDMA_IMG / 16; e += 64) ((float4*)img0)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
@@ -319,17 +414,36 @@ __global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, long
     long long b = (long long)blockIdx.x * 4 + wave;
     if (b >= B) return;
     DmaPlan pl;
-    dma_plan_init(pl, tp, tl, F, lane, b, b_stride);
+    GatherPlan<NI> gp;
+    long long sel[NI], chk[NI];
+    if constexpr (GATHER) {
+        gather_plan_init<NI>(gp, tp, tl, F, lane);
+        gather_fetch<NI>(sel, chk, tq, to, F, lane, b, ga.idx_bits);
+        gather_issue<NI>(gp, sel, chk, tr, lane, b, ga.idx_bits, ga.err, img0_lds);
+        if (b + b_stride < B) gather_fetch<NI>(sel, chk, tq, to, F, lane, b + b_stride, ga.idx_bits);
+    } else {
+        dma_plan_init(pl, tp, tl, F, lane, b, b_stride);
+    }
 
     const int g = lane >> 4, li = lane & 15;
     const int P = self ? F * (F + 1) / 2 : F * (F - 1) / 2;
     const int NB = (F + 15) >> 4;
     int cur = 0;
-    dma_issue<NI>(pl, img0_lds);
+    if constexpr (!GATHER) dma_issue<NI>(pl, img0_lds);
     for (; b < B; b += b_stride) {
         const bool more = b + b_stride < B;
-        if (more) { dma_issue<NI>(pl, img0_lds + (cur ^ 1) * IDMA_IMG); wait_vmcnt_i<NI>(); }
-        else wait_vmcnt_i<0>();
+        if constexpr (GATHER) {
+            // everything issued so far has landed: this sample's rows (DMA) and the NEXT sample's row selectors (registers);
+            // the next sample's rows go out now and stay in flight while this one is multiplied, the selectors after it follow
+            wait_vmcnt_i<0>();
+            if (more) {
+                gather_issue<NI>(gp, sel, chk, tr, lane, b + b_stride, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IDMA_IMG);
+                if (b + 2 * b_stride < B) gather_fetch<NI>(sel, chk, tq, to, F, lane, b + 2 * b_stride, ga.idx_bits);
+            }
+        } else {
+            if (more) { dma_issue<NI>(pl, img0_lds + (cur ^ 1) * IDMA_IMG); wait_vmcnt_i<NI>(); }
+            else wait_vmcnt_i<0>();
+        }
         const char* my = img0 + cur * IDMA_IMG;
         float* Rb = R + b * ldr;
         for (int r = 0; r < NB; ++r) {
@@ -476,6 +590,7 @@ __global__ __launch_bounds__(256, 2) void interact_fwd_pf_kernel(FeatArgs fa, lo
     }
 }
 
+
 // backward, D = 128: dT = (dZ + dZ^T) · T per sample, T by LDS-DMA (same images as the forward kernel), the
 // dR row by LDS-DMA too.  The symmetric S = dZ + dZ^T is never materialised: the 16x16x4 MFMA A fragment of a
 // lane is S[16r + li][4kk + g], whose source position inside the dR row depends only on the lane -> 4*NB*NB LDS
@@ -484,8 +599,8 @@ __global__ __launch_bounds__(256, 2) void interact_fwd_pf_kernel(FeatArgs fa, lo
 // with float4s of dT rows (16-byte, 256-B-per-row coalesced stores through the {pointer, stride} table).
 constexpr int IDMA_DR_BYTES = 3072;      // dR row image (<= 656 floats for F = 32 with self pairs)
 
-template <int NI>
-__global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, FeatArgs da, long long B, int F, int self,
+template <int NI, bool GATHER>
+__global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, FeatArgs da, GatherArgs ga, long long B, int F, int self,
                                                                const float* __restrict__ dR, long long ldr) {
     constexpr int NB = (2 * NI + 15) / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -495,13 +610,17 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
     long long* tl = tp + DLRM_MAX_FEATURES;
     long long* dp = tl + DLRM_MAX_FEATURES;
     long long* dl = dp + DLRM_MAX_FEATURES;
-    char* img0 = (char*)(dl + DLRM_MAX_FEATURES) + (size_t)wave * (2 * IDMA_IMG + 2 * IDMA_DR_BYTES);
+    long long* tq = dl + DLRM_MAX_FEATURES;                 // gather mode only
+    long long* to = tq + DLRM_MAX_FEATURES;
+    long long* tr = to + DLRM_MAX_FEATURES;
+    char* img0 = (char*)(tr + DLRM_MAX_FEATURES) + (size_t)wave * (2 * IDMA_IMG + 2 * IDMA_DR_BYTES);
     char* drow0 = img0 + 2 * IDMA_IMG;
     const unsigned img0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)img0;
     const unsigned drow0_lds = img0_lds + 2 * IDMA_IMG;
 
     table_to_lds(fa, tp, tl, F);
     table_to_lds(da, dp, dl, F);
+    if constexpr (GATHER) gather_to_lds(ga, tq, to, tr, F);
     for (int e = lane; e < (2 * IDMA_IMG + 2 * IDMA_DR_BYTES) / 16; e += 64) ((float4*)img0)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
@@ -509,7 +628,10 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
     long long b = (long long)blockIdx.x * 4 + wave;
     if (b >= B) return;
     DmaPlan pl;
-    dma_plan_init(pl, tp, tl, F, lane, b, b_stride);
+    GatherPlan<NI> gp;
+    long long sel[NI], chk[NI];
+    if constexpr (GATHER) gather_plan_init<NI>(gp, tp, tl, F, lane);
+    else dma_plan_init(pl, tp, tl, F, lane, b, b_stride);
     // dR row: lane covers bytes [1024*c + 16*lane, +16) of the row, c < nr; lanes past the row pitch are masked
     const int nr = __builtin_amdgcn_readfirstlane((int)((ldr * 4 + 1023) / 1024));
     const char* dr_src = (const char*)(dR + b * ldr) + 16 * lane;
@@ -553,11 +675,24 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
         }
 
     int cur = 0;
-    dma_issue<NI>(pl, img0_lds);
+    if constexpr (GATHER) {
+        gather_fetch<NI>(sel, chk, tq, to, F, lane, b, ga.idx_bits);
+        gather_issue<NI>(gp, sel, chk, tr, lane, b, ga.idx_bits, ga.err, img0_lds);
+        if (b + b_stride < B) gather_fetch<NI>(sel, chk, tq, to, F, lane, b + b_stride, ga.idx_bits);
+    } else {
+        dma_issue<NI>(pl, img0_lds);
+    }
     issue_dr(drow0_lds);
     for (; b < B; b += b_stride) {
         const bool more = b + b_stride < B;
-        if (more) {
+        if constexpr (GATHER) {
+            wait_vmcnt_i<0>();         // this sample's rows + dR row have landed, so have the next sample's row selectors
+            if (more) {
+                gather_issue<NI>(gp, sel, chk, tr, lane, b + b_stride, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IDMA_IMG);
+                issue_dr(drow0_lds + (cur ^ 1) * IDMA_DR_BYTES);
+                if (b + 2 * b_stride < B) gather_fetch<NI>(sel, chk, tq, to, F, lane, b + 2 * b_stride, ga.idx_bits);
+            }
+        } else if (more) {
             dma_issue<NI>(pl, img0_lds + (cur ^ 1) * IDMA_IMG);
             issue_dr(drow0_lds + (cur ^ 1) * IDMA_DR_BYTES);
             wait_vmcnt_rt(NI + nr);
@@ -642,9 +777,45 @@ static int pick_grid(int64_t B) {
 
 }  // namespace
 
+static int fill_gather(GatherArgs& ga, int F, const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
+                       int64_t* err) {
+    ga.err = (long long*)err; ga.idx_bits = idx_bits;
+    const void* any_idx = nullptr; const void* any_off = nullptr;
+    for (int f = 0; gidx && f < F; ++f) if (gidx[f]) { any_idx = gidx[f]; any_off = goff ? goff[f] : nullptr; break; }
+    for (int f = 0; f < DLRM_MAX_FEATURES; ++f) {
+        const bool g = gidx && f < F && gidx[f];
+        if (g && (!goff || !goff[f] || !grows || grows[f] <= 0)) return DLRM_E_ARG;
+        // plain features: a valid dummy pointer (their loads are unconditional and ignored) and rows = -1
+        ga.idx[f] = g ? gidx[f] : any_idx; ga.off[f] = g ? goff[f] : any_off; ga.rows[f] = g ? grows[f] : -1;
+    }
+    return 0;
+}
+
+extern "C" int dlrm_interact_gather_ok(int F, int D) { return (D == IDMA_D && F >= 1 && F <= IDMA_ROWS) ? 1 : 0; }
+
+static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                             const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
+                             int self_interaction, float* R, int64_t ldr, int64_t* err, void* stream);
+
 extern "C" int dlrm_interact_fwd(int64_t B, int F, int D, const void* const* feat_host,
                                  const int64_t* feat_ld_host, int self_interaction, float* R,
                                  int64_t ldr, void* stream) {
+    return interact_fwd_impl(B, F, D, feat_host, feat_ld_host, nullptr, nullptr, nullptr, 64, self_interaction, R, ldr, nullptr, stream);
+}
+
+extern "C" int dlrm_interact_fwd_gather(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                                        const void* const* index_host, const void* const* offsets_host,
+                                        const int64_t* rows_host, int idx_bits, int self_interaction, float* R, int64_t ldr,
+                                        int64_t* err, void* stream) {
+    if (!index_host || !offsets_host || !rows_host) return DLRM_E_ARG;
+    if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
+    return interact_fwd_impl(B, F, D, feat_host, feat_ld_host, index_host, offsets_host, rows_host, idx_bits, self_interaction, R,
+                             ldr, err, stream);
+}
+
+static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                             const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
+                             int self_interaction, float* R, int64_t ldr, int64_t* err, void* stream) {
     if (B <= 0 || F <= 0 || D <= 0 || !feat_host || !feat_ld_host || !R) return DLRM_E_ARG;
     if (F > DLRM_MAX_FEATURES) {
         fprintf(stderr, "libdlrm_hip: dlrm_interact_fwd: F=%d exceeds %d features\n", F, DLRM_MAX_FEATURES);
@@ -657,6 +828,30 @@ extern "C" int dlrm_interact_fwd(int64_t B, int F, int D, const void* const* fea
     if (rc) return rc;
     int vec = (D % 4 == 0);
     for (int f = 0; f < F; ++f) vec = vec && dlrm_aligned16(feat_host[f]) && (feat_ld_host[f] % 4 == 0);
+    GatherArgs ga;
+    rc = fill_gather(ga, F, gidx, goff, grows, idx_bits, err);
+    if (rc) return rc;
+    if (gidx) {          // gathered features exist only in the D = 128 LDS-DMA kernel
+        if (!(D == IDMA_D && F <= IDMA_ROWS && vec && dlrm_aligned16(R) && ldr % 4 == 0)) return DLRM_E_MODE;
+        const size_t lds = 5 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * 2 * (size_t)IDMA_IMG;
+        int64_t nb = (B + 3) / 4; if (nb > 256) nb = 256;
+        const int ni = (F + 1) / 2;
+#define FWD_G(NIV)                                                                                           \
+        do {                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)interact_fwd_dma_kernel<NIV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((interact_fwd_dma_kernel<NIV, true>), dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, fa, ga, \
+                               (long long)B, F, self_interaction ? 1 : 0, R, (long long)ldr);                \
+        } while (0)
+        switch (ni) {
+            case 1: FWD_G(1); break;   case 2: FWD_G(2); break;   case 3: FWD_G(3); break;   case 4: FWD_G(4); break;
+            case 5: FWD_G(5); break;   case 6: FWD_G(6); break;   case 7: FWD_G(7); break;   case 8: FWD_G(8); break;
+            case 9: FWD_G(9); break;   case 10: FWD_G(10); break; case 11: FWD_G(11); break; case 12: FWD_G(12); break;
+            case 13: FWD_G(13); break; case 14: FWD_G(14); break; case 15: FWD_G(15); break; default: FWD_G(16); break;
+        }
+#undef FWD_G
+        DLRM_LAUNCH_CHECK();
+        return 0;
+    }
     static int fwd_variant = -1;      // env DLRM_INTERACT_FWD=pf: the register-prefetch kernel instead of the LDS-DMA one (0 = pf, 1 = dma)
     if (fwd_variant < 0) { const char* e = getenv("DLRM_INTERACT_FWD"); fwd_variant = (e && !strcmp(e, "pf")) ? 0 : 1; }
     int64_t max_ld = 0;
@@ -683,13 +878,13 @@ extern "C" int dlrm_interact_fwd(int64_t B, int F, int D, const void* const* fea
         return 0;
     }
     if (interact_dma_ok(F, D, vec) && dlrm_aligned16(R) && ldr % 4 == 0) {
-        const size_t lds = 2 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * 2 * (size_t)IDMA_IMG;   // 129 KiB: one workgroup per CU
+        const size_t lds = 5 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * 2 * (size_t)IDMA_IMG;   // 130.5 KiB: one workgroup per CU
         int64_t nb = (B + 3) / 4; if (nb > 256) nb = 256;
         const int ni = (F + 1) / 2;
 #define FWD_DMA(NIV)                                                                                         \
         do {                                                                                                 \
-            (void)hipFuncSetAttribute((const void*)interact_fwd_dma_kernel<NIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL(interact_fwd_dma_kernel<NIV>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, fa, \
+            (void)hipFuncSetAttribute((const void*)interact_fwd_dma_kernel<NIV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((interact_fwd_dma_kernel<NIV, false>), dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, fa, ga, \
                                (long long)B, F, self_interaction ? 1 : 0, R, (long long)ldr);                \
         } while (0)
         switch (ni) {
@@ -716,10 +911,34 @@ extern "C" int dlrm_interact_fwd(int64_t B, int F, int D, const void* const* fea
     return 0;
 }
 
+static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                             const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
+                             int self_interaction, const float* dR, int64_t ldr, void* const* dfeat_host,
+                             const int64_t* dfeat_ld_host, int64_t* err, void* stream);
+
 extern "C" int dlrm_interact_bwd(int64_t B, int F, int D, const void* const* feat_host,
                                  const int64_t* feat_ld_host, int self_interaction, const float* dR,
                                  int64_t ldr, void* const* dfeat_host, const int64_t* dfeat_ld_host,
                                  void* stream) {
+    return interact_bwd_impl(B, F, D, feat_host, feat_ld_host, nullptr, nullptr, nullptr, 64, self_interaction, dR, ldr, dfeat_host,
+                             dfeat_ld_host, nullptr, stream);
+}
+
+extern "C" int dlrm_interact_bwd_gather(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                                        const void* const* index_host, const void* const* offsets_host,
+                                        const int64_t* rows_host, int idx_bits, int self_interaction, const float* dR,
+                                        int64_t ldr, void* const* dfeat_host, const int64_t* dfeat_ld_host, int64_t* err,
+                                        void* stream) {
+    if (!index_host || !offsets_host || !rows_host) return DLRM_E_ARG;
+    if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
+    return interact_bwd_impl(B, F, D, feat_host, feat_ld_host, index_host, offsets_host, rows_host, idx_bits, self_interaction, dR,
+                             ldr, dfeat_host, dfeat_ld_host, err, stream);
+}
+
+static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                             const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
+                             int self_interaction, const float* dR, int64_t ldr, void* const* dfeat_host,
+                             const int64_t* dfeat_ld_host, int64_t* err, void* stream) {
     if (B <= 0 || F <= 0 || D <= 0 || !feat_host || !feat_ld_host || !dR || !dfeat_host || !dfeat_ld_host)
         return DLRM_E_ARG;
     if (F > DLRM_MAX_FEATURES) return DLRM_E_RANGE;
@@ -735,15 +954,27 @@ extern "C" int dlrm_interact_bwd(int64_t B, int F, int D, const void* const* fea
     {
         int dvec = 1;
         for (int f = 0; f < F; ++f) dvec = dvec && dlrm_aligned16(dfeat_host[f]) && (dfeat_ld_host[f] % 4 == 0);
-        if (interact_dma_ok(F, D, vec) && dvec && dlrm_aligned16(dR) && ldr % 4 == 0 && ldr * 4 <= IDMA_DR_BYTES) {
-            const size_t lds_dma = 4 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * (2 * (size_t)IDMA_IMG + 2 * (size_t)IDMA_DR_BYTES);
+        GatherArgs ga;
+        rc = fill_gather(ga, F, gidx, goff, grows, idx_bits, err);
+        if (rc) return rc;
+        const bool dma_path = (gidx ? (D == IDMA_D && F <= IDMA_ROWS && vec) : interact_dma_ok(F, D, vec)) && dvec && dlrm_aligned16(dR) &&
+                              ldr % 4 == 0 && ldr * 4 <= IDMA_DR_BYTES;
+        if (gidx && !dma_path) return DLRM_E_MODE;
+        if (dma_path) {
+            const size_t lds_dma = 7 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * (2 * (size_t)IDMA_IMG + 2 * (size_t)IDMA_DR_BYTES);
             int64_t nb = (B + 3) / 4; if (nb > 256) nb = 256;
             const int ni = (F + 1) / 2;
 #define BWD_DMA(NIV)                                                                                         \
             do {                                                                                             \
-                (void)hipFuncSetAttribute((const void*)interact_bwd_dma_kernel<NIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma); \
-                hipLaunchKernelGGL(interact_bwd_dma_kernel<NIV>, dim3((unsigned)nb), dim3(256), lds_dma, (hipStream_t)stream, fa, da, \
-                                   (long long)B, F, self_interaction ? 1 : 0, dR, (long long)ldr);           \
+                if (gidx) {                                                                                  \
+                    (void)hipFuncSetAttribute((const void*)interact_bwd_dma_kernel<NIV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma); \
+                    hipLaunchKernelGGL((interact_bwd_dma_kernel<NIV, true>), dim3((unsigned)nb), dim3(256), lds_dma, (hipStream_t)stream, fa, da, ga, \
+                                       (long long)B, F, self_interaction ? 1 : 0, dR, (long long)ldr);       \
+                } else {                                                                                     \
+                    (void)hipFuncSetAttribute((const void*)interact_bwd_dma_kernel<NIV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma); \
+                    hipLaunchKernelGGL((interact_bwd_dma_kernel<NIV, false>), dim3((unsigned)nb), dim3(256), lds_dma, (hipStream_t)stream, fa, da, ga, \
+                                       (long long)B, F, self_interaction ? 1 : 0, dR, (long long)ldr);       \
+                }                                                                                            \
             } while (0)
             switch (ni) {
                 case 1: BWD_DMA(1); break;   case 2: BWD_DMA(2); break;   case 3: BWD_DMA(3); break;   case 4: BWD_DMA(4); break;

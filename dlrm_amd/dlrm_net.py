@@ -28,7 +28,8 @@ import torch.nn as nn
 
 from . import ext_dist, ops
 from .functional import (BCEElementwiseFunction, BCELossFunction, CatFunction, ChunkPackFunction, ClampFunction,
-                         EmbeddingBagsFunction, InteractFunction, MLPFunction, MSELossFunction, OutSlot)
+                         EmbeddingBagsFunction, GatherInteractFunction, InteractFunction, MLPFunction, MSELossFunction,
+                         OutSlot)
 from .functional import _side_stream
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, BagBatch
 
@@ -202,6 +203,11 @@ class DLRM_Net(nn.Module):
         # optimizer step.  Same kernels, same arithmetic, same results; optimizer.step() returns with the caller's stream
         # ordered after the update.
         self.overlap_streams = os.environ.get("DLRM_OVERLAP", "0") == "1"
+        # OPT-IN (DLRM_FUSE_EMB_INTERACT=1): single-process forward with ONE lookup per bag (the Criteo data sets) and D = 128 — the
+        # interaction kernels gather the embedding rows themselves (dlrm_interact_fwd_gather): apply_emb's pooled-embedding
+        # buffer is never written or re-read.  Bit-identical results, but measured slower than the two kernels in this round
+        # (profiles/r03/ceilings.md), hence off by default.
+        self.fuse_emb_interact = os.environ.get("DLRM_FUSE_EMB_INTERACT", "0") == "1"
         self._bound_optimizer = None        # weakref to the optimizer that owns the tables (learnt at its first step)
         self._side_keep: list = []          # tensors the side stream still reads (released at the join)
         # > 1: the pooled-embedding all-to-all of the distributed forward is pipelined in that many batch chunks (opt-in)
@@ -417,6 +423,14 @@ class DLRM_Net(nn.Module):
         n_out = self.bot_l[-2].out_features if isinstance(self.bot_l[-2], nn.Linear) else D
         if self.arch_interaction_op == "dot" and n_out != D:
             sys.exit("ERROR: bottom MLP output (%d) and embedding dimension (%d) differ" % (n_out, D))
+        if (self.fuse_emb_interact and self.arch_interaction_op == "dot" and dense_x.is_cuda and ops.gather_ok(1 + T, D)
+                and not any(w is not None for w in (self.v_W_l or []))):
+            bags = self._bags(lS_o, lS_i, None)
+            if all(n == B for n in bags.nnz) and all(e.weight.data_ptr() % 16 == 0 for e in self.emb_l):
+                x = self.apply_mlp(dense_x, self.bot_l)
+                z = GatherInteractFunction.apply(self._stash_embedding_grad, D, bool(self.arch_interaction_itself), bags, x,
+                                                 *self._emb_weights(self.emb_l))
+                return self._clamp(self.apply_mlp(z, self.top_l))
         feat = torch.empty((B, n_out + T * D), dtype=torch.float32, device=dense_x.device)
         if self.overlap_streams and dense_x.is_cuda:
             # pooled lookups (HBM-bound) on the side stream beside the bottom-MLP GEMMs (MFMA-bound): they only meet at the

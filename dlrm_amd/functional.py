@@ -236,6 +236,39 @@ class InteractFunction(Function):
         return (None, None, None, *dblocks)
 
 
+class GatherInteractFunction(Function):
+    """apply_emb + interact_features fused for one-lookup-per-bag batches (dlrm_s_pytorch.py:407-462 + 483-504):
+    R = [x | lower-triangular dots of (x, E_1[idx_1], ..., E_T[idx_T])], the embedding rows fetched by the interaction kernel
+    itself — the [B, T*D] pooled-embedding buffer is neither written nor read back.  Backward recomputes nothing: it gathers
+    the same rows again, writes dx and the [B, T*D] gradient of the gathered rows, and hands the latter to `sink` (the fused
+    sparse update), exactly like EmbeddingBagsFunction.backward."""
+
+    @staticmethod
+    def forward(ctx, sink, D, self_interaction, bags, x, *weights):
+        x = _rowmajor(x)
+        F = 1 + len(weights)
+        Wd = ops.interact_out_width(F, D, self_interaction)
+        R = torch.empty((x.size(0), _round4(Wd)), dtype=torch.float32, device=x.device)
+        ops.interact_fwd_gather(x, weights, bags, D, self_interaction, R)
+        ctx.sink, ctx.bags, ctx.weights = sink, bags, weights
+        ctx.D, ctx.self_interaction = D, self_interaction
+        ctx.save_for_backward(x)
+        return R                                   # [B, round4(width)], zero padding columns (what MLPFunction takes as is)
+
+    @staticmethod
+    def backward(ctx, dR):
+        (x,) = ctx.saved_tensors
+        dR = _rowmajor(dR)
+        B, D, T = x.size(0), ctx.D, len(ctx.weights)
+        flat = torch.empty(B * (1 + T) * D, dtype=torch.float32, device=dR.device)
+        dx, dE = flat[:B * D].view(B, D), flat[B * D:].view(B, T * D)
+        ops.interact_bwd_gather(x, ctx.weights, ctx.bags, D, ctx.self_interaction, dR, dx, dE)
+        if ctx.sink is None:
+            raise RuntimeError("dlrm_amd: embedding backward needs a gradient sink (fused update)")
+        ctx.sink(ctx.weights, ctx.bags, dE)
+        return (None, None, None, None, dx) + (None,) * T
+
+
 class ChunkPackFunction(Function):
     """Re-orders the rows of the pooled-embedding send buffer for a PIPELINED all-to-all.
 

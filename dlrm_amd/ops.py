@@ -114,6 +114,10 @@ def check_index_errors(device=None, sync: bool = False) -> None:
         if int(blk[0]) != 0:
             _, t, idx, rows = blk.tolist()
             blk.zero_()
+            if rows == -1:
+                raise IndexError(f"dlrm_amd: the fused one-lookup-per-bag embedding + interaction path met a bag of table {t} that "
+                                 f"does not start at its own position (offset {-idx - 1}); set model.fuse_emb_interact = False for "
+                                 f"multi-hot / ragged batches (cuda:{key})")
             raise IndexError(f"dlrm_amd: embedding index out of range: table {t}, index {idx}, rows {rows} (cuda:{key})")
 
 
@@ -343,6 +347,56 @@ def interact_fwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool,
                                    C.c_void_p(R.data_ptr()), _ld(R), _stream(R))
     _lib.check(rc, "dlrm_interact_fwd")
     return R
+
+
+def gather_ok(F: int, D: int) -> bool:
+    return bool(_lib.load().dlrm_interact_gather_ok(F, D))
+
+
+def _gather_desc(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: BagBatch, D: int):
+    """feature 0 = the [B, D] block x, features 1..T = the tables addressed through the bags' indices"""
+    if bags.T != len(weights) or any(n != bags.B for n in bags.nnz):
+        raise RuntimeError("dlrm_amd: the fused embedding + interaction path needs exactly one lookup per bag")
+    if bags._psw is not None:
+        raise RuntimeError("dlrm_amd: the fused embedding + interaction path does not take per-sample weights")
+    _req(x, "x", ndim=2)
+    ptrs = [x.data_ptr()] + [w.data_ptr() for w in weights]
+    lds = [_ld(x)] + [D] * len(weights)
+    F = len(ptrs)
+    gidx = (C.c_void_p * F)(None, *[C.c_void_p(bags._idx[k]) for k in range(bags.T)])
+    goff = (C.c_void_p * F)(None, *[C.c_void_p(bags._off[k]) for k in range(bags.T)])
+    rows = _lib.i64_array([0] + [w.size(0) for w in weights])
+    return F, _lib.ptr_array(ptrs), _lib.i64_array(lds), gidx, goff, rows
+
+
+def interact_fwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: BagBatch, D: int, self_interaction: bool,
+                        R: torch.Tensor) -> torch.Tensor:
+    """R = interaction of [x | one-hot embedding rows], the rows fetched by the kernel itself (no pooled-embedding buffer)."""
+    lib = _lib.load()
+    F, p, ld, gidx, goff, rows = _gather_desc(x, weights, bags, D)
+    _req(R, "R", ndim=2)
+    if R.size(0) != bags.B or x.size(0) != bags.B or R.size(1) < interact_out_width(F, D, self_interaction):
+        raise RuntimeError("dlrm_amd: interact_fwd_gather shape mismatch")
+    with _timed("emb_interact_fwd"):
+        rc = lib.dlrm_interact_fwd_gather(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(bool(self_interaction)),
+                                          C.c_void_p(R.data_ptr()), _ld(R), C.c_void_p(_err_block(R.device).data_ptr()), _stream(R))
+    _lib.check(rc, "dlrm_interact_fwd_gather")
+    return R
+
+
+def interact_bwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: BagBatch, D: int, self_interaction: bool,
+                        dR: torch.Tensor, dx: torch.Tensor, dE: torch.Tensor) -> None:
+    """dx [B, D] = gradient of x; dE [B, T*D] = gradients of the T gathered rows (the dout of the fused embedding update)."""
+    lib = _lib.load()
+    F, p, ld, gidx, goff, rows = _gather_desc(x, weights, bags, D)
+    _req(dR, "dR", ndim=2); _req(dx, "dx", ndim=2); _req(dE, "dE", ndim=2)
+    dptrs = [dx.data_ptr()] + [dE.data_ptr() + 4 * k * D for k in range(bags.T)]
+    dlds = [_ld(dx)] + [_ld(dE)] * bags.T
+    with _timed("emb_interact_bwd"):
+        rc = lib.dlrm_interact_bwd_gather(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(bool(self_interaction)),
+                                          C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
+                                          C.c_void_p(_err_block(dR.device).data_ptr()), _stream(dR))
+    _lib.check(rc, "dlrm_interact_bwd_gather")
 
 
 def interact_bwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool, dR: torch.Tensor,

@@ -141,6 +141,26 @@ int dlrm_interact_bwd(int64_t B, int F, int D,
                       int self_interaction, const float* dR, int64_t ldr,
                       void* const* dfeat_host, const int64_t* dfeat_ld_host, void* stream);
 
+/* K1 + K6 fused for one-lookup-per-bag inputs (the Criteo data sets: offsets = arange, dlrm_data_pytorch.py:334-337):
+ * features whose index_host[f] != NULL are NOT [B, D] matrices but EmbeddingBag tables — feature f of sample b is row
+ * index_host[f][b] of the table at feat_host[f] (feat_ld_host[f] = D), fetched by the interaction kernel itself.  The
+ * pooled-embedding buffer that dlrm_emb_fwd would write and dlrm_interact_* read back (2 x T x B x D x 4 bytes: 1.7 GB of the
+ * forward's 2.4 GB at Criteo-Terabyte shapes) never exists; results are bit-identical to dlrm_emb_fwd + dlrm_interact_fwd.
+ *   offsets_host[f] : the table's bag starts; the kernels verify offsets[b] == b (one lookup per bag) — a violation, or an
+ *                     index outside [0, rows_host[f]), is reported through `err` ({1, table, index, rows}; rows = -1 marks a
+ *                     bag-layout violation) and row 0 is read instead.
+ * Available when dlrm_interact_gather_ok(F, D) (D = 128, F <= 32, 16-byte aligned operands); otherwise DLRM_E_MODE and the
+ * caller runs the two kernels.  The backward writes dfeat rows exactly like dlrm_interact_bwd (the gradient of a gathered
+ * feature is the dout operand of dlrm_emb_bwd_*). */
+int dlrm_interact_gather_ok(int F, int D);
+int dlrm_interact_fwd_gather(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                             const void* const* index_host, const void* const* offsets_host, const int64_t* rows_host,
+                             int idx_bits, int self_interaction, float* R, int64_t ldr, int64_t* err, void* stream);
+int dlrm_interact_bwd_gather(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                             const void* const* index_host, const void* const* offsets_host, const int64_t* rows_host,
+                             int idx_bits, int self_interaction, const float* dR, int64_t ldr,
+                             void* const* dfeat_host, const int64_t* dfeat_ld_host, int64_t* err, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * K5  MLP layer = nn.Linear + activation  (dlrm_s_pytorch.py:216,238-241,405), fp32 MFMA.
  *   Y[M,N] = act(X[M,K] · W[N,K]^T + bias[N])

@@ -570,6 +570,51 @@ def test_emb_bwd_coo_is_the_reference_sparse_gradient():
             assert np.array_equal(vals[t].cpu().numpy(), want.astype(np.float32)), t
 
 
+@pytest.mark.parametrize("T,B,idx_dtype,itself", [(26, 5000, torch.int64, False), (26, 4099, torch.int32, False), (3, 777, torch.int64, True),
+                                                  (31, 300, torch.int64, False), (7, 64, torch.int32, True)])
+def test_gather_interaction_is_bit_identical_to_the_two_kernels(T, B, idx_dtype, itself):
+    """dlrm_interact_fwd_gather / _bwd_gather (one lookup per bag, D = 128: the interaction kernel fetches the embedding rows
+    itself) against dlrm_emb_fwd + dlrm_interact_fwd / _bwd: the SAME bits for R, dx and the embedding-row gradients; a
+    non-one-hot bag layout and an out-of-range index are reported through the error block."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(T * B)
+    D = 128
+    rows = [int(r) for r in rng.integers(1, 5000, size=T)]
+    Ws = [to_dev(rng.standard_normal((n, D)).astype(np.float32)) for n in rows]
+    idx = torch.stack([to_dev(rng.integers(0, n, size=B)) for n in rows]).to(idx_dtype)
+    off = torch.arange(B, device=dev()).repeat(T, 1).to(idx_dtype)
+    x = to_dev(rng.standard_normal((B, D)).astype(np.float32))
+    bags = ops.BagBatch(off, idx)
+    F = T + 1
+    W_ = ops.interact_out_width(F, D, itself)
+    ldr = (W_ + 3) & ~3
+    # reference route: pooled embeddings into a feature buffer, then the plain interaction kernels
+    feat = torch.empty((B, F * D), device=dev())
+    feat[:, :D] = x
+    ops.emb_fwd(Ws, bags, feat[:, D:])
+    R0 = torch.empty((B, ldr), device=dev())
+    ops.interact_fwd([feat[:, :D], feat[:, D:]], D, itself, R0)
+    R1 = torch.full((B, ldr), 7.0, device=dev())
+    ops.interact_fwd_gather(x, Ws, bags, D, itself, R1)
+    assert torch.equal(R0, R1)
+    dR = to_dev(rng.standard_normal((B, ldr)).astype(np.float32))
+    d0 = torch.empty((B, F * D), device=dev())
+    ops.interact_bwd([feat[:, :D], feat[:, D:]], D, itself, dR, [d0[:, :D], d0[:, D:]])
+    dx, dE = torch.empty((B, D), device=dev()), torch.empty((B, T * D), device=dev())
+    ops.interact_bwd_gather(x, Ws, bags, D, itself, dR, dx, dE)
+    assert torch.equal(d0[:, :D], dx) and torch.equal(d0[:, D:], dE)
+    ops.check_index_errors(sync=True)
+    # violations are reported
+    bad_off = off.clone(); bad_off[T - 1, 5] = 4
+    ops.interact_fwd_gather(x, Ws, ops.BagBatch(bad_off, idx), D, itself, R1)
+    with pytest.raises(IndexError, match="one-lookup-per-bag"):
+        ops.check_index_errors(sync=True)
+    bad_idx = idx.clone(); bad_idx[0, 3] = rows[0]
+    ops.interact_fwd_gather(x, Ws, ops.BagBatch(off, bad_idx), D, itself, R1)
+    with pytest.raises(IndexError, match="out of range"):
+        ops.check_index_errors(sync=True)
+
+
 # ------------------------------------------------------------------------------------------ config 5 inputs: Multihot
 @pytest.mark.parametrize("id_dtype", [torch.int64, torch.int32])
 def test_multihot_expand_matches_reference_class(id_dtype):
