@@ -55,6 +55,7 @@ SIGNATURES = {
     "dlrm_act_bwd": (_i32, [_i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     "dlrm_loss_workspace_bytes": (_i64, [_i64]),
     "dlrm_bce_loss": (_i32, [_i64, _vp, _vp, _vp, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "dlrm_bce_logits_loss": (_i32, [_i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
     "dlrm_mse_loss": (_i32, [_i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
     "dlrm_scale_by_device_scalar": (_i32, [_i64, _vp, _vp, _vp, _vp]),
     "dlrm_sgd_dense": (_i32, [_i64, _vp, _vp, _f32, _vp]),

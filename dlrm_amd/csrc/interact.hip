@@ -27,6 +27,14 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) float gfloat;
 typedef __attribute__((address_space(1))) floatx4 gfloatx4;
 
+// position of the pair (i, j), j <= i, in the flattened interaction output.  `self` is a mode word: bit 0 = pairs include the
+// diagonal (--arch-interaction-itself), bit 1 = torchrec order — torch.triu_indices(F, F, offset=1), i.e. pair (j, i) of the
+// upper triangle enumerated row by row (torchrec InteractionArch) — instead of the reference's tril order (dlrm_s_pytorch.py:499-501).
+__device__ __forceinline__ int pair_pos(int i, int j, int F, int mode) {
+    if (mode & 2) return j * F - j * (j + 1) / 2 + (i - j - 1);
+    return ((mode & 1) ? i * (i + 1) / 2 : i * (i - 1) / 2) + j;
+}
+
 #define DLRM_MAX_FEATURES 64
 struct FeatArgs {
     const float* p[DLRM_MAX_FEATURES];
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(256) void interact_fwd_kernel(FeatArgs fa, long lon
     __syncthreads();
 
     const int g = lane >> 4, li = lane & 15;
-    const int P = self ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    const int P = (self & 1) ? F * (F + 1) / 2 : F * (F - 1) / 2;
     const int nsteps = Dp >> 4;
 
     for (long long base = (long long)blockIdx.x * 4; base < B; base += (long long)gridDim.x * 4) {
@@ -136,8 +144,8 @@ __global__ __launch_bounds__(256) void interact_fwd_kernel(FeatArgs fa, long lon
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int i = 16 * r + 4 * g + q;   // C/D layout: row = 4*(lane>>4)+reg, col = lane&15
-                        if (i < F && (self ? (j <= i) : (j < i))) {
-                            const int p = (self ? i * (i + 1) / 2 : i * (i - 1) / 2) + j;
+                        if (i < F && ((self & 1) ? (j <= i) : (j < i))) {
+                            const int p = pair_pos(i, j, F, self);
                             Rb[D + p] = acc[q];
                         }
                     }
@@ -190,10 +198,10 @@ __global__ __launch_bounds__(256) void interact_bwd_kernel(FeatArgs fa, FeatArgs
                 float v = 0.f;
                 if (j < F) {
                     if (i == j) {
-                        if (self) v = 2.f * dRb[D + i * (i + 1) / 2 + i];
+                        if (self & 1) v = 2.f * dRb[D + pair_pos(i, i, F, self)];
                     } else {
                         const int hi = i > j ? i : j, lo = i > j ? j : i;
-                        v = dRb[D + (self ? hi * (hi + 1) / 2 : hi * (hi - 1) / 2) + lo];
+                        v = dRb[D + pair_pos(hi, lo, F, self)];
                     }
                 }
                 S[i * SS + j] = v;
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, Gath
     }
 
     const int g = lane >> 4, li = lane & 15;
-    const int P = self ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    const int P = (self & 1) ? F * (F + 1) / 2 : F * (F - 1) / 2;
     const int NB = (F + 15) >> 4;
     int cur = 0;
     if constexpr (!GATHER) dma_issue<NI>(pl, img0_lds);
@@ -466,8 +474,8 @@ __global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, Gath
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = 16 * r + 4 * g + q;
-                    if (i < F && (self ? (j <= i) : (j < i))) {
-                        const int p = (self ? i * (i + 1) / 2 : i * (i - 1) / 2) + j;
+                    if (i < F && ((self & 1) ? (j <= i) : (j < i))) {
+                        const int p = pair_pos(i, j, F, self);
                         Rb[IDMA_D + p] = acc[q];
                     }
                 }
@@ -543,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void interact_fwd_pf_kernel(FeatArgs fa, lo
     }
 
     const int g = lane >> 4, li = lane & 15;
-    const int P = self ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    const int P = (self & 1) ? F * (F + 1) / 2 : F * (F - 1) / 2;
     const int NB = (F + 15) >> 4;
     const int W4 = (int)(ldr >> 2);                          // float4 segments of one R row (ldr % 4 == 0 on this path)
 
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void interact_fwd_pf_kernel(FeatArgs fa, lo
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = 16 * r + 4 * g + q;
-                    if (i < F && (self ? (j <= i) : (j < i))) orow[(self ? i * (i + 1) / 2 : i * (i - 1) / 2) + j] = acc[q];
+                    if (i < F && ((self & 1) ? (j <= i) : (j < i))) orow[pair_pos(i, j, F, self)] = acc[q];
                 }
             }
         }
@@ -653,10 +661,10 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
             const int i = 16 * r + li, j = 4 * kk + g;
             int off = 0; float sc = 0.f;
             if (i < F && j < F) {
-                if (i == j) { if (self) { off = IDMA_D + i * (i + 1) / 2 + i; sc = 2.f; } }
+                if (i == j) { if (self & 1) { off = IDMA_D + pair_pos(i, i, F, self); sc = 2.f; } }
                 else {
                     const int hi = i > j ? i : j, lo = i > j ? j : i;
-                    off = IDMA_D + (self ? hi * (hi + 1) / 2 : hi * (hi - 1) / 2) + lo; sc = 1.f;
+                    off = IDMA_D + pair_pos(hi, lo, F, self); sc = 1.f;
                 }
             }
             a_off[r][kk] = off * 4; a_scale[r][kk] = sc;
@@ -821,7 +829,8 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
         fprintf(stderr, "libdlrm_hip: dlrm_interact_fwd: F=%d exceeds %d features\n", F, DLRM_MAX_FEATURES);
         return DLRM_E_RANGE;
     }
-    const int P = self_interaction ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    if (self_interaction < 0 || self_interaction > 2) return DLRM_E_MODE;     // 0 tril, 1 tril + diagonal, 2 torchrec triu order
+    const int P = (self_interaction & 1) ? F * (F + 1) / 2 : F * (F - 1) / 2;
     if (ldr < D + P) return DLRM_E_ARG;
     FeatArgs fa;
     int rc = fill_feat(fa, F, feat_host, feat_ld_host);
@@ -840,7 +849,7 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
         do {                                                                                                 \
             (void)hipFuncSetAttribute((const void*)interact_fwd_dma_kernel<NIV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             hipLaunchKernelGGL((interact_fwd_dma_kernel<NIV, true>), dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, fa, ga, \
-                               (long long)B, F, self_interaction ? 1 : 0, R, (long long)ldr);                \
+                               (long long)B, F, self_interaction & 3, R, (long long)ldr);                \
         } while (0)
         switch (ni) {
             case 1: FWD_G(1); break;   case 2: FWD_G(2); break;   case 3: FWD_G(3); break;   case 4: FWD_G(4); break;
@@ -865,7 +874,7 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
         do {                                                                                                 \
             (void)hipFuncSetAttribute((const void*)interact_fwd_pf_kernel<NIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             hipLaunchKernelGGL(interact_fwd_pf_kernel<NIV>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, fa, \
-                               (long long)B, F, self_interaction ? 1 : 0, R, (long long)ldr);                \
+                               (long long)B, F, self_interaction & 3, R, (long long)ldr);                \
         } while (0)
         switch (ni) {
             case 1: FWD_PF(1); break;   case 2: FWD_PF(2); break;   case 3: FWD_PF(3); break;   case 4: FWD_PF(4); break;
@@ -885,7 +894,7 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
         do {                                                                                                 \
             (void)hipFuncSetAttribute((const void*)interact_fwd_dma_kernel<NIV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             hipLaunchKernelGGL((interact_fwd_dma_kernel<NIV, false>), dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, fa, ga, \
-                               (long long)B, F, self_interaction ? 1 : 0, R, (long long)ldr);                \
+                               (long long)B, F, self_interaction & 3, R, (long long)ldr);                \
         } while (0)
         switch (ni) {
             case 1: FWD_DMA(1); break;   case 2: FWD_DMA(2); break;   case 3: FWD_DMA(3); break;   case 4: FWD_DMA(4); break;
@@ -905,7 +914,7 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
     }
     (void)hipFuncSetAttribute((const void*)interact_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(interact_fwd_kernel, dim3(pick_grid(B)), dim3(256), lds, (hipStream_t)stream, fa,
-                       (long long)B, F, D, self_interaction ? 1 : 0, R, (long long)ldr, vec,
+                       (long long)B, F, D, self_interaction & 3, R, (long long)ldr, vec,
                        vec ? log2_exact(D / 4) : -1);
     DLRM_LAUNCH_CHECK();
     return 0;
@@ -942,7 +951,8 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
     if (B <= 0 || F <= 0 || D <= 0 || !feat_host || !feat_ld_host || !dR || !dfeat_host || !dfeat_ld_host)
         return DLRM_E_ARG;
     if (F > DLRM_MAX_FEATURES) return DLRM_E_RANGE;
-    const int P = self_interaction ? F * (F + 1) / 2 : F * (F - 1) / 2;
+    if (self_interaction < 0 || self_interaction > 2) return DLRM_E_MODE;     // 0 tril, 1 tril + diagonal, 2 torchrec triu order
+    const int P = (self_interaction & 1) ? F * (F + 1) / 2 : F * (F - 1) / 2;
     if (ldr < D + P) return DLRM_E_ARG;
     FeatArgs fa, da;
     int rc = fill_feat(fa, F, feat_host, feat_ld_host);
@@ -969,11 +979,11 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
                 if (gidx) {                                                                                  \
                     (void)hipFuncSetAttribute((const void*)interact_bwd_dma_kernel<NIV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma); \
                     hipLaunchKernelGGL((interact_bwd_dma_kernel<NIV, true>), dim3((unsigned)nb), dim3(256), lds_dma, (hipStream_t)stream, fa, da, ga, \
-                                       (long long)B, F, self_interaction ? 1 : 0, dR, (long long)ldr);       \
+                                       (long long)B, F, self_interaction & 3, dR, (long long)ldr);       \
                 } else {                                                                                     \
                     (void)hipFuncSetAttribute((const void*)interact_bwd_dma_kernel<NIV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma); \
                     hipLaunchKernelGGL((interact_bwd_dma_kernel<NIV, false>), dim3((unsigned)nb), dim3(256), lds_dma, (hipStream_t)stream, fa, da, ga, \
-                                       (long long)B, F, self_interaction ? 1 : 0, dR, (long long)ldr);       \
+                                       (long long)B, F, self_interaction & 3, dR, (long long)ldr);       \
                 }                                                                                            \
             } while (0)
             switch (ni) {
@@ -1001,7 +1011,7 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
     do {                                                                                                 \
         (void)hipFuncSetAttribute((const void*)interact_bwd_kernel<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(interact_bwd_kernel<NBV>, grid, block, lds, st, fa, da, (long long)B, F, D,   \
-                           self_interaction ? 1 : 0, dR, (long long)ldr, vec, d4s);                      \
+                           self_interaction & 3, dR, (long long)ldr, vec, d4s);                      \
     } while (0)
     switch (NB) {
         case 1: BWD_LAUNCH(1); break;

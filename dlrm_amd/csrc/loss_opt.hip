@@ -43,6 +43,33 @@ __global__ __launch_bounds__(kLossBlock) void bce_kernel(long long B, const floa
     }
 }
 
+// BCEWithLogitsLoss(mean) per torch: loss = (1 - t) * x + m + log(exp(-m) + exp(-x - m)), m = max(-x, 0); grad = (sigmoid(x) - t) / B
+__global__ __launch_bounds__(kLossBlock) void bce_logits_kernel(long long B, const float* __restrict__ x, const float* __restrict__ t,
+                                                                float gscale, float* __restrict__ dx, float* __restrict__ partials) {
+    __shared__ float red[kLossBlock / 64];
+    float local = 0.f;
+    const long long base = ((long long)blockIdx.x * kLossBlock + threadIdx.x) * kLossPerThread;
+#pragma unroll
+    for (int k = 0; k < kLossPerThread; ++k) {
+        const long long i = base + k;
+        if (i < B) {
+            const float xi = x[i], ti = t[i];
+            const float m = fmaxf(-xi, 0.f);
+            local += (1.f - ti) * xi + m + logf(expf(-m) + expf(-xi - m));
+            if (dx) dx[i] = (1.f / (1.f + expf(-xi)) - ti) * gscale;
+        }
+    }
+    local = dlrm_wave_sum(local);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < kLossBlock / 64; ++k) s += red[k];
+        partials[blockIdx.x] = s;
+    }
+}
+
 __global__ __launch_bounds__(kLossBlock) void mse_kernel(long long B, const float* __restrict__ p,
                                                          const float* __restrict__ t, float gscale,
                                                          float* __restrict__ dp, float* __restrict__ partials) {
@@ -248,6 +275,20 @@ extern "C" int dlrm_bce_loss(int64_t B, const float* p, const float* target, con
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bce_kernel, dim3(nblk), dim3(kLossBlock), 0, st, (long long)B, p, target, weights, w_neg, w_pos,
                        grad_scale / (float)B, dp, (float*)partials);
+    DLRM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, nblk, (const float*)partials, 1.0 / (double)B, loss_out);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_bce_logits_loss(int64_t B, const float* logits, const float* target, float grad_scale,
+                                    float* loss_out, float* dlogits, void* partials, void* stream) {
+    if (B <= 0 || !logits || !target || !loss_out || !partials) return DLRM_E_ARG;
+    const int64_t per_block = (int64_t)kLossBlock * kLossPerThread;
+    const int nblk = (int)((B + per_block - 1) / per_block);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(nblk), dim3(kLossBlock), 0, st, (long long)B, logits, target,
+                       grad_scale / (float)B, dlogits, (float*)partials);
     DLRM_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, nblk, (const float*)partials, 1.0 / (double)B, loss_out);
     DLRM_LAUNCH_CHECK();

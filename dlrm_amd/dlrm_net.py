@@ -271,6 +271,15 @@ class DLRM_Net(nn.Module):
             sys.exit("ERROR: --loss-function=" + str(loss_function) + " is not supported")
         EmbeddingUpdateHook.register(self)
 
+    def _interaction_mode(self) -> int:
+        """0: strictly lower triangle, reference order (dlrm_s_pytorch.py:499-501); 1: with the diagonal (--arch-interaction-itself);
+        2: torchrec's torch.triu_indices(F, F, 1) order (dlrm_amd.torchrec_variant)"""
+        if getattr(self, "interaction_order", "tril") == "triu":
+            if self.arch_interaction_itself:
+                sys.exit("ERROR: the torchrec (triu) interaction order has no self-interaction")
+            return 2
+        return 1 if self.arch_interaction_itself else 0
+
     def set_mlp_arith(self, name: str) -> None:
         """Arithmetic of both towers' GEMMs (FusedMLP.arith): "f32" | "bf16x6" | "bf16"."""
         ops.arith_code(name)
@@ -314,7 +323,7 @@ class DLRM_Net(nn.Module):
     def interact_features(self, x, ly):
         if self.arch_interaction_op == "dot":
             D = x.size(1)
-            return InteractFunction.apply(D, bool(self.arch_interaction_itself), False, x, *ly)
+            return InteractFunction.apply(D, self._interaction_mode(), False, x, *ly)
         if self.arch_interaction_op == "cat":
             return CatFunction.apply(None, x, *ly)
         sys.exit("ERROR: --arch-interaction-op=" + str(self.arch_interaction_op) + " is not supported")
@@ -428,7 +437,7 @@ class DLRM_Net(nn.Module):
             bags = self._bags(lS_o, lS_i, None)
             if all(n == B for n in bags.nnz) and all(e.weight.data_ptr() % 16 == 0 for e in self.emb_l):
                 x = self.apply_mlp(dense_x, self.bot_l)
-                z = GatherInteractFunction.apply(self._stash_embedding_grad, D, bool(self.arch_interaction_itself), bags, x,
+                z = GatherInteractFunction.apply(self._stash_embedding_grad, D, self._interaction_mode(), bags, x,
                                                  *self._emb_weights(self.emb_l))
                 return self._clamp(self.apply_mlp(z, self.top_l))
         feat = torch.empty((B, n_out + T * D), dtype=torch.float32, device=dense_x.device)
@@ -447,7 +456,7 @@ class DLRM_Net(nn.Module):
         if self.arch_interaction_op == "cat":
             z = CatFunction.apply(OutSlot(feat), x, E)      # the feature buffer IS cat([x] + ly, 1): nothing is copied
         else:
-            z = InteractFunction.apply(D, bool(self.arch_interaction_itself), True, x, E)   # [B, round4(width)], zero padded
+            z = InteractFunction.apply(D, self._interaction_mode(), True, x, E)   # [B, round4(width)], zero padded
         return self._clamp(self.apply_mlp(z, self.top_l))
 
     def distributed_forward(self, dense_x, lS_o, lS_i):
@@ -474,7 +483,7 @@ class DLRM_Net(nn.Module):
         x = self.apply_mlp(dense_x, self.bot_l)                             # overlaps the exchange
         ly = list(req.wait())                                               # N x [B/N, T_s*D], read in place
         if self.arch_interaction_op == "dot":
-            z = InteractFunction.apply(D, bool(self.arch_interaction_itself), True, x, *ly)
+            z = InteractFunction.apply(D, self._interaction_mode(), True, x, *ly)
         else:
             z = self.interact_features(x, ly)
         return self._clamp(self.apply_mlp(z, self.top_l))
@@ -496,7 +505,7 @@ class DLRM_Net(nn.Module):
         outs = []
         for c in range(C):
             ly = list(reqs[c].wait())                                           # N x [Bc, T_s*D]
-            z = InteractFunction.apply(D, bool(self.arch_interaction_itself), True, x[c * Bc:(c + 1) * Bc], *ly)
+            z = InteractFunction.apply(D, self._interaction_mode(), True, x[c * Bc:(c + 1) * Bc], *ly)
             outs.append(self.apply_mlp(z, self.top_l))
         return self._clamp(torch.cat(outs, dim=0))
 

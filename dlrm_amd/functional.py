@@ -363,6 +363,22 @@ class BCELossFunction(Function):
         return ops.scale_by_scalar(dp, g.reshape(1).float()).view(ctx.shape), None, None, None
 
 
+class BCEWithLogitsLossFunction(Function):
+    """BCEWithLogitsLoss(reduction='mean') on raw logits (torchrec DLRMTrain); loss and dL/dlogits in one kernel pass."""
+
+    @staticmethod
+    def forward(ctx, z, target):
+        loss, dz = ops.bce_logits_loss(z.contiguous(), target.contiguous(), 1.0, want_grad=True)
+        ctx.save_for_backward(dz)
+        ctx.shape = z.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return ops.scale_by_scalar(dz, g.reshape(1).float()).view(ctx.shape), None
+
+
 class BCEElementwiseFunction(Function):
     """BCELoss(reduction='none'): the per-sample loss the reference's wbce path multiplies by class weights and averages
     in loss_fn_wrap (dlrm_s_pytorch.py:388-391, 150-156)."""

@@ -331,8 +331,10 @@ def _feature_table(tensors: Sequence[torch.Tensor], D: int):
     return B, ptrs, lds
 
 
-def interact_out_width(F: int, D: int, self_interaction: bool) -> int:
-    return D + (F * (F + 1) // 2 if self_interaction else F * (F - 1) // 2)
+def interact_out_width(F: int, D: int, self_interaction) -> int:
+    """self_interaction: False/0 = strictly lower triangle (the reference's order), True/1 = with the diagonal, 2 = torchrec's
+    torch.triu_indices(F, F, 1) order (same pairs as 0, permuted columns)"""
+    return D + (F * (F + 1) // 2 if (int(self_interaction) & 1) else F * (F - 1) // 2)
 
 
 def interact_fwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool, R: torch.Tensor) -> torch.Tensor:
@@ -343,7 +345,7 @@ def interact_fwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool,
     if R.size(0) != B or R.size(1) < interact_out_width(F, D, self_interaction):
         raise RuntimeError("dlrm_amd: interact_fwd output shape mismatch")
     with _timed("interact_fwd"):
-        rc = lib.dlrm_interact_fwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(bool(self_interaction)),
+        rc = lib.dlrm_interact_fwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(self_interaction),
                                    C.c_void_p(R.data_ptr()), _ld(R), _stream(R))
     _lib.check(rc, "dlrm_interact_fwd")
     return R
@@ -378,7 +380,7 @@ def interact_fwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: 
     if R.size(0) != bags.B or x.size(0) != bags.B or R.size(1) < interact_out_width(F, D, self_interaction):
         raise RuntimeError("dlrm_amd: interact_fwd_gather shape mismatch")
     with _timed("emb_interact_fwd"):
-        rc = lib.dlrm_interact_fwd_gather(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(bool(self_interaction)),
+        rc = lib.dlrm_interact_fwd_gather(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(self_interaction),
                                           C.c_void_p(R.data_ptr()), _ld(R), C.c_void_p(_err_block(R.device).data_ptr()), _stream(R))
     _lib.check(rc, "dlrm_interact_fwd_gather")
     return R
@@ -393,7 +395,7 @@ def interact_bwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: 
     dptrs = [dx.data_ptr()] + [dE.data_ptr() + 4 * k * D for k in range(bags.T)]
     dlds = [_ld(dx)] + [_ld(dE)] * bags.T
     with _timed("emb_interact_bwd"):
-        rc = lib.dlrm_interact_bwd_gather(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(bool(self_interaction)),
+        rc = lib.dlrm_interact_bwd_gather(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(self_interaction),
                                           C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
                                           C.c_void_p(_err_block(dR.device).data_ptr()), _stream(dR))
     _lib.check(rc, "dlrm_interact_bwd_gather")
@@ -409,7 +411,7 @@ def interact_bwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool,
         raise RuntimeError("dlrm_amd: interact_bwd shape mismatch")
     F = len(ptrs)
     with _timed("interact_bwd"):
-        rc = lib.dlrm_interact_bwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(bool(self_interaction)),
+        rc = lib.dlrm_interact_bwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(self_interaction),
                                    C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
                                    _stream(dR))
     _lib.check(rc, "dlrm_interact_bwd")
@@ -583,6 +585,23 @@ def bce_loss(p: torch.Tensor, target: torch.Tensor, weights: Optional[torch.Tens
                                C.c_void_p(ws.data_ptr()), _stream())
     _lib.check(rc, "dlrm_bce_loss")
     return loss, dp
+
+
+def bce_logits_loss(z: torch.Tensor, target: torch.Tensor, grad_scale: float, want_grad: bool):
+    """BCEWithLogitsLoss(mean) on raw logits (torchrec DLRMTrain): returns (loss[1], dz or None)."""
+    lib = _lib.load()
+    _req(z, "logits"); _req(target, "target")
+    if not z.is_contiguous() or not target.is_contiguous() or z.numel() != target.numel():
+        raise RuntimeError("dlrm_amd: bce_logits_loss needs contiguous logits/target of equal size")
+    B = z.numel()
+    loss = torch.empty(1, dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z) if want_grad else None
+    ws = _loss_ws(B, z.device)
+    rc = lib.dlrm_bce_logits_loss(B, C.c_void_p(z.data_ptr()), C.c_void_p(target.data_ptr()), float(grad_scale),
+                                  C.c_void_p(loss.data_ptr()), C.c_void_p(dz.data_ptr()) if dz is not None else None,
+                                  C.c_void_p(ws.data_ptr()), _stream(z))
+    _lib.check(rc, "dlrm_bce_logits_loss")
+    return loss, dz
 
 
 def mse_loss(p: torch.Tensor, target: torch.Tensor, grad_scale: float, want_grad: bool):

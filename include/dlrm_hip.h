@@ -129,6 +129,10 @@ int dlrm_emb_bwd_rowwise_adagrad(int T, int64_t B, int D,
  *   R[b, D + p(i,j)]     = <feature i, feature j>,  j < i (j <= i if self_interaction),
  *                          p enumerates pairs row-major: (1,0),(2,0),(2,1),(3,0)...  (:499-501)
  *   columns [D+P, ldr) of R are zero-filled (ldr may pad the row for alignment).
+ * self_interaction is a mode: 0 = strictly lower triangle in the reference's order, 1 = with the diagonal
+ * (--arch-interaction-itself), 2 = the strictly upper triangle in torch.triu_indices(F, F, 1) order, i.e. pairs
+ * (0,1),(0,2)...(0,F-1),(1,2)... — what torchrec's InteractionArch emits (BASELINE.json configs[4]; same dot products,
+ * permuted columns).  The same mode goes to dlrm_interact_bwd.
  */
 int dlrm_interact_fwd(int64_t B, int F, int D,
                       const void* const* feat_host, const int64_t* feat_ld_host,
@@ -241,6 +245,11 @@ int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, const float* Y
 int64_t dlrm_loss_workspace_bytes(int64_t B);
 int dlrm_bce_loss(int64_t B, const float* p, const float* target, const float* weights, float w_neg, float w_pos,
                   float grad_scale, float* loss_out, float* dp, void* partials, void* stream);
+/* BCEWithLogitsLoss(reduction="mean") on raw logits — the loss of torchrec's DLRMTrain (BASELINE.json configs[4]; the over-arch
+ * ends without a sigmoid, torchrec_dlrm/dlrm_main.py:650): loss = mean((1-t)*x + m + log(exp(-m) + exp(-x-m))), m = max(-x, 0)
+ * (torch's formula), dlogits = (sigmoid(x) - t) / B * grad_scale. */
+int dlrm_bce_logits_loss(int64_t B, const float* logits, const float* target, float grad_scale,
+                         float* loss_out, float* dlogits, void* partials, void* stream);
 /* MSELoss(mean): loss = mean((p-t)^2), dp = 2(p-t)/B*grad_scale */
 int dlrm_mse_loss(int64_t B, const float* p, const float* target,
                   float grad_scale, float* loss_out, float* dp, void* partials, void* stream);

@@ -344,3 +344,56 @@ def test_launcher_trains_under_the_unmodified_reference_run(tmp_path):
     assert len(lo) >= 6 and len(lo) == len(lr_), (ours.stdout[-1500:], ref.stdout[-1500:])
     for (i, a), (j, b) in zip(lo, lr_):
         assert i == j and abs(float(a) - float(b)) <= 2e-6 + 1e-5 * float(b), (i, a, b)     # printed with 6 decimals
+
+
+@pytest.mark.parametrize("D,hot,rows", [(128, [3, 1, 7, 2, 1], [50, 7, 3000, 11, 400]), (16, [2, 1, 5], [30, 9, 100])])
+def test_torchrec_variant_with_multihot_inputs_matches_oracle(D, hot, rows):
+    """BASELINE.json configs[4] semantics end to end on the GPU: dlrm_amd.torchrec_variant.DLRM + DLRMTrain (triu interaction
+    order, logits, BCEWithLogitsLoss) fed by dlrm_amd.multihot.Multihot (int32 multi-hot bags expanded on the device), against
+    the oracle's restatement of torchrec's published model, over 2 SGD steps — plus one step with the fused row-wise Adagrad
+    (the optimizer the benchmark uses) against the C oracle's row-wise Adagrad."""
+    from dlrm_amd.multihot import Multihot
+    from dlrm_amd.optim import FusedRWSAdagrad, FusedSGD
+    from dlrm_amd.torchrec_variant import DLRM, DLRMTrain
+    device = torch.device("cuda:0")
+    rng = np.random.default_rng(D)
+    B, dense_in = 64, 13
+    np.random.seed(5)
+    model = DLRM(rows, D, dense_in, [32, D], [48, 24, 1]).to(device)
+    assert not isinstance(list(model.top_l.children())[-1], (torch.nn.ReLU, torch.nn.Sigmoid))
+    init = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    train = DLRMTrain(model)
+    mh = Multihot(hot, rows, B, device=device, seed=3)
+    tabs = [t.cpu().numpy() for t in mh.multi_hot_tables_l]
+    ref = O.OracleDLRM(init, pair_order="triu", final_top_act_none=True, loss="bce_logits")
+    opt = FusedSGD(model.parameters(), lr=0.3)
+    for s in range(2):
+        ids = np.stack([rng.integers(0, n, size=B) for n in rows])
+        X = rng.random((B, dense_in)).astype(np.float32)
+        labels = rng.integers(0, 2, size=B)
+        lS_o, lS_i = mh.to_model_inputs(torch.from_numpy(ids).to(device).int())
+        loss, (loss_d, logits, _) = train(torch.from_numpy(X).to(device), lS_o, lS_i, torch.from_numpy(labels).to(device))
+        v, o = O.multihot_expand(ids, tabs)
+        off = [(o[t * B:(t + 1) * B] - o[t * B]).astype(np.int64) for t in range(len(rows))]
+        idx = [v[o[t * B]:o[(t + 1) * B]].astype(np.int64) for t in range(len(rows))]
+        want_loss, want_logits = ref.train_step(X, off, idx, labels.reshape(B, 1).astype(np.float32), 0.3)
+        np.testing.assert_allclose(logits.cpu().numpy(), want_logits, rtol=2e-5, atol=2e-6)
+        assert abs(float(loss) - want_loss) <= 1e-5 * abs(want_loss), (s, float(loss), want_loss)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    sd = model.state_dict()
+    for k, v in ref.p.items():
+        np.testing.assert_allclose(sd[k].cpu().numpy(), v, rtol=1e-4, atol=5e-6, err_msg=k)
+    # the benchmark's optimizer: fused row-wise Adagrad, lr 0.005, eps 1e-8 — one step must move only the touched rows
+    opt2 = FusedRWSAdagrad(model.parameters(), lr=0.005, eps=1e-8)
+    before = [e.weight.detach().clone() for e in model.emb_l]
+    loss, _ = train(torch.from_numpy(X).to(device), lS_o, lS_i, torch.from_numpy(labels).to(device))
+    opt2.zero_grad()
+    loss.backward()
+    opt2.step()
+    for t, (e, w0) in enumerate(zip(model.emb_l, before)):
+        touched = torch.zeros(rows[t], dtype=torch.bool, device=device)
+        touched[lS_i[t].long()] = True
+        changed = (e.weight != w0).any(dim=1)
+        assert bool((changed & ~touched).sum() == 0) and bool(changed.sum() > 0), t

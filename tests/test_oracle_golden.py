@@ -272,3 +272,46 @@ def test_multihot_restatement_matches_reference_class():
             assert v.dtype == np.int32 and np.array_equal(v, d[f"{c['tag']}.b{b}.values"])
             assert o.dtype == np.int64 and np.array_equal(o, d[f"{c['tag']}.b{b}.offsets"])
             assert o[-1] == b * sum(c["sizes"])
+
+
+def test_torchrec_variant_restatement_against_torch_ops():
+    """BASELINE configs[4] model semantics (torchrec/models/dlrm.py — third-party, absent: parity UNPINNED): the oracle's
+    restatement (triu pair order, logits out of a bare last Linear, BCEWithLogitsLoss) against an independent composition of
+    the torch operators torchrec's published model is made of (bmm + torch.triu_indices + cat, F.linear/relu,
+    F.binary_cross_entropy_with_logits, autograd, SGD)."""
+    import torch
+    import torch.nn.functional as Fn
+    rng = np.random.default_rng(4)
+    D, rows, B = 8, [11, 5, 40], 24
+    ln_bot, ln_top = [6, 16, D], [D + 6, 12, 1]
+    p = {}
+    for k, n in enumerate(rows):
+        p[f"emb_l.{k}.weight"] = rng.standard_normal((n, D)).astype(np.float32) * 0.3
+    for name, ln in (("bot_l", ln_bot), ("top_l", ln_top)):
+        for i in range(len(ln) - 1):
+            p[f"{name}.{2 * i}.weight"] = (rng.standard_normal((ln[i + 1], ln[i])) / np.sqrt(ln[i])).astype(np.float32)
+            p[f"{name}.{2 * i}.bias"] = rng.standard_normal(ln[i + 1]).astype(np.float32) * 0.1
+    X = rng.random((B, 6)).astype(np.float32)
+    hot = [3, 1, 2]
+    idx = [rng.integers(0, n, size=B * h).astype(np.int64) for n, h in zip(rows, hot)]
+    off = [np.arange(B, dtype=np.int64) * h for h in hot]
+    T = rng.integers(0, 2, size=(B, 1)).astype(np.float32)
+    m = O.OracleDLRM(p, pair_order="triu", final_top_act_none=True, loss="bce_logits")
+    loss, Z = m.train_step(X, off, idx, T, 0.5)
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+    x = torch.tensor(X)
+    for i in range(2):
+        x = torch.relu(Fn.linear(x, tp[f"bot_l.{2 * i}.weight"], tp[f"bot_l.{2 * i}.bias"]))
+    ly = [Fn.embedding_bag(torch.tensor(idx[k]), tp[f"emb_l.{k}.weight"], torch.tensor(off[k]), mode="sum") for k in range(3)]
+    comb = torch.stack([x] + ly, dim=1)
+    inter = torch.bmm(comb, comb.transpose(1, 2))
+    iu = torch.triu_indices(4, 4, offset=1)
+    z = torch.cat([x, inter[:, iu[0], iu[1]]], dim=1)
+    z = torch.relu(Fn.linear(z, tp["top_l.0.weight"], tp["top_l.0.bias"]))
+    logits = Fn.linear(z, tp["top_l.2.weight"], tp["top_l.2.bias"])
+    E = Fn.binary_cross_entropy_with_logits(logits, torch.tensor(T))
+    E.backward()
+    np.testing.assert_allclose(Z, logits.detach().numpy(), rtol=1e-5, atol=1e-6)
+    assert abs(loss - float(E)) <= 1e-6 * abs(float(E))
+    for k, v in tp.items():
+        np.testing.assert_allclose(m.p[k], (v - 0.5 * v.grad).detach().numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
