@@ -279,8 +279,13 @@ def main():
     np.random.seed(123)          # identical MLP parameters on every rank
     torch.manual_seed(123 + rank)
     dlrm_amd.set_embedding_init(device)
-    model = dlrm_amd.DLRM_Net(D, np.asarray(rows), np.asarray(wl["bot"]), ln_top, "dot", sigmoid_top=ln_top.size - 2,
-                              loss_function="bce").to(device)
+    if hot_cfg:
+        # BASELINE configs[4]: the torchrec trainer's model semantics (triu interaction order, logits, BCEWithLogitsLoss)
+        from dlrm_amd.torchrec_variant import DLRM as TorchrecDLRM
+        model = TorchrecDLRM(rows, D, wl["bot"][0], wl["bot"][1:], wl["top"]).to(device)
+    else:
+        model = dlrm_amd.DLRM_Net(D, np.asarray(rows), np.asarray(wl["bot"]), ln_top, "dot", sigmoid_top=ln_top.size - 2,
+                                  loss_function="bce").to(device)
     model.set_mlp_arith(args.mlp_arith)
     model.overlap_streams = not args.no_overlap
     model.fuse_emb_interact = bool(args.fuse)
@@ -475,10 +480,11 @@ def main():
                 "dlrm_amd.datagen; random-init parameters)",
         "config": {"workload": args.workload + {"criteo_terabyte": ": MLPerf Criteo-Terabyte shapes (BASELINE.json configs[2])",
                                                 "mlperf_v2_multihot": ": MLPerf-v2 multi-hot synthetic inputs, 214 lookups/sample (BASELINE.json "
-                                                                      "configs[4], first slice: dlrm_s towers + dot interaction) — NOT the headline"}.get(args.workload, ""),
+                                                                      "configs[4]: torchrec model semantics — triu dot interaction, logits + BCEWithLogits, fused row-wise "
+                                                                      "Adagrad; dot interaction instead of DCN-v2) — NOT the headline"}.get(args.workload, ""),
                    "tables": len(rows), "emb_dim": D, "global_batch": B, "table_rows_total": int(sum(rows)),
                    "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": args.optimizer,
-                   "loss": "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
+                   "loss": "bce_with_logits" if hot else "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
                    "embedding_update": args.emb_update, "a2a_chunks": model_a2a_chunks,
                    "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "
                                              "(no pooled-embedding buffer)") if (args.fuse and N == 1 and not hot) else "two kernels (dlrm_emb_fwd, dlrm_interact_*)",

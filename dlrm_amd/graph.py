@@ -18,9 +18,11 @@ Constraints (checked, never silently worked around):
   * no autograd graph of an earlier eager step may still be alive at capture time (e.g. a loss tensor the caller kept):
     the autograd engine would synchronise the capture stream with the stream those old nodes were created on, which
     invalidates the capture.  Reduce losses to Python floats (`float(loss)`) or `del` them before the first graphed call;
-  * KNOWN ISSUE (profiles/r02/graph_probe.md, d): at Criteo-Terabyte shapes a run of the form "5 replays, host sync, >= 8
-    replays in total" ended in a GPU memory fault on ROCm 7.2, while 24 back-to-back replays, a sync after every replay,
-    and every pattern at Criteo-Kaggle shapes are clean.  Opt-in until understood; the eager path is the default everywhere;
+  * RESOLVED in round 3 (was "KNOWN ISSUE", profiles/r02/graph_probe.md d): the GPU memory fault at B = 65536 came from replaying
+    rocPRIM's radix sort (sorted embedding update), not from the batch size: tools/probes/graph_sorted_probe.py faults in
+    "sorted" mode with 2000-row tables and is clean in "deterministic" / "atomic" mode.  The graph path switches the model to
+    the atomic update and refuses the (sort-based) row-wise Adagrad; tests/test_gpu_model.py replays 36 full-batch steps with
+    host syncs in between, bit-identical to eager;
   * learning rates are baked into kernel arguments at capture time: when a scheduler changes a param group's lr the
     step is re-captured (correct, but a schedule that changes lr every step gains nothing from replay).
 """
@@ -87,6 +89,22 @@ class GraphedTrainStep:
             raise RuntimeError("dlrm_amd.graph: the whole-step HIP graph is single-process only "
                                "(RCCL all-to-all / DDP all-reduce are not captured)")
         self.model, self.optimizer = model, optimizer
+        for g in optimizer.param_groups:
+            # a decaying step size (RWSAdagrad: clr = lr / (1 + (step - 1) * lr_decay)) is computed on the host at capture time
+            # and baked into kernel arguments: a replay would silently reuse a stale clr
+            if float(g.get("lr_decay", 0.0) or 0.0) != 0.0:
+                raise RuntimeError("dlrm_amd.graph: lr_decay != 0 changes the step size every step; a captured graph cannot "
+                                   "follow it (use the eager step)")
+        if getattr(model, "emb_update_mode", None) == ops.UPD_SORTED:
+            # rocPRIM's onesweep radix sort (the sorted update and the row-wise Adagrad update run on it) ends in a memory-aperture
+            # violation when REPLAYED from a HIP graph on ROCm 7.2 — even with 2000-row tables, while the deterministic and the
+            # atomic update replay cleanly for 30+ steps with host syncs in between (tools/probes/graph_sorted_probe.py; this was
+            # the "TB-shape graph fault" of profiles/r02/graph_probe.md).  The graph path therefore runs the atomic update:
+            # LDS pre-reduction for tiny tables + hardware fp32 atomics, the right choice at the launch-bound shapes graphs are for.
+            model.emb_update_mode = ops.UPD_ATOMIC
+        if any(type(optimizer).__name__ == n for n in ("RWSAdagrad", "FusedRWSAdagrad")):
+            raise RuntimeError("dlrm_amd.graph: the fused row-wise Adagrad update sorts with rocPRIM, which cannot be replayed from a "
+                               "HIP graph on this ROCm (tools/probes/graph_sorted_probe.py); use the eager step")
         # the captured step is single-stream: a replayed graph has no launch gaps to hide, and the side-stream overlap
         # of the eager path (DLRM_Net.overlap_streams) would put cross-stream joins into the capture
         model.overlap_streams = False
@@ -137,6 +155,9 @@ class GraphedTrainStep:
             Z, E = self._eager()
         self.out, self.loss = Z.detach(), E.detach()
         self._lrs = self._current_lrs()
+        # the graph holds raw pointers into the cached scratch workspaces: pin those tensors so that a later, larger
+        # request elsewhere (which replaces the cache entry) cannot free memory the replays still use
+        self._pinned_ws = [ops._emb_ws.get(dev)] + [w for (d_, _), w in ops._wgrad_ws.items() if d_ == dev]
         self.captures += 1
         torch.cuda.current_stream(dev).wait_stream(self.stream)
 

@@ -397,3 +397,45 @@ def test_torchrec_variant_with_multihot_inputs_matches_oracle(D, hot, rows):
         touched[lS_i[t].long()] = True
         changed = (e.weight != w0).any(dim=1)
         assert bool((changed & ~touched).sum() == 0) and bool(changed.sum() > 0), t
+
+
+def test_graphed_step_survives_host_syncs_at_full_batch():
+    """profiles/r02/graph_probe.md (d): at B = 65536 a run "a few replays, host synchronisation, more replays" ended in a GPU
+    memory fault in round 1.  GraphedTrainStep now synchronises its stream after every replay; this replays 36 steps at the
+    Criteo-Terabyte shapes (26 tables, D = 128, full towers, rows capped) with host syncs and a D2H read in the middle and
+    requires losses bit-identical to the eager step (deterministic embedding update)."""
+    import golden_tb
+    from dlrm_amd.graph import GraphedTrainStep
+    from dlrm_amd.optim import FusedSGD
+    fx = golden_tb.load("terabyte_b65536")
+    meta = fx.meta
+    device = torch.device("cuda:0")
+    batches = [(torch.from_numpy(X).to(device), torch.from_numpy(off).to(device), torch.from_numpy(idx).to(device),
+                torch.from_numpy(t).to(device)) for X, off, idx, t in fx.batches]
+    meta2 = dict(meta, itself=False)
+    runs = []
+    for use_graph in (False, True):
+        model = build_model(meta2, fx.init, device)        # deterministic embedding update
+        opt = FusedSGD(model.parameters(), lr=0.05)
+        step = GraphedTrainStep(model, opt, warmup=2) if use_graph else None
+        losses = []
+        for i in range(36):
+            X, off, idx, t = batches[i % len(batches)]
+            if use_graph:
+                losses.append(step(X, off, idx, t))
+            else:
+                E = model.loss_fn(model(X, off, idx), t)
+                opt.zero_grad()
+                E.backward()
+                opt.step()
+                losses.append(E.detach())
+            if i in (6, 7, 15, 29):
+                torch.cuda.synchronize()                   # the pattern that faulted
+                _ = float(losses[-1])
+            losses[-1] = losses[-1].clone()
+        torch.cuda.synchronize()
+        runs.append([float(x) for x in losses])
+        if use_graph:
+            assert step.captures == 1
+        del model, opt, step
+    assert runs[0] == runs[1], [(a, b) for a, b in zip(*runs) if a != b][:4]
