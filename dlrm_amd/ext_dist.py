@@ -291,3 +291,102 @@ def all_gather(x: torch.Tensor, lengths: Optional[List[int]], dim: int = 0) -> t
     elif not isinstance(lengths, (list, tuple)):
         lengths = [lengths] * my_size
     return _AllGather.apply(x, list(lengths), dim)
+
+
+# ------------------------------------------------------------------------------------------------
+# input distribution of key-major id batches and row-wise shard collectives.
+# The reference's torchrec trainer leaves both to torchrec's DistributedModelParallel (third-party, absent:
+# torchrec_dlrm/dlrm_main.py:669-673); `dlrm_s_pytorch.py` avoids them by replicating the inputs on every rank (:1541-1548).
+# ------------------------------------------------------------------------------------------------
+def _host_staged(t: torch.Tensor) -> bool:
+    return t.is_cuda and dist.get_backend() == "gloo"       # the 1-GPU test rig: several ranks on one device, gloo rendezvous
+
+
+def kjt_input_dist(values: torch.Tensor, hot: Sequence[int], tw_owner: Sequence[int], rw_tables: Sequence[int]):
+    """Every rank holds the ids of ITS batch slice for ALL tables, key-major like the KJT the reference builds per rank
+    (`values` = cat over tables t of [Bl * hot[t]] ids, multi_hot_criteo.py:200-214).  Returns, in GLOBAL batch order,
+      tw: {t: ids [B * hot[t]]} for the table-wise tables this rank owns   (one all_to_all_single of ids), and
+      rw: {t: ids [B * hot[t]]} for every row-wise table                   (one all_gather of ids)
+    tw_owner[t] = owning rank of table t, or -1 for row-wise tables."""
+    N, me = my_size, my_rank
+    T = len(hot)
+    seg = [0]
+    Bl = None
+    for h in hot:
+        seg.append(seg[-1] + h)
+    if values.numel() % seg[-1] != 0:
+        raise RuntimeError("kjt_input_dist: values length is not a multiple of the lookups per sample")
+    Bl = values.numel() // seg[-1]
+    piece = lambda t: values[Bl * seg[t]:Bl * seg[t + 1]]
+    owned = [[t for t in range(T) if tw_owner[t] == r] for r in range(N)]
+    # ---- table-wise: destination-major send buffer
+    send = torch.cat([piece(t) for r in range(N) for t in owned[r]]) if any(owned) else values.new_empty(0)
+    send_counts = [Bl * sum(hot[t] for t in owned[r]) for r in range(N)]
+    mine = owned[me]
+    per_src = Bl * sum(hot[t] for t in mine)
+    recv = values.new_empty(N * per_src)
+    if sum(send_counts) + recv.numel() > 0:
+        if _host_staged(values):
+            h_out = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(h_out, send.cpu(), [per_src] * N, send_counts)
+            recv.copy_(h_out)
+        else:
+            dist.all_to_all_single(recv, send, [per_src] * N, send_counts)
+    tw, o = {}, 0
+    rv = recv.view(N, per_src) if per_src else recv
+    for t in mine:                                             # [N, Bl*h_t] -> [B*h_t]: source-major == global batch order
+        w = Bl * hot[t]
+        tw[t] = rv[:, o:o + w].reshape(-1)
+        o += w
+    # ---- row-wise: everybody needs everybody's ids
+    rw = {}
+    if rw_tables:
+        mine_rw = torch.cat([piece(t) for t in rw_tables])
+        gathered = values.new_empty(N * mine_rw.numel())
+        if _host_staged(values):
+            h_out = torch.empty(gathered.shape, dtype=gathered.dtype)
+            dist.all_gather_into_tensor(h_out, mine_rw.cpu())
+            gathered.copy_(h_out)
+        else:
+            dist.all_gather_into_tensor(gathered, mine_rw.contiguous())
+        gv, o = gathered.view(N, -1), 0
+        for t in rw_tables:
+            w = Bl * hot[t]
+            rw[t] = gv[:, o:o + w].reshape(-1)
+            o += w
+    return tw, rw
+
+
+class _ReduceScatterRows(Function):
+    """[B, W] partial sums on every rank -> this rank's batch slice [B/N, W] of their sum; backward = all-gather of the gradient.
+    RCCL reduce_scatter_tensor; gloo (CPU tests, 1-GPU rig) has none: all_reduce + slice there."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B = x.size(0)
+        Bl = B // my_size
+        ctx.B = B
+        if dist.get_backend() == "gloo":
+            h = x.cpu() if x.is_cuda else x.clone()
+            dist.all_reduce(h)
+            return h[my_rank * Bl:(my_rank + 1) * Bl].to(x.device).contiguous()
+        out = x.new_empty((Bl, x.size(1)))
+        dist.reduce_scatter_tensor(out, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out = g.new_empty((ctx.B, g.size(1)))
+        if _host_staged(g):
+            h = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h, g.cpu())
+            out.copy_(h)
+        else:
+            dist.all_gather_into_tensor(out, g)
+        return out
+
+
+def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
+    return _ReduceScatterRows.apply(x)

@@ -206,13 +206,17 @@ class InteractFunction(Function):
 
     @staticmethod
     def forward(ctx, D, self_interaction, padded, *blocks):
+        order = None
+        if blocks and isinstance(blocks[0], (list, tuple)):          # optional leading feature permutation (see ops.interact_fwd)
+            order, blocks = list(blocks[0]), blocks[1:]
         blocks = tuple(_rowmajor(b) for b in blocks)
         B = blocks[0].size(0)
         F = sum(b.size(1) // D for b in blocks)
         Wd = ops.interact_out_width(F, D, self_interaction)
         ldr = _round4(Wd)
         Rfull = torch.empty((B, ldr), dtype=torch.float32, device=blocks[0].device)
-        ops.interact_fwd(blocks, D, self_interaction, Rfull)
+        ops.interact_fwd(blocks, D, self_interaction, Rfull, order=order)
+        ctx.order = order
         ctx.D, ctx.self_interaction, ctx.width = D, self_interaction, Wd
         ctx.save_for_backward(*blocks)
         # padded=True hands out the whole [B, round4(width)] buffer (zero padding columns) for MLPFunction
@@ -232,8 +236,8 @@ class InteractFunction(Function):
             n = B * b.size(1)
             dblocks.append(flat[o:o + n].view(B, b.size(1)))
             o += n
-        ops.interact_bwd(blocks, ctx.D, ctx.self_interaction, dR, dblocks)
-        return (None, None, None, *dblocks)
+        ops.interact_bwd(blocks, ctx.D, ctx.self_interaction, dR, dblocks, order=ctx.order)
+        return (None, None, None, *dblocks) if ctx.order is None else (None, None, None, None, *dblocks)
 
 
 class GatherInteractFunction(Function):

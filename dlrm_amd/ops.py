@@ -135,6 +135,7 @@ class BagBatch:
         if len(lS_o) != T:
             raise RuntimeError("dlrm_amd: offsets / indices table counts differ")
         self.T = T
+        self.ignore_oob = False   # True: out-of-range ids are expected (row-wise shards: ids of other ranks' rows) — skipped, not reported
         self.keep = []  # keep tensors alive while kernels may still read them
         if isinstance(lS_i, torch.Tensor) and isinstance(lS_o, torch.Tensor) and lS_i.dim() == 2 and lS_o.dim() == 2:
             # stacked [T, n] inputs (what the reference's collate functions build, dlrm_data_pytorch.py:686,337): the
@@ -233,7 +234,7 @@ def emb_fwd(weights: Sequence[torch.Tensor], bags: BagBatch, out: torch.Tensor) 
     with _timed("emb_fwd"):
         rc = lib.dlrm_emb_fwd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
                               bags.idx_bits, C.c_void_p(out.data_ptr()), _ld(out),
-                              C.c_void_p(_err_block(out.device).data_ptr()), _stream(out))
+                              None if bags.ignore_oob else C.c_void_p(_err_block(out.device).data_ptr()), _stream(out))
     _lib.check(rc, "dlrm_emb_fwd")
     return out
 
@@ -267,7 +268,7 @@ def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Ten
     with _timed("emb_bwd_sgd"):
         rc = lib.dlrm_emb_bwd_sgd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
                                   bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout), float(lr), int(mode),
-                                  ws_ptr, ws_bytes, C.c_void_p(_err_block(dout.device).data_ptr()), _stream(dout))
+                                  ws_ptr, ws_bytes, None if bags.ignore_oob else C.c_void_p(_err_block(dout.device).data_ptr()), _stream(dout))
     _lib.check(rc, "dlrm_emb_bwd_sgd")
 
 
@@ -294,7 +295,7 @@ def emb_bwd_rowwise_adagrad(weights: Sequence[torch.Tensor], states: Sequence[to
         rc = lib.dlrm_emb_bwd_rowwise_adagrad(bags.T, bags.B, D, wp, sp, rows, bags._idx, bags._off, bags._nnz,
                                               bags._psw, bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout),
                                               float(lr), float(eps), C.c_void_p(ws.data_ptr()), ws.numel(),
-                                              C.c_void_p(_err_block(dout.device).data_ptr()), _stream(dout))
+                                              None if bags.ignore_oob else C.c_void_p(_err_block(dout.device).data_ptr()), _stream(dout))
     _lib.check(rc, "dlrm_emb_bwd_rowwise_adagrad")
 
 
@@ -337,9 +338,17 @@ def interact_out_width(F: int, D: int, self_interaction) -> int:
     return D + (F * (F + 1) // 2 if (int(self_interaction) & 1) else F * (F - 1) // 2)
 
 
-def interact_fwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool, R: torch.Tensor) -> torch.Tensor:
+def _permute(order, *lists):
+    return lists if order is None else tuple([l[i] for i in order] for l in lists)
+
+
+def interact_fwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool, R: torch.Tensor, order=None) -> torch.Tensor:
+    """order: optional permutation — canonical feature f is the order[f]-th feature of the block list (lets the interaction read
+    features that live in several buffers, e.g. all-to-all blocks of table-wise shards + the reduce-scatter block of row-wise
+    ones, in global table order without copying them together)"""
     lib = _lib.load()
     B, ptrs, lds = _feature_table(blocks, D)
+    ptrs, lds = _permute(order, ptrs, lds)
     _req(R, "R", ndim=2)
     F = len(ptrs)
     if R.size(0) != B or R.size(1) < interact_out_width(F, D, self_interaction):
@@ -402,10 +411,11 @@ def interact_bwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: 
 
 
 def interact_bwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool, dR: torch.Tensor,
-                 dblocks: Sequence[torch.Tensor]) -> None:
+                 dblocks: Sequence[torch.Tensor], order=None) -> None:
     lib = _lib.load()
     B, ptrs, lds = _feature_table(blocks, D)
     B2, dptrs, dlds = _feature_table(dblocks, D)
+    ptrs, lds, dptrs, dlds = _permute(order, ptrs, lds, dptrs, dlds)
     _req(dR, "dR", ndim=2)
     if B != B2 or len(ptrs) != len(dptrs) or dR.size(0) != B:
         raise RuntimeError("dlrm_amd: interact_bwd shape mismatch")

@@ -66,3 +66,129 @@ class DLRMTrain(nn.Module):
         lab = labels.to(torch.float32).reshape(logits.shape)
         loss = self.loss_fn(logits, lab)
         return loss, (loss.detach(), logits.detach(), labels)
+
+
+class ShardedDLRM(DLRM_Net):
+    """the same model on N ranks with PLANNED sharding (dlrm_amd.sharding.plan) and NON-replicated inputs.
+
+      * every rank feeds only its batch slice: dense [B/N, 13] and key-major ids (`values`: for table t the B/N * hot[t] ids of
+        its samples — the per-rank KJT of the reference's torchrec loader, multi_hot_criteo.py:200-214);
+      * `ext_dist.kjt_input_dist`: one all-to-all of ids brings every table-wise table's whole-batch ids to its owner, one
+        all-gather gives every rank the whole-batch ids of the row-wise tables;
+      * table-wise tables: pooled for the whole batch by the owner, pooled rows to the sample owners by the existing all-to-all;
+      * row-wise tables: every rank pools the rows of ITS contiguous row range (ids of other ranges are skipped by the kernel:
+        `BagBatch.ignore_oob`), the partial sums meet in a reduce-scatter over the batch; backward all-gathers the gradient rows
+        and every rank updates its own rows;
+      * interaction on the local batch slice reads the all-to-all blocks and the reduce-scatter block IN PLACE in global table
+        order through the kernel's {pointer, stride} table (`InteractFunction(order=...)`).
+    Embedding gradients are not divided by N (the reference's behaviour in both trainers: the loss is the mean over the LOCAL
+    batch; DDP averages only the dense parameters)."""
+
+    def __init__(self, num_embeddings_per_feature: Sequence[int], multi_hot_sizes: Sequence[int], embedding_dim: int,
+                 dense_in_features: int, dense_arch_layer_sizes: Sequence[int], over_arch_layer_sizes: Sequence[int],
+                 global_batch: int, plan=None):
+        from . import ext_dist, sharding
+        from .dlrm_net import EmbeddingUpdateHook
+        super().__init__()                                   # empty shell: flags, pending list, stream state
+        N, me = max(ext_dist.my_size, 1), max(ext_dist.my_rank, 0)
+        rows, hot, D = [int(n) for n in num_embeddings_per_feature], [int(h) for h in multi_hot_sizes], int(embedding_dim)
+        self.plan = plan if plan is not None else sharding.plan(rows, hot, D, N, global_batch)
+        self.rows, self.hot, self.m_spa, self.world, self.rank = rows, hot, D, N, me
+        self.arch_interaction_op, self.arch_interaction_itself, self.interaction_order = "dot", False, "triu"
+        self.loss_threshold, self.weighted_pooling, self.quantize_emb, self.ndevices = 0.0, None, False, -1
+        self.tw_owner = [-1] * len(rows)
+        for s_ in self.plan.shards:
+            if s_.kind == "table":
+                self.tw_owner[s_.table] = s_.rank
+        self.rw_tables = self.plan.row_wise()
+        self.tw_mine = self.plan.table_wise(me)
+        self.tw_per_rank = self.plan.tables_per_rank()
+        if N > 1 and min(self.tw_per_rank) == 0:
+            raise ValueError("ShardedDLRM: every rank needs at least one table-wise table (plan %s)" % self.tw_per_rank)
+        self.rw_range = {s_.table: s_.row_ranges[me] for s_ in self.plan.shards if s_.kind == "row"}
+        T = len(rows)
+        F = T + 1
+        ln_bot = np.asarray([dense_in_features] + list(dense_arch_layer_sizes))
+        ln_top = np.asarray([D + F * (F - 1) // 2] + list(over_arch_layer_sizes))
+        local_rows = [rows[t] for t in self.tw_mine] + [self.rw_range[t][1] - self.rw_range[t][0] for t in self.rw_tables]
+        saved = ext_dist.my_size
+        ext_dist.my_size = 1                                 # create_emb: build exactly the listed (local) tables
+        try:
+            self.emb_l, self.v_W_l = self.create_emb(D, np.asarray(local_rows), None)
+        finally:
+            ext_dist.my_size = saved
+        self.bot_l = self.create_mlp(ln_bot, -1)
+        top = self.create_mlp(ln_top, -1)
+        self.top_l = FusedMLP(*list(top.children())[:-1])    # bare last Linear -> logits
+        self.loss_fn = FusedBCEWithLogitsLoss()
+        # canonical feature f (0 = dense, 1 + t = table t) -> position in the block list [x | a2a block of rank 0.. | rw block]
+        pos, k = {}, 1
+        for r in range(N):
+            for t in self.plan.table_wise(r):
+                pos[t] = k
+                k += 1
+        for t in self.rw_tables:
+            pos[t] = k
+            k += 1
+        self.feature_order = [0] + [pos[t] for t in range(T)]
+        self._offs = {}
+        EmbeddingUpdateHook.register(self)
+
+    def load_full_state(self, full: dict) -> None:
+        """copy this rank's shards out of a full (single-process) state_dict: emb_l.{t}.weight, bot_l.*, top_l.*"""
+        with torch.no_grad():
+            j = 0
+            for t in self.tw_mine:
+                self.emb_l[j].weight.copy_(torch.as_tensor(full[f"emb_l.{t}.weight"]))
+                j += 1
+            for t in self.rw_tables:
+                lo, hi = self.rw_range[t]
+                self.emb_l[j].weight.copy_(torch.as_tensor(full[f"emb_l.{t}.weight"])[lo:hi])
+                j += 1
+            for name, p in list(self.bot_l.named_parameters()):
+                p.copy_(torch.as_tensor(full[f"bot_l.{name}"]))
+            for name, p in list(self.top_l.named_parameters()):
+                p.copy_(torch.as_tensor(full[f"top_l.{name}"]))
+
+    def _bag_starts(self, B: int, h: int, like: torch.Tensor) -> torch.Tensor:
+        key = (B, h, like.device, like.dtype)
+        if key not in self._offs:
+            self._offs[key] = torch.arange(B, device=like.device, dtype=like.dtype) * h
+        return self._offs[key]
+
+    def forward(self, dense_x, values):
+        from . import ext_dist, ops
+        from .functional import EmbeddingBagsFunction, InteractFunction
+        N, D = self.world, self.m_spa
+        Bl = dense_x.size(0)
+        B = Bl * N
+        ops.check_index_errors()
+        if N > 1:
+            tw, rw = ext_dist.kjt_input_dist(values, self.hot, self.tw_owner, self.rw_tables)
+        else:                                                # one rank: every table is "mine", nothing is exchanged
+            seg, tw, rw = 0, {}, {}
+            for t, h in enumerate(self.hot):
+                tw[t] = values[seg:seg + Bl * h]
+                seg += Bl * h
+        n_tw = len(self.tw_mine)
+        w_tw = [self.emb_l[j].weight for j in range(n_tw)]
+        w_rw = [self.emb_l[n_tw + j].weight for j in range(len(self.rw_tables))]
+        bags = ops.BagBatch([self._bag_starts(B, self.hot[t], values) for t in self.tw_mine], [tw[t] for t in self.tw_mine])
+        E_tw = EmbeddingBagsFunction.apply(self._stash_embedding_grad, bags, None, *w_tw)          # [B, n_tw * D]
+        blocks = []
+        if N > 1:
+            req = ext_dist.alltoall([E_tw], self.tw_per_rank, emb_dim=D)
+        if self.rw_tables:
+            ids = []
+            for t in self.rw_tables:                         # ids of other ranks' rows become -1: skipped by the kernels
+                lo, hi = self.rw_range[t]
+                v = rw[t]
+                ids.append(torch.where((v >= lo) & (v < hi), v - lo, torch.full_like(v, -1)))
+            bags_rw = ops.BagBatch([self._bag_starts(B, self.hot[t], values) for t in self.rw_tables], ids)
+            bags_rw.ignore_oob = True
+            E_rw = EmbeddingBagsFunction.apply(self._stash_embedding_grad, bags_rw, None, *w_rw)   # partial sums, whole batch
+            E_rw = ext_dist.reduce_scatter_rows(E_rw)                                              # [B/N, n_rw * D]
+        x = self.apply_mlp(dense_x, self.bot_l)
+        blocks = [x] + (list(req.wait()) if N > 1 else [E_tw]) + ([E_rw] if self.rw_tables else [])
+        z = InteractFunction.apply(D, self._interaction_mode(), True, list(self.feature_order), *blocks)
+        return self.apply_mlp(z, self.top_l)

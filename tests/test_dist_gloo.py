@@ -146,3 +146,85 @@ def test_pipelined_exchange_equals_single_exchange(size, T, B, D, C):
             assert np.array_equal(results[r]["outs1"][s], results[r]["outs2"][s]), (r, s)
         assert np.array_equal(results[r]["g1"], results[r]["g2"]), r
         assert np.abs(results[r]["g1"]).min() > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# planned sharding, key-major id input distribution, row-wise shard collectives
+# ---------------------------------------------------------------------------------------------------------------------
+MLPERF_ROWS = [40000000, 39060, 17295, 7424, 20265, 3, 7122, 1543, 63, 40000000, 3067956, 405282, 10, 2209, 11938, 155, 4, 976, 14,
+               40000000, 40000000, 40000000, 590152, 12973, 108, 36]
+MLPERF_HOT = [3, 2, 1, 2, 6, 1, 1, 1, 1, 7, 3, 8, 1, 6, 9, 5, 1, 1, 1, 12, 100, 27, 10, 3, 1, 1]
+
+
+def test_sharding_plan_balances_the_mlperf_v2_tables():
+    """The reference's contiguous blocks leave one rank with 1.6x / 2.6x / 5.0x the mean lookup traffic at 2 / 4 / 8 ranks (the
+    100-hot 40 M-row table); the planner shards the tables nobody can absorb row-wise and places the rest longest-first."""
+    from dlrm_amd import sharding as S
+    for world, ref_imb in ((2, 1.6), (4, 2.5), (8, 4.9)):
+        p = S.plan(MLPERF_ROWS, MLPERF_HOT, 128, world, 65536)
+        assert sorted(s.table for s in p.shards) == list(range(26))                     # every table placed exactly once
+        assert 20 in p.row_wise() and p.imbalance() < 1.05
+        assert min(p.tables_per_rank()) >= 1 and max(p.rank_bytes) <= 250e9
+        for s in p.shards:
+            if s.kind == "row":
+                assert s.row_ranges[0][0] == 0 and s.row_ranges[-1][1] == MLPERF_ROWS[s.table]
+                assert all(a[1] == b[0] for a, b in zip(s.row_ranges, s.row_ranges[1:]))
+        own = S.reference_plan(26, world)
+        rc = [sum(p.cost[t] for t in range(26) if own[t] == r) for r in range(world)]
+        assert max(rc) / (sum(rc) / world) > ref_imb
+    assert S.split_rows(10, 4) == ((0, 3), (3, 6), (6, 8), (8, 10))
+    one = S.plan([5, 6], [1, 2], 16, 1, 8)
+    assert one.row_wise() == [] and one.table_wise(0) == [0, 1]
+
+
+def _kjt_worker(rank, size, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank))
+    from dlrm_amd import ext_dist
+    ext_dist.init_distributed(rank=rank, local_rank=rank, size=size, use_gpu=False, backend="gloo")
+    hot = [2, 1, 3, 1, 2]
+    owner = [1 % size, 0, -1, (size - 1), 0]                  # table 2 is row-wise
+    Bl = 4
+    # id of (table t, global sample g, slot j) = 10000*t + 10*g + j
+    vals = []
+    for t, h in enumerate(hot):
+        for b in range(Bl):
+            g = rank * Bl + b
+            vals += [10000 * t + 10 * g + j for j in range(h)]
+    tw, rw = ext_dist.kjt_input_dist(torch.tensor(vals, dtype=torch.int32), hot, owner, [2])
+    # row-wise partial sums: rank r contributes (r + 1) * ones -> reduce-scatter gives sum, backward all-gathers
+    x = torch.full((Bl * size, 3), float(rank + 1), requires_grad=True)
+    y = ext_dist.reduce_scatter_rows(x * torch.arange(Bl * size, dtype=torch.float32).view(-1, 1))
+    (y * (rank + 1)).sum().backward()
+    q.put((rank, {"tw": {t: v.numpy().copy() for t, v in tw.items()}, "rw": {t: v.numpy().copy() for t, v in rw.items()},
+                  "y": y.detach().numpy().copy(), "gx": x.grad.numpy().copy()}))
+    ext_dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("size", [2, 4])
+def test_kjt_input_dist_and_row_wise_collectives(size):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_kjt_worker, args=(r, size, port, q)) for r in range(size)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(size))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    hot, Bl = [2, 1, 3, 1, 2], 4
+    owner = [1 % size, 0, -1, (size - 1), 0]
+    B = Bl * size
+    want = lambda t: np.asarray([10000 * t + 10 * g + j for g in range(B) for j in range(hot[t])], dtype=np.int32)
+    for r in range(size):
+        assert sorted(results[r]["tw"]) == [t for t in range(5) if owner[t] == r]
+        for t, v in results[r]["tw"].items():
+            assert np.array_equal(v, want(t)), (r, t)                     # whole batch, global order, on the owner only
+        assert list(results[r]["rw"]) == [2] and np.array_equal(results[r]["rw"][2], want(2))
+        tot = sum(range(1, size + 1))
+        rows = np.arange(r * Bl, (r + 1) * Bl, dtype=np.float32).reshape(-1, 1)
+        assert np.array_equal(results[r]["y"], np.repeat(rows * tot, 3, axis=1))
+        # d/dx[g] = (owner_of_row(g) + 1) * g   (the owner's upstream gradient, all-gathered back to every rank)
+        g = np.arange(B, dtype=np.float32)
+        assert np.array_equal(results[r]["gx"], np.repeat(((g // Bl + 1) * g).reshape(-1, 1), 3, axis=1))
