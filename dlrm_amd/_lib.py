@@ -36,6 +36,8 @@ SIGNATURES = {
     "dlrm_emb_bwd_workspace_bytes": (_i64, [_i32, _pi64, _pi64]),
     "dlrm_emb_bwd_sgd": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64,
                                 _f32, _i32, _vp, _i64, _vp, _vp]),
+    "dlrm_pool_weights_gather": (_i32, [_i32, _pi64, _pp, _pi64, _i32, _pp, _pp, _vp, _vp]),
+    "dlrm_emb_psw_grad": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _i32, _vp, _i64, _pp, _vp]),
     "dlrm_emb_bwd_coo": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _i32, _vp, _i64, _pp, _vp]),
     "dlrm_emb_adagrad_workspace_bytes": (_i64, [_i32, _i32, _pi64, _pi64]),
     "dlrm_emb_bwd_rowwise_adagrad": (_i32, [_i32, _i64, _i32, _pp, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32,

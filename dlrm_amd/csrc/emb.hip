@@ -350,6 +350,54 @@ __global__ __launch_bounds__(256) void emb_bwd_coo_kernel(EmbArgs a, CooArgs ca,
 }
 
 // -------------------------------------------------------------------------------------------
+// learned / fixed pooling weights (--weighted-pooling, dlrm_s_pytorch.py:289-293, 425-428):
+//   forward   psw_t[i] = vW_t[idx_t[i]]                                  (`v_W_l[k].gather(0, indices)`)
+//   backward  dvW_t[idx_t[i]] += < dout[bag(i), t*D:(t+1)*D], W_t[idx_t[i], :] >      (EmbeddingBag's per_sample_weights
+//             gradient followed by the gather's scatter-add, fused: one wavefront per bag, a wave-wide dot per lookup)
+// -------------------------------------------------------------------------------------------
+struct PoolArgs { float* vw[DLRM_MAX_TABLES_PER_LAUNCH]; float* out[DLRM_MAX_TABLES_PER_LAUNCH]; };
+
+template <typename IT>
+__global__ __launch_bounds__(256) void pool_weights_gather_kernel(EmbArgs a, PoolArgs pa) {
+    const int t = blockIdx.y;
+    const IT* __restrict__ idx = (const IT*)a.idx[t];
+    const float* __restrict__ vw = pa.vw[t];
+    float* __restrict__ out = pa.out[t];
+    const long long n = a.nnz[t], rows = a.rows[t];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = (long long)idx[i];
+        float v = 0.f;
+        if (dlrm_index_ok(r, rows)) v = vw[r]; else dlrm_report_bad_index(a.err, a.slot[t], r, rows);
+        out[i] = v;
+    }
+}
+
+template <typename IT>
+__global__ __launch_bounds__(256) void emb_psw_grad_kernel(EmbArgs a, PoolArgs pa, long long B, int D,
+                                                           const float* __restrict__ dout, long long dout_ld) {
+    const int t = blockIdx.y;
+    const float* __restrict__ W = a.w[t];
+    const IT* __restrict__ idx = (const IT*)a.idx[t];
+    const IT* __restrict__ off = (const IT*)a.off[t];
+    float* __restrict__ dvw = pa.vw[t];
+    const long long nnz = a.nnz[t], rows = a.rows[t];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long b = (long long)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    const long long s = (long long)off[b];
+    const long long e = (b + 1 < B) ? (long long)off[b + 1] : nnz;
+    const float* g = dout + b * dout_ld + (long long)a.slot[t] * D;
+    for (long long i = s; i < e; ++i) {
+        const long long r = (long long)idx[i];
+        if (!dlrm_index_ok(r, rows)) continue;                 // already reported by the forward pass
+        float acc = 0.f;
+        for (int d = lane; d < D; d += 64) acc = __builtin_fmaf(g[d], W[r * D + d], acc);
+        acc = dlrm_wave_sum(acc);
+        if (lane == 0) atomicAdd(dvw + r, acc);
+    }
+}
+
+// -------------------------------------------------------------------------------------------
 // host-side dispatch
 // -------------------------------------------------------------------------------------------
 struct Shape { int vec, lpb, nch; };
@@ -560,6 +608,63 @@ extern "C" int dlrm_emb_bwd_coo(int T, int64_t B, int D, const void* const* offs
         dim3 grid((unsigned)((B + 3) / 4), (unsigned)n, 1), block(256, 1, 1);
         if (idx_bits == 64) hipLaunchKernelGGL(emb_bwd_coo_kernel<long long>, grid, block, 0, st, a, ca, (long long)B, D, dout, (long long)dout_ld);
         else                hipLaunchKernelGGL(emb_bwd_coo_kernel<int>, grid, block, 0, st, a, ca, (long long)B, D, dout, (long long)dout_ld);
+        DLRM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int dlrm_pool_weights_gather(int T, const int64_t* rows_host, const void* const* indices_host, const int64_t* nnz_host,
+                                        int idx_bits, const void* const* vw_host, void* const* psw_out_host, int64_t* err,
+                                        void* stream) {
+    if (T <= 0 || !rows_host || !indices_host || !nnz_host || !vw_host || !psw_out_host) return DLRM_E_ARG;
+    if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
+    hipStream_t st = (hipStream_t)stream;
+    for (int t0 = 0; t0 < T; t0 += DLRM_MAX_TABLES_PER_LAUNCH) {
+        const int n = (T - t0 < DLRM_MAX_TABLES_PER_LAUNCH) ? T - t0 : DLRM_MAX_TABLES_PER_LAUNCH;
+        EmbArgs a = {};
+        PoolArgs pa = {};
+        a.err = (long long*)err;
+        long long most = 0;
+        for (int k = 0; k < DLRM_MAX_TABLES_PER_LAUNCH; ++k) {
+            const int t = t0 + (k < n ? k : 0);
+            if (nnz_host[t] < 0 || rows_host[t] <= 0 || (nnz_host[t] > 0 && (!indices_host[t] || !vw_host[t] || !psw_out_host[t]))) return DLRM_E_ARG;
+            a.idx[k] = indices_host[t]; a.nnz[k] = k < n ? nnz_host[t] : 0; a.rows[k] = rows_host[t]; a.slot[k] = t;
+            pa.vw[k] = (float*)vw_host[t]; pa.out[k] = (float*)psw_out_host[t];
+            if (k < n && nnz_host[t] > most) most = nnz_host[t];
+        }
+        if (most == 0) continue;
+        long long nb = (most + 255) / 256; if (nb > 1024) nb = 1024;
+        dim3 grid((unsigned)nb, (unsigned)n, 1), block(256);
+        if (idx_bits == 64) hipLaunchKernelGGL(pool_weights_gather_kernel<long long>, grid, block, 0, st, a, pa);
+        else                hipLaunchKernelGGL(pool_weights_gather_kernel<int>, grid, block, 0, st, a, pa);
+        DLRM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int dlrm_emb_psw_grad(int T, int64_t B, int D, const void* const* weight_host, const int64_t* rows_host,
+                                 const void* const* indices_host, const void* const* offsets_host, const int64_t* nnz_host,
+                                 int idx_bits, const float* dout, int64_t dout_ld, void* const* dvw_host, void* stream) {
+    int rc = check_common(T, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host, idx_bits);
+    if (rc) return rc;
+    if (!dout || dout_ld < (int64_t)T * D || !dvw_host) return DLRM_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int t = 0; t < T; ++t) {                    // dvW is an OUTPUT: zeroed here, then accumulated with atomics
+        if (!dvw_host[t]) return DLRM_E_ARG;
+        hipError_t e = hipMemsetAsync(dvw_host[t], 0, (size_t)rows_host[t] * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    for (int t0 = 0; t0 < T; t0 += DLRM_MAX_TABLES_PER_LAUNCH) {
+        const int n = (T - t0 < DLRM_MAX_TABLES_PER_LAUNCH) ? T - t0 : DLRM_MAX_TABLES_PER_LAUNCH;
+        int ids[DLRM_MAX_TABLES_PER_LAUNCH];
+        for (int k = 0; k < n; ++k) ids[k] = t0 + k;
+        EmbArgs a;
+        fill_args(a, ids, n, (void* const*)weight_host, rows_host, indices_host, offsets_host, nnz_host, nullptr, nullptr);
+        PoolArgs pa = {};
+        for (int k = 0; k < DLRM_MAX_TABLES_PER_LAUNCH; ++k) pa.vw[k] = (float*)dvw_host[t0 + (k < n ? k : 0)];
+        dim3 grid((unsigned)((B + 3) / 4), (unsigned)n, 1), block(256);
+        if (idx_bits == 64) hipLaunchKernelGGL(emb_psw_grad_kernel<long long>, grid, block, 0, st, a, pa, (long long)B, D, dout, (long long)dout_ld);
+        else                hipLaunchKernelGGL(emb_psw_grad_kernel<int>, grid, block, 0, st, a, pa, (long long)B, D, dout, (long long)dout_ld);
         DLRM_LAUNCH_CHECK();
     }
     return 0;

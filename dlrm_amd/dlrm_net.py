@@ -249,8 +249,10 @@ class DLRM_Net(nn.Module):
                      "GPU (torchrun) to use table-sharded embeddings over RCCL" % ndevices)
         self.emb_l, pool_w = self.create_emb(m_spa, ln_emb, weighted_pooling)
         if self.weighted_pooling == "learned":
-            sys.exit("ERROR: learned weighted pooling is not supported by the MI355X DLRM_Net yet")
-        self.v_W_l = pool_w
+            # dlrm_s_pytorch.py:370-375: the per-row pooling weights become parameters (state_dict keys v_W_l.{k})
+            self.v_W_l = nn.ParameterList([nn.Parameter(w) for w in pool_w])
+        else:
+            self.v_W_l = pool_w
         self.bot_l = self.create_mlp(ln_bot, sigmoid_bot)
         self.top_l = self.create_mlp(ln_top, sigmoid_top)
 
@@ -293,10 +295,21 @@ class DLRM_Net(nn.Module):
         return layers(x)
 
     def _bags(self, lS_o, lS_i, v_W_l) -> BagBatch:
-        psw = None
-        if v_W_l is not None and any(w is not None for w in v_W_l):
-            psw = [None if w is None else w.to(lS_i[k].device).gather(0, lS_i[k].long()) for k, w in enumerate(v_W_l)]
-        return BagBatch(lS_o, lS_i, psw)
+        return BagBatch(lS_o, lS_i, None)        # pooling weights, if any, are gathered on the device inside EmbeddingBagsFunction
+
+    def _pool_weights(self, v_W_l, device) -> list:
+        if v_W_l is None or not any(w is not None for w in v_W_l):
+            return []
+        if any(w is None for w in v_W_l):
+            sys.exit("ERROR: pooling weights must be given for all tables or for none")
+        out = []
+        for k, w in enumerate(v_W_l):
+            if w.device != device:                       # "fixed" weights are plain tensors the reference moves by hand (:1324-1326)
+                w = w.to(device)
+                if not isinstance(v_W_l, nn.ParameterList):
+                    v_W_l[k] = w
+            out.append(w)
+        return out
 
     def _emb_weights(self, emb_l) -> List[torch.Tensor]:
         return [e.weight for e in emb_l]
@@ -304,7 +317,8 @@ class DLRM_Net(nn.Module):
     def _emb_packed(self, lS_o, lS_i, emb_l, v_W_l, out_slot: Optional[OutSlot] = None):
         """[B, T*D] pooled embeddings of all given tables, one kernel launch."""
         bags = self._bags(lS_o, lS_i, v_W_l)
-        return EmbeddingBagsFunction.apply(self._stash_embedding_grad, bags, out_slot, *self._emb_weights(emb_l))
+        ws = self._emb_weights(emb_l)
+        return EmbeddingBagsFunction.apply(self._stash_embedding_grad, bags, out_slot, *ws, *self._pool_weights(v_W_l, ws[0].device))
 
     def apply_emb(self, lS_o, lS_i, emb_l, v_W_l):
         """Reference-shaped result: a list with one [B, D] tensor per table (dlrm_s_pytorch.py:407-462)."""

@@ -180,22 +180,33 @@ class EmbeddingBagsFunction(Function):
     optimizer steps.  Reference: DLRM_Net.apply_emb (dlrm_s_pytorch.py:407-462)."""
 
     @staticmethod
-    def forward(ctx, sink, bags, out_slot, *weights):
-        T = len(weights)
+    def forward(ctx, sink, bags, out_slot, *tensors):
+        # tensors = the T tables, optionally followed by T pooling-weight vectors [rows_t] (--weighted-pooling: `v_W_l`,
+        # dlrm_s_pytorch.py:289-293,370-375): psw = v_W[idx] is gathered here and, when the vectors are Parameters
+        # ("learned"), their dense gradient comes back from backward
+        T = bags.T
+        weights, vws = tensors[:T], tensors[T:]
         D = weights[0].size(1)
+        if vws:
+            ops.pool_weights_gather(vws, bags)
         out = out_slot.get() if out_slot is not None else alloc2d(bags.B, T * D, weights[0])
         ops.emb_fwd(weights, bags, out)
         ctx.sink = sink
         ctx.bags = bags
         ctx.weights = weights  # parameters (leaves) — kept by reference, not via save_for_backward
+        ctx.vws = vws
         return out
 
     @staticmethod
     def backward(ctx, dout):
         if ctx.sink is None:
             raise RuntimeError("dlrm_amd: embedding backward needs a gradient sink (fused update)")
-        ctx.sink(ctx.weights, ctx.bags, _rowmajor(dout))
-        return (None, None, None) + (None,) * len(ctx.weights)
+        dout = _rowmajor(dout)
+        dvw = (None,) * len(ctx.vws)
+        if ctx.vws and any(ctx.needs_input_grad[3 + len(ctx.weights):]):
+            dvw = tuple(ops.emb_psw_grad(ctx.weights, ctx.bags, dout, ctx.vws))    # before the update touches the tables
+        ctx.sink(ctx.weights, ctx.bags, dout)
+        return (None, None, None) + (None,) * len(ctx.weights) + dvw
 
 
 class InteractFunction(Function):

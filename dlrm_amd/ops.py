@@ -206,6 +206,38 @@ class BagBatch:
             self._psw = _lib.ptr_array(ptrs)
 
 
+def pool_weights_gather(vws: Sequence[torch.Tensor], bags: "BagBatch") -> List[torch.Tensor]:
+    """psw[t][i] = vws[t][idx_t[i]] (`v_W_l[k].gather(0, indices)`, dlrm_s_pytorch.py:425-426) for all tables in one launch;
+    attaches the result to `bags` as its per-sample weights."""
+    lib = _lib.load()
+    if len(vws) != bags.T:
+        raise RuntimeError("dlrm_amd: pool_weights_gather needs one weight vector per table")
+    for v in vws:
+        _req(v, "pooling weights", ndim=1)
+    dev = vws[0].device
+    psw = [torch.empty(n, dtype=torch.float32, device=dev) for n in bags.nnz]
+    rc = lib.dlrm_pool_weights_gather(bags.T, _lib.i64_array([v.numel() for v in vws]), bags._idx, bags._nnz, bags.idx_bits,
+                                      _lib.ptr_array([v.data_ptr() for v in vws]),
+                                      _lib.ptr_array([p_.data_ptr() if p_.numel() else 0 for p_ in psw]),
+                                      C.c_void_p(_err_block(dev).data_ptr()), _stream(vws[0]))
+    _lib.check(rc, "dlrm_pool_weights_gather")
+    bags.keep += psw
+    bags._psw = _lib.ptr_array([p_.data_ptr() if p_.numel() else 0 for p_ in psw])
+    return psw
+
+
+def emb_psw_grad(weights: Sequence[torch.Tensor], bags: "BagBatch", dout: torch.Tensor, like: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """dense gradients of the learned pooling-weight vectors: dvW_t[r] = sum_{lookups of row r} <dout[bag], W_t[r]>"""
+    lib = _lib.load()
+    D, wp, rows = _weights_desc(weights)
+    _req(dout, "dout", ndim=2)
+    dvw = [torch.empty_like(v) for v in like]
+    rc = lib.dlrm_emb_psw_grad(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags.idx_bits,
+                               C.c_void_p(dout.data_ptr()), _ld(dout), _lib.ptr_array([g.data_ptr() for g in dvw]), _stream(dout))
+    _lib.check(rc, "dlrm_emb_psw_grad")
+    return dvw
+
+
 def bag_index_tensor(bags: "BagBatch", k: int) -> torch.Tensor:
     """the 1-D index tensor of table k as it was passed in (the COO gradient's indices, verbatim)"""
     return bags._idx_src[k]

@@ -94,6 +94,18 @@ int dlrm_emb_bwd_sgd(int T, int64_t B, int D,
                      const float* dout, int64_t dout_ld, float lr, int mode,
                      void* workspace, int64_t workspace_bytes, int64_t* err, void* stream);
 
+/* Pooling weights (--weighted-pooling fixed | learned; dlrm_s_pytorch.py:289-293, 370-375, 425-428).
+ * dlrm_pool_weights_gather: psw_out_host[t][i] = vw_host[t][indices_host[t][i]]  (`v_W_l[k].gather(0, indices)`); the result is
+ *   the psw_host operand of dlrm_emb_fwd / dlrm_emb_bwd_*.
+ * dlrm_emb_psw_grad (learned weights): dvw_host[t][r] = sum over lookups i of table t with index r of
+ *   <dout[bag(i), t*D:(t+1)*D], W_t[r, :]> — EmbeddingBag's per_sample_weights gradient followed by the gather's scatter-add,
+ *   one pass; dvw_host[t] (device float[rows_host[t]]) is overwritten.  Call it BEFORE the embedding update of the step. */
+int dlrm_pool_weights_gather(int T, const int64_t* rows_host, const void* const* indices_host, const int64_t* nnz_host,
+                             int idx_bits, const void* const* vw_host, void* const* psw_out_host, int64_t* err, void* stream);
+int dlrm_emb_psw_grad(int T, int64_t B, int D, const void* const* weight_host, const int64_t* rows_host,
+                      const void* const* indices_host, const void* const* offsets_host, const int64_t* nnz_host,
+                      int idx_bits, const float* dout, int64_t dout_ld, void* const* dvw_host, void* stream);
+
 /* K2 alone: the reference's sparse COO gradient, materialised (escape hatch: `--fused-emb-update=0`, or any
  * optimizer the fused kernels do not implement, e.g. torch.optim.Adagrad / the reference's --optimizer=adagrad).
  * Replaces: autograd EmbeddingBagBackward (dlrm_s_pytorch.py:1613).

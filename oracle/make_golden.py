@@ -75,7 +75,7 @@ def sd_np(model, prefix):
 
 def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, lr, loss, itself=False,
                      num_idx=10, fixed=False, seed=123, round_targets=True, compact=False, interaction="dot",
-                     loss_threshold=0.0, loss_weights=None):
+                     loss_threshold=0.0, loss_weights=None, weighted_pooling=None):
     ln_emb = np.asarray(ln_emb)
     ln_bot = np.asarray(ln_bot)
     F = ln_emb.size + 1
@@ -89,7 +89,12 @@ def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, l
     if loss == "wbce":          # the reference reads the CLI global `args.loss_weights` (dlrm_s_pytorch.py:391)
         ref.args = types.SimpleNamespace(loss_weights=loss_weights, loss_function="wbce")
     model = ref.DLRM_Net(m_spa, ln_emb, ln_bot, ln_top, arch_interaction_op=interaction, arch_interaction_itself=itself,
-                         sigmoid_bot=-1, sigmoid_top=ln_top.size - 2, loss_function=loss, loss_threshold=loss_threshold)
+                         sigmoid_bot=-1, sigmoid_top=ln_top.size - 2, loss_function=loss, loss_threshold=loss_threshold,
+                         weighted_pooling=weighted_pooling)
+    if weighted_pooling == "learned":       # all-ones weights would hide a wrong gather: start from distinct values
+        with torch.no_grad():
+            for k, w in enumerate(model.v_W_l):
+                w.copy_(torch.tensor(np.random.RandomState(50 + k).uniform(0.5, 1.5, size=w.shape).astype(np.float32)))
     ref.dlrm = model            # loss_fn_wrap uses the module globals `dlrm` and `args` (:148-156)
     out = {}
     out.update(sd_np(model, "init"))
@@ -117,7 +122,7 @@ def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, l
     out["losses"] = np.asarray(losses, dtype=np.float64)
     meta = dict(name=name, m_spa=int(m_spa), ln_emb=ln_emb.tolist(), ln_bot=ln_bot.tolist(), ln_top=ln_top.tolist(),
                 B=B, steps=steps, lr=lr, loss=loss, itself=bool(itself), sigmoid_top=int(ln_top.size - 2),
-                interaction=interaction, loss_threshold=float(loss_threshold),
+                interaction=interaction, loss_threshold=float(loss_threshold), weighted_pooling=weighted_pooling,
                 loss_ws=None if loss_weights is None else [float(x) for x in loss_weights.split("-")],
                 torch=torch.__version__, reference="facebookresearch/dlrm @ /root/reference (2025-10-03)")
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
@@ -554,6 +559,10 @@ def main(which):
         # clamp (:607-610), --loss-function=wbce with --loss-weights (:388-391, loss_fn_wrap :150-156), multi-hot bags
         capture_training(ref, dp, "cat_wbce_clamp", 8, [30, 5, 200, 11], [7, 24, 8], [16, 1], B=96, steps=3, lr=0.3, loss="wbce",
                          num_idx=4, interaction="cat", loss_threshold=0.45, loss_weights="0.3-1.7", round_targets=True)
+    if which in ("all", "train", "options", "learned"):
+        # --weighted-pooling=learned: per-row pooling weights as parameters (dlrm_s_pytorch.py:289-293, 370-375, 425-428), multi-hot bags
+        capture_training(ref, dp, "learned_pooling", 8, [20, 3, 150], [6, 12, 8], [10, 1], B=48, steps=3, lr=0.3, loss="bce",
+                         num_idx=5, weighted_pooling="learned")
     if which in ("all", "kaggle"):
         # BASELINE.json configs[1]: Criteo-Kaggle shapes — 26 tables, D = 16, bot 13-512-256-64-16, top 512-256-1
         # (bench/dlrm_s_criteo_kaggle.sh:24), batch 2048, one lookup per bag; table rows capped at 600 to keep the fixture small

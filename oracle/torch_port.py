@@ -26,7 +26,7 @@ class TorchPortDLRM:
         self.interaction, self.loss_threshold = interaction, float(loss_threshold)
         self.loss_ws = None if loss_ws is None else torch.as_tensor(loss_ws, dtype=torch.float64)
         self.p = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-        self.T = sum(1 for k in self.p if k.startswith("emb_l."))
+        self.T = sum(1 for k in self.p if k.startswith("emb_l.") and k.endswith(".weight"))
         self.nbot = sum(1 for k in self.p if k.startswith("bot_l.") and k.endswith(".weight"))
         self.ntop = sum(1 for k in self.p if k.startswith("top_l.") and k.endswith(".weight"))
         self.sigmoid_top, self.self_interaction, self.loss = sigmoid_top, self_interaction, loss
@@ -41,7 +41,9 @@ class TorchPortDLRM:
 
     def forward(self, X, lS_o: List[torch.Tensor], lS_i: List[torch.Tensor]):
         x = self._tower(X, "bot_l", self.nbot, -1)
-        ly = [F.embedding_bag(lS_i[k], self.p[f"emb_l.{k}.weight"], lS_o[k], mode="sum", sparse=True)
+        # --weighted-pooling=learned: per_sample_weights = v_W_l[k].gather(0, indices)   dlrm_s_pytorch.py:425-426
+        ly = [F.embedding_bag(lS_i[k], self.p[f"emb_l.{k}.weight"], lS_o[k], mode="sum", sparse=True,
+                              per_sample_weights=(self.p[f"v_W_l.{k}"].gather(0, lS_i[k]) if f"v_W_l.{k}" in self.p else None))
               for k in range(self.T)]
         B, D = x.shape
         if self.interaction == "cat":

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 
 # kaggle_b2048 = BASELINE.json configs[1] shapes (26 tables, D = 16, bot 13-512-256-64-16, top 512-256-1, batch 2048; rows capped)
 # cat_wbce_clamp: "cat" interaction + --loss-threshold clamp + --loss-function=wbce, all as HIP kernels
-FIXTURES = ["config1_b128", "cli_default_mse", "self_interact_d12", "multihot_hotrows", "kaggle_b2048", "cat_wbce_clamp"]
+# learned_pooling: --weighted-pooling=learned — pooling weights gathered on the device, their dense gradient from dlrm_emb_psw_grad
+FIXTURES = ["config1_b128", "cli_default_mse", "self_interact_d12", "multihot_hotrows", "kaggle_b2048", "cat_wbce_clamp",
+            "learned_pooling"]
 
 
 def build_model(meta, init, device, deterministic=True, mode=None):
@@ -21,7 +23,8 @@ def build_model(meta, init, device, deterministic=True, mode=None):
     np.random.seed(0)
     m = dlrm_amd.DLRM_Net(meta["m_spa"], np.asarray(meta["ln_emb"]), np.asarray(meta["ln_bot"]), np.asarray(meta["ln_top"]),
                           arch_interaction_op=meta.get("interaction", "dot"), arch_interaction_itself=meta["itself"], sigmoid_bot=-1,
-                          sigmoid_top=meta["sigmoid_top"], loss_function=meta["loss"], loss_threshold=meta.get("loss_threshold", 0.0))
+                          sigmoid_top=meta["sigmoid_top"], loss_function=meta["loss"], loss_threshold=meta.get("loss_threshold", 0.0),
+                          weighted_pooling=meta.get("weighted_pooling"))
     if meta["loss"] == "wbce":
         m.loss_ws = torch.tensor(meta["loss_ws"], dtype=torch.float64)      # the reference takes it from the CLI global (:391)
     with torch.no_grad():

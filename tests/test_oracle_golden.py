@@ -11,7 +11,9 @@ from conftest import GOLDEN, golden_batches, load_golden, params_with_prefix
 from oracle import oracle as O
 
 # cat_wbce_clamp: "cat" interaction + --loss-threshold clamp + --loss-function=wbce (the remaining --arch-* surface)
-TRAIN_FIXTURES = ["config1_b128", "cli_default_mse", "self_interact_d12", "multihot_hotrows", "kaggle_b2048", "cat_wbce_clamp"]
+# learned_pooling: --weighted-pooling=learned (per-row pooling weights as parameters, state_dict keys v_W_l.{k})
+TRAIN_FIXTURES = ["config1_b128", "cli_default_mse", "self_interact_d12", "multihot_hotrows", "kaggle_b2048", "cat_wbce_clamp",
+                  "learned_pooling"]
 
 
 def model_options(meta):
