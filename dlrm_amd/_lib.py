@@ -74,6 +74,9 @@ SIGNATURES = {
     "dlrm_copy_blocks": (_i32, [_i64, _i32, _pp, _pi64, _pp, _pi64, C.POINTER(_i32), _vp]),
     "dlrm_bce_elementwise": (_i32, [_i64, _vp, _vp, _vp, _vp]),
     "dlrm_bce_elementwise_bwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp]),
+    "dlrm_cross_fwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp]),
+    "dlrm_cross_bwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "dlrm_add": (_i32, [_i64, _vp, _vp, _vp, _vp]),
     "dlrm_clamp": (_i32, [_i64, _vp, _f32, _f32, _vp, _vp]),
     "dlrm_clamp_bwd": (_i32, [_i64, _vp, _f32, _f32, _vp, _vp, _vp]),
 }

@@ -228,6 +228,33 @@ __global__ __launch_bounds__(256) void bce_elementwise_bwd_kernel(long long n, c
         dp[i] = dloss[i] * (pi - t[i]) / fmaxf((1.f - pi) * pi, 1e-12f);
     }
 }
+// DCN-v2 low-rank cross layer, elementwise part (torchrec LowRankCrossNet: x_{l+1} = x_0 * (W_l (V_l x_l) + b_l) + x_l; the two
+// products are dlrm_linear_fwd calls): forward out = x0 * u + xl; backward du = g * x0 and dx0 (+)= g * u.
+__global__ __launch_bounds__(256) void cross_fwd_kernel(long long n4, const float4* __restrict__ x0, const float4* __restrict__ u,
+                                                        const float4* __restrict__ xl, float4* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 a = x0[i], b = u[i], c = xl[i];
+        out[i] = make_float4(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y), __builtin_fmaf(a.z, b.z, c.z), __builtin_fmaf(a.w, b.w, c.w));
+    }
+}
+__global__ __launch_bounds__(256) void cross_bwd_kernel(long long n4, const float4* __restrict__ g, const float4* __restrict__ x0,
+                                                        const float4* __restrict__ u, float4* __restrict__ du,
+                                                        float4* __restrict__ dx0, int accumulate) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 gg = g[i], a = x0[i], b = u[i];
+        du[i] = make_float4(gg.x * a.x, gg.y * a.y, gg.z * a.z, gg.w * a.w);
+        float4 d = accumulate ? dx0[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        d.x = __builtin_fmaf(gg.x, b.x, d.x); d.y = __builtin_fmaf(gg.y, b.y, d.y); d.z = __builtin_fmaf(gg.z, b.z, d.z); d.w = __builtin_fmaf(gg.w, b.w, d.w);
+        dx0[i] = d;
+    }
+}
+__global__ __launch_bounds__(256) void add_kernel(long long n4, const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 x = a[i], y = b[i];
+        out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    }
+}
+
 // torch.clamp(x, lo, hi) of the predictions (--loss-threshold, dlrm_s_pytorch.py:580-583,607-610) and its backward
 // (gradient passes where lo <= x <= hi, torch's clamp_backward mask)
 __global__ __launch_bounds__(256) void clamp_kernel(long long n, const float* __restrict__ x, float lo, float hi, float* __restrict__ y) {
@@ -405,6 +432,38 @@ extern "C" int dlrm_clamp(int64_t n, const float* x, float lo, float hi, float* 
 extern "C" int dlrm_clamp_bwd(int64_t n, const float* x, float lo, float hi, const float* dy, float* dx, void* stream) {
     if (n <= 0 || !x || !dy || !dx || !(lo <= hi)) return DLRM_E_ARG;
     hipLaunchKernelGGL(clamp_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (long long)n, x, lo, hi, dy, dx);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline bool vec4_ok(int64_t n, const void* a, const void* b, const void* c, const void* d, const void* e) {
+    return n % 4 == 0 && dlrm_aligned16(a) && dlrm_aligned16(b) && (!c || dlrm_aligned16(c)) && (!d || dlrm_aligned16(d)) && (!e || dlrm_aligned16(e));
+}
+
+extern "C" int dlrm_cross_fwd(int64_t n, const float* x0, const float* u, const float* xl, float* out, void* stream) {
+    if (n <= 0 || !x0 || !u || !xl || !out) return DLRM_E_ARG;
+    if (!vec4_ok(n, x0, u, xl, out, nullptr)) return DLRM_E_ALIGN;
+    hipLaunchKernelGGL(cross_fwd_kernel, dim3(ew_blocks(n / 4) * 2), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)x0,
+                       (const float4*)u, (const float4*)xl, (float4*)out);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const float* u, float* du, float* dx0, int accumulate,
+                              void* stream) {
+    if (n <= 0 || !g || !x0 || !u || !du || !dx0) return DLRM_E_ARG;
+    if (!vec4_ok(n, g, x0, u, du, dx0)) return DLRM_E_ALIGN;
+    hipLaunchKernelGGL(cross_bwd_kernel, dim3(ew_blocks(n / 4) * 2), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)g,
+                       (const float4*)x0, (const float4*)u, (float4*)du, (float4*)dx0, accumulate ? 1 : 0);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_add(int64_t n, const float* a, const float* b, float* out, void* stream) {
+    if (n <= 0 || !a || !b || !out) return DLRM_E_ARG;
+    if (!vec4_ok(n, a, b, out, nullptr, nullptr)) return DLRM_E_ALIGN;
+    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n / 4) * 2), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)a,
+                       (const float4*)b, (float4*)out);
     DLRM_LAUNCH_CHECK();
     return 0;
 }

@@ -284,6 +284,59 @@ class GatherInteractFunction(Function):
         return (None, None, None, None, dx) + (None,) * T
 
 
+class LowRankCrossNetFunction(Function):
+    """DCN-v2 interaction (torchrec.modules.crossnet.LowRankCrossNet, the MLPerf-v2 default: torchrec_dlrm/dlrm_main.py:608-619):
+        x_{l+1} = x_0 * (W_l (V_l x_l) + b_l) + x_l,   l = 0 .. L-1,   on the flattened feature buffer x_0 [B, F*D].
+    forward(arith, x0, V_0, W_0, b_0, V_1, ...): V_l [r, in], W_l [in, r], b_l [in].  Both products run on the MLP GEMM kernels
+    (act none), the elementwise halves on dlrm_cross_fwd / _bwd; backward is written out by hand so that the three gradient
+    streams into x_0 (through every layer's Hadamard factor, and through x_l of layer 0) are accumulated by our kernels instead
+    of autograd's ATen adds."""
+
+    @staticmethod
+    def forward(ctx, arith, x0, *params):
+        x0 = x0.contiguous()
+        L = len(params) // 3
+        M, n_in = x0.shape
+        xs, vs, us = [x0], [], []
+        for l in range(L):
+            V, W, b = params[3 * l], params[3 * l + 1], params[3 * l + 2]
+            v = alloc2d(M, V.size(0), x0)
+            ops.linear_fwd(xs[-1], V, None, ACT_NONE, v, arith)
+            u = torch.empty((M, n_in), dtype=torch.float32, device=x0.device)
+            ops.linear_fwd(v, W, b, ACT_NONE, u, arith)
+            xs.append(ops.cross_fwd(x0, u, xs[-1]))
+            vs.append(v); us.append(u)
+        ctx.arith, ctx.L = arith, L
+        ctx.save_for_backward(*params, *xs[:-1], *vs, *us)
+        return xs[-1]
+
+    @staticmethod
+    def backward(ctx, g):
+        L, arith = ctx.L, ctx.arith
+        sv = ctx.saved_tensors
+        params, xs, vs, us = sv[:3 * L], sv[3 * L:4 * L], sv[4 * L:5 * L], sv[5 * L:6 * L]
+        x0 = xs[0]
+        M, n_in = x0.shape
+        g = g.contiguous()
+        dx0 = torch.empty_like(x0)
+        grads = [None] * (3 * L)
+        for l in range(L - 1, -1, -1):
+            V, W = params[3 * l], params[3 * l + 1]
+            du = ops.cross_bwd(g, x0, us[l], dx0, accumulate=(l != L - 1))        # du = g * x0;  dx0 (+)= g * u_l
+            dW, db = torch.empty_like(W), torch.empty(W.size(0), dtype=torch.float32, device=g.device)
+            ops.linear_bwd_weight(du, vs[l], dW, db, arith=arith)
+            dv = alloc2d(M, V.size(0), x0)
+            ops.linear_bwd_data(du, W, None, ACT_NONE, dv, arith)
+            dV = torch.empty_like(V)
+            ops.linear_bwd_weight(dv, xs[l], dV, None, arith=arith)
+            dxl = torch.empty_like(x0)
+            ops.linear_bwd_data(dv, V, None, ACT_NONE, dxl, arith)
+            g = ops.add(g, dxl)                                                   # gradient reaching x_l: identity path + V path
+            grads[3 * l], grads[3 * l + 1], grads[3 * l + 2] = dV, dW, db
+        dx0 = ops.add(dx0, g)                                                     # x_l of layer 0 IS x_0
+        return (None, dx0, *grads)
+
+
 class ChunkPackFunction(Function):
     """Re-orders the rows of the pooled-embedding send buffer for a PIPELINED all-to-all.
 

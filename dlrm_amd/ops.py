@@ -792,6 +792,42 @@ def bce_elementwise_bwd(p: torch.Tensor, target: torch.Tensor, dloss: torch.Tens
     return dp
 
 
+def _flat3(*ts):
+    n = ts[0].numel()
+    for t in ts:
+        _req(t, "operand")
+        if not t.is_contiguous() or t.numel() != n:
+            raise RuntimeError("dlrm_amd: elementwise operands must be contiguous and of equal size")
+    return n
+
+
+def cross_fwd(x0: torch.Tensor, u: torch.Tensor, xl: torch.Tensor) -> torch.Tensor:
+    """x0 * u + xl (DCN-v2 cross layer, elementwise half)"""
+    n = _flat3(x0, u, xl)
+    out = torch.empty_like(x0)
+    _lib.check(_lib.load().dlrm_cross_fwd(n, C.c_void_p(x0.data_ptr()), C.c_void_p(u.data_ptr()), C.c_void_p(xl.data_ptr()),
+                                          C.c_void_p(out.data_ptr()), _stream(out)), "dlrm_cross_fwd")
+    return out
+
+
+def cross_bwd(g: torch.Tensor, x0: torch.Tensor, u: torch.Tensor, dx0: torch.Tensor, accumulate: bool) -> torch.Tensor:
+    """returns du = g * x0; dx0 (+)= g * u"""
+    n = _flat3(g, x0, u, dx0)
+    du = torch.empty_like(g)
+    _lib.check(_lib.load().dlrm_cross_bwd(n, C.c_void_p(g.data_ptr()), C.c_void_p(x0.data_ptr()), C.c_void_p(u.data_ptr()),
+                                          C.c_void_p(du.data_ptr()), C.c_void_p(dx0.data_ptr()), int(bool(accumulate)), _stream(g)),
+               "dlrm_cross_bwd")
+    return du
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    n = _flat3(a, b)
+    out = torch.empty_like(a)
+    _lib.check(_lib.load().dlrm_add(n, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), _stream(a)),
+               "dlrm_add")
+    return out
+
+
 def clamp(x: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
     lib = _lib.load()
     _req(x, "x")

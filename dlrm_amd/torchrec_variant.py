@@ -192,3 +192,65 @@ class ShardedDLRM(DLRM_Net):
         blocks = [x] + (list(req.wait()) if N > 1 else [E_tw]) + ([E_rw] if self.rw_tables else [])
         z = InteractFunction.apply(D, self._interaction_mode(), True, list(self.feature_order), *blocks)
         return self.apply_mlp(z, self.top_l)
+
+
+class LowRankCrossNet(nn.Module):
+    """torchrec.modules.crossnet.LowRankCrossNet(in_features, num_layers, low_rank): parameters V_kernels[l] [low_rank, in],
+    W_kernels[l] [in, low_rank] (xavier-normal), bias[l] [in] (zeros); x_{l+1} = x_0 * (W_l (V_l x_l) + b_l) + x_l."""
+
+    arith = "f32"
+
+    def __init__(self, in_features: int, num_layers: int, low_rank: int):
+        super().__init__()
+        self.V_kernels, self.W_kernels, self.bias = nn.ParameterList(), nn.ParameterList(), nn.ParameterList()
+        std = np.sqrt(2.0 / (in_features + low_rank))
+        for _ in range(num_layers):
+            self.V_kernels.append(nn.Parameter(torch.tensor(np.random.normal(0.0, std, size=(low_rank, in_features)).astype(np.float32))))
+            self.W_kernels.append(nn.Parameter(torch.tensor(np.random.normal(0.0, std, size=(in_features, low_rank)).astype(np.float32))))
+            self.bias.append(nn.Parameter(torch.zeros(in_features, dtype=torch.float32)))
+
+    def forward(self, x0):
+        from . import ops
+        from .functional import LowRankCrossNetFunction
+        flat = [p for l in range(len(self.bias)) for p in (self.V_kernels[l], self.W_kernels[l], self.bias[l])]
+        return LowRankCrossNetFunction.apply(ops.arith_code(self.arith), x0, *flat)
+
+
+class DLRM_DCN(DLRM_Net):
+    """torchrec.models.dlrm.DLRM_DCN (the MLPerf-v2 model, torchrec_dlrm/dlrm_main.py:608-619): dense arch and pooled embeddings
+    are concatenated to [B, F*D] — the feature buffer the bottom tower and the embedding kernel write side by side — and passed
+    through a DCN-v2 low-rank cross network; the over-arch takes its [B, F*D] output and ends with a bare Linear (logits)."""
+
+    def __init__(self, num_embeddings_per_feature: Sequence[int], embedding_dim: int, dense_in_features: int,
+                 dense_arch_layer_sizes: Sequence[int], over_arch_layer_sizes: Sequence[int], dcn_num_layers: int,
+                 dcn_low_rank_dim: int):
+        if list(dense_arch_layer_sizes)[-1] != embedding_dim:
+            raise ValueError("dense_arch_layer_sizes[-1] must equal the embedding dimension")
+        F = len(num_embeddings_per_feature) + 1
+        ln_bot = np.asarray([dense_in_features] + list(dense_arch_layer_sizes))
+        ln_top = np.asarray([F * embedding_dim] + list(over_arch_layer_sizes))
+        super().__init__(embedding_dim, np.asarray(list(num_embeddings_per_feature)), ln_bot, ln_top, arch_interaction_op="cat",
+                         sigmoid_bot=-1, sigmoid_top=-1, loss_function="bce")
+        arith = self.top_l.arith
+        self.top_l = FusedMLP(*list(self.top_l.children())[:-1])
+        self.top_l.arith = arith
+        self.crossnet = LowRankCrossNet(F * embedding_dim, dcn_num_layers, dcn_low_rank_dim)
+        self.loss_fn = FusedBCEWithLogitsLoss()
+
+    def set_mlp_arith(self, name: str) -> None:
+        super().set_mlp_arith(name)
+        self.crossnet.arith = name
+
+    def interact_features(self, x, ly):
+        return self.crossnet(super().interact_features(x, ly))
+
+    def sequential_forward(self, dense_x, lS_o, lS_i):
+        from . import ops
+        from .functional import CatFunction, OutSlot
+        ops.check_index_errors()
+        B, T, D = dense_x.size(0), len(self.emb_l), self.m_spa
+        feat = torch.empty((B, (1 + T) * D), dtype=torch.float32, device=dense_x.device)
+        x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :D]))
+        E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l, out_slot=OutSlot(feat[:, D:]))
+        z = self.crossnet(CatFunction.apply(OutSlot(feat), x, E))          # the feature buffer IS cat([dense, sparse]): no copy
+        return self.apply_mlp(z, self.top_l)

@@ -352,6 +352,15 @@ int dlrm_copy_blocks(int64_t M, int nblk, const void* const* src_host, const int
 int dlrm_bce_elementwise(int64_t n, const float* p, const float* target, float* loss, void* stream);
 int dlrm_bce_elementwise_bwd(int64_t n, const float* p, const float* target, const float* dloss, float* dp, void* stream);
 
+/* DCN-v2 interaction (MLPerf-v2's default, torchrec_dlrm/dlrm_main.py:608-619; torchrec LowRankCrossNet, not in the tree):
+ *   x_{l+1} = x_0 * (W_l (V_l x_l) + b_l) + x_l  on the flattened [B, F*D] feature buffer.  The two products of a layer are
+ *   dlrm_linear_fwd calls (act none; V without bias); these are the elementwise halves, contiguous fp32 arrays of n elements
+ *   (n % 4 == 0, 16-byte aligned):  dlrm_cross_fwd  out = x0 * u + xl;   dlrm_cross_bwd  du = g * x0,  dx0 (+)= g * u
+ *   (accumulate != 0 adds into dx0);  dlrm_add  out = a + b  (the gradient reaching x_l through the V product joins g). */
+int dlrm_cross_fwd(int64_t n, const float* x0, const float* u, const float* xl, float* out, void* stream);
+int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const float* u, float* du, float* dx0, int accumulate, void* stream);
+int dlrm_add(int64_t n, const float* a, const float* b, float* out, void* stream);
+
 /* torch.clamp(p, lo, hi) of the predictions and its backward (--loss-threshold, dlrm_s_pytorch.py:580-583, 607-610):
  * y = min(max(x, lo), hi);  dx = dy where lo <= x <= hi, else 0. */
 int dlrm_clamp(int64_t n, const float* x, float lo, float hi, float* y, void* stream);

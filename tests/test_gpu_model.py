@@ -442,3 +442,76 @@ def test_graphed_step_survives_host_syncs_at_full_batch():
             assert step.captures == 1
         del model, opt, step
     assert runs[0] == runs[1], [(a, b) for a, b in zip(*runs) if a != b][:4]
+
+
+@pytest.mark.parametrize("B,n,r,L,arith", [(300, 64, 16, 3, "f32"), (4096, 3456, 512, 3, "f32"), (4096, 3456, 512, 2, "bf16x6"), (70, 20, 4, 1, "f32")])
+def test_dcn_v2_cross_network_matches_oracle(B, n, r, L, arith):
+    """LowRankCrossNetFunction (DCN-v2, the MLPerf-v2 interaction: GEMM kernels + dlrm_cross_fwd / _bwd, hand-written backward)
+    against the float64 oracle: output, gradient of x_0 and of every V / W / bias — at the benchmark's 27 x 128 -> rank 512 shape too."""
+    from dlrm_amd import ops
+    from dlrm_amd.functional import LowRankCrossNetFunction
+    device = torch.device("cuda:0")
+    rng = np.random.default_rng(B + n)
+    x0 = rng.standard_normal((B, n)).astype(np.float32)
+    Vs = [(rng.standard_normal((r, n)) / np.sqrt(n)).astype(np.float32) for _ in range(L)]
+    Ws = [(rng.standard_normal((n, r)) / np.sqrt(r)).astype(np.float32) for _ in range(L)]
+    bs = [(rng.standard_normal(n) * 0.1).astype(np.float32) for _ in range(L)]
+    g = rng.standard_normal((B, n)).astype(np.float32)
+    want, cache = O.crossnet_fwd(x0, Vs, Ws, bs)
+    dx0, dVs, dWs, dbs = O.crossnet_bwd(g, Vs, Ws, cache)
+    tx0 = torch.from_numpy(x0).to(device).requires_grad_(True)
+    ps = [torch.from_numpy(a).to(device).requires_grad_(True) for l in range(L) for a in (Vs[l], Ws[l], bs[l])]
+    out = LowRankCrossNetFunction.apply(ops.arith_code(arith), tx0, *ps)
+    out.backward(torch.from_numpy(g).to(device))
+    scale = lambda a: max(1.0, float(np.abs(a).max()))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=2e-5, atol=2e-5 * scale(want))
+    np.testing.assert_allclose(tx0.grad.cpu().numpy(), dx0, rtol=1e-4, atol=2e-5 * scale(dx0))
+    for l in range(L):
+        np.testing.assert_allclose(ps[3 * l].grad.cpu().numpy(), dVs[l], rtol=1e-4, atol=3e-5 * scale(dVs[l]))
+        np.testing.assert_allclose(ps[3 * l + 1].grad.cpu().numpy(), dWs[l], rtol=1e-4, atol=3e-5 * scale(dWs[l]))
+        np.testing.assert_allclose(ps[3 * l + 2].grad.cpu().numpy(), dbs[l], rtol=1e-4, atol=3e-5 * scale(dbs[l]))
+
+
+def test_dlrm_dcn_model_trains_like_a_torch_composition():
+    """torchrec_variant.DLRM_DCN (dense arch + pooled embeddings -> DCN-v2 cross network -> over arch -> logits, BCEWithLogits)
+    for 2 SGD steps against the same model composed of torch CPU operators with autograd (torchrec itself is absent: UNPINNED)."""
+    import torch.nn.functional as Fn
+    from dlrm_amd.optim import FusedSGD
+    from dlrm_amd.torchrec_variant import DLRM_DCN
+    device = torch.device("cuda:0")
+    rng = np.random.default_rng(12)
+    D, rows, B, hot = 16, [40, 9, 300], 48, [2, 1, 4]
+    np.random.seed(2)
+    model = DLRM_DCN(rows, D, 13, [24, D], [32, 1], dcn_num_layers=2, dcn_low_rank_dim=8)
+    with torch.no_grad():
+        for b_ in model.crossnet.bias:
+            b_.copy_(torch.from_numpy((rng.standard_normal(b_.shape) * 0.1).astype(np.float32)))
+    ref = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    model = model.to(device)
+    opt = FusedSGD(model.parameters(), lr=0.2)
+    ropt = torch.optim.SGD(list(ref.values()), lr=0.2)
+    for s in range(2):
+        X = torch.from_numpy(rng.random((B, 13)).astype(np.float32))
+        idx = [torch.from_numpy(rng.integers(0, n, size=B * h)) for n, h in zip(rows, hot)]
+        off = [torch.arange(B) * h for h in hot]
+        T = torch.from_numpy(rng.integers(0, 2, size=(B, 1)).astype(np.float32))
+        logits = model(X.to(device), [o.to(device) for o in off], [i.to(device) for i in idx])
+        E = model.loss_fn(logits, T.to(device))
+        x = X
+        for i in range(2):
+            x = torch.relu(Fn.linear(x, ref[f"bot_l.{2 * i}.weight"], ref[f"bot_l.{2 * i}.bias"]))
+        ly = [Fn.embedding_bag(idx[k], ref[f"emb_l.{k}.weight"], off[k], mode="sum", sparse=False) for k in range(3)]
+        x0 = torch.cat([x] + ly, dim=1)
+        xl = x0
+        for l in range(2):
+            xl = x0 * (Fn.linear(Fn.linear(xl, ref[f"crossnet.V_kernels.{l}"]), ref[f"crossnet.W_kernels.{l}"]) + ref[f"crossnet.bias.{l}"]) + xl
+        z = torch.relu(Fn.linear(xl, ref["top_l.0.weight"], ref["top_l.0.bias"]))
+        rl = Fn.linear(z, ref["top_l.2.weight"], ref["top_l.2.bias"])
+        RE = Fn.binary_cross_entropy_with_logits(rl, T)
+        np.testing.assert_allclose(logits.detach().cpu().numpy(), rl.detach().numpy(), rtol=5e-5, atol=5e-6)
+        assert abs(float(E) - float(RE)) <= 1e-5 * abs(float(RE))
+        opt.zero_grad(); E.backward(); opt.step()
+        ropt.zero_grad(); RE.backward(); ropt.step()
+    sd = model.state_dict()
+    for k, v in ref.items():
+        np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=2e-4, atol=1e-5, err_msg=k)
