@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="override the global batch (default: the workload's)")
     ap.add_argument("--row-cap", type=int, default=0, help="cap table rows (debug / small-memory runs)")
     ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--interaction", default="", choices=["", "dot", "dcn"],
+                    help="mlperf_v2_multihot only: dcn (default there) = DCN-v2 low-rank cross network, 3 layers, rank 512 — the MLPerf-v2 "
+                         "model (torchrec_dlrm/dlrm_main.py:608-619); dot = torchrec's triu dot interaction")
     ap.add_argument("--no-overlap", action="store_true",
                     help="single-stream schedule: by default the HBM-bound embedding kernels (pooled lookups; fused sparse update) "
                          "run on a second HIP stream beside the MFMA-bound bottom-MLP GEMMs they do not depend on "
@@ -238,6 +241,7 @@ def main():
         if "--mlp-arith" not in " ".join(sys.argv) and "DLRM_MLP_ARITH" not in os.environ:
             args.mlp_arith = "bf16"
         args.no_cpu_baseline = True      # the CPU baseline leg times the headline workload only
+        args.no_overlap = True           # 1.4 ms of multi-hot lookups beside 0.15 ms of bottom-MLP GEMMs: nothing to hide (measured)
     if args.batch:
         wl["batch"] = args.batch
     if args.row_cap:
@@ -281,8 +285,12 @@ def main():
     dlrm_amd.set_embedding_init(device)
     if hot_cfg:
         # BASELINE configs[4]: the torchrec trainer's model semantics (triu interaction order, logits, BCEWithLogitsLoss)
-        from dlrm_amd.torchrec_variant import DLRM as TorchrecDLRM
-        model = TorchrecDLRM(rows, D, wl["bot"][0], wl["bot"][1:], wl["top"]).to(device)
+        from dlrm_amd.torchrec_variant import DLRM as TorchrecDLRM, DLRM_DCN
+        if (args.interaction or "dcn") == "dcn":
+            model = DLRM_DCN(rows, D, wl["bot"][0], wl["bot"][1:], wl["top"], dcn_num_layers=3, dcn_low_rank_dim=512).to(device)
+            ln_top = np.asarray([nf * D] + wl["top"])
+        else:
+            model = TorchrecDLRM(rows, D, wl["bot"][0], wl["bot"][1:], wl["top"]).to(device)
     else:
         model = dlrm_amd.DLRM_Net(D, np.asarray(rows), np.asarray(wl["bot"]), ln_top, "dot", sigmoid_top=ln_top.size - 2,
                                   loss_function="bce").to(device)
@@ -399,6 +407,10 @@ def main():
     fwd_fl = sum(2.0 * Bl * a * b for ln in (bot, top) for a, b in zip(ln[:-1], ln[1:]))
     wgrad_fl = fwd_fl
     dgrad_fl = fwd_fl - 2.0 * Bl * bot[0] * bot[1]      # the first bottom layer needs no data gradient
+    dcn = hot is not None and (args.interaction or "dcn") == "dcn"
+    if dcn:                                             # 3 cross layers x two [F*D x 512] products, each forward / dgrad / wgrad
+        cross = 3 * 2 * 2.0 * Bl * (nf * D) * 512
+        fwd_fl, dgrad_fl, wgrad_fl = fwd_fl + cross, dgrad_fl + cross, wgrad_fl + cross
     F = nf
     inter_bytes = Bl * (F * D * 4 + (D + F * (F - 1) // 2) * 4)
     # fused lookups + interaction (one lookup per bag): forward reads T rows + indices + bag starts + x, writes R; backward reads the
@@ -480,10 +492,11 @@ def main():
                 "dlrm_amd.datagen; random-init parameters)",
         "config": {"workload": args.workload + {"criteo_terabyte": ": MLPerf Criteo-Terabyte shapes (BASELINE.json configs[2])",
                                                 "mlperf_v2_multihot": ": MLPerf-v2 multi-hot synthetic inputs, 214 lookups/sample (BASELINE.json "
-                                                                      "configs[4]: torchrec model semantics — triu dot interaction, logits + BCEWithLogits, fused row-wise "
-                                                                      "Adagrad; dot interaction instead of DCN-v2) — NOT the headline"}.get(args.workload, ""),
+                                                                      "configs[4]: torchrec model semantics — DCN-v2 (3 layers, rank 512) or triu dot interaction, logits + "
+                                                                      "BCEWithLogits, fused row-wise Adagrad) — NOT the headline"}.get(args.workload, ""),
                    "tables": len(rows), "emb_dim": D, "global_batch": B, "table_rows_total": int(sum(rows)),
                    "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": args.optimizer,
+                   "interaction": ("dcn_v2 (3 layers, rank 512)" if dcn else "dot (torchrec triu order)") if hot else "dot",
                    "loss": "bce_with_logits" if hot else "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
                    "embedding_update": args.emb_update, "a2a_chunks": model_a2a_chunks,
                    "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "

@@ -15,12 +15,13 @@
 //           run's end by binary search in the sorted keys, adds the edge partials in order and applies the update.
 // Every sum has a fixed order: results are run-to-run deterministic (hot rows are re-associated per 64 lookups
 // relative to the reference's strictly sequential coalesce).
+#include <stdlib.h>
 #include "sorted_common.h"
 
 namespace {
 
 constexpr int kG = 64;          // sorted entries per lane group
-constexpr int kC = 4;           // gradient rows in flight per lane group
+// kC = gradient rows in flight per lane group: template parameter (env DLRM_ADAGRAD_KC, default 4)
 
 struct AdagradArgs {
     float* state[DLRM_MAX_TABLES_PER_LAUNCH];      // row-wise accumulator ("momentum") of each table, [rows]
@@ -72,7 +73,7 @@ __device__ __forceinline__ void adagrad_apply(float* __restrict__ wrow, float* _
     if (lig == 0) *mom_r = m;
 }
 
-template <int VEC, int LPB, int NCH, typename KT>
+template <int VEC, int LPB, int NCH, typename KT, int kC>
 __global__ __launch_bounds__(256) void adagrad_groups_kernel(SortedArgs sa, AdagradArgs aa, long long L, int D, int row_bits,
                                                              const KT* __restrict__ keys, const unsigned* __restrict__ vals,
                                                              const unsigned* __restrict__ bag_of,
@@ -257,12 +258,20 @@ static int run_adagrad(int n, const int* ids, int64_t B, int D, void* const* wei
     Shape s;
     rc = pick(D, vec_ok, &s);
     if (rc) return rc;
+    static int kc = -1;        // gradient rows requested together per lane group; env DLRM_ADAGRAD_KC = 1 (default) | 2 | 4.  Measured on one box:
+                               // 0.667 / 0.719 / 0.736 ms at Criteo-Terabyte shapes, 5.28 / 5.55 / 5.8 ms for the 214-lookup multi-hot batch —
+                               // the kernel wants waves, not deeper per-wave prefetch (a variant that also prefetched the table rows: 0.88 ms)
+    if (kc < 0) { const char* e = getenv("DLRM_ADAGRAD_KC"); kc = e ? atoi(e) : 1; }
     const size_t groups = (L + kG - 1) / kG;
     const int gpb = 256 / s.lpb;
     dim3 grid((unsigned)((groups + gpb - 1) / gpb), 1, 1), block(256);
 #define ADA(V, LP, NC)                                                                                                         \
     do {                                                                                                                       \
-        hipLaunchKernelGGL((adagrad_groups_kernel<V, LP, NC, KT>), grid, block, 0, st, sa, aa, (long long)L, D, row_bits, keys, \
+        if (kc == 1) hipLaunchKernelGGL((adagrad_groups_kernel<V, LP, NC, KT, 1>), grid, block, 0, st, sa, aa, (long long)L, D, row_bits, keys, \
+                           vals, bag_of, dout, (long long)dout_ld, clr, eps, ef, el);                                          \
+        else if (kc == 2) hipLaunchKernelGGL((adagrad_groups_kernel<V, LP, NC, KT, 2>), grid, block, 0, st, sa, aa, (long long)L, D, row_bits, keys, \
+                           vals, bag_of, dout, (long long)dout_ld, clr, eps, ef, el);                                          \
+        else hipLaunchKernelGGL((adagrad_groups_kernel<V, LP, NC, KT, 4>), grid, block, 0, st, sa, aa, (long long)L, D, row_bits, keys, \
                            vals, bag_of, dout, (long long)dout_ld, clr, eps, ef, el);                                          \
         DLRM_LAUNCH_CHECK();                                                                                                   \
         hipLaunchKernelGGL((adagrad_fixup_kernel<V, LP, NC, KT>), grid, block, 0, st, sa, aa, (long long)L, D, row_bits, keys,  \

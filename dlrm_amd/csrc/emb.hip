@@ -16,6 +16,7 @@
 //     (U independent 512 B reads in flight per half-wave) before any dependent add, which is
 //     what keeps HBM busy for one-hot (Criteo) inputs where every bag has exactly one row.
 //   * bags with more rows continue with a 4-deep load pipeline per bag.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -501,6 +502,21 @@ extern "C" int dlrm_emb_fwd(int T, int64_t B, int D, const void* const* weight_h
         EmbArgs a;
         fill_args(a, ids, n, (void* const*)weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host, err);
         dim3 grid((unsigned)((B + bags_per_block - 1) / bags_per_block), (unsigned)n, 1), block(256, 1, 1);
+        // bags per lane group for the D = 128 shape: 2 (default; env DLRM_EMB_FWD_U = 1 | 2 | 4 | 8).  Measured on one box at
+        // Criteo-Terabyte shapes: U = 1 0.356 ms, 2 0.282, 4 0.315, 8 0.312 — two independent row loads per half-wave and twice
+        // the waves beat four loads per half-wave
+        static int u_alt = -1;
+        if (u_alt < 0) { const char* e = getenv("DLRM_EMB_FWD_U"); u_alt = e ? atoi(e) : 2; }
+        if (u_alt && sh.vec == 4 && sh.lpb == 32 && sh.nch == 1 && (u_alt == 1 || u_alt == 2 || u_alt == 8)) {
+            const int bpb = (256 / 32) * u_alt;
+            dim3 g2((unsigned)((B + bpb - 1) / bpb), (unsigned)n, 1);
+#define EMB_FWD_U(UU) do { if (idx_bits == 64) hipLaunchKernelGGL((emb_fwd_kernel<4, 32, 1, long long, UU>), g2, block, 0, st, a, (long long)B, D, out, (long long)out_ld); \
+                           else hipLaunchKernelGGL((emb_fwd_kernel<4, 32, 1, int, UU>), g2, block, 0, st, a, (long long)B, D, out, (long long)out_ld); } while (0)
+            if (u_alt == 1) EMB_FWD_U(1); else if (u_alt == 2) EMB_FWD_U(2); else EMB_FWD_U(8);
+#undef EMB_FWD_U
+            DLRM_LAUNCH_CHECK();
+            continue;
+        }
         if (idx_bits == 64) EMB_DISPATCH_SHAPE(emb_fwd_kernel, long long, a, (long long)B, D, out, (long long)out_ld);
         else                EMB_DISPATCH_SHAPE(emb_fwd_kernel, int, a, (long long)B, D, out, (long long)out_ld);
         DLRM_LAUNCH_CHECK();

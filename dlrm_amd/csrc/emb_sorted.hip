@@ -160,9 +160,17 @@ static int run_sorted(int n, const int* ids, int64_t B, int D, void* const* weig
     constexpr int kQ = 8;                            // chunks per group: 64 / nch consecutive entries per group
     const size_t per_wg = (size_t)gpb * cc * kQ;
     dim3 ugrid((unsigned)((L + per_wg - 1) / per_wg), 1, 1);
-#define SU(V, LP, NC) hipLaunchKernelGGL((sorted_update_kernel<V, LP, NC, KT, 8 / NC, kQ>), ugrid, block, 0, st, sa, (long long)L, D, \
-                                         row_bits, (const KT*)keys_out, (const unsigned*)vals_out, (const unsigned*)bag_of, dout, \
-                                         (long long)dout_ld, neg_lr)
+    static int cdiv = -1;       // entries per chunk (x NCH registers), 64 entries per group either way; env DLRM_SORTED_C = 8 | 4 (default) | 2.  Measured on
+                                // one box (profiles/r03/ceilings.md): 0.626 / 0.524 / 0.538 ms for the whole update at Criteo-Terabyte shapes — occupancy beats
+                                // per-wave loads in flight
+    if (cdiv < 0) { const char* e = getenv("DLRM_SORTED_C"); cdiv = e ? atoi(e) : 4; }
+#define SU_ARGS ugrid, block, 0, st, sa, (long long)L, D, row_bits, (const KT*)keys_out, (const unsigned*)vals_out, (const unsigned*)bag_of, dout, (long long)dout_ld, neg_lr
+#define SU(V, LP, NC)                                                                                              \
+    do {                                                                                                           \
+        if (cdiv == 2 && NC == 1)      hipLaunchKernelGGL((sorted_update_kernel<V, LP, NC, KT, 2, 32>), SU_ARGS);   \
+        else if (cdiv == 4 && NC == 1) hipLaunchKernelGGL((sorted_update_kernel<V, LP, NC, KT, 4, 16>), SU_ARGS);   \
+        else                           hipLaunchKernelGGL((sorted_update_kernel<V, LP, NC, KT, 8 / NC, kQ>), SU_ARGS); \
+    } while (0)
     const int key = vec * 10000 + lpb * 10 + nch;
     switch (key) {
         case 40041: SU(4, 4, 1); break;   case 40081: SU(4, 8, 1); break;   case 40161: SU(4, 16, 1); break;
@@ -174,6 +182,7 @@ static int run_sorted(int n, const int* ids, int64_t B, int D, void* const* weig
         default: return DLRM_E_RANGE;
     }
 #undef SU
+#undef SU_ARGS
     DLRM_LAUNCH_CHECK();
     return 0;
 }
