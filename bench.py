@@ -498,7 +498,8 @@ def main():
                    "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": args.optimizer,
                    "interaction": ("dcn_v2 (3 layers, rank 512)" if dcn else "dot (torchrec triu order)") if hot else "dot",
                    "loss": "bce_with_logits" if hot else "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
-                   "embedding_update": args.emb_update, "a2a_chunks": model_a2a_chunks,
+                   "embedding_update": args.emb_update if graphed is None else "atomic (the HIP-graph path: rocPRIM's sort cannot be replayed, dlrm_amd/graph.py)",
+                   "a2a_chunks": model_a2a_chunks,
                    "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "
                                              "(no pooled-embedding buffer)") if (args.fuse and N == 1 and not hot) else "two kernels (dlrm_emb_fwd, dlrm_interact_*)",
                    "streams": ("single stream" if (args.no_overlap or graphed is not None) else

@@ -37,4 +37,21 @@ cd $GRAFT_REPO_ROOT
 python tools/pmc_fold.py $OUT
 find $OUT -name "p_counter_collection.csv" -size +8M -delete; find $OUT -name "*kernel_trace.csv" -size +8M -delete
 fi
+export DLRM_BENCH_WATCHDOG=120
+extra() { name=$1; shift; timeout 400 python bench.py "$@" --no-alt-arith > $OUT/$name.json 2> $OUT/$name.err; echo "== $name rc=$?"; grep -v amdgpu.ids $OUT/$name.err | tail -3 | cut -c1-300; python - <<PY
+import json
+try:
+    d=json.load(open("$OUT/$name.json")); print("  value %.0f  ms %.4f  loss %.5f dtype %s" % (d["value"], d["ms_per_step"], d["final_loss"], d["dtype"]))
+except Exception as e: print("  no json", e)
+PY
+}
+extra bench_no_overlap --steps 20 --warmup 5 --no-cpu-baseline --no-parity-check --no-overlap
+extra tb_graph --steps 20 --warmup 5 --graph --no-cpu-baseline --no-parity-check
+extra kaggle_eager --workload criteo_kaggle --steps 200 --warmup 10 --no-kernel-timers --no-cpu-baseline
+extra kaggle_graph --workload criteo_kaggle --steps 200 --warmup 10 --graph --no-cpu-baseline
+extra tb_rwsadagrad --steps 20 --warmup 5 --optimizer rwsadagrad --lr 0.0001 --no-cpu-baseline --no-parity-check
+extra tb_bf16 --steps 20 --warmup 5 --mlp-arith bf16 --no-cpu-baseline --no-parity-check
+extra tb_bf16x6 --steps 20 --warmup 5 --mlp-arith bf16x6 --no-cpu-baseline
+extra mlperf_v2_multihot_dcn --workload mlperf_v2_multihot --steps 10 --warmup 3
+extra mlperf_v2_multihot_dot --workload mlperf_v2_multihot --interaction dot --steps 10 --warmup 3
 du -sh $OUT
