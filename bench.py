@@ -66,10 +66,12 @@ def parse():
     ap.add_argument("--interaction", default="", choices=["", "dot", "dcn"],
                     help="mlperf_v2_multihot only: dcn (default there) = DCN-v2 low-rank cross network, 3 layers, rank 512 — the MLPerf-v2 "
                          "model (torchrec_dlrm/dlrm_main.py:608-619); dot = torchrec's triu dot interaction")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="single-stream schedule: by default the HBM-bound embedding kernels (pooled lookups; fused sparse update) "
-                         "run on a second HIP stream beside the MFMA-bound bottom-MLP GEMMs they do not depend on "
-                         "(DLRM_Net.overlap_streams)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="headline on two HIP streams: the HBM-bound embedding kernels (pooled lookups; fused sparse update) beside the "
+                         "MFMA-bound bottom-MLP GEMMs they do not depend on (DLRM_Net.overlap_streams).  Default: single stream — the "
+                         "gain is 0.2-1.7 % (profiles/r03/ceilings.md) and overlapped kernels stretch each other's event times, which "
+                         "would blur the per-kernel roofline; the 2-stream schedule is measured in the same run as alt_stream_overlap")
+    ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--fuse", action="store_true",
                     help="N = 1, one lookup per bag, D = 128: the interaction kernels fetch the embedding rows themselves and the "
                          "pooled-embedding buffer never exists (DLRM_Net.fuse_emb_interact; bit-identical results, measured slower "
@@ -181,7 +183,7 @@ def parity_check(args, device):
     import golden_tb
     mode = {"sorted": 2, "atomic": 0, "deterministic": 1}[args.emb_update]
     try:
-        rel = golden_tb.run_on_gpu(device, arith=args.mlp_arith, mode=mode, check=True, overlap=not args.no_overlap,
+        rel = golden_tb.run_on_gpu(device, arith=args.mlp_arith, mode=mode, check=True, overlap=bool(args.overlap) and not args.no_overlap,
                                    fuse=bool(args.fuse))
         return {"fixture": "tests/golden/terabyte_b65536.npz (3 training steps of the live reference at B=65536, T=26, D=128, "
                            "towers 13-512-256-128 / 479-1024-1024-512-256-1, lr 1.0, rows capped at 2000)",
@@ -295,7 +297,7 @@ def main():
         model = dlrm_amd.DLRM_Net(D, np.asarray(rows), np.asarray(wl["bot"]), ln_top, "dot", sigmoid_top=ln_top.size - 2,
                                   loss_function="bce").to(device)
     model.set_mlp_arith(args.mlp_arith)
-    model.overlap_streams = not args.no_overlap
+    model.overlap_streams = bool(args.overlap) and not args.no_overlap
     model.fuse_emb_interact = bool(args.fuse)
     model.a2a_chunks = max(args.a2a_chunks, 1) if N > 1 else 1
     model.emb_update_mode = {"sorted": ops.UPD_SORTED, "atomic": ops.UPD_ATOMIC, "deterministic": ops.UPD_DETERMINISTIC}[args.emb_update]
@@ -502,7 +504,7 @@ def main():
                    "a2a_chunks": model_a2a_chunks,
                    "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "
                                              "(no pooled-embedding buffer)") if (args.fuse and N == 1 and not hot) else "two kernels (dlrm_emb_fwd, dlrm_interact_*)",
-                   "streams": ("single stream" if (args.no_overlap or graphed is not None) else
+                   "streams": ("single stream" if (not args.overlap or args.no_overlap or graphed is not None) else
                                "2 HIP streams: embedding lookups / fused sparse update on a side stream beside the bottom-MLP GEMMs "
                                "(per-kernel event times then overlap: their sum exceeds the step time)"),
                    "launch": "HIP graph replay of the captured step (dlrm_amd.graph)" if graphed is not None else "eager (one C-ABI call per kernel)",
@@ -562,6 +564,23 @@ def main():
                                    "final_loss": float(loss_alt.detach()),
                                    "note": "opt-in (--mlp-arith bf16x6); parity-tested at the fp32 tolerances"}
         del loss_alt
+    if N == 1 and graphed is None and not hot and not (args.overlap and not args.no_overlap):
+        # the same step on two HIP streams (embedding kernels beside the bottom-MLP GEMMs): beside the headline, never instead
+        model.overlap_streams = True
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss_o = step(i)
+        torch.cuda.synchronize()
+        dto = (time.perf_counter() - t0) / args.steps
+        model.overlap_streams = False
+        model._join_side_stream()
+        result["alt_stream_overlap"] = {"value": B / dto, "unit": "samples/s", "ms_per_step": dto * 1e3, "final_loss": float(loss_o.detach()),
+                                        "note": "DLRM_Net.overlap_streams: pooled lookups beside the bottom-MLP forward GEMMs, fused sparse "
+                                                "update beside the bottom-MLP backward + dense step; same kernels, same results"}
+        del loss_o
     if N == 1 and graphed is None and args.alt_graph:
         # the same step captured once in a HIP graph and replayed (dlrm_amd.graph): removes the host launch path; reported
         # beside the headline value.  Never allowed to break the headline line.

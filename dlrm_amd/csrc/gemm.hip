@@ -730,9 +730,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int N, int K, int sp
                                                             long long lddw, int accumulate, const float* __restrict__ rs_part,
                                                             float* __restrict__ dbias) {
     // bias gradient: the k-slices' row sums of dY^T, summed in slice order (deterministic; no zero-fill, no atomics)
-    if (rs_part && blockIdx.x == 0) {
-        for (int n = threadIdx.x; n < N; n += 256) {
+    if (rs_part) {          // one thread per bias element, spread over the grid; slice order fixed, loads unrolled (independent addresses)
+        for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < N; n += (long long)gridDim.x * 256) {
             float a = accumulate ? dbias[n] : 0.f;
+#pragma unroll 8
             for (int s_ = 0; s_ < splits; ++s_) a += rs_part[(long long)s_ * N + n];
             dbias[n] = a;
         }

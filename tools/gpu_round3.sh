@@ -45,7 +45,7 @@ try:
 except Exception as e: print("  no json", e)
 PY
 }
-extra bench_no_overlap --steps 20 --warmup 5 --no-cpu-baseline --no-parity-check --no-overlap
+extra bench_overlap --steps 20 --warmup 5 --no-cpu-baseline --no-parity-check --overlap
 extra tb_graph --steps 20 --warmup 5 --graph --no-cpu-baseline --no-parity-check
 extra kaggle_eager --workload criteo_kaggle --steps 200 --warmup 10 --no-kernel-timers --no-cpu-baseline
 extra kaggle_graph --workload criteo_kaggle --steps 200 --warmup 10 --graph --no-cpu-baseline
