@@ -353,6 +353,7 @@ class DLRM_Net(nn.Module):
     def _join_side_stream(self) -> None:
         if self._side_keep:
             dev = self._side_keep[0].device
+            ops.timer_mark()
             torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
             self._side_keep = []
 
@@ -370,6 +371,7 @@ class DLRM_Net(nn.Module):
             if plan is not None and plan[0] == "sgd":
                 cur, side = torch.cuda.current_stream(dout.device), _side_stream(dout.device)
                 if cur != side:                      # (distributed forward: the lookups ran on the main stream)
+                    ops.timer_mark()
                     side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     ops.emb_bwd_sgd(weights, bags, dout, plan[1], self.emb_update_mode)
@@ -400,6 +402,7 @@ class DLRM_Net(nn.Module):
             # launched from the step pre-hook: on the side stream, beside the dense optimizer step (joined in the post-hook)
             dev = pending[0][2].device
             side = _side_stream(dev)
+            ops.timer_mark()
             side.wait_stream(torch.cuda.current_stream(dev))
             self._side_keep += [p_[2] for p_ in pending]
             if optimizer is not None and self._bound_optimizer is None and self._owned_by(optimizer):
@@ -459,10 +462,12 @@ class DLRM_Net(nn.Module):
             # pooled lookups (HBM-bound) on the side stream beside the bottom-MLP GEMMs (MFMA-bound): they only meet at the
             # interaction.  The side stream first waits for everything already enqueued (inputs, the previous update).
             main, side = torch.cuda.current_stream(dense_x.device), _side_stream(dense_x.device)
+            ops.timer_mark()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l, out_slot=OutSlot(feat[:, n_out:]))
             x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :n_out]))
+            ops.timer_mark()
             main.wait_stream(side)
         else:
             x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :n_out]))

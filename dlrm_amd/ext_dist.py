@@ -149,6 +149,12 @@ class _Exchange:
         self.buffer = None
 
 
+def _mark():
+    """ends bench.py's open per-kernel timing run: what follows on the stream is a wait for a collective, not a kernel"""
+    from . import ops
+    ops.timer_mark()
+
+
 class _Done:
     def wait(self):
         return True
@@ -158,6 +164,9 @@ def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_counts: List[int], in_
     """One asynchronous all_to_all_single.  On RCCL ("nccl") and on gloo with host tensors this is the
     collective itself.  gloo has no device all-to-all: GPU tensors under gloo (the 1-GPU test rig that runs
     several ranks on one device) are staged through host memory, synchronously."""
+    if inp.is_cuda:
+        from . import ops
+        ops.timer_mark()          # per-kernel timing runs (bench.py) end where a collective is enqueued
     if inp.is_cuda and dist.get_backend() == "gloo":
         h_in, h_out = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(h_out, h_in, out_counts, in_counts)
@@ -185,6 +194,7 @@ class _A2AStart(Function):
     @staticmethod
     def backward(ctx, _unused):
         ex = ctx.ex
+        _mark()
         ex.work.wait()                          # reverse exchange launched by _A2AWait.backward
         ex.work = None
         g = ex.buffer.view(ex.batch, -1)        # [B, T_loc*D]
@@ -197,6 +207,7 @@ class _A2AStart(Function):
 class _A2AWait(Function):
     @staticmethod
     def forward(ctx, ex: _Exchange, recv):
+        _mark()
         ex.work.wait()
         ex.work = None
         ex.send_keepalive = None

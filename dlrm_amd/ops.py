@@ -27,44 +27,95 @@ def _stream(t: Optional[torch.Tensor] = None) -> C.c_void_p:
 
 
 class KernelTimers:
-    """Optional per-call HIP-event timing of the C-ABI launches, on the stream they are enqueued on.
-    Enabled by bench.py inside its timed region (two hipEventRecord per call, no synchronisation until
-    `summary()`); disabled (None) by default."""
+    """Optional HIP-event timing of the C-ABI launches, on the stream they are enqueued on (bench.py turns it on inside its
+    timed region; None by default).
+
+    One event is recorded where the launch CATEGORY changes (e.g. linear_fwd -> emb_fwd), not around every launch: a run of
+    consecutive launches of one category on one stream is a single (start, end) pair, and the end of one run is the start
+    of the next.  Event records are not free on this hardware — each is a barrier packet, ~5 us of idle queue: two per
+    launch cost 0.33 ms of a 9.1 ms step (rocprofv3 trace, profiles/r03/ceilings.md) and inflated every per-kernel time
+    by 10 us — so this keeps ~35 of them per step instead of 120.  A run's time covers whatever the stream executed
+    between its first launch and the next category's first launch: `mark()` closes the open run early wherever something
+    that is not a kernel of this library follows (a collective, a cross-stream wait)."""
 
     def __init__(self):
-        self.records = {}   # name -> list[(start_event, end_event)]
-        self.enabled = True # bench.py samples a subset of its timed steps (the event pairs cost ~0.4 ms per step)
+        self.records = {}          # name -> {"calls": launches, "pairs": [(start_event, end_event), ...]}
+        self._enabled = True       # bench.py samples a subset of its timed steps
+        self._open = None          # [name, start_event, torch stream, launches]
+
+    @property
+    def enabled(self):
+        return self._enabled
+
+    @enabled.setter
+    def enabled(self, on):
+        if not on:
+            self.mark()
+        self._enabled = bool(on)
+
+    def _close(self, end_event):
+        name, start, _, calls = self._open
+        rec = self.records.setdefault(name, {"calls": 0, "pairs": []})
+        rec["calls"] += calls
+        rec["pairs"].append((start, end_event))
+        self._open = None
+
+    def mark(self):
+        """close the open run now (its end event is recorded on the stream the run was launched on)"""
+        if self._open is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(self._open[2])
+            self._close(e)
+
+    def enter(self, name):
+        if not self._enabled:
+            return
+        st = torch.cuda.current_stream()
+        o = self._open
+        if o is not None and o[2] == st:
+            if o[0] == name:
+                o[3] += 1
+                return
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(st)
+            self._close(e)                       # shared: end of the previous run == start of this one
+        else:
+            self.mark()                          # a run on another stream ends with an event of its own
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(st)
+        self._open = [name, e, st, 1]
 
     def summary(self):
+        self.mark()
         torch.cuda.synchronize()
         out = {}
-        for name, evs in self.records.items():
-            ms = [a.elapsed_time(b) for a, b in evs]
-            out[name] = {"calls": len(ms), "total_ms": float(sum(ms)), "avg_ms": float(sum(ms) / max(len(ms), 1))}
+        for name, rec in self.records.items():
+            total = float(sum(a.elapsed_time(b) for a, b in rec["pairs"]))
+            out[name] = {"calls": rec["calls"], "total_ms": total, "avg_ms": total / max(rec["calls"], 1)}
         return out
 
 
 timers: Optional[KernelTimers] = None
 
 
+def timer_mark() -> None:
+    """called by code that enqueues non-library work (collectives, cross-stream waits): ends the open timing run"""
+    if timers is not None:
+        timers.mark()
+
+
 class _timed:
-    __slots__ = ("name", "a")
+    __slots__ = ("name",)
 
     def __init__(self, name):
         self.name = name
 
     def __enter__(self):
-        self.a = None
-        if timers is not None and timers.enabled:
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.a.record()
+        if timers is not None:
+            timers.enter(self.name)
         return self
 
     def __exit__(self, *exc):
-        if self.a is not None and timers is not None:
-            b = torch.cuda.Event(enable_timing=True)
-            b.record()
-            timers.records.setdefault(self.name, []).append((self.a, b))
         return False
 
 

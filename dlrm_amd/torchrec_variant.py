@@ -3,7 +3,7 @@
 `torchrec_dlrm/dlrm_main.py:598-653` builds `torchrec.models.dlrm.DLRM` and wraps it in `DLRMTrain`.  torchrec itself is a
 third-party dependency that is NOT vendored in the reference (requirements.txt:9, unpinned nightly) and is not installed here,
 so this module restates its published model (torchrec/models/dlrm.py: SparseArch, DenseArch, InteractionArch, OverArch,
-DLRMTrain) — parity for THIS variant is therefore "unpinned": it is checked against the CPU oracle's restatement and against
+DLRMTrain) — parity for THIS variant is therefore "unpinned": it is checked against the test suite's CPU restatement and against
 torch operators, not against torchrec output.  What differs from `dlrm_s_pytorch.DLRM_Net` (same math otherwise):
   * InteractionArch keeps the strictly UPPER triangle in `torch.triu_indices(F, F, offset=1)` order — the same pairwise dots
     as the reference's tril order, permuted columns (interaction mode 2 of `dlrm_interact_fwd`);
