@@ -85,6 +85,10 @@ def parse():
                          "--no-kernel-timers: events cannot be recorded inside a replay)")
     ap.add_argument("--alt-graph", action="store_true",
                     help="after the timed region, also measure the same step replayed as one HIP graph (reported as alt_hip_graph)")
+    ap.add_argument("--dense-sync", choices=["ddp", "flat"], default="ddp",
+                    help="N > 1: gradient all-reduce of the data-parallel MLP towers: torch DistributedDataParallel (the reference, "
+                         "dlrm_s_pytorch.py:1329-1336; default) or dlrm_amd.ext_dist.FlatDDP (one flat buffer the weight-gradient GEMMs "
+                         "write into, one collective per tower); the other one is measured in the same run as alt_dense_sync")
     ap.add_argument("--no-kernel-timers", action="store_true", help="no per-kernel HIP events in the timed region (no roofline)")
     ap.add_argument("--timer-every", type=int, default=4,
                     help="per-kernel HIP events are recorded on every n-th step of the timed region (an event is a queue barrier, "
@@ -259,16 +263,46 @@ def main():
 
     import faulthandler
 
+    import threading
+    partial = {"json": None}      # the finished headline line: printed by the watchdog if a LATER, optional measurement hangs
+    wd = {"deadline": None, "what": ""}
+
+    def _watch():
+        while True:
+            time.sleep(1.0)
+            dl = wd["deadline"]
+            if dl is not None and time.monotonic() > dl:
+                print(f"[bench rank {os.environ.get('RANK', '0')}] watchdog expired: {wd['what']}", file=sys.stderr, flush=True)
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                if partial["json"] is not None:
+                    if os.environ.get("RANK", "0") == "0":
+                        d_ = json.loads(partial["json"])
+                        d_["incomplete"] = "an optional measurement after the headline did not finish (%s); headline value unaffected" % wd["what"]
+                        print(json.dumps(d_), flush=True)
+                    os._exit(0)
+                os._exit(3)
+
     def watchdog(seconds, what):
-        """(re-)arm the hang watchdog: after `seconds` all Python stacks go to stderr and the process exits (code 3)"""
-        faulthandler.cancel_dump_traceback_later()
+        """(re-)arm the hang watchdog (N > 1): when it expires all Python stacks go to stderr and the process exits — with code 3
+        while the headline is still being measured, with the finished headline JSON line (rank 0) and code 0 afterwards"""
         if N > 1 and seconds > 0:
             print(f"[bench rank {os.environ.get('RANK', '0')}] watchdog {seconds}s: {what}", file=sys.stderr, flush=True)
-            faulthandler.dump_traceback_later(seconds, repeat=False, exit=True)
+            wd["what"], wd["deadline"] = what, time.monotonic() + seconds
+        else:
+            wd["deadline"] = None
+
+    if N > 1:
+        threading.Thread(target=_watch, daemon=True).start()
 
     if N > 1:
         watchdog(args.hang_timeout, "rendezvous + RCCL all_to_all capability probe")
-        ext_dist.init_distributed(use_gpu=True, backend="nccl")   # RCCL
+        # DLRM_BENCH_SELFTEST_GLOO=1 (development only): every rank on cuda:0 over gloo with host-staged exchanges — exercises
+        # this file's whole N > 1 control flow on a 1-GPU box; the line it prints is marked and is not a measurement
+        selftest = os.environ.get("DLRM_BENCH_SELFTEST_GLOO", "0") == "1"
+        if selftest:
+            ext_dist.init_distributed(local_rank=0, use_gpu=True, backend="gloo")
+        else:
+            ext_dist.init_distributed(use_gpu=True, backend="nccl")   # RCCL
         device = torch.device("cuda", ext_dist.my_local_rank)
     else:
         ext_dist.my_size, ext_dist.my_rank = 1, 0
@@ -302,8 +336,9 @@ def main():
     model.a2a_chunks = max(args.a2a_chunks, 1) if N > 1 else 1
     model.emb_update_mode = {"sorted": ops.UPD_SORTED, "atomic": ops.UPD_ATOMIC, "deterministic": ops.UPD_DETERMINISTIC}[args.emb_update]
     if N > 1:
-        model.bot_l = ext_dist.DDP(model.bot_l, device_ids=[device.index])
-        model.top_l = ext_dist.DDP(model.top_l, device_ids=[device.index])
+        wrap = ext_dist.FlatDDP if args.dense_sync == "flat" else ext_dist.DDP
+        model.bot_l = wrap(model.bot_l, device_ids=[device.index])
+        model.top_l = wrap(model.top_l, device_ids=[device.index])
         groups = [{"params": [p for e in model.emb_l for p in e.parameters()], "lr": args.lr},
                   {"params": model.bot_l.parameters(), "lr": args.lr},
                   {"params": model.top_l.parameters(), "lr": args.lr}]
@@ -362,7 +397,7 @@ def main():
         torch.distributed.all_gather_object(uuids, uuid)
         dist_info = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
                      "distinct_gpus": len(set(uuids)), "tables_per_rank": list(model.n_emb_per_rank) if model.n_emb_per_rank else None}
-        if len(set(uuids)) != N:
+        if len(set(uuids)) != N and not selftest:
             sys.exit("ERROR: %d ranks share %d GPUs; one process per GPU is required" % (N, len(set(uuids))))
         watchdog(args.hang_timeout, "first training step (RCCL all-to-all + DDP all-reduce for the first time)")
     for i in range(args.warmup):
@@ -499,7 +534,7 @@ def main():
                    "tables": len(rows), "emb_dim": D, "global_batch": B, "table_rows_total": int(sum(rows)),
                    "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": args.optimizer,
                    "interaction": ("dcn_v2 (3 layers, rank 512)" if dcn else "dot (torchrec triu order)") if hot else "dot",
-                   "loss": "bce_with_logits" if hot else "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs" % N) if N > 1 else "single GPU",
+                   "loss": "bce_with_logits" if hot else "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs (dense gradients: %s)" % (N, args.dense_sync)) if N > 1 else "single GPU",
                    "embedding_update": args.emb_update if graphed is None else "atomic (the HIP-graph path: rocPRIM's sort cannot be replayed, dlrm_amd/graph.py)",
                    "a2a_chunks": model_a2a_chunks,
                    "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "
@@ -514,7 +549,8 @@ def main():
                                          "(reduced precision: NOT the headline configuration)"}[args.mlp_arith]},
         "final_loss": final_loss,
         "parity_check": parity,
-        "kernel_timing": "HIP events on the launch stream around every C-ABI call, on %d of the %d timed steps" % (timed_steps, args.steps),
+        "kernel_timing": "HIP events on the launch stream, one per change of launch category (a run of consecutive launches of one category "
+                         "is one event pair; dlrm_amd.ops.KernelTimers), on %d of the %d timed steps" % (timed_steps, args.steps),
         "roofline": roof(dom) if dom else None,
         "roofline_embedding": roof("emb_fwd") if "emb_fwd" in kernels else None,
         "embedding_hbm_gbps": {"fwd": kernels.get("emb_fwd", {}).get("achieved"),
@@ -522,6 +558,7 @@ def main():
         "kernels": kernels,
     }
     result.update(result_extra)
+    partial["json"] = json.dumps(result)            # from here on a hang in an optional measurement cannot lose the headline
     if N == 1 and "emb_fwd" not in kernels:
         # fused forward: no separate embedding kernel ran inside the step.  BASELINE.json's second metric is the embedding kernel's
         # HBM rate, so the stand-alone dlrm_emb_fwd (what the unfused / multi-hot / distributed paths launch) is measured here.
@@ -628,42 +665,83 @@ def main():
                         if alt_c > 1 else "the reference schedule: one all-to-all per direction, bottom MLP overlapping it"}
             del loss_alt
             model.a2a_chunks = model_a2a_chunks
+        # ---- the OTHER dense-gradient synchronisation, same process, same parameters -------------------------------------------
+        if not hot:
+            try:
+                import gc
+                other = "flat" if args.dense_sync == "ddp" else "ddp"
+                watchdog(args.hang_timeout + 20 * args.steps, "alternative dense-gradient all-reduce (%s)" % other)
+                if os.environ.get("DLRM_BENCH_SELFTEST_HANG") == "alt":        # development: proves the watchdog still prints the headline
+                    time.sleep(10 ** 6)
+                inner_b, inner_t = model.bot_l.module, model.top_l.module
+                model.bot_l = model.top_l = None
+                gc.collect()                                   # the old wrappers (their autograd hooks) go away
+                if other == "flat":
+                    model.bot_l, model.top_l = ext_dist.FlatDDP(inner_b), ext_dist.FlatDDP(inner_t)
+                else:
+                    from dlrm_amd import functional as _fn
+                    _fn.GRAD_ARENAS.clear()
+                    model.bot_l = ext_dist.DDP(inner_b, device_ids=[device.index])
+                    model.top_l = ext_dist.DDP(inner_t, device_ids=[device.index])
+                for i in range(2):
+                    step(i)
+                torch.distributed.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    loss_alt = step(i)
+                torch.cuda.synchronize()
+                torch.distributed.barrier()
+                tt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+                torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+                dtf = float(tt.item()) / args.steps
+                result["alt_dense_sync"] = {
+                    "dense_sync": other, "value": B / dtf, "unit": "samples/s", "ms_per_step": dtf * 1e3, "final_loss": float(loss_alt.detach()),
+                    "note": "ext_dist.FlatDDP: the weight-gradient GEMMs write into one flat buffer per tower, one in-place all-reduce launched "
+                            "when the tower's last gradient is ready, no bucket copies" if other == "flat" else "torch DistributedDataParallel"}
+                del loss_alt
+            except Exception as e:                       # noqa: BLE001 - never allowed to break the headline line
+                result["alt_dense_sync"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         # ---- the collectives alone, at the step's exact sizes, HIP events on the stream they are enqueued on ---------------
-        watchdog(args.hang_timeout, "collective micro-measurements")
-        Tl_, D_ = len(local_tables), D
-        splits = model.n_emb_per_rank or [Tl_] * N
-        send = torch.empty(B * Tl_ * D_, device=device)
-        recv = torch.empty((B // N) * sum(splits) * D_, device=device)
-        send_counts = [(B // N) * Tl_ * D_] * N
-        recv_counts = [(B // N) * t * D_ for t in splits]
-        flat = torch.empty(sum(p.numel() for p in model.bot_l.parameters()) + sum(p.numel() for p in model.top_l.parameters()), device=device)
+        try:
+            watchdog(args.hang_timeout, "collective micro-measurements")
+            Tl_, D_ = len(local_tables), D
+            splits = model.n_emb_per_rank or [Tl_] * N
+            send = torch.empty(B * Tl_ * D_, device=device)
+            recv = torch.empty((B // N) * sum(splits) * D_, device=device)
+            send_counts = [(B // N) * Tl_ * D_] * N
+            recv_counts = [(B // N) * t * D_ for t in splits]
+            flat = torch.empty(sum(p.numel() for p in model.bot_l.parameters()) + sum(p.numel() for p in model.top_l.parameters()), device=device)
 
-        def timed(fn, iters=10):
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize()
-            torch.distributed.barrier()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(iters):
-                fn()
-            b.record()
-            torch.cuda.synchronize()
-            t = torch.tensor([a.elapsed_time(b) / iters], device=device, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            return float(t.item())
-        a2a_f = timed(lambda: torch.distributed.all_to_all_single(recv, send, recv_counts, send_counts))
-        a2a_b = timed(lambda: torch.distributed.all_to_all_single(send, recv, send_counts, recv_counts))
-        ar = timed(lambda: torch.distributed.all_reduce(flat))
-        off_node = send.numel() * 4 * (N - 1) / N
-        result["collectives"] = {
-            "a2a_fwd_ms": a2a_f, "a2a_bwd_ms": a2a_b, "allreduce_ms": ar, "timing": "HIP events, max over ranks, 10 back-to-back calls",
-            "a2a_send_bytes_per_rank": send.numel() * 4, "a2a_bytes_leaving_rank": off_node,
-            "a2a_fwd_gbps_per_rank": off_node / (a2a_f * 1e-3) / 1e9, "allreduce_bytes": flat.numel() * 4,
-            "in_step": "2 all-to-alls (forward + backward) + 1 bucketed DDP all-reduce per step"}
+            def timed(fn, iters=10):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                torch.distributed.barrier()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(iters):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                t = torch.tensor([a.elapsed_time(b) / iters], device=device, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                return float(t.item())
+            a2a_f = timed(lambda: torch.distributed.all_to_all_single(recv, send, recv_counts, send_counts))
+            a2a_b = timed(lambda: torch.distributed.all_to_all_single(send, recv, send_counts, recv_counts))
+            ar = timed(lambda: torch.distributed.all_reduce(flat))
+            off_node = send.numel() * 4 * (N - 1) / N
+            result["collectives"] = {
+                "a2a_fwd_ms": a2a_f, "a2a_bwd_ms": a2a_b, "allreduce_ms": ar, "timing": "HIP events, max over ranks, 10 back-to-back calls",
+                "a2a_send_bytes_per_rank": send.numel() * 4, "a2a_bytes_leaving_rank": off_node,
+                "a2a_fwd_gbps_per_rank": off_node / (a2a_f * 1e-3) / 1e9, "allreduce_bytes": flat.numel() * 4,
+                "in_step": "2 all-to-alls (forward + backward) + the dense-gradient all-reduce of each tower (--dense-sync %s) per step" % args.dense_sync}
+        except Exception as e:                           # noqa: BLE001 - diagnostic section, never breaks the headline line
+            result["collectives"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         result["distributed"] = dist_info
-        faulthandler.cancel_dump_traceback_later()
-        del send, recv, flat
+        if selftest:
+            result["selftest"] = "DLRM_BENCH_SELFTEST_GLOO=1: all ranks on ONE GPU over gloo with host-staged exchanges — control-flow test, NOT a measurement"
+        watchdog(0, "")
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         del model, opt, batches
         torch.cuda.empty_cache()

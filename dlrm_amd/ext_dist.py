@@ -305,6 +305,96 @@ def all_gather(x: torch.Tensor, lengths: Optional[List[int]], dim: int = 0) -> t
 
 
 # ------------------------------------------------------------------------------------------------
+# flat-buffer gradient all-reduce for the data-parallel MLP towers
+# ------------------------------------------------------------------------------------------------
+class FlatDDP(torch.nn.Module):
+    """Data-parallel wrapper of one MLP tower with the surface the reference uses of DistributedDataParallel
+    (`ext_dist.DDP(dlrm.bot_l, device_ids=[...])`, dlrm_s_pytorch.py:1329-1336: `.module`, forward, averaged gradients after
+    backward, "module."-prefixed state_dict keys) and one difference in mechanics: the gradients of all parameters live in ONE
+    flat fp32 buffer that is all-reduced in place by a single collective.
+
+      * dlrm_amd's weight-gradient GEMMs write dW / db straight into that buffer (functional.GRAD_ARENAS) and autograd adopts
+        those views as `.grad` — DDP's copy into its bucket and the copy back do not exist; any other gradient producer
+        (plain torch layers, accumulation over several backward passes) is copied in when the last gradient has arrived;
+      * the collective is launched from the hook of the LAST parameter to receive its gradient: for the top tower that is the
+        moment its backward ends, so the all-reduce runs on RCCL's stream beside the interaction backward, the reverse
+        all-to-all, the fused embedding update and the bottom-tower backward; the compute stream waits for it at the end of
+        the backward pass (autograd engine callback), before the optimizer can read `.grad`;
+      * average = ReduceOp.AVG on RCCL, sum + one scale kernel elsewhere (gloo has no AVG).
+    Parameters are broadcast from rank 0 at construction, as DDP does.  Every parameter must receive a gradient in every
+    backward pass (true for the towers; DDP's find_unused_parameters machinery is not reproduced)."""
+
+    def __init__(self, module: torch.nn.Module, device_ids=None, broadcast: bool = True):
+        super().__init__()
+        self.module = module
+        self._params = [p for p in module.parameters() if p.requires_grad]
+        if not self._params:
+            raise RuntimeError("FlatDDP: the module has no trainable parameter")
+        dev = self._params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in self._params):
+            raise RuntimeError("FlatDDP: all parameters must be fp32 tensors on one device")
+        if my_size > 1 and broadcast:
+            with torch.no_grad():
+                for p in self._params:
+                    dist.broadcast(p, 0)
+        self._offsets, n = [], 0
+        for p in self._params:
+            self._offsets.append(n)
+            n += (p.numel() + 3) & ~3                      # every view starts 16-byte aligned
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._ready = 0
+        self._work = None
+        self._callback_queued = False
+        self._avg = my_size > 1 and dist.get_backend() == "nccl"
+        from . import functional
+        for p, o in zip(self._params, self._offsets):
+            functional.GRAD_ARENAS[p.data_ptr()] = (self.flat, o)
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def _view(self, i: int) -> torch.Tensor:
+        p, o = self._params[i], self._offsets[i]
+        return self.flat[o:o + p.numel()].view(p.shape)
+
+    def _on_grad(self, p) -> None:
+        from . import functional
+        functional.ARENA_BUSY.discard(p.data_ptr())
+        if not self._callback_queued:
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+        self._ready += 1
+        if self._ready == len(self._params):
+            self._launch()
+
+    def _launch(self) -> None:
+        with torch.no_grad():
+            for i, p in enumerate(self._params):
+                v = self._view(i)
+                if p.grad.data_ptr() != v.data_ptr():      # produced elsewhere (or accumulated): move it into the flat buffer
+                    v.copy_(p.grad)
+                    p.grad = v
+        if my_size > 1:
+            _mark()
+            self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, async_op=True)
+
+    def _finalize(self) -> None:
+        ready, self._ready, self._callback_queued = self._ready, 0, False
+        from . import functional
+        functional.ARENA_BUSY.difference_update(p.data_ptr() for p in self._params)
+        if ready != len(self._params):
+            self._work = None
+            raise RuntimeError("FlatDDP: %d of %d parameters received a gradient in this backward pass" % (ready, len(self._params)))
+        if self._work is not None:
+            _mark()
+            self._work.wait()                               # RCCL: the compute stream waits for the collective's stream
+            self._work = None
+            if not self._avg:
+                self.flat.mul_(1.0 / my_size)
+
+
+# ------------------------------------------------------------------------------------------------
 # SURVEY §8 f-3: input distribution of key-major id batches and row-wise shard collectives.
 # The reference's torchrec trainer leaves both to torchrec's DistributedModelParallel (third-party, absent:
 # torchrec_dlrm/dlrm_main.py:669-673); `dlrm_s_pytorch.py` avoids them by replicating the inputs on every rank (:1541-1548).

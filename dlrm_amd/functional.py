@@ -37,6 +37,28 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
+# parameter storage address -> (flat fp32 gradient buffer, element offset): the weight-gradient GEMMs of MLPFunction write
+# such a parameter's gradient straight into the flat buffer that ext_dist.FlatDDP all-reduces (no bucket copy in, none out)
+GRAD_ARENAS = {}
+ARENA_BUSY = set()      # slots handed out in the running backward pass whose gradient autograd has not accumulated yet
+
+
+def _grad_out(p: torch.Tensor) -> torch.Tensor:
+    key = p.data_ptr()
+    a = GRAD_ARENAS.get(key)
+    if a is None:
+        return torch.empty_like(p)
+    flat, off = a
+    v = flat[off:off + p.numel()].view(p.shape)
+    # one writer per slot: a second use of the tower in the same backward pass (the pipelined exchange applies the top tower once per
+    # chunk) or the gradient of an earlier backward pass still living there (accumulation) get a tensor of their own — autograd sums
+    # them and FlatDDP moves the sum into the flat buffer
+    if key in ARENA_BUSY or (p.grad is not None and p.grad.data_ptr() == v.data_ptr()):
+        return torch.empty_like(p)
+    ARENA_BUSY.add(key)
+    return v
+
+
 def _round4(n: int) -> int:
     return (n + 3) & ~3
 
@@ -148,8 +170,8 @@ class MLPFunction(Function):
             X_i = x if i == 0 else outs[i - 1]
             # first layer on a zero-padded input: the gradient is written at the parameter's true width (the padding
             # columns of X are dropped inside the kernel) — contiguous, no slicing / re-packing afterwards
-            dW = torch.empty_like(params[2 * i])
-            db = torch.empty(W.size(0), dtype=torch.float32, device=x.device)
+            dW = _grad_out(params[2 * i])
+            db = _grad_out(params[2 * i + 1])
             if side is not None:
                 side.wait_event(main.record_event())
                 with torch.cuda.stream(side):

@@ -228,3 +228,74 @@ def test_kjt_input_dist_and_row_wise_collectives(size):
         # d/dx[g] = (owner_of_row(g) + 1) * g   (the owner's upstream gradient, all-gathered back to every rank)
         g = np.arange(B, dtype=np.float32)
         assert np.array_equal(results[r]["gx"], np.repeat(((g // Bl + 1) * g).reshape(-1, 1), 3, axis=1))
+
+
+def _flat_ddp_worker(rank, size, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank))
+    from dlrm_amd import ext_dist
+    ext_dist.init_distributed(rank=rank, local_rank=rank, size=size, use_gpu=False, backend="gloo")
+
+    def tower(seed):
+        torch.manual_seed(seed)          # rank-dependent on purpose: construction must broadcast rank 0's parameters
+        return torch.nn.Sequential(torch.nn.Linear(6, 9), torch.nn.ReLU(), torch.nn.Linear(9, 5), torch.nn.ReLU(), torch.nn.Linear(5, 1))
+
+    a, b = ext_dist.DDP(tower(100 + rank)), ext_dist.FlatDDP(tower(200 + rank))
+    with torch.no_grad():
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            pb.copy_(pa)                 # same starting point (DDP broadcast rank 0's at construction, FlatDDP its own)
+    oa, ob = torch.optim.SGD(a.parameters(), lr=0.1), torch.optim.SGD(b.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(7 + rank)
+    res = {"grads": [], "params": None, "in_flat": []}
+    for step in range(3):
+        x = torch.randn(8, 6, generator=g)
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            m(x).pow(2).mean().backward()
+        res["grads"].append([(pa.grad - pb.grad).abs().max().item() for pa, pb in zip(a.parameters(), b.parameters())])
+        res["in_flat"].append(all(p.grad.data_ptr() == b._view(i).data_ptr() for i, p in enumerate(b._params)))
+        oa.step(); ob.step()
+    # accumulation over two backward passes without zero_grad: DDP and FlatDDP must still agree
+    x1, x2 = torch.randn(8, 6, generator=g), torch.randn(8, 6, generator=g)
+    for m, o in ((a, oa), (b, ob)):
+        o.zero_grad()
+        m(x1).pow(2).mean().backward()
+        m(x2).pow(2).mean().backward()
+    res["accum"] = [(pa.grad - pb.grad).abs().max().item() for pa, pb in zip(a.parameters(), b.parameters())]
+    res["params"] = [p.detach().numpy().copy() for p in b.parameters()]
+    res["keys"] = list(b.state_dict().keys())
+    # a tower whose second half gets no gradient must raise, not hang or silently skip the collective
+    c = ext_dist.FlatDDP(tower(300), broadcast=False)
+    try:
+        c.module[0](torch.randn(2, 6)).sum().backward()
+        res["partial"] = "no error"
+    except RuntimeError as e:
+        res["partial"] = str(e)
+    q.put((rank, res))
+    ext_dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_flat_ddp_equals_ddp(size):
+    """ext_dist.FlatDDP (one flat gradient buffer, one all-reduce launched by the last gradient hook, waited for at the end of
+    backward) against torch's DistributedDataParallel on the same tower: averaged gradients over 3 SGD steps, gradient
+    accumulation, identical parameters on all ranks, DDP-style state_dict keys."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_ddp_worker, args=(r, size, port, q)) for r in range(size)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(size))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(size):
+        for step, gs in enumerate(results[r]["grads"]):
+            assert max(gs) < 1e-6, (r, step, gs)
+        assert all(results[r]["in_flat"])
+        assert max(results[r]["accum"]) < 1e-6, results[r]["accum"]
+        assert results[r]["keys"][0] == "module.0.weight"
+        assert "parameters received a gradient" in results[r]["partial"]
+        for pa, pb in zip(results[0]["params"], results[r]["params"]):
+            assert np.array_equal(pa, pb)

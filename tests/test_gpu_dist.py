@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, size, port, q, chunks=1, fixture="dist2_tiny"):
+def _worker(rank, size, port, q, chunks=1, fixture="dist2_tiny", dense_sync="ddp"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK="0")
     import dlrm_amd
     from dlrm_amd import ext_dist, ops
@@ -44,8 +44,9 @@ def _worker(rank, size, port, q, chunks=1, fixture="dist2_tiny"):
     model = model.to(dev)
     model.emb_update_mode = ops.UPD_DETERMINISTIC
     model.a2a_chunks = chunks                # > 1: pipelined all-to-all (DLRM_Net._pipelined_exchange_forward)
-    model.bot_l = ext_dist.DDP(model.bot_l, device_ids=[0])
-    model.top_l = ext_dist.DDP(model.top_l, device_ids=[0])
+    wrap = ext_dist.FlatDDP if dense_sync == "flat" else ext_dist.DDP
+    model.bot_l = wrap(model.bot_l, device_ids=[0])
+    model.top_l = wrap(model.top_l, device_ids=[0])
     opt = torch.optim.SGD([{"params": [p for e in model.emb_l for p in e.parameters()], "lr": meta["lr"]},
                            {"params": model.bot_l.parameters(), "lr": meta["lr"]},
                            {"params": model.top_l.parameters(), "lr": meta["lr"]}], lr=meta["lr"])
@@ -59,6 +60,10 @@ def _worker(rank, size, port, q, chunks=1, fixture="dist2_tiny"):
         res[f"s{s}.loss"] = float(E)
         opt.zero_grad()
         E.backward()
+        if dense_sync == "flat":
+            # the weight-gradient GEMMs wrote straight into the flat all-reduce buffers: no gradient was copied
+            for tower in (model.bot_l, model.top_l):
+                assert all(p.grad.data_ptr() == tower._view(i).data_ptr() for i, p in enumerate(tower._params))
         opt.step()
     torch.cuda.synchronize()
     for j, g in enumerate(model.local_emb_indices):
@@ -72,18 +77,20 @@ def _worker(rank, size, port, q, chunks=1, fixture="dist2_tiny"):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("fixture,chunks", [("dist2_tiny", 1), ("dist2_tiny", 2), ("dist8_t26", 1), ("dist8_t26", 2)],
+@pytest.mark.parametrize("fixture,chunks,dense_sync", [("dist2_tiny", 1, "ddp"), ("dist2_tiny", 2, "ddp"), ("dist8_t26", 1, "ddp"),
+                                                       ("dist8_t26", 2, "ddp"), ("dist2_tiny", 1, "flat"), ("dist8_t26", 2, "flat")],
                          ids=["2ranks-single-exchange", "2ranks-pipelined-2-chunks", "8ranks-26tables-single-exchange",
-                              "8ranks-26tables-pipelined-2-chunks"])
-def test_multi_rank_training_matches_reference_multi_rank_run(fixture, chunks):
+                              "8ranks-26tables-pipelined-2-chunks", "2ranks-flat-allreduce", "8ranks-26tables-pipelined-flat-allreduce"])
+def test_multi_rank_training_matches_reference_multi_rank_run(fixture, chunks, dense_sync):
     """dist8_t26: the real Criteo partition — 26 tables over 8 ranks ([4,4,3,3,3,3,3,3]), B = 64 (8 per rank) — through
-    DLRM_Net.distributed_forward, ext_dist.alltoall() and DDP, against the reference's own 8-rank run."""
+    DLRM_Net.distributed_forward, ext_dist.alltoall() and DDP (or ext_dist.FlatDDP: one flat gradient buffer the weight-gradient
+    GEMMs write into, one all-reduce per tower), against the reference's own 8-rank run."""
     d, meta = load_golden(fixture)
     size = meta["size"]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, size, port, q, chunks, fixture)) for r in range(size)]
+    procs = [ctx.Process(target=_worker, args=(r, size, port, q, chunks, fixture, dense_sync)) for r in range(size)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=600) for _ in range(size))
