@@ -72,6 +72,8 @@ def parse():
                          "gain is 0.2-1.7 % (profiles/r03/ceilings.md) and overlapped kernels stretch each other's event times, which "
                          "would blur the per-kernel roofline; the 2-stream schedule is measured in the same run as alt_stream_overlap")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-alt-overlap", action="store_true", help="do not also measure the 2-stream schedule (profiling runs: keeps the "
+                                                                    "rocprofv3 / PMC statistics to the single-stream headline steps)")
     ap.add_argument("--fuse", action="store_true",
                     help="N = 1, one lookup per bag, D = 128: the interaction kernels fetch the embedding rows themselves and the "
                          "pooled-embedding buffer never exists (DLRM_Net.fuse_emb_interact; bit-identical results, measured slower "
@@ -601,7 +603,7 @@ def main():
                                    "final_loss": float(loss_alt.detach()),
                                    "note": "opt-in (--mlp-arith bf16x6); parity-tested at the fp32 tolerances"}
         del loss_alt
-    if N == 1 and graphed is None and not hot and not (args.overlap and not args.no_overlap):
+    if N == 1 and graphed is None and not hot and not (args.overlap and not args.no_overlap) and not args.no_alt_overlap:
         # the same step on two HIP streams (embedding kernels beside the bottom-MLP GEMMs): beside the headline, never instead
         model.overlap_streams = True
         for i in range(3):

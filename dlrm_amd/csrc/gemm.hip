@@ -404,15 +404,27 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
+    // Workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest, then z); each XCD has its own L2.  The dispatch
+    // index is re-mapped so that every XCD works on a CONTIGUOUS range of the (k-slice, tile) space:
+    //   * one k-slice (forward / data gradient): neighbouring tiles — they share an A row panel — meet in one L2;
+    //   * split-k (weight gradient): all output tiles of a k-slice sit on ONE XCD and march through the same rows of dY and X
+    //     together, so HBM delivers every row once per launch instead of once per XCD (PMC FETCH_SIZE of the five big layers: 926 -> 348 MB per
+    //     launch = 1.00 x the algorithmic dY + X bytes; same step time — the kernel is MFMA-bound — profiles/r03/ceilings.md).
     const int nwg = g.tiles_m * g.tiles_n;
-    int id = blockIdx.x;
+    int id, zs;
     {
-        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, local = id >> 3;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        const int total = nwg * (int)gridDim.z, lin = (int)blockIdx.z * nwg + (int)blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = lin & 7, local = lin >> 3;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        zs = w / nwg; id = w - zs * nwg;
+        if (g.debug & 32) {                  // tuning aid: the round-3 mapping (tiles re-mapped inside every k-slice on its own)
+            const int q1 = nwg >> 3, r1 = nwg & 7, x1 = (int)blockIdx.x & 7, l1 = (int)blockIdx.x >> 3;
+            id = (x1 < r1 ? x1 * (q1 + 1) : r1 * (q1 + 1) + (x1 - r1) * q1) + l1; zs = (int)blockIdx.z;
+        }
     }
     const int tile_m = id / g.tiles_n, tile_n = id - tile_m * g.tiles_n;
     const long long m0 = (long long)tile_m * BMt, n0 = (long long)tile_n * BNt;
-    const long long k_begin = (long long)blockIdx.z * g.kchunk;
+    const long long k_begin = (long long)zs * g.kchunk;
     const long long k_end = (k_begin + g.kchunk < g.K) ? k_begin + g.kchunk : g.K;
     const int nk = (int)((k_end - k_begin) / BK3);
 
@@ -628,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             const float v = rs[t] + __shfl_xor(rs[t], 32, 64);
             const long long m = m0 + wm * 32 * TM + t * 32 + l31;
             if (lane < 32 && m < g.M) {
-                if (g.rowsum_split_stride) g.rowsumA[(long long)blockIdx.z * g.rowsum_split_stride + m] = v;
+                if (g.rowsum_split_stride) g.rowsumA[(long long)zs * g.rowsum_split_stride + m] = v;
                 else atomicAdd(g.rowsumA + m, v);
             }
         }
@@ -680,7 +692,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
                 }
             }
             if (!live) continue;
-            float* c = g.C + (long long)blockIdx.z * g.c_split_stride + m * g.ldc + nb;
+            float* c = g.C + (long long)zs * g.c_split_stride + m * g.ldc + nb;
             if constexpr (MASKED) {
                 if (use_bits) {         // ReLU derivative from the sign bits the forward pass stored: element it*4 + c sits at bit 31 - (it*4 + c)
                     const unsigned wv = mkb[tm & 1];

@@ -23,14 +23,14 @@ try:
 except Exception as e: print("no bench json", e)
 PY
 echo "== rocprof"
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $GRAFT_REPO_ROOT/$OUT/rocprof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt-arith --no-parity-check > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err ); echo "rocprof rc=$?"
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $GRAFT_REPO_ROOT/$OUT/rocprof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt-arith --no-parity-check --no-alt-overlap > $GRAFT_REPO_ROOT/$OUT/rocprof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/rocprof.err ); echo "rocprof rc=$?"
 f=$(find $OUT/rocprof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -24 "$f"
 find $OUT/rocprof -name "*kernel_trace.csv" -size +20M -delete
 if [ "${3:-pmc}" = "pmc" ]; then
 echo "== pmc"
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-alt-arith --no-parity-check > $GRAFT_REPO_ROOT/$OUT/$c.log 2>&1
+  timeout 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-alt-arith --no-parity-check --no-alt-overlap > $GRAFT_REPO_ROOT/$OUT/$c.log 2>&1
   echo "rc=$? $c"
 done
 cd $GRAFT_REPO_ROOT
