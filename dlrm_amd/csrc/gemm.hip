@@ -427,7 +427,6 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     const long long k_begin = (long long)zs * g.kchunk;
     const long long k_end = (k_begin + g.kchunk < g.K) ? k_begin + g.kchunk : g.K;
     const int nk = (int)((k_end - k_begin) / BK3);
-
     // ---- DMA plan: wave w owns chunks w, w+4, ... of the A image (TM of them) and of the B image (TN)
     unsigned offA[TM], offB[TN];
 #pragma unroll
@@ -495,7 +494,11 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     const bool mask_pf = MASKED && !use_bits && g.mask != nullptr && g.vecC && full_n;
     float4 mk[2][8];
     // bit form of the same mask: every lane holds ITS 32 sign bits of the band (one dword: 256 B per 32 x 64 band instead of 8 KB)
-    unsigned mkb[2] = {0u, 0u};
+    unsigned mkb[TM];       // ALL bands' words are loaded before the first store of the epilogue: a load issued between the store bursts makes
+                            // the compiler drain vmcnt — i.e. wait for every store issued so far to complete — before the word is used
+                            // (measured: the masked data-gradient GEMM 4-12 % slower than the unmasked one; with this, equal)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) mkb[i] = 0u;
     auto bits_fetch = [&](int band, unsigned& dst) {
         const long long mb = (m0 + wm * 32 * TM + band * 32) >> 5;
         const long long nbk = (n0 + wn * 64) >> 6;
@@ -526,7 +529,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             // vmcnt queue and the counted wait of kt == nk-2 (which leaves TM+TN newer operations in flight) and the
             // final vmcnt(0) stay correct
             if (mask_pf && kt + 2 == nk) mask_fetch(0, mk[0]);
-            if (use_bits && kt + 2 == nk) bits_fetch(0, mkb[0]);
+            if (use_bits && kt + 2 == nk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) bits_fetch(i, mkb[i]);
+            }
         }
         if constexpr (ARITH == 0) {
 #pragma unroll
@@ -552,6 +558,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
 #pragma unroll
                 for (int t = 0; t < TM; ++t) rs[t] += (fa[t].x + fa[t].y) + (fa[t].z + fa[t].w);
             }
+            if constexpr (!A_KC && !B_KC) __builtin_amdgcn_s_setprio(1);    // weight gradient (32 scalar LDS fragment reads per half tile): -1.5 %; nil elsewhere
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -568,6 +575,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].w, fa[tm].w, acc[tm][tn], 0, 0, 0);
+            if constexpr (!A_KC && !B_KC) __builtin_amdgcn_s_setprio(0);
         }
         } else {
             // 32x32x16 bf16 operand: lane supplies row (lane & 31), k = 8*(lane>>5) + 0..7 -> the whole 16-k tile is one step
@@ -650,6 +658,12 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     // (transposes back to [m][n]) -> 16-byte row segments.  Transposed C/D layout of the 32x32 MFMA:
     // lane owns m_local = lane & 31 and n_local = 8*q + 4*(lane>>5) + {0..3} for q = reg>>2.
     static_assert(4 * 32 * EPI_LD * 4 <= NSTAGE3 * STAGE, "epilogue staging does not fit the ring");
+    if constexpr (MASKED) {
+        // the words were requested two k-tiles ago and the loop's final vmcnt(0) has retired them; the compiler cannot see that
+        // through the hand-placed waits, and would drain vmcnt (= wait for the previous band's STORES) in front of every later use
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(mkb[i]));
+    }
     float* S = lds + wave * (32 * EPI_LD);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias) {
@@ -658,13 +672,15 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         if (nb + 2 < g.N) bv.z = g.bias[nb + 2];
         if (nb + 3 < g.N) bv.w = g.bias[nb + 3];
     }
-    if constexpr (MASKED) { if (mask_pf && nk < 2) mask_fetch(0, mk[0]); if (use_bits && nk < 2) bits_fetch(0, mkb[0]); }
+    if constexpr (MASKED) { if (mask_pf && nk < 2) mask_fetch(0, mk[0]); if (use_bits && nk < 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) bits_fetch(i, mkb[i]);
+        } }
     const bool write_bits = A_KC && B_KC && g.bits_out != nullptr;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         if constexpr (MASKED) {
             if (mask_pf && tm + 1 < TM) mask_fetch(tm + 1, mk[(tm + 1) & 1]);
-            if (use_bits && tm + 1 < TM) bits_fetch(tm + 1, mkb[(tm + 1) & 1]);
         }
         unsigned myword = 0u;                      // forward: this lane's 32 sign bits of the band, shifted in one element at a time
 #pragma unroll
@@ -695,7 +711,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             float* c = g.C + (long long)zs * g.c_split_stride + m * g.ldc + nb;
             if constexpr (MASKED) {
                 if (use_bits) {         // ReLU derivative from the sign bits the forward pass stored: element it*4 + c sits at bit 31 - (it*4 + c)
-                    const unsigned wv = mkb[tm & 1];
+                    const unsigned wv = mkb[tm];
                     if (!((wv >> (31 - (it * 4 + 0))) & 1u)) v.x = 0.f;
                     if (!((wv >> (31 - (it * 4 + 1))) & 1u)) v.y = 0.f;
                     if (!((wv >> (31 - (it * 4 + 2))) & 1u)) v.z = 0.f;

@@ -14,8 +14,16 @@ DEV = torch.device("cuda:0")
 
 
 def timeit(fn, iters=10, warm=3):
-    for _ in range(warm):
+    # the clocks fall within milliseconds of an idle queue (allocation, host work) and take ~30 launches to come back: 1134 us for
+    # the first dozen 1024x1024 GEMMs of a process, 989 us from then on (tools/probes/alloc_modes.py) — warm up by TIME, not by count
+    import time
+    t_end = time.perf_counter() + 0.06
+    n = 0
+    while n < warm or time.perf_counter() < t_end:
         fn()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -40,14 +48,19 @@ def gemm(shapes):
         db = torch.zeros(N, device=DEV)
         fl = 2.0 * M * N * K
         t_f = timeit(lambda: ops.linear_fwd(X, W, b, 1, Y, ARITH))
+        bits = ops.relu_bits_alloc(M, K, DEV) if K % 4 == 0 else None      # sign bits of X as the forward of the previous layer stores them
+        if bits is not None:
+            Xf = torch.empty(M, K, device=DEV)
+            ops.linear_fwd(torch.randn(M, 64, device=DEV), torch.randn(K, 64, device=DEV), None, 1, Xf, ARITH, relu_bits=bits)
+        t_db = timeit(lambda: ops.linear_bwd_data(dY, W, Xf, 1, dX, ARITH, relu_bits=bits)) if bits is not None else float("nan")
         t_d = timeit(lambda: ops.linear_bwd_data(dY, W, X, 1, dX, ARITH))
         t_d0 = timeit(lambda: ops.linear_bwd_data(dY, W, None, 0, dX, ARITH))
         t_w = timeit(lambda: ops.linear_bwd_weight(dY, X, dW, db, arith=ARITH))
         r = dict(M=M, N=N, K=K, fwd_us=t_f * 1e3, fwd_tf=fl / t_f / 1e9, dgrad_us=t_d * 1e3, dgrad_tf=fl / t_d / 1e9,
                  dgrad_plain_us=t_d0 * 1e3, dgrad_plain_tf=fl / t_d0 / 1e9, wgrad_us=t_w * 1e3, wgrad_tf=fl / t_w / 1e9)
         out.append(r)
-        print("gemm M=%d N=%d K=%d | fwd %.1f us %.1f TF | dgrad %.1f us %.1f TF (plain %.1f us %.1f TF) | wgrad %.1f us %.1f TF"
-              % (M, N, K, r["fwd_us"], r["fwd_tf"], r["dgrad_us"], r["dgrad_tf"], r["dgrad_plain_us"], r["dgrad_plain_tf"],
+        print("gemm M=%d N=%d K=%d | fwd %.1f us %.1f TF | dgrad bits %.1f us, fp32 mask %.1f us %.1f TF (plain %.1f us %.1f TF) | wgrad %.1f us %.1f TF"
+              % (M, N, K, r["fwd_us"], r["fwd_tf"], t_db * 1e3, r["dgrad_us"], r["dgrad_tf"], r["dgrad_plain_us"], r["dgrad_plain_tf"],
                  r["wgrad_us"], r["wgrad_tf"]), flush=True)
     return out
 
