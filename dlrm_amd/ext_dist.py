@@ -394,6 +394,13 @@ class FlatDDP(torch.nn.Module):
                 self.flat.mul_(1.0 / my_size)
 
 
+TorchDDP = DDP
+if os.environ.get("DLRM_DENSE_SYNC", "ddp") == "flat":
+    # the reference's run() calls ext_dist.DDP(dlrm.bot_l, device_ids=[...]) (dlrm_s_pytorch.py:1329-1336): under the launcher this
+    # environment switch gives it the flat-buffer wrapper instead of torch's DistributedDataParallel
+    DDP = FlatDDP
+
+
 # ------------------------------------------------------------------------------------------------
 # input distribution of key-major id batches and row-wise shard collectives.
 # The reference's torchrec trainer leaves both to torchrec's DistributedModelParallel (third-party, absent:
