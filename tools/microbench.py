@@ -47,6 +47,12 @@ def gemm(shapes):
         dW = torch.empty(N, K, device=DEV)
         db = torch.zeros(N, device=DEV)
         fl = 2.0 * M * N * K
+        t_lib = float("nan")
+        if os.environ.get("MICROBENCH_TORCH", "0") == "1" and K % 4 == 0:
+            # the vendor library's fp32 GEMM on the same operands (torch.mm -> hipBLASLt / rocBLAS; no bias, no activation, no TF32)
+            torch.backends.cuda.matmul.allow_tf32 = False
+            Xc, Wt = X.contiguous(), W.t().contiguous()
+            t_lib = timeit(lambda: torch.mm(Xc, Wt, out=Y))
         t_f = timeit(lambda: ops.linear_fwd(X, W, b, 1, Y, ARITH))
         bits = ops.relu_bits_alloc(M, K, DEV) if K % 4 == 0 else None      # sign bits of X as the forward of the previous layer stores them
         if bits is not None:
@@ -59,6 +65,8 @@ def gemm(shapes):
         r = dict(M=M, N=N, K=K, fwd_us=t_f * 1e3, fwd_tf=fl / t_f / 1e9, dgrad_us=t_d * 1e3, dgrad_tf=fl / t_d / 1e9,
                  dgrad_plain_us=t_d0 * 1e3, dgrad_plain_tf=fl / t_d0 / 1e9, wgrad_us=t_w * 1e3, wgrad_tf=fl / t_w / 1e9)
         out.append(r)
+        if t_lib == t_lib:
+            print("      vendor library fp32 GEMM (torch.mm, Y = X W^T without bias / activation): %.1f us %.1f TF" % (t_lib * 1e3, fl / t_lib / 1e9), flush=True)
         print("gemm M=%d N=%d K=%d | fwd %.1f us %.1f TF | dgrad bits %.1f us, fp32 mask %.1f us %.1f TF (plain %.1f us %.1f TF) | wgrad %.1f us %.1f TF"
               % (M, N, K, r["fwd_us"], r["fwd_tf"], t_db * 1e3, r["dgrad_us"], r["dgrad_tf"], r["dgrad_plain_us"], r["dgrad_plain_tf"],
                  r["wgrad_us"], r["wgrad_tf"]), flush=True)
