@@ -63,6 +63,39 @@ __global__ __launch_bounds__(256) void expand_kernel(EmbArgs a, SortedArgs sa, l
     }
 }
 
+// The same expansion for multi-hot batches, one thread per LOOKUP: with one thread per bag, neighbouring lanes write `hot` entries apart
+// (0.54 ms for the 14 M lookups of the MLPerf-v2 batch, 0.4 TB/s); here every store is coalesced and the bag of a position is found by a
+// binary search over the table's offsets (256 KB per table at B = 65536: cache-resident, and neighbouring positions walk the same path).
+template <typename IT, typename KT>
+__global__ __launch_bounds__(256) void expand_positions_kernel(EmbArgs a, SortedArgs sa, long long B, int row_bits,
+                                                               KT* __restrict__ keys, unsigned* __restrict__ vals,
+                                                               unsigned* __restrict__ bag_of) {
+    const int t = blockIdx.y;
+    const IT* __restrict__ idx = (const IT*)a.idx[t];
+    const IT* __restrict__ off = (const IT*)a.off[t];
+    const long long nnz = a.nnz[t];
+    const long long base = sa.base[t];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (long long)gridDim.x * 256) {
+        // owner of position i = the LAST bag whose start is <= i (empty bags share their start with the bag that follows them and own
+        // nothing; off[0] == 0 as EmbeddingBag requires)
+        long long lo = 0, hi = B - 1;
+        while (lo < hi) {
+            const long long mid = (lo + hi + 1) >> 1;
+            if ((long long)off[mid] <= i) lo = mid; else hi = mid - 1;
+        }
+        long long r = (long long)idx[i];
+        unsigned bag = (unsigned)lo;
+        if (!dlrm_index_ok(r, a.rows[t])) {
+            dlrm_report_bad_index(a.err, a.slot[t], r, a.rows[t]);
+            r = 0; bag = DLRM_DEAD_BAG;
+        }
+        const long long pos = base + i;
+        keys[pos] = ((KT)t << row_bits) | (KT)r;
+        vals[pos] = (unsigned)pos;
+        bag_of[pos] = bag;
+    }
+}
+
 static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 static int bits_for(long long n) { int b = 0; while (((long long)1 << b) < n) ++b; return b < 1 ? 1 : b; }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -118,11 +151,25 @@ static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight
     unsigned* vals_in = (unsigned*)(ws + lo.vals_in);
     unsigned* vals_out = (unsigned*)(ws + lo.vals_out);
     unsigned* bag_of = (unsigned*)(ws + lo.bag_of);
-    dim3 grid((unsigned)((B + 255) / 256), (unsigned)n, 1), block(256);
-    if (idx_bits == 64)
-        hipLaunchKernelGGL((expand_kernel<long long, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
-    else
-        hipLaunchKernelGGL((expand_kernel<int, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
+    dim3 block(256);
+    if (L > (size_t)2 * (size_t)n * (size_t)B) {
+        // multi-hot: one thread per lookup (coalesced stores).  grid.x covers the largest table in one sweep, capped; smaller tables'
+        // surplus blocks exit at once
+        long long mx = 0;
+        for (int k = 0; k < n; ++k) if (a.nnz[k] > mx) mx = a.nnz[k];
+        long long gx = (mx + 255) / 256; if (gx > 8192) gx = 8192; if (gx < 1) gx = 1;
+        dim3 grid((unsigned)gx, (unsigned)n, 1);
+        if (idx_bits == 64)
+            hipLaunchKernelGGL((expand_positions_kernel<long long, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
+        else
+            hipLaunchKernelGGL((expand_positions_kernel<int, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
+    } else {
+        dim3 grid((unsigned)((B + 255) / 256), (unsigned)n, 1);
+        if (idx_bits == 64)
+            hipLaunchKernelGGL((expand_kernel<long long, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
+        else
+            hipLaunchKernelGGL((expand_kernel<int, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
+    }
     DLRM_LAUNCH_CHECK();
     size_t tb = lo.temp_bytes;
     hipError_t e = rocprim::radix_sort_pairs(ws + lo.temp, tb, (const KT*)keys_in, keys_out, (const unsigned*)vals_in,
