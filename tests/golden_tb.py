@@ -115,7 +115,7 @@ def run_on_gpu(device, arith="f32", mode=None, steps=None, check=True, name="ter
     for s, (X, off, idx, tgt) in enumerate(fx.batches[:steps]):
         Z = model(torch.from_numpy(X).to(device), torch.from_numpy(off).to(device), torch.from_numpy(idx).to(device))
         E = model.loss_fn(Z, torch.from_numpy(tgt).to(device))
-        rel.append(abs(float(E) - fx.losses[s]) / abs(fx.losses[s]))
+        rel.append(abs(float(E.detach()) - fx.losses[s]) / abs(fx.losses[s]))
         if check:
             close(Z.detach().cpu().numpy(), d[f"s{s}.Z"], rtol=2e-5, atol=1e-6)
         opt.zero_grad()

@@ -57,7 +57,7 @@ def _worker(rank, size, port, q, chunks=1, fixture="dist2_tiny", dense_sync="ddp
         Tl = torch.from_numpy(T)[ext_dist.get_my_slice(T.shape[0])].to(dev)
         E = model.loss_fn(Z, Tl)
         res[f"s{s}.Z"] = Z.detach().cpu().numpy()
-        res[f"s{s}.loss"] = float(E)
+        res[f"s{s}.loss"] = float(E.detach())
         opt.zero_grad()
         E.backward()
         if dense_sync == "flat":
@@ -233,3 +233,45 @@ def test_sharded_dlrm_two_ranks_matches_single_process_oracle():
             elif k.startswith("final.top_l."):
                 np.testing.assert_allclose(v, ref.p[k[len("final."):]], rtol=1e-4, atol=5e-6, err_msg=k)
     assert len({t for t, _ in seen}) == T and len([1 for t, _ in seen if t == 2]) == 2      # the row-wise table came back in two shards
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py --gpus 2: the whole N > 1 control flow on ONE GPU (gloo, both ranks on cuda:0, reduced sizes) — not a measurement
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_bench_n2(extra_env, extra_args, timeout):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DLRM_BENCH_SELFTEST_GLOO="1", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--warmup", "1", "--batch", "4096",
+           "--row-cap", "50000"] + extra_args
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stderr[-3000:])
+    return json.loads(lines[-1]), r.stderr
+
+
+@pytest.mark.parametrize("dense_sync", ["ddp", "flat"])
+def test_bench_two_rank_control_flow(dense_sync):
+    """headline (reference exchange schedule) + alternative exchange schedule + the other dense-gradient synchronisation + collective
+    timings + process-group report, end to end through torchrun, as the driver launches it"""
+    d, _ = _run_bench_n2({}, ["--steps", "3", "--hang-timeout", "120", "--dense-sync", dense_sync], 600)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and "selftest" in d
+    assert dense_sync in d["config"]["parallelism"] and d["config"]["a2a_chunks"] == 1
+    assert d["alt_a2a_pipelined"]["value"] > 0 and d["alt_a2a_pipelined"]["a2a_chunks"] > 1
+    other = d["alt_dense_sync"]
+    assert other.get("dense_sync") == ("flat" if dense_sync == "ddp" else "ddp") and other["value"] > 0, other
+    # same model, same batches, same arithmetic: the alternative schedules train to the same loss
+    assert abs(other["final_loss"] - d["alt_a2a_pipelined"]["final_loss"]) < 5e-3
+    assert d["distributed"]["world_size"] == 2 and d["collectives"].get("allreduce_ms", 0) > 0
+    assert "linear_fwd" in d["kernels"] and d["roofline"] is not None
+
+
+def test_bench_prints_its_headline_when_an_optional_measurement_hangs():
+    """DLRM_BENCH_SELFTEST_HANG=alt blocks inside the optional dense-sync measurement: the watchdog must print the finished headline
+    line (marked "incomplete") and exit 0 instead of losing the run"""
+    d, err = _run_bench_n2({"DLRM_BENCH_SELFTEST_HANG": "alt"}, ["--steps", "1", "--hang-timeout", "3"], 300)
+    assert d["value"] > 0 and "incomplete" in d and "alt_dense_sync" not in d
+    assert "watchdog expired" in err

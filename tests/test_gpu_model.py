@@ -57,10 +57,10 @@ def test_training_matches_reference_golden(name, mode, arith):
         Td = torch.from_numpy(T).to(device)
         E = loss_like_reference(model, Z, Td)
         if meta["loss"] == "wbce":          # the fully fused weighted BCE (one kernel) equals the script's composition
-            assert abs(float(model.weighted_bce(Z.detach(), Td)) - float(E)) <= 2e-6 * abs(float(E))
+            assert abs(float(model.weighted_bce(Z.detach(), Td)) - float(E.detach())) <= 2e-6 * abs(float(E.detach()))
         np.testing.assert_allclose(Z.detach().cpu().numpy(), d[f"s{s}.Z"], rtol=2e-5, atol=1e-6)
         # the north-star bar: fp32 loss within 1e-5 relative of the reference CPU path
-        assert abs(float(E) - d["losses"][s]) <= 1e-5 * abs(d["losses"][s])
+        assert abs(float(E.detach()) - d["losses"][s]) <= 1e-5 * abs(d["losses"][s])
         opt.zero_grad()
         E.backward()
         for e in model.emb_l:
@@ -88,7 +88,7 @@ def test_rwsadagrad_training_matches_reference_golden():
         Z = model(torch.from_numpy(X).to(device), [torch.from_numpy(o).to(device) for o in lS_o],
                   [torch.from_numpy(i).to(device) for i in lS_i])
         E = model.loss_fn(Z, torch.from_numpy(T).to(device))
-        assert abs(float(E) - d["losses"][s]) <= 1e-5 * abs(d["losses"][s]), (s, float(E), d["losses"][s])
+        assert abs(float(E.detach()) - d["losses"][s]) <= 1e-5 * abs(d["losses"][s]), (s, float(E.detach()), d["losses"][s])
         opt.zero_grad()
         E.backward()
         opt.step()
@@ -281,7 +281,7 @@ def test_coo_escape_hatch_runs_any_torch_optimizer(route):
             Z = model(torch.from_numpy(X).to(device), [torch.from_numpy(o).to(device) for o in lS_o],
                       [torch.from_numpy(i).to(device) for i in lS_i])
             E = model.loss_fn(Z, torch.from_numpy(T).to(device))
-            assert abs(float(E) - d["losses"][s]) <= 1e-5 * abs(d["losses"][s])
+            assert abs(float(E.detach()) - d["losses"][s]) <= 1e-5 * abs(d["losses"][s])
             opt.zero_grad()
             E.backward()
             g = model.emb_l[0].weight.grad
@@ -306,7 +306,7 @@ def test_coo_escape_hatch_runs_any_torch_optimizer(route):
         E = model.loss_fn(Z, torch.from_numpy(T).to(device))
         loss_ref, _ = ref.train_step(torch.from_numpy(X), [torch.from_numpy(o) for o in lS_o],
                                      [torch.from_numpy(i) for i in lS_i], torch.from_numpy(T))
-        assert abs(float(E) - loss_ref) <= 1e-5 * abs(loss_ref), (s, float(E), loss_ref)
+        assert abs(float(E.detach()) - loss_ref) <= 1e-5 * abs(loss_ref), (s, float(E.detach()), loss_ref)
         opt.zero_grad()
         E.backward()
         opt.step()
@@ -509,9 +509,54 @@ def test_dlrm_dcn_model_trains_like_a_torch_composition():
         rl = Fn.linear(z, ref["top_l.2.weight"], ref["top_l.2.bias"])
         RE = Fn.binary_cross_entropy_with_logits(rl, T)
         np.testing.assert_allclose(logits.detach().cpu().numpy(), rl.detach().numpy(), rtol=5e-5, atol=5e-6)
-        assert abs(float(E) - float(RE)) <= 1e-5 * abs(float(RE))
+        assert abs(float(E.detach()) - float(RE)) <= 1e-5 * abs(float(RE))
         opt.zero_grad(); E.backward(); opt.step()
         ropt.zero_grad(); RE.backward(); ropt.step()
     sd = model.state_dict()
     for k, v in ref.items():
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=2e-4, atol=1e-5, err_msg=k)
+
+
+def test_kernel_timers_runs_partition_the_step():
+    """bench.py's per-kernel timers (ops.KernelTimers): one HIP event per change of launch category.  The category runs of an
+    instrumented step must account for every launch (call counts) and add up to the step's GPU time (they share their boundary events)."""
+    import dlrm_amd
+    from dlrm_amd import ops
+    from dlrm_amd.optim import FusedSGD
+    dev = torch.device("cuda:0")
+    np.random.seed(1)
+    m = dlrm_amd.DLRM_Net(16, np.asarray([50, 60, 70]), np.asarray([13, 32, 16]), np.asarray([22, 32, 1]), "dot", sigmoid_top=1,
+                          loss_function="bce").to(dev)
+    opt = FusedSGD(m.parameters(), lr=0.1)
+    B = 512
+    X = torch.rand(B, 13, device=dev)
+    off = torch.arange(B, device=dev).repeat(3, 1)
+    idx = torch.randint(0, 50, (3, B), device=dev)
+    T = torch.rand(B, 1, device=dev).round()
+
+    def step():
+        E = m.loss_fn(m(X, off, idx), T)
+        opt.zero_grad()
+        E.backward()
+        opt.step()
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    ops.timers = ops.KernelTimers()
+    try:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ops.timers.enabled = True
+        step()
+        ops.timers.enabled = False          # closes the last run
+        b.record()
+        step()                              # not instrumented: nothing may be added
+        s = ops.timers.summary()
+    finally:
+        ops.timers = None
+    wall = a.elapsed_time(b)
+    assert s["linear_fwd"]["calls"] == 4 and s["linear_bwd_weight"]["calls"] == 4 and s["linear_bwd_data"]["calls"] == 3
+    assert s["emb_fwd"]["calls"] == 1 and s["emb_bwd_sgd"]["calls"] == 1 and s["interact_fwd"]["calls"] == 1
+    total = sum(v["total_ms"] for v in s.values())
+    assert 0.5 * wall <= total <= 1.05 * wall, (total, wall, s)
