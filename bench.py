@@ -177,7 +177,13 @@ def cpu_baseline(wl, args):
     return {"value": B / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "ms_per_step": dt * 1e3,
             "sample": f"{args.cpu_steps} steps of global batch {B}, tables capped at {args.cpu_row_cap} rows "
-                      f"(oracle/torch_port.py: the reference's torch CPU operator calls, {torch.get_num_threads()} threads)"}
+                      f"(oracle/torch_port.py: the reference's torch CPU operator calls, {torch.get_num_threads()} threads)",
+            "deviations": [f"tables capped at {args.cpu_row_cap} rows (the 96 GB of tables do not fit the host; SURVEY 8d suggested 4 M)",
+                           f"{torch.get_num_threads()} torch threads of {os.cpu_count()} hardware threads (torch's default: physical cores)",
+                           "random weights / inputs of its own (same shapes and distributions as the GPU run, not the same values)",
+                           "the tril index lists of interact_features are built once and cached; the reference rebuilds them every call",
+                           "a port of the reference's operator calls (bit-pinned by tests/test_oracle_golden.py), not /root/reference itself, "
+                           "which does not exist on the GPU box"]}
 
 
 def parity_check(args, device):
