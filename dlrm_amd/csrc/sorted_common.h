@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void expand_positions_kernel(EmbArgs a, Sorted
         }
         long long r = (long long)idx[i];
         unsigned bag = (unsigned)lo;
-        if (!dlrm_index_ok(r, a.rows[t])) {
+        if (i < (long long)off[0]) { r = 0; bag = DLRM_DEAD_BAG; }           // in front of the first bag: belongs to no bag (EmbeddingBag requires off[0] == 0)
+        else if (!dlrm_index_ok(r, a.rows[t])) {
             dlrm_report_bad_index(a.err, a.slot[t], r, a.rows[t]);
             r = 0; bag = DLRM_DEAD_BAG;
         }
