@@ -874,9 +874,18 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
     // fast path preconditions: 16-byte vector access to both operands, every k-slice a multiple of 16
     const bool k16 = (g.K % BK3 == 0) && (g.kchunk % BK3 == 0);
     if (gemm_path() != 2 && g.vecA && g.vecB && k16 && g.lda % 4 == 0 && g.ldb % 4 == 0) {
-        // 256-row tiles when they still give every CU two workgroups, else 128-row tiles
+        // Tile height.  Split-k (weight gradient): 256-row tiles when they still give every CU two workgroups, else 128-row tiles.
+        // One k-slice (forward, data gradient): 128-row tiles — three workgroups per CU (48 KB of LDS each) — except when the 256-row
+        // tiling fits exactly one round of 2 x 256 resident workgroups.  Warm microbench, M = 65536 (profiles/r03/ceilings.md):
+        // forward 13 -> 512: 44 -> 36 us, 480 -> 1024: 503 -> 486, 1024 -> 1024: 996 -> 985; data gradient with out = 1024 / K = 512:
+        // 547 -> 521, out = 512 / K = 256: 162 -> 146; the one-round shapes (512 -> 256 forward, out = 256 data gradient) lose 1-4 %
+        // with the small tiles and keep the large ones; the weight gradient loses 20 % with them.
         const long long wg256 = ((g.M + 255) / 256) * ((g.N + 127) / 128) * splits;
-        const bool big = g.M >= 256 && wg256 >= 512;
+        static int force_tm = -1;      // tuning aid: DLRM_GEMM_TM=2 forces the 128-row tiles, 4 the round-2 rule
+        if (force_tm < 0) { const char* e = getenv("DLRM_GEMM_TM"); force_tm = e ? atoi(e) : 0; }
+        bool big = g.M >= 256 && wg256 >= 512;
+        if (splits == 1 && force_tm != 4) big = g.M >= 256 && wg256 > 384 && wg256 <= 512;
+        if (force_tm == 2) big = false;
         if (fast) *fast = true;
         if (arith == DLRM_ARITH_BF16X6)
             return big ? launch_gemm3<A_KC, B_KC, 4, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 1>(g, splits, st);
