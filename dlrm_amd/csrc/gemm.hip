@@ -884,7 +884,9 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
         static int force_tm = -1;      // tuning aid: DLRM_GEMM_TM=2 forces the 128-row tiles, 4 the round-2 rule
         if (force_tm < 0) { const char* e = getenv("DLRM_GEMM_TM"); force_tm = e ? atoi(e) : 0; }
         bool big = g.M >= 256 && wg256 >= 512;
-        if (splits == 1 && force_tm != 4) big = g.M >= 256 && wg256 > 384 && wg256 <= 512;
+        // (fp32 MFMA only: the bf16x6 / bf16 main loops split or round every fragment they load, and the smaller tiles reuse a fragment
+        // for half as many products — bf16x6 step 6.51 -> 6.93 ms with them)
+        if (splits == 1 && force_tm != 4 && arith == DLRM_ARITH_F32) big = g.M >= 256 && wg256 > 384 && wg256 <= 512;
         if (force_tm == 2) big = false;
         if (fast) *fast = true;
         if (arith == DLRM_ARITH_BF16X6)
