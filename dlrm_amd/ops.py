@@ -322,14 +322,17 @@ def emb_fwd(weights: Sequence[torch.Tensor], bags: BagBatch, out: torch.Tensor) 
     return out
 
 
-_emb_ws = {}   # device -> cached workspace tensor for the sorted update
+_emb_ws = {}   # (device, stream) -> cached workspace of the sort-based updates.  Per stream, like the split-k slabs: kernels of one stream
+               # are ordered, so one workspace suffices — and a workspace allocated under one stream is never handed to kernels of another
+               # (the caching allocator orders re-use of freed memory within the allocating stream only)
 
 
 def _emb_workspace(need: int, device) -> torch.Tensor:
-    ws = _emb_ws.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _emb_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=device)
-        _emb_ws[device] = ws
+        _emb_ws[key] = ws
     return ws
 
 
