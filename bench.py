@@ -514,7 +514,7 @@ def main():
         t = pmc["kernels"].get(n) if pmc else None
         stale = bool(t and t.get("stale"))
         if stale:
-            note = "stale: %s was measured on an older version of this kernel's sources (re-run tools/gpu_pmc_traffic.sh)" % pmc["_file"]
+            note = "stale: %s was measured on an older version of this kernel's sources (re-run tools/gpu_prof.sh + tools/pmc_to_json.py)" % pmc["_file"]
         elif t and k["unit"] == "GB/s":
             note = ("HBM bytes per call from rocprofv3 PMC passes of this workload (%s; FETCH_SIZE x2 gfx950 correction + "
                     "WRITE_SIZE; source hashes match HEAD), algorithmic bytes per call = %d" %
