@@ -224,3 +224,17 @@ def test_chunk_pack_permutation_and_gradient():
     assert torch.equal(E.grad, want)
     with pytest.raises(RuntimeError, match="split"):
         ChunkPackFunction.apply(torch.zeros(10, 2), 3, 2)
+
+
+def test_dense_sync_environment_switch_resolves_ddp_to_the_flat_wrapper():
+    """DLRM_DENSE_SYNC=flat: the reference's run() calls ext_dist.DDP(tower, device_ids=[...]) and gets the flat-buffer wrapper
+    (same constructor surface); unset, ext_dist.DDP is torch's DistributedDataParallel, re-exported as the reference does."""
+    import subprocess
+    import sys
+    code = ("from dlrm_amd import ext_dist; import inspect; "
+            "print(ext_dist.DDP.__name__, 'device_ids' in inspect.signature(ext_dist.FlatDDP.__init__).parameters, ext_dist.TorchDDP.__name__)")
+    for env, want in (({"DLRM_DENSE_SYNC": "flat"}, "FlatDDP True DistributedDataParallel"), ({}, "DistributedDataParallel True DistributedDataParallel")):
+        e = {k: v for k, v in os.environ.items() if k != "DLRM_DENSE_SYNC"}
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == want, (r.stdout, r.stderr[-500:])
