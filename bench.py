@@ -92,7 +92,7 @@ def parse():
                          "dlrm_s_pytorch.py:1329-1336; default) or dlrm_amd.ext_dist.FlatDDP (one flat buffer the weight-gradient GEMMs "
                          "write into, one collective per tower); the other one is measured in the same run as alt_dense_sync")
     ap.add_argument("--no-kernel-timers", action="store_true", help="no per-kernel HIP events in the timed region (no roofline)")
-    ap.add_argument("--timer-every", type=int, default=4,
+    ap.add_argument("--timer-every", type=int, default=10,
                     help="per-kernel HIP events are recorded on every n-th step of the timed region (an event is a queue barrier, "
                          "~5 us: one per change of launch category, ~0.1 ms per instrumented step; dlrm_amd.ops.KernelTimers)")
     ap.add_argument("--cpu-row-cap", type=int, default=1000000)
