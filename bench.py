@@ -682,13 +682,14 @@ def main():
                 if os.environ.get("DLRM_BENCH_SELFTEST_HANG") == "alt":        # development: proves the watchdog still prints the headline
                     time.sleep(10 ** 6)
                 inner_b, inner_t = model.bot_l.module, model.top_l.module
+                for w_ in (model.bot_l, model.top_l):
+                    if hasattr(w_, "release"):
+                        w_.release()                           # FlatDDP: hooks and flat-buffer slots leave the parameters
                 model.bot_l = model.top_l = None
                 gc.collect()                                   # the old wrappers (their autograd hooks) go away
                 if other == "flat":
                     model.bot_l, model.top_l = ext_dist.FlatDDP(inner_b), ext_dist.FlatDDP(inner_t)
                 else:
-                    from dlrm_amd import functional as _fn
-                    _fn.GRAD_ARENAS.clear()
                     model.bot_l = ext_dist.DDP(inner_b, device_ids=[device.index])
                     model.top_l = ext_dist.DDP(inner_t, device_ids=[device.index])
                 for i in range(2):

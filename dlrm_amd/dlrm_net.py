@@ -367,7 +367,7 @@ class DLRM_Net(nn.Module):
             # node runs on the side stream its forward ran on, so the update overlaps the bottom-MLP backward that autograd
             # runs next on the main stream — with the learning rate the optimizer holds at this moment (the reference reads
             # it at step(), a few microseconds later in the same loop body: dlrm_s_pytorch.py:1611-1621)
-            plan = _embedding_update_plan(opt, weights)
+            plan = _embedding_update_plan(opt, weights) if _is_plain_sgd(opt) else None     # (the Adagrad plan advances state["step"]: only built where it is applied)
             if plan is not None and plan[0] == "sgd":
                 cur, side = torch.cuda.current_stream(dout.device), _side_stream(dout.device)
                 if cur != side:                      # (distributed forward: the lookups ran on the main stream)
@@ -386,6 +386,10 @@ class DLRM_Net(nn.Module):
     def _materialize_coo_grads(weights, bags, dout):
         """emb.weight.grad (+)= the reference's sparse COO gradient: indices = the lookup indices verbatim (uncoalesced),
         values = dout[bag(i)] * psw[i] (EmbeddingBagBackward, dlrm_s_pytorch.py:1613)."""
+        if getattr(bags, "ignore_oob", False):
+            sys.exit("ERROR: fused_emb_update = False (sparse COO gradients) cannot be combined with row-wise table shards, whose "
+                     "out-of-range ids are other ranks' rows")
+        ops.check_index_errors(sync=True)        # the reference raises in forward; never hand an out-of-range id to an optimizer's scatter
         D = weights[0].size(1)
         values = ops.emb_bwd_coo(bags, dout, D)
         for k, (w, v) in enumerate(zip(weights, values)):
@@ -404,7 +408,7 @@ class DLRM_Net(nn.Module):
             side = _side_stream(dev)
             ops.timer_mark()
             side.wait_stream(torch.cuda.current_stream(dev))
-            self._side_keep += [p_[2] for p_ in pending]
+            self._side_keep += [p_[2] for p_ in pending] + [t for p_ in pending for t in p_[1].keep]
             if optimizer is not None and self._bound_optimizer is None and self._owned_by(optimizer):
                 self._bound_optimizer = weakref.ref(optimizer)
         with torch.cuda.stream(side) if side is not None else _NullCtx():
@@ -415,7 +419,9 @@ class DLRM_Net(nn.Module):
             if lr is not None:
                 ops.emb_bwd_sgd(weights, bags, dout, lr, self.emb_update_mode)
                 continue
-            plan = _embedding_update_plan(optimizer, weights, count=sum(1 for p_ in pending if p_[0] is weights))
+            # parked backward passes over THESE tables (`weights` is a fresh tuple per forward call: compare the tables themselves)
+            key = tuple(id(w) for w in weights)
+            plan = _embedding_update_plan(optimizer, weights, count=sum(1 for p_ in pending if tuple(id(w) for w in p_[0]) == key))
             if plan is None:
                 self._pending_emb.append((weights, bags, dout))   # another optimizer owns these tables
             elif plan[0] == "coo":
@@ -527,6 +533,10 @@ class DLRM_Net(nn.Module):
             z = InteractFunction.apply(D, self._interaction_mode(), True, x[c * Bc:(c + 1) * Bc], *ly)
             outs.append(self.apply_mlp(z, self.top_l))
         return self._clamp(torch.cat(outs, dim=0))
+
+
+def _is_plain_sgd(optimizer) -> bool:
+    return isinstance(optimizer, torch.optim.SGD) and not _is_rwsadagrad(optimizer)
 
 
 def _is_rwsadagrad(optimizer) -> bool:

@@ -20,6 +20,7 @@ from __future__ import annotations
 import builtins
 import os
 import sys
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -347,9 +348,30 @@ class FlatDDP(torch.nn.Module):
         self._callback_queued = False
         self._avg = my_size > 1 and dist.get_backend() == "nccl"
         from . import functional
+        self._hooks = []
+        on_grad = weakref.WeakMethod(self._on_grad)             # the parameters must not keep their wrapper alive
+
+        def hook(p, _m=on_grad):
+            f = _m()
+            if f is not None:
+                f(p)
         for p, o in zip(self._params, self._offsets):
-            functional.GRAD_ARENAS[p.data_ptr()] = (self.flat, o)
-            p.register_post_accumulate_grad_hook(self._on_grad)
+            functional.set_grad_arena(p, self.flat, o)
+            self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+        # a discarded wrapper takes its slots (and its hooks) with it: the parameters fall back to ordinary gradient tensors
+        self._finalizer = weakref.finalize(self, FlatDDP._release, list(self._params), list(self._hooks))
+
+    @staticmethod
+    def _release(params, hooks) -> None:
+        from . import functional
+        for h in hooks:
+            h.remove()
+        for p in params:
+            functional.set_grad_arena(p, None)
+
+    def release(self) -> None:
+        """Detach the wrapper from its parameters (what garbage collection of the wrapper does as well)."""
+        self._finalizer()
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
@@ -360,7 +382,7 @@ class FlatDDP(torch.nn.Module):
 
     def _on_grad(self, p) -> None:
         from . import functional
-        functional.ARENA_BUSY.discard(p.data_ptr())
+        functional.ARENA_BUSY.discard(id(p))
         if not self._callback_queued:
             self._callback_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
@@ -382,7 +404,7 @@ class FlatDDP(torch.nn.Module):
     def _finalize(self) -> None:
         ready, self._ready, self._callback_queued = self._ready, 0, False
         from . import functional
-        functional.ARENA_BUSY.difference_update(p.data_ptr() for p in self._params)
+        functional.ARENA_BUSY.difference_update(id(p) for p in self._params)
         if ready != len(self._params):
             self._work = None
             raise RuntimeError("FlatDDP: %d of %d parameters received a gradient in this backward pass" % (ready, len(self._params)))
@@ -473,6 +495,8 @@ class _ReduceScatterRows(Function):
     def forward(ctx, x):
         x = x.contiguous()
         B = x.size(0)
+        if B % my_size != 0:
+            sys.exit("ERROR: batch_size %d can not split across %d ranks evenly" % (B, my_size))
         Bl = B // my_size
         ctx.B = B
         if dist.get_backend() == "gloo":

@@ -12,6 +12,8 @@ from __future__ import annotations
 import os
 from typing import List, Optional, Sequence
 
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -37,19 +39,35 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
-# parameter storage address -> (flat fp32 gradient buffer, element offset): the weight-gradient GEMMs of MLPFunction write
-# such a parameter's gradient straight into the flat buffer that ext_dist.FlatDDP all-reduces (no bucket copy in, none out)
-GRAD_ARENAS = {}
-ARENA_BUSY = set()      # slots handed out in the running backward pass whose gradient autograd has not accumulated yet
+# A parameter wrapped by ext_dist.FlatDDP carries `p._dlrm_grad_arena = (weakref to the flat fp32 gradient buffer, element offset)`:
+# the weight-gradient GEMMs of MLPFunction write such a parameter's gradient straight into the flat buffer that FlatDDP all-reduces
+# (no bucket copy in, none out).  The slot lives ON the Parameter object (not in a table keyed by its address): a tower that is
+# moved with .to(), re-created, or whose wrapper is discarded can never be redirected into a stale buffer.
+ARENA_BUSY = set()      # id(parameter) of slots handed out in the running backward pass whose gradient autograd has not accumulated yet
+
+
+def set_grad_arena(p: torch.Tensor, flat: Optional[torch.Tensor], offset: int = 0) -> None:
+    if flat is None:
+        if hasattr(p, "_dlrm_grad_arena"):
+            del p._dlrm_grad_arena
+        ARENA_BUSY.discard(id(p))
+        return
+    p._dlrm_grad_arena = (weakref.ref(flat), int(offset))
 
 
 def _grad_out(p: torch.Tensor) -> torch.Tensor:
-    key = p.data_ptr()
-    a = GRAD_ARENAS.get(key)
-    if a is None:
+    a = getattr(p, "_dlrm_grad_arena", None)
+    flat = a[0]() if a is not None else None
+    if flat is None:
         return torch.empty_like(p)
-    flat, off = a
+    off = a[1]
+    if (flat.device != p.device or flat.dtype != p.dtype or off < 0 or off + p.numel() > flat.numel()
+            or (flat.data_ptr() + 4 * off) % 16 != 0):
+        raise RuntimeError("dlrm_amd: the flat gradient buffer of this parameter does not match it any more (device %s vs %s, "
+                           "%d + %d of %d elements); re-wrap the tower in ext_dist.FlatDDP after moving it"
+                           % (flat.device, p.device, off, p.numel(), flat.numel()))
     v = flat[off:off + p.numel()].view(p.shape)
+    key = id(p)
     # one writer per slot: a second use of the tower in the same backward pass (the pipelined exchange applies the top tower once per
     # chunk) or the gradient of an earlier backward pass still living there (accumulation) get a tensor of their own — autograd sums
     # them and FlatDDP moves the sum into the flat buffer

@@ -154,6 +154,50 @@ def test_embedding_update_plan_for_sgd_and_rowwise_adagrad():
         assert abs(clr2 - 0.5 / 1.1) < 1e-12 and states2[0] is states[0] and opt.state[tables[0]]["step"] == 2
 
 
+def test_accumulation_guard_compares_tables_not_argument_tuples():
+    """every forward call hands EmbeddingBagsFunction a FRESH tuple of the same tables, so two parked backward
+    passes must be recognised by table identity; with tuple identity the guard of the non-linear row-wise update never fired."""
+    import dlrm_amd
+    from dlrm_amd.optim import FusedRWSAdagrad
+    tables = [torch.nn.Parameter(torch.zeros(7, 4)), torch.nn.Parameter(torch.zeros(3, 4))]
+    opt = FusedRWSAdagrad(tables, lr=0.1)
+    shell = dlrm_amd.DLRM_Net()
+    pending = [(tuple(tables), None, None), (tuple(tables), None, None)]        # two distinct tuples, same tables
+    assert pending[0][0] is not pending[1][0]
+    with pytest.raises(SystemExit) as e:
+        shell._apply_pending(pending, opt, None)
+    assert "gradient accumulation" in str(e.value)
+    assert opt.state[tables[0]].get("step", 0) == 0                             # refused before any state was advanced
+    # tables of ANOTHER model parked beside them do not count
+    other = [torch.nn.Parameter(torch.zeros(5, 4))]
+    opt2 = FusedRWSAdagrad(tables + other, lr=0.1)
+    from dlrm_amd.dlrm_net import _embedding_update_plan
+    key = tuple(id(w) for w in tables)
+    assert sum(1 for p_ in [(tuple(tables),), (tuple(other),)] if tuple(id(w) for w in p_[0]) == key) == 1
+    assert _embedding_update_plan(opt2, tables, count=1)[0] == "rwsadagrad"
+
+
+def test_flat_gradient_slots_live_on_the_parameter_and_die_with_the_wrapper():
+    """the flat-buffer slot of a FlatDDP-wrapped parameter is an attribute of the Parameter (validated at use), not an
+    entry of a process-global table keyed by its address; releasing / collecting the wrapper removes it."""
+    import gc
+    from dlrm_amd import ext_dist, functional
+    tower = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.ReLU())
+    w = ext_dist.FlatDDP(tower, broadcast=False)
+    p = tower[0].weight
+    v = functional._grad_out(p)
+    assert v.data_ptr() == w.flat.data_ptr() and v.shape == p.shape
+    functional.ARENA_BUSY.clear()
+    assert not hasattr(functional, "GRAD_ARENAS")
+    p._dlrm_grad_arena = (p._dlrm_grad_arena[0], 10 ** 6)                       # a slot that no longer fits is an error, not a stray write
+    with pytest.raises(RuntimeError):
+        functional._grad_out(p)
+    del w
+    gc.collect()
+    assert not hasattr(p, "_dlrm_grad_arena")
+    assert functional._grad_out(p).data_ptr() != 0 and not functional.ARENA_BUSY
+
+
 def test_fused_rwsadagrad_hyperparameter_checks():
     from dlrm_amd.optim import FusedRWSAdagrad
     p = [torch.nn.Parameter(torch.zeros(3))]
