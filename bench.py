@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the pre-run check of this exact configuration against the golden fixture of the live reference")
+    ap.add_argument("--parity-fixture", default="terabyte_b65536", choices=["terabyte_b65536", "terabyte_b65536_cap4m"],
+                    help="golden fixture of the pre-run parity check: rows capped at 2000 (default; seconds) or at 4 M (the "
+                         "HBM-resident regime; ~2 min of host time to regenerate the reference's 14.5 GB of initial tables)")
     ap.add_argument("--no-alt-arith", action="store_true", help="skip the extra bf16x6 measurement")
     ap.add_argument("--graph", action="store_true",
                     help="run the timed region as HIP-graph replays of the captured step (dlrm_amd.graph; N=1 only, implies "
@@ -196,14 +199,17 @@ def parity_check(args, device):
     mode = {"sorted": 2, "atomic": 0, "deterministic": 1}[args.emb_update]
     try:
         rel = golden_tb.run_on_gpu(device, arith=args.mlp_arith, mode=mode, check=True, overlap=bool(args.overlap) and not args.no_overlap,
-                                   fuse=bool(args.fuse))
-        return {"fixture": "tests/golden/terabyte_b65536.npz (3 training steps of the live reference at B=65536, T=26, D=128, "
-                           "towers 13-512-256-128 / 479-1024-1024-512-256-1, lr 1.0, rows capped at 2000)",
+                                   fuse=bool(args.fuse), name=args.parity_fixture)
+        return {"fixture": "tests/golden/%s.npz (3 training steps of the live reference at B=65536, T=26, D=128, "
+                           "towers 13-512-256-128 / 479-1024-1024-512-256-1, lr 1.0, rows capped at %s)"
+                           % (args.parity_fixture, "4000000" if args.parity_fixture.endswith("cap4m") else "2000"),
                 "rel_err": max(rel), "rel_err_per_step": rel, "bar": 1e-5, "pass": bool(max(rel) <= 1e-5),
                 "also_checked": "predictions rtol 2e-5, 3 step-0 gradients rtol 2e-4, final MLP parameters and table rows/column sums rtol 1e-4",
+                "other_fixture": "tests/golden/terabyte_b65536_cap4m.npz (rows capped at 4 M: HBM-resident tables) is checked by "
+                                 "tests/test_gpu_model.py and by --parity-fixture terabyte_b65536_cap4m",
                 "mlp_arith": args.mlp_arith, "embedding_update": args.emb_update}
     except AssertionError as e:
-        return {"fixture": "tests/golden/terabyte_b65536.npz", "pass": False, "error": str(e)[:400]}
+        return {"fixture": "tests/golden/%s.npz" % args.parity_fixture, "pass": False, "error": str(e)[:400]}
 
 
 # kernel category -> the sources its kernels are compiled from: PMC traffic measured on an older version of ANY of them is stale

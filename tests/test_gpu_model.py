@@ -260,6 +260,19 @@ def test_terabyte_full_batch_matches_reference_golden(arith, overlap, fuse):
     assert len(rel) == 3 and max(rel) <= 1e-5, rel
 
 
+def test_terabyte_full_batch_hbm_resident_tables_match_reference_golden():
+    """the same 3 reference training steps at B = 65536 with the seven big tables capped at 4 M rows instead of
+    2000 (fixture terabyte_b65536_cap4m: 14.5 GB of tables, 22-bit row keys, rows looked up 0-3 times per batch) — the sorted
+    update's long-key / few-duplicates regime and the lookups' HBM-resident regime pinned to the live reference: losses 1e-5,
+    predictions, MLP parameters, head / tail / TOUCHED rows and fp64 column sums of every table."""
+    import golden_tb
+    import psutil
+    if psutil.virtual_memory().available < 24e9:
+        pytest.skip("needs ~16 GB of host RAM to regenerate the reference's initial tables")
+    rel = golden_tb.run_on_gpu(torch.device("cuda:0"), name="terabyte_b65536_cap4m")
+    assert max(rel) <= 1e-5, rel
+
+
 @pytest.mark.parametrize("route", ["flag", "auto"])
 def test_coo_escape_hatch_runs_any_torch_optimizer(route):
     """--fused-emb-update=0 / optimizers the fused kernels do not implement (the reference's --optimizer=adagrad is
@@ -315,11 +328,21 @@ def test_coo_escape_hatch_runs_any_torch_optimizer(route):
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=2e-4, atol=5e-6, err_msg=k)
 
 
-_REF = os.environ.get("DLRM_REFERENCE", "")
+def _reference_dir() -> str:
+    """$DLRM_REFERENCE (a checkout), else oracle/_ref: the reference compiled where it lay by `make -C oracle ref`
+    (__graft_entry__.build() runs it in the build container; the directory travels to the GPU box with the tree)."""
+    env = os.environ.get("DLRM_REFERENCE", "")
+    if env and os.path.isfile(os.path.join(env, "dlrm_s_pytorch.py")):
+        return env
+    from oracle.build_ref import ref_dir
+    return ref_dir() or ""
 
 
-@pytest.mark.skipif(not os.path.isfile(os.path.join(_REF, "dlrm_s_pytorch.py")),
-                    reason="set DLRM_REFERENCE to a facebookresearch/dlrm checkout (it does not exist on the round's GPU box)")
+_REF = _reference_dir()
+
+
+@pytest.mark.skipif(not _REF, reason="no reference: neither $DLRM_REFERENCE nor a usable oracle/_ref (run `make -C oracle ref` where a "
+                                     "checkout exists)")
 def test_launcher_trains_under_the_unmodified_reference_run(tmp_path):
     """`python -m dlrm_amd.launch` — the reference's own run() (CLI, data generation, training loop, timing,
     printing, LR scheduler) with OUR DLRM_Net / ext_dist swapped in — trains on the GPU end to end: losses are printed by the

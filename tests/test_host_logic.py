@@ -198,6 +198,36 @@ def test_flat_gradient_slots_live_on_the_parameter_and_die_with_the_wrapper():
     assert functional._grad_out(p).data_ptr() != 0 and not functional.ARENA_BUSY
 
 
+def test_oracle_ref_recipe_builds_an_importable_sourceless_reference(tmp_path):
+    """`make -C oracle ref` (oracle/build_ref.py): the reference's modules compiled where they lie into oracle/_ref/*.pyc — no
+    source text in the tree — import and run on a box without a checkout (here: a subprocess that cannot see /root/reference)."""
+    import subprocess
+    import sys
+    from oracle import build_ref
+    if os.path.isfile(os.path.join(REFERENCE, "dlrm_s_pytorch.py")):
+        assert build_ref.build(REFERENCE, quiet=True) == build_ref.OUT
+    d = build_ref.ref_dir()
+    if d is None:
+        pytest.skip("no reference checkout and no prebuilt oracle/_ref")
+    assert not [f for _, _, fs in os.walk(d) for f in fs if f.endswith(".py")], "reference SOURCES must never be copied"
+    manifest = json.load(open(os.path.join(d, "MANIFEST.json")))
+    assert set(manifest["modules"]) >= {"dlrm_s_pytorch.py", "extend_distributed.py", "optim/rwsadagrad.py"}
+    probe = ("import sys, types; tb = types.ModuleType('torch.utils.tensorboard'); tb.SummaryWriter = object; import torch.utils; "
+             "sys.modules['torch.utils.tensorboard'] = tb; sys.path[:] = [p for p in sys.path if 'reference' not in p]; "
+             "sys.path.insert(0, %r); import dlrm_s_pytorch as r, optim.rwsadagrad as o; "
+             "assert r.__file__.endswith('.pyc') and hasattr(r, 'DLRM_Net') and hasattr(o, 'RWSAdagrad'); print('ok')" % d)
+    r = subprocess.run([sys.executable, "-c", probe], cwd=tmp_path, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    # the launcher accepts the compiled tree as --reference
+    base = [sys.executable, "-m", "dlrm_amd.launch", "--reference", d, "--", "--arch-sparse-feature-size=16",
+            "--arch-embedding-size=100-100", "--arch-mlp-bot=13-32-16", "--arch-mlp-top=19-8-1", "--mini-batch-size=16",
+            "--data-generation=random", "--num-batches=2", "--nepochs=0"]
+    r = subprocess.run(base, cwd=tmp_path, env=dict(os.environ, PYTHONPATH=ROOT, PYTHONDONTWRITEBYTECODE="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_fused_rwsadagrad_hyperparameter_checks():
     from dlrm_amd.optim import FusedRWSAdagrad
     p = [torch.nn.Parameter(torch.zeros(3))]
