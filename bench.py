@@ -49,6 +49,13 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MFMA_PEAK_TF = 157.3  # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16; MI355X_MICROARCH.md: ~2.5 PF dense, 2495 TF measured)
+MEASURED_BF16_MFMA_TF = 2495.0
+# MLP arithmetic -> (matrix-pipe peak the GEMMs are priced against, MFMA FLOPs issued per algorithmic FLOP, measured peak):
+# bf16x6 issues six bf16 products per fp32 product, so its ALGORITHMIC rate is bounded by the bf16 peak / 6.  A `frac` above 1 is
+# impossible by construction: the denominator is always the pipe the instructions run on.
+ARITH_PEAK = {"f32": (FP32_MFMA_PEAK_TF, 1.0, 155.0), "bf16": (BF16_MFMA_PEAK_TF, 1.0, MEASURED_BF16_MFMA_TF),
+              "bf16x6": (BF16_MFMA_PEAK_TF / 6.0, 6.0, MEASURED_BF16_MFMA_TF / 6.0)}
 # what MI355X_MICROARCH.md MEASURES as achievable on the box (float4 device copy; back-to-back fp32 MFMA): reported beside spec
 MEASURED_HBM_GBS = 6290.0
 MEASURED_FP32_MFMA_TF = 155.0
@@ -95,11 +102,12 @@ def parse():
                          "dlrm_s_pytorch.py:1329-1336; default) or dlrm_amd.ext_dist.FlatDDP (one flat buffer the weight-gradient GEMMs "
                          "write into, one collective per tower); the other one is measured in the same run as alt_dense_sync")
     ap.add_argument("--no-kernel-timers", action="store_true", help="no per-kernel HIP events in the timed region (no roofline)")
-    ap.add_argument("--timer-every", type=int, default=10,
+    ap.add_argument("--timer-every", type=int, default=4,
                     help="per-kernel HIP events are recorded on every n-th step of the timed region (an event is a queue barrier, "
                          "~5 us: one per change of launch category, ~0.1 ms per instrumented step; dlrm_amd.ops.KernelTimers)")
-    ap.add_argument("--cpu-row-cap", type=int, default=1000000)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-row-cap", type=int, default=4000000, help="row cap of the baseline legs' tables (SURVEY 8d: 4 M)")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed iterations of the CPU baseline (median reported)")
+    ap.add_argument("--cpu-warmup", type=int, default=3)
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
     ap.add_argument("--a2a-chunks", type=int, default=int(os.environ.get("DLRM_A2A_CHUNKS", "1")),
                     help="N > 1: schedule of the HEADLINE measurement. 1 (default) = the reference schedule: one all-to-all per "
@@ -152,41 +160,57 @@ def make_batches(n, B, rows, device, seed, hot=None):
     return (out, expand_ms) if hot else out
 
 
-def cpu_baseline(wl, args):
-    """oracle/torch_port.py (the reference's own CPU operator calls) on the host cores, bounded sample."""
+def baseline_state(model, batch, wl, ln_top, args):
+    """What the baseline legs run on: the GPU run's own MLP weights, the first `cpu_row_cap` rows of its tables and its first
+    batch, copied to the host (same weights, same pre-generated inputs)."""
+    cap = args.cpu_row_cap
+    X, off, idx, T = batch
+    tables = [e.weight.detach()[:cap].cpu().contiguous() for e in model.emb_l]
+    rows = torch.tensor([t.shape[0] for t in tables], dtype=idx.dtype, device=idx.device).view(-1, 1)
+    mlp = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if not k.startswith("emb_l.")}
+    return {"m_spa": wl["D"], "ln_bot": list(wl["bot"]), "ln_top": [int(v) for v in ln_top], "tables": tables, "mlp": mlp,
+            "batch": (X.cpu(), off.cpu(), (idx % rows).cpu(), T.cpu()), "row_cap": cap}
+
+
+def baseline_legs(state, args, device):
+    """The reference timed beside the GPU path, in the same run on the same box: `cpu_baseline` on the host cores and
+    `stock_gpu_baseline` (the unmodified reference with --use-gpu semantics on the same MI355X).  With oracle/_ref present (the
+    reference compiled where it lay, `make -C oracle ref`) both run the REAL reference ("kind": "reference"); without it the CPU
+    leg falls back to oracle/torch_port.py, the bit-pinned port of its operator calls ("kind": "port")."""
+    from oracle import ref_baseline
+    out = ref_baseline.run(state, args.lr, cpu_warmup=args.cpu_warmup, cpu_steps=args.cpu_steps, gpu_device=device)
+    if out is not None:
+        cpu, stock = out
+        return {"cpu_baseline": cpu, "stock_gpu_baseline": stock}
     from oracle.torch_port import TorchPortDLRM
-    torch.manual_seed(0)
-    rows = [min(r, args.cpu_row_cap) for r in wl["rows"]]
-    D, B = wl["D"], wl["batch"]
-    nf = len(rows) + 1
-    ln_top = [D + nf * (nf - 1) // 2] + wl["top"]
-    params = {}
-    for k, n in enumerate(rows):
-        params[f"emb_l.{k}.weight"] = torch.empty(n, D).uniform_(-np.sqrt(1 / n), np.sqrt(1 / n))
-    for name, ln in (("bot_l", wl["bot"]), ("top_l", ln_top)):
-        for i in range(len(ln) - 1):
-            params[f"{name}.{2 * i}.weight"] = torch.randn(ln[i + 1], ln[i]) * np.sqrt(2 / (ln[i] + ln[i + 1]))
-            params[f"{name}.{2 * i}.bias"] = torch.randn(ln[i + 1]) * np.sqrt(1 / ln[i + 1])
-    m = TorchPortDLRM(params, sigmoid_top=len(ln_top) - 2, loss="bce", lr=args.lr)
-    X = torch.rand(B, 13)
-    idx = [torch.randint(0, r, (B,)) for r in rows]
-    off = [torch.arange(B)] * len(rows)
-    T = torch.round(torch.rand(B, 1))
-    m.train_step(X, off, idx, T)                      # warm-up
-    t0 = time.time()
-    for _ in range(args.cpu_steps):
+    default_threads = torch.get_num_threads()
+    torch.set_num_threads(os.cpu_count())
+    params = {f"emb_l.{k}.weight": t for k, t in enumerate(state["tables"])}
+    params.update(state["mlp"])
+    m = TorchPortDLRM(params, sigmoid_top=len(state["ln_top"]) - 2, loss="bce", lr=args.lr)
+    X, off, idx, T = state["batch"]
+    off, idx = list(off), list(idx)
+    times = []
+    for it in range(args.cpu_warmup + args.cpu_steps):
+        t0 = time.time()
         m.train_step(X, off, idx, T)
-    dt = (time.time() - t0) / args.cpu_steps
-    return {"value": B / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "ms_per_step": dt * 1e3,
-            "sample": f"{args.cpu_steps} steps of global batch {B}, tables capped at {args.cpu_row_cap} rows "
-                      f"(oracle/torch_port.py: the reference's torch CPU operator calls, {torch.get_num_threads()} threads)",
-            "deviations": [f"tables capped at {args.cpu_row_cap} rows (the 96 GB of tables do not fit the host; SURVEY 8d suggested 4 M)",
-                           f"{torch.get_num_threads()} torch threads of {os.cpu_count()} hardware threads (torch's default: physical cores)",
-                           "random weights / inputs of its own (same shapes and distributions as the GPU run, not the same values)",
-                           "the tril index lists of interact_features are built once and cached; the reference rebuilds them every call",
-                           "a port of the reference's operator calls (bit-pinned by tests/test_oracle_golden.py), not /root/reference itself, "
-                           "which does not exist on the GPU box"]}
+        if it >= args.cpu_warmup:
+            times.append((time.time() - t0) * 1e3)
+    med = float(np.median(times))
+    B = X.shape[0]
+    torch.set_num_threads(default_threads)
+    return {"cpu_baseline": {
+        "value": B / (med * 1e-3), "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "ms_per_step": med,
+        "ms_per_step_min_max": [float(min(times)), float(max(times))],
+        "sample": f"{args.cpu_warmup} warm-up + {args.cpu_steps} timed steps (median) of global batch {B}, tables capped at "
+                  f"{state['row_cap']} rows, the GPU run's own MLP weights / table rows / first batch (oracle/torch_port.py: the "
+                  f"reference's torch CPU operator calls)",
+        "threads": {"used": os.cpu_count(), "os_cpu_count": os.cpu_count(), "torch_default": default_threads},
+        "parallel_info": torch.__config__.parallel_info().strip().splitlines()[:8],
+        "deviations": [f"tables capped at {state['row_cap']} rows (the 96 GB of tables do not fit the host)",
+                       "oracle/_ref (the compiled reference) is absent on this box: a port of the reference's operator calls "
+                       "(bit-pinned by tests/test_oracle_golden.py), with the tril index lists cached"]},
+        "stock_gpu_baseline": None}
 
 
 def parity_check(args, device):
@@ -210,6 +234,35 @@ def parity_check(args, device):
                 "mlp_arith": args.mlp_arith, "embedding_update": args.emb_update}
     except AssertionError as e:
         return {"fixture": "tests/golden/%s.npz" % args.parity_fixture, "pass": False, "error": str(e)[:400]}
+
+
+def parity_check_v2(args, device, interaction):
+    """--workload mlperf_v2_multihot: before anything is timed, this workload's configuration (torchrec model semantics, 214 int32
+    lookups per sample through dlrm_amd.multihot, fused row-wise Adagrad + dense Adagrad lr 0.005 eps 1e-8, B = 65536, tables capped at
+    200 k rows) trains 3 steps against tests/golden/mlperf_v2_{dot,dcn}_b65536.npz (oracle/make_golden_v2.py: the reference's own
+    RWSAdagrad driving a torch-operator restatement of the torchrec model) — once in fp32 (bar 1e-5 where the configuration is
+    well-conditioned, see tests/golden_v2.py) and once in the arithmetic being benchmarked (bf16: a measured, stated tolerance)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_v2
+    if not golden_v2.available(interaction):
+        return {"fixture": "tests/golden/mlperf_v2_%s_b65536.npz" % interaction, "pass": None, "error": "fixture not present"}
+    out = {"fixture": "tests/golden/mlperf_v2_%s_b65536.npz (3 steps at B=65536, 214 lookups/sample, rows capped at 200000; optimizer = the "
+                      "reference's optim/rwsadagrad.py, model = torch-operator restatement of torchrec's DLRM%s: UNPINNED third-party semantics)"
+                      % (interaction, "_DCN" if interaction == "dcn" else ""),
+           "bars": {"loss_rtol": golden_v2.LOSS_RTOL, "logit_atol": golden_v2.LOGIT_ATOL,
+                    "note": "bench variant (zero initial accumulator): step 0 at the bar, steps 1-2 at max(bar, 4 x the fixture's own fp32-vs-fp64 "
+                            "spread: Adagrad's first step is a sign descent); conditioned variant (initial accumulator 1.0): all 3 steps at the bar"}}
+    ok = True
+    for arith in sorted({"f32", args.mlp_arith}, key=lambda a: a != "f32"):
+        try:
+            out[arith] = golden_v2.run_on_gpu(device, interaction, arith)
+            out[arith]["pass"] = True
+        except AssertionError as e:
+            out[arith] = {"pass": False, "error": str(e)[:400]}
+            ok = False
+        torch.cuda.empty_cache()
+    out["pass"] = ok
+    return out
 
 
 # kernel category -> the sources its kernels are compiled from: PMC traffic measured on an older version of ANY of them is stale
@@ -365,6 +418,9 @@ def main():
     if N == 1 and args.workload == "criteo_terabyte" and not args.no_parity_check:
         parity = parity_check(args, device)
         torch.cuda.empty_cache()
+    if N == 1 and args.workload == "mlperf_v2_multihot" and not args.no_parity_check and not args.row_cap and not args.batch:
+        parity = parity_check_v2(args, device, args.interaction or "dcn")
+        torch.cuda.empty_cache()
     model_a2a_chunks = model.a2a_chunks if N > 1 else 1
     hot = wl.get("hot")
     expand_ms = None
@@ -469,6 +525,7 @@ def main():
     gi_fwd_bytes = B * (Tl * (R + 2 * isz) + D * 4 + (D + F * (F - 1) // 2) * 4)
     gi_bwd_bytes = B * (Tl * (R + 2 * isz) + D * 4 + (D + F * (F - 1) // 2) * 4 + (1 + Tl) * R)
 
+    mfma_peak, mfma_issue_ratio, mfma_measured = ARITH_PEAK[args.mlp_arith]
     kernels = {}
     for name, work, unit, peak, bound in (
             ("emb_fwd", emb_fwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
@@ -478,9 +535,9 @@ def main():
             ("emb_interact_bwd", gi_bwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("interact_fwd", inter_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
             ("interact_bwd", 2 * inter_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
-            ("linear_fwd", fwd_fl, "TFLOP/s", FP32_MFMA_PEAK_TF, "mfma"),
-            ("linear_bwd_data", dgrad_fl, "TFLOP/s", FP32_MFMA_PEAK_TF, "mfma"),
-            ("linear_bwd_weight", wgrad_fl, "TFLOP/s", FP32_MFMA_PEAK_TF, "mfma")):
+            ("linear_fwd", fwd_fl, "TFLOP/s", mfma_peak, "mfma"),
+            ("linear_bwd_data", dgrad_fl, "TFLOP/s", mfma_peak, "mfma"),
+            ("linear_bwd_weight", wgrad_fl, "TFLOP/s", mfma_peak, "mfma")):
         k = ksum.get(name)
         if not k:
             continue
@@ -489,7 +546,7 @@ def main():
         ach = work / (per_step_ms * 1e-3) / scale
         kernels[name] = {"ms_per_step": per_step_ms, "launches_per_step": k["calls"] / max(timed_steps, 1),
                          "avg_launch_ms": k["avg_ms"], "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                         "frac": ach / peak, "frac_of_measured_peak": ach / (MEASURED_HBM_GBS if unit == "GB/s" else MEASURED_FP32_MFMA_TF),
+                         "frac": ach / peak, "frac_of_measured_peak": ach / (MEASURED_HBM_GBS if unit == "GB/s" else mfma_measured),
                          "algorithmic_work_per_step": work}
     for name in ("act_bwd", "bce_loss", "sgd_dense"):
         if name in ksum:
@@ -527,8 +584,11 @@ def main():
                     (pmc["_file"], k["algorithmic_work_per_step"] // max(int(round(k["launches_per_step"])), 1)))
         else:
             note = ("HBM bytes per call from rocprofv3 PMC passes (%s; source hashes match HEAD)" % pmc["_file"]) if t else None
-        measured_peak = MEASURED_HBM_GBS if k["unit"] == "GB/s" else MEASURED_FP32_MFMA_TF
+        measured_peak = MEASURED_HBM_GBS if k["unit"] == "GB/s" else mfma_measured
         return {"kernel": kname.get(n, n), "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
+                "peak_note": None if k["unit"] == "GB/s" else
+                {"f32": "dense fp32 MFMA peak", "bf16": "dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)",
+                 "bf16x6": "dense bf16 MFMA peak / 6: six bf16 products are issued per fp32 product"}[args.mlp_arith],
                 "unit": k["unit"], "frac": k["frac"],
                 "frac_of_measured_peak": k["achieved"] / measured_peak, "measured_peak": measured_peak,
                 "traffic": t["traffic_bytes"] if (t and not stale) else None, "traffic_note": note,
@@ -758,9 +818,10 @@ def main():
             result["selftest"] = "DLRM_BENCH_SELFTEST_GLOO=1: all ranks on ONE GPU over gloo with host-staged exchanges — control-flow test, NOT a measurement"
         watchdog(0, "")
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
+        state = baseline_state(model, batches[0], wl, ln_top, args)
         del model, opt, batches
         torch.cuda.empty_cache()
-        result["cpu_baseline"] = cpu_baseline(wl, args)
+        result.update(baseline_legs(state, args, device))
     if rank == 0:
         print(json.dumps(result))
     if N > 1:

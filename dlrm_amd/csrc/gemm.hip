@@ -393,9 +393,25 @@ __device__ __forceinline__ unsigned dma_offset(int c, int lane, long long ld, lo
     }
 }
 
-template <bool A_KC, bool B_KC, int TM, int ARITH, bool ROWSUM>
+// FRAG = 1 (native fp32 only): VECTOR fragments for k-strided operands.  The LDS image of such an operand is [16 k][cols]; a lane
+// feeds sub-tile t of its wave with column (t*32 + r) at four k rows — four ds_read_b32 per sub-tile and k-group, 48 scalar LDS
+// reads per 16-k tile in the weight-gradient GEMM where BOTH operands are k-strided.  With FRAG the wave's sub-tiles are
+// INTERLEAVED instead of stacked: sub-tile t owns columns TM*r + t (r = 0..31), so the TM (TN) values a lane needs at one k are
+// adjacent and ONE ds_read_b128 (b64) at a fixed k row feeds all its sub-tiles: 12 vector reads per 16-k tile instead of 48
+// scalar ones (conflict-free: 32 lanes read 512 / 256 contiguous bytes).  The interleave is undone for free by the epilogue,
+// which already passes every band through LDS: band t's staged rows are the output rows TM*row + t, and the two column
+// sub-tiles are written to LDS column-interleaved so that a staged row is again a contiguous run of output columns.
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int N> struct FVec;
+template <> struct FVec<2> { using T = floatx2; };
+template <> struct FVec<4> { using T = floatx4; };
+
+template <bool A_KC, bool B_KC, int TM, int ARITH, bool ROWSUM, int FRAG = 0>
 __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     constexpr int TN = 2;
+    constexpr bool A_IL = FRAG && !A_KC, B_IL = FRAG && !B_KC;      // operand's sub-tiles interleaved (see above)
+    static_assert(!FRAG || ARITH == 0, "vector fragments are implemented for the native fp32 main loop");
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
     constexpr int A_BYTES = BMt * BK3 * 4, B_BYTES = BNt * BK3 * 4, STAGE = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -422,7 +438,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             id = (x1 < r1 ? x1 * (q1 + 1) : r1 * (q1 + 1) + (x1 - r1) * q1) + l1; zs = (int)blockIdx.z;
         }
     }
-    const int tile_m = id / g.tiles_n, tile_n = id - tile_m * g.tiles_n;
+    // (integer division runs on the vector ALU: the quotients are wave-uniform but live in VGPRs.  The DMA base pointers derived
+    // from them are "s" operands of the inline asm below — pinned to SGPRs here, not left to the register allocator)
+    zs = __builtin_amdgcn_readfirstlane(zs);
+    const int tile_m = __builtin_amdgcn_readfirstlane(id / g.tiles_n), tile_n = __builtin_amdgcn_readfirstlane(id - tile_m * g.tiles_n);
     const long long m0 = (long long)tile_m * BMt, n0 = (long long)tile_n * BNt;
     const long long k_begin = (long long)zs * g.kchunk;
     const long long k_end = (k_begin + g.kchunk < g.K) ? k_begin + g.kchunk : g.K;
@@ -452,10 +471,10 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         fa_off[j] = A_KC ? (unsigned)((wm * 32 * TM + l31) * 64 + (((2 * j + h) ^ ((l31 >> 2) & 3)) * 16))
-                         : (unsigned)((((8 * j + 4 * h) * BMt) + wm * 32 * TM + l31) * 4);
+                         : (unsigned)((((8 * j + 4 * h) * BMt) + wm * 32 * TM + (A_IL ? TM * l31 : l31)) * 4);
         fb_off[j] = (unsigned)A_BYTES +
                     (B_KC ? (unsigned)((wn * 32 * TN + l31) * 64 + (((2 * j + h) ^ ((l31 >> 2) & 3)) * 16))
-                          : (unsigned)((((8 * j + 4 * h) * BNt) + wn * 32 * TN + l31) * 4));
+                          : (unsigned)((((8 * j + 4 * h) * BNt) + wn * 32 * TN + (B_IL ? TN * l31 : l31)) * 4));
     }
 
     // bf16x6 operand layout: lane half h owns k = 8h..8h+7 -> k-quads 2h, 2h+1 (k-contiguous) or k-rows 8h.. (k-strided)
@@ -538,6 +557,13 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float4 fa[TM], fb[TN];
+            if constexpr (A_IL) {           // one vector read per k row feeds all TM sub-tiles (rows TM*r + t)
+                using VA = typename FVec<TM>::T;
+                const char* pa = ldsb + cur + fa_off[j];
+                const VA a0 = *(const VA*)(pa), a1 = *(const VA*)(pa + BMt * 4), a2 = *(const VA*)(pa + 2 * BMt * 4), a3 = *(const VA*)(pa + 3 * BMt * 4);
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[t] = make_float4(a0[t], a1[t], a2[t], a3[t]);
+            } else {
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 if (A_KC) fa[t] = *(const float4*)(ldsb + cur + fa_off[j] + t * 32 * 64);
@@ -546,6 +572,14 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
                     fa[t] = make_float4(p[0], p[BMt], p[2 * BMt], p[3 * BMt]);
                 }
             }
+            }
+            if constexpr (B_IL) {
+                using VB = typename FVec<TN>::T;
+                const char* pb = ldsb + cur + fb_off[j];
+                const VB b0 = *(const VB*)(pb), b1 = *(const VB*)(pb + BNt * 4), b2 = *(const VB*)(pb + 2 * BNt * 4), b3 = *(const VB*)(pb + 3 * BNt * 4);
+#pragma unroll
+                for (int t = 0; t < TN; ++t) fb[t] = make_float4(b0[t], b1[t], b2[t], b3[t]);
+            } else {
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
                 if (B_KC) fb[t] = *(const float4*)(ldsb + cur + fb_off[j] + t * 32 * 64);
@@ -554,11 +588,12 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
                     fb[t] = make_float4(p[0], p[BNt], p[2 * BNt], p[3 * BNt]);
                 }
             }
+            }
             if (do_rowsum) {
 #pragma unroll
                 for (int t = 0; t < TM; ++t) rs[t] += (fa[t].x + fa[t].y) + (fa[t].z + fa[t].w);
             }
-            if constexpr (!A_KC && !B_KC) __builtin_amdgcn_s_setprio(1);    // weight gradient (32 scalar LDS fragment reads per half tile): -1.5 %; nil elsewhere
+            if constexpr (!A_KC && !B_KC && !FRAG) __builtin_amdgcn_s_setprio(1);    // weight gradient with SCALAR fragments (32 ds_read_b32 per half tile): -1.5 %; nil elsewhere
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -575,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].w, fa[tm].w, acc[tm][tn], 0, 0, 0);
-            if constexpr (!A_KC && !B_KC) __builtin_amdgcn_s_setprio(0);
+            if constexpr (!A_KC && !B_KC && !FRAG) __builtin_amdgcn_s_setprio(0);
         }
         } else {
             // 32x32x16 bf16 operand: lane supplies row (lane & 31), k = 8*(lane>>5) + 0..7 -> the whole 16-k tile is one step
@@ -646,7 +681,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const float v = rs[t] + __shfl_xor(rs[t], 32, 64);
-            const long long m = m0 + wm * 32 * TM + t * 32 + l31;
+            const long long m = m0 + wm * 32 * TM + (A_IL ? TM * l31 + t : t * 32 + l31);
             if (lane < 32 && m < g.M) {
                 if (g.rowsum_split_stride) g.rowsumA[(long long)zs * g.rowsum_split_stride + m] = v;
                 else atomicAdd(g.rowsumA + m, v);
@@ -683,6 +718,16 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             if (mask_pf && tm + 1 < TM) mask_fetch(tm + 1, mk[(tm + 1) & 1]);
         }
         unsigned myword = 0u;                      // forward: this lane's 32 sign bits of the band, shifted in one element at a time
+        if constexpr (B_IL) {
+            // column sub-tiles interleaved (output column 2*n_local + tn): element e of quad q lands at staged column 16q + 8h + 2e + tn
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v0 = make_float4(acc[tm][0][4 * q], acc[tm][1][4 * q], acc[tm][0][4 * q + 1], acc[tm][1][4 * q + 1]);
+                const float4 v1 = make_float4(acc[tm][0][4 * q + 2], acc[tm][1][4 * q + 2], acc[tm][0][4 * q + 3], acc[tm][1][4 * q + 3]);
+                *(float4*)__builtin_assume_aligned(S + l31 * EPI_LD + 16 * q + 8 * h, 16) = v0;
+                *(float4*)__builtin_assume_aligned(S + l31 * EPI_LD + 16 * q + 8 * h + 4, 16) = v1;
+            }
+        } else {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -690,10 +735,11 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
                 float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
                 *(float4*)__builtin_assume_aligned(S + l31 * EPI_LD + tn * 32 + 8 * q + 4 * h, 16) = v;
             }
+        }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + (lane >> 4);
-            const long long m = m0 + wm * 32 * TM + tm * 32 + row;
+            const long long m = m0 + wm * 32 * TM + (A_IL ? TM * row + tm : tm * 32 + row);   // (row sub-tiles interleaved: staged row r of band tm is output row TM*r + tm)
             const bool live = m < g.M && nb < g.N;
             float4 v = *(const float4*)__builtin_assume_aligned(S + row * EPI_LD + c4, 16);
             v.x = act_apply(v.x + bv.x, g.act); v.y = act_apply(v.y + bv.y, g.act);
@@ -838,7 +884,7 @@ __global__ __launch_bounds__(256) void relu_bits_kernel(long long M, int N, cons
 
 static int pow2ceil_i(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <bool A_KC, bool B_KC, int TM, int ARITH>
+template <bool A_KC, bool B_KC, int TM, int ARITH, int FRAG = 0>
 static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     constexpr bool ROWSUM = !A_KC && !B_KC;          // only the weight-gradient GEMM carries the bias-gradient row sums
     constexpr int BMt = 64 * TM, BNt = 128;
@@ -853,11 +899,11 @@ static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     static bool attr_done[DLRM_MAX_DEVICES] = {};      // the attribute is per (function, device)
     const int dev = dlrm_current_device();
     if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[dev] = true;
     }
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), block(256);
-    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM>), grid, block, lds, st, g);
+    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG>), grid, block, lds, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
 }
@@ -888,7 +934,18 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
         // for half as many products — bf16x6 step 6.51 -> 6.93 ms with them)
         if (splits == 1 && force_tm != 4 && arith == DLRM_ARITH_F32) big = g.M >= 256 && wg256 > 384 && wg256 <= 512;
         if (force_tm == 2) big = false;
+        // k-strided operands (data gradient: W; weight gradient: dY and X) are read with vector fragments over interleaved sub-tiles
+        // (FRAG, see gemm3_kernel).  Tuning aids: DLRM_GEMM_FRAG=0 -> the scalar-fragment kernels of rounds 1-2;
+        // DLRM_WGRAD_TM=2 -> 128-row weight-gradient tiles (three workgroups per CU; lost 20 % with scalar fragments).
+        static int frag = -1, wgrad_tm = -1;
+        if (frag < 0) { const char* e = getenv("DLRM_GEMM_FRAG"); frag = e ? atoi(e) : 1; }
+        if (wgrad_tm < 0) { const char* e = getenv("DLRM_WGRAD_TM"); wgrad_tm = e ? atoi(e) : 0; }
+        if (splits > 1 && wgrad_tm == 2) big = false;
         if (fast) *fast = true;
+        if constexpr (!A_KC || !B_KC) {
+            if (arith == DLRM_ARITH_F32 && frag)
+                return big ? launch_gemm3<A_KC, B_KC, 4, 0, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0, 1>(g, splits, st);
+        }
         if (arith == DLRM_ARITH_BF16X6)
             return big ? launch_gemm3<A_KC, B_KC, 4, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 1>(g, splits, st);
         if (arith == DLRM_ARITH_BF16)

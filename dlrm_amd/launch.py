@@ -42,7 +42,7 @@ def load_reference(reference_dir: str, device_tables: bool = False):
     from dlrm_amd import ext_dist
 
     if not any(os.path.isfile(os.path.join(reference_dir, "dlrm_s_pytorch" + ext)) for ext in (".py", ".pyc")):
-        # (.pyc: a checkout compiled into a sourceless tree, e.g. this repository's `make -C oracle ref`)
+        # (.pyc: a checkout compiled into a sourceless tree with py_compile)
         sys.exit("ERROR: %s does not contain dlrm_s_pytorch.py" % reference_dir)
     _stub_tensorboard_if_missing()
     if reference_dir not in sys.path:

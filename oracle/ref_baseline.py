@@ -1,0 +1,138 @@
+"""Baseline legs of bench.py that run the REAL reference — TEST / BASELINE INFRASTRUCTURE ONLY (never the product path).
+
+`oracle/_ref/` holds the reference's modules compiled where they lay (oracle/build_ref.py).  This file drives the
+UNMODIFIED `dlrm_s_pytorch.DLRM_Net` through the reference's own loop body (dlrm_s_pytorch.py:1574-1621:
+`dlrm_wrap` -> `loss_fn_wrap` -> `optimizer.zero_grad()` -> `E.backward()` -> `optimizer.step()`, timed between
+`time_wrap` calls like :1558,1626) in the two places SURVEY.md 8(d) names:
+
+  * `cpu_baseline` ("kind": "reference"): on the host cores of the GPU box, `torch.set_num_threads(os.cpu_count())`,
+    tables capped at `row_cap` rows (the 96 GB of tables do not fit a host), the GPU run's OWN MLP weights, the first
+    `row_cap` rows of its tables and its first batch (indices folded into the capped tables), >= 3 warm-up + >= 10 timed
+    iterations, median;
+  * `stock_gpu_baseline`: the same module moved to the MI355X exactly as `--use-gpu` does (`dlrm.to(device)`, :1314-1316;
+    ndevices = 1): stock PyTorch-ROCm ATen kernels (EmbeddingBag, addmm, bmm, index, sparse SGD) on the same GPU, same
+    capped tables, same batch.
+
+The reference's constructor draws every table from numpy's global RNG through a float64 temporary (:280-284: ~30 s per
+4 M x 128 table on one core).  The baseline needs the GPU run's weights anyway, so the model is constructed with 3-row tables
+and each `emb_l[k]` is then replaced by what `create_emb` itself builds for the real size —
+`nn.EmbeddingBag(n, m, mode="sum", sparse=True)` holding the given weight (:277-284) — a parameter load, not a code change.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+from .build_ref import ref_dir
+
+
+def load_reference():
+    """import dlrm_s_pytorch from oracle/_ref (tensorboard stubbed: dlrm_s_pytorch.py:101 imports it unconditionally)."""
+    d = ref_dir()
+    if d is None:
+        return None
+    if "dlrm_s_pytorch" in sys.modules and getattr(sys.modules["dlrm_s_pytorch"], "__file__", "").startswith(d):
+        return sys.modules["dlrm_s_pytorch"]
+    try:
+        import torch.utils.tensorboard  # noqa: F401
+    except Exception:
+        tb = types.ModuleType("torch.utils.tensorboard")
+        tb.SummaryWriter = type("SummaryWriter", (), {"__init__": lambda s, *a, **k: None, "add_scalar": lambda s, *a, **k: None,
+                                                     "close": lambda s: None})
+        sys.modules["torch.utils.tensorboard"] = tb
+    sys.modules.pop("extend_distributed", None)          # the launcher may have aliased it to dlrm_amd.ext_dist: the baseline is stock
+    sys.path.insert(0, d)
+    try:
+        import dlrm_s_pytorch as ref
+    finally:
+        sys.path.remove(d)
+    return ref
+
+
+def build_model(ref, m_spa, ln_bot, ln_top, tables, mlp_state, ndevices=-1):
+    """The reference's DLRM_Net (dot interaction, sigmoid on the last top layer, BCE) holding the given parameters."""
+    T = len(tables)
+    np.random.seed(0)
+    model = ref.DLRM_Net(m_spa, np.asarray([3] * T), np.asarray(ln_bot), np.asarray(ln_top), arch_interaction_op="dot",
+                         arch_interaction_itself=False, sigmoid_bot=-1, sigmoid_top=len(ln_top) - 2, ndevices=ndevices,
+                         loss_function="bce")
+    for k, w in enumerate(tables):
+        model.emb_l[k] = torch.nn.EmbeddingBag(w.shape[0], w.shape[1], mode="sum", sparse=True, _weight=w)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in mlp_state.items():
+            assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+            sd[k].copy_(v)
+    return model
+
+
+def time_loop(ref, model, batch, lr, use_gpu, device, warmup, steps):
+    """The loop body of dlrm_s_pytorch.py:1574-1621 on one resident batch; returns the per-iteration times (ms) and the last loss."""
+    ref.dlrm = model
+    ref.args = types.SimpleNamespace(loss_function="bce")
+    opt = torch.optim.SGD(model.parameters(), lr=lr)
+    X, lS_o, lS_i, T = batch
+    times, loss = [], None
+    for it in range(warmup + steps):
+        t1 = ref.time_wrap(use_gpu)
+        Z = ref.dlrm_wrap(X, lS_o, lS_i, use_gpu, device, ndevices=1)
+        E = ref.loss_fn_wrap(Z, T, use_gpu, device)
+        L = E.detach().cpu().numpy()                     # :1592 (a per-step D2H read, part of the reference's step)
+        opt.zero_grad()
+        E.backward()
+        opt.step()
+        t2 = ref.time_wrap(use_gpu)
+        if it >= warmup:
+            times.append((t2 - t1) * 1e3)
+        loss = float(L)
+    return times, loss
+
+
+def run(state, lr, cpu_warmup=3, cpu_steps=10, gpu_warmup=3, gpu_steps=10, gpu_device=None):
+    """state: m_spa, ln_bot, ln_top, tables (list of CPU fp32 [rows, D]), mlp (state_dict names -> CPU tensors), batch
+    (X [B,13] f32, lS_o [T,B] i64, lS_i [T,B] i64, T [B,1] f32; CPU), row_cap.  Returns (cpu_baseline, stock_gpu_baseline) or None
+    when oracle/_ref is absent."""
+    ref = load_reference()
+    if ref is None:
+        return None
+    B = state["batch"][0].shape[0]
+    default_threads = torch.get_num_threads()
+    torch.set_num_threads(os.cpu_count())                # all host hardware threads
+    model = build_model(ref, state["m_spa"], state["ln_bot"], state["ln_top"], state["tables"], state["mlp"])
+    times, loss = time_loop(ref, model, state["batch"], lr, False, torch.device("cpu"), cpu_warmup, cpu_steps)
+    med = float(np.median(times))
+    cpu = {"value": B / (med * 1e-3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "reference",
+           "ms_per_step": med, "ms_per_step_min_max": [float(min(times)), float(max(times))], "final_loss": loss,
+           "sample": "%d warm-up + %d timed iterations (median) of the reference's own DLRM_Net + loop body (oracle/_ref: "
+                     "dlrm_s_pytorch compiled where it lay) at global batch %d, tables capped at %d rows, the GPU run's own MLP "
+                     "weights / first %d table rows / first batch" % (cpu_warmup, cpu_steps, B, state["row_cap"], state["row_cap"]),
+           "threads": {"used": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "torch_default": default_threads},
+           "parallel_info": torch.__config__.parallel_info().strip().splitlines()[:8],
+           "deviations": ["tables capped at %d rows (SURVEY 8d: the 96 GB of tables do not fit the host; random access over >= 2 GB "
+                          "tables is already DRAM-bound); indices of the GPU batch folded into the capped tables (idx %% rows)"
+                          % state["row_cap"],
+                          "tables loaded into nn.EmbeddingBag(sum, sparse=True) modules after constructing the model small (the "
+                          "constructor's float64 numpy draw of 4 M x 128 values takes ~30 s per table and would be overwritten)"]}
+    stock = None
+    if gpu_device is not None and torch.cuda.is_available():
+        try:
+            torch.set_num_threads(default_threads)
+            model.ndevices = 1                            # what --use-gpu computes for one GPU (:1079)
+            model = model.to(gpu_device)                  # :1314-1316
+            gt, gloss = time_loop(ref, model, state["batch"], lr, True, gpu_device, gpu_warmup, gpu_steps)
+            gmed = float(np.median(gt))
+            stock = {"value": B / (gmed * 1e-3), "unit": "samples/s", "ms_per_step": gmed,
+                     "ms_per_step_min_max": [float(min(gt)), float(max(gt))], "final_loss": gloss,
+                     "what": "the UNMODIFIED reference DLRM_Net with --use-gpu semantics on the same MI355X: stock PyTorch-ROCm ATen "
+                             "kernels (EmbeddingBag, addmm, bmm + index, BCELoss, sparse SGD), same capped tables / weights / batch as "
+                             "cpu_baseline; %d warm-up + %d timed iterations, median; includes the reference's per-step H2D input "
+                             "copies and loss D2H read (dlrm_s_pytorch.py:129-145,1592)" % (gpu_warmup, gpu_steps),
+                     "torch": torch.__version__}
+        except Exception as e:                            # noqa: BLE001 - a baseline must never break the headline line
+            stock = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    return cpu, stock

@@ -344,3 +344,37 @@ def test_crossnet_restatement_against_torch_autograd():
         np.testing.assert_allclose(dVs[l], tV[l].grad.numpy(), rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(dWs[l], tW[l].grad.numpy(), rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(dbs[l], tb[l].grad.numpy(), rtol=1e-10, atol=1e-12)
+
+
+def test_reference_baseline_leg_runs_the_compiled_reference_and_agrees_with_the_port():
+    """bench.py's baseline leg (oracle/ref_baseline.py): the REAL reference imported from oracle/_ref (`make -C oracle ref`), given
+    the GPU run's weights and batch, run through its own loop body — and the port used when oracle/_ref is absent computes the
+    same step (losses over 3 iterations equal to 1e-6): the two `cpu_baseline.kind`s time the same arithmetic."""
+    import torch
+    from oracle import ref_baseline
+    from oracle.torch_port import TorchPortDLRM
+    if ref_baseline.load_reference() is None:
+        pytest.skip("oracle/_ref not built (no reference checkout in this environment)")
+    rng = np.random.default_rng(4)
+    rows, D, B = [50, 3, 400], 8, 64
+    ln_bot, ln_top = [13, 16, D], [D + 6, 12, 1]
+    tables = [torch.from_numpy(rng.uniform(-0.3, 0.3, (n, D)).astype(np.float32)) for n in rows]
+    mlp = {}
+    for name, ln in (("bot_l", ln_bot), ("top_l", ln_top)):
+        for i in range(len(ln) - 1):
+            mlp[f"{name}.{2 * i}.weight"] = torch.from_numpy(rng.normal(0, 0.3, (ln[i + 1], ln[i])).astype(np.float32))
+            mlp[f"{name}.{2 * i}.bias"] = torch.from_numpy(rng.normal(0, 0.3, ln[i + 1]).astype(np.float32))
+    X = torch.from_numpy(rng.random((B, 13)).astype(np.float32))
+    idx = torch.stack([torch.from_numpy(rng.integers(0, n, B)) for n in rows])
+    off = torch.arange(B).repeat(len(rows), 1)
+    T = torch.from_numpy(np.round(rng.random((B, 1))).astype(np.float32))
+    state = {"m_spa": D, "ln_bot": ln_bot, "ln_top": ln_top, "tables": [t.clone() for t in tables], "mlp": {k: v.clone() for k, v in mlp.items()},
+             "batch": (X, off, idx, T), "row_cap": 400}
+    cpu, stock = ref_baseline.run(state, lr=0.5, cpu_warmup=1, cpu_steps=2, gpu_device=None)
+    assert cpu["kind"] == "reference" and stock is None and cpu["value"] > 0 and len(cpu["ms_per_step_min_max"]) == 2
+    params = {f"emb_l.{k}.weight": t.clone() for k, t in enumerate(tables)}
+    params.update({k: v.clone() for k, v in mlp.items()})
+    port = TorchPortDLRM(params, sigmoid_top=len(ln_top) - 2, loss="bce", lr=0.5)
+    for _ in range(3):
+        loss, _ = port.train_step(X, list(off), list(idx), T)
+    assert abs(loss - cpu["final_loss"]) <= 1e-6 * abs(loss), (loss, cpu["final_loss"])
