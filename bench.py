@@ -177,8 +177,10 @@ def baseline_legs(state, args, device):
     `stock_gpu_baseline` (the unmodified reference with --use-gpu semantics on the same MI355X).  With oracle/_ref present (the
     reference compiled where it lay, `make -C oracle ref`) both run the REAL reference ("kind": "reference"); without it the CPU
     leg falls back to oracle/torch_port.py, the bit-pinned port of its operator calls ("kind": "port")."""
+    import contextlib
     from oracle import ref_baseline
-    out = ref_baseline.run(state, args.lr, cpu_warmup=args.cpu_warmup, cpu_steps=args.cpu_steps, gpu_device=device)
+    with contextlib.redirect_stdout(sys.stderr):        # the reference prints at import ("Unable to import mlperf_logging"): stdout carries ONE JSON line
+        out = ref_baseline.run(state, args.lr, cpu_warmup=args.cpu_warmup, cpu_steps=args.cpu_steps, gpu_device=device)
     if out is not None:
         cpu, stock = out
         return {"cpu_baseline": cpu, "stock_gpu_baseline": stock}
