@@ -128,13 +128,16 @@ def parse():
     return ap.parse_args()
 
 
-def make_batches(n, B, rows, device, seed, hot=None):
+def make_batches(n, B, rows, device, seed, hot=None, local_rows=None):
     """Synthetic batches in the reference's layout (dlrm_data_pytorch.py:899-960 with one lookup per bag, as the Criteo
     data sets have): indices and offsets as stacked [T, B] int64 tensors (row t = table t), generated on the device by
     dlrm_amd.datagen (same distributions as the reference generator, Philox stream).
     hot = per-table multi-hot sizes (MLPerf-v2): the 1-hot ids are expanded on the device through HBM-resident lookup
     tables (dlrm_amd.multihot.Multihot = torchrec_dlrm/multi_hot.py:80-159) into int32 bags of hot[t] ids; returns the
-    per-batch expansion time as well (HIP events)."""
+    per-batch expansion time as well (HIP events).
+    local_rows (a slice; sharded model, N > 1): the batch is the SAME global batch on every rank (same seed), but only this rank's
+    samples are kept and expanded — (X[slice], values, None, T[slice]) with `values` the key-major ids of those samples (the per-rank
+    KJT of the reference's torchrec loader, multi_hot_criteo.py:200-214): inputs are NOT replicated."""
     from dlrm_amd.datagen import UniformBatchGenerator
     gen = UniformBatchGenerator(13, rows, 1, True, round_targets=True, seed=seed, device=device,
                                 index_dtype=torch.int32 if hot else torch.int64)
@@ -147,6 +150,16 @@ def make_batches(n, B, rows, device, seed, hot=None):
         X, lS_o, lS_i, T = gen.batch(B, batch_no=k)
         if mh is None:
             out.append((X, torch.stack(lS_o), torch.stack(lS_i), T))
+        elif local_rows is not None:
+            ids = torch.stack(lS_i)[:, local_rows].contiguous()
+            mh.expand(ids, want_global_offsets=False)                     # warm
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            values, _, _ = mh.expand(ids, want_global_offsets=False)
+            b.record()
+            torch.cuda.synchronize()
+            expand_ms.append(a.elapsed_time(b))
+            out.append((X[local_rows].contiguous(), values, None, T[local_rows].contiguous()))
         else:
             ids = torch.stack(lS_i)
             mh.to_model_inputs(ids)                                       # warm
@@ -158,6 +171,14 @@ def make_batches(n, B, rows, device, seed, hot=None):
             expand_ms.append(a.elapsed_time(b))
             out.append((X, off, idx, T))
     return (out, expand_ms) if hot else out
+
+
+def _block_partition_imbalance(plan, N):
+    """max / mean per-rank cost of the reference's contiguous block partition (extend_distributed.py:47-62) for the same tables"""
+    from dlrm_amd import sharding
+    owner = sharding.reference_plan(len(plan.cost), N)
+    per = [sum(c for c, o in zip(plan.cost, owner) if o == r) for r in range(N)]
+    return max(per) / (sum(per) / N)
 
 
 def baseline_state(model, batch, wl, ln_top, args):
@@ -388,7 +409,20 @@ def main():
     np.random.seed(123)          # identical MLP parameters on every rank
     torch.manual_seed(123 + rank)
     dlrm_amd.set_embedding_init(device)
-    if hot_cfg:
+    sharded = bool(hot_cfg) and N > 1
+    shard_plan = None
+    if sharded:
+        # BASELINE configs[4] on N GPUs (torchrec_dlrm/dlrm_main.py:654-673 leaves this to torchrec's planner + DMP):
+        # planned sharding — tables nobody can absorb ROW-WISE over all ranks (MLPerf-v2 at 8 ranks: tables 20 and 21), the rest
+        # table-wise longest-first —, per-rank input slices exchanged by ext_dist.kjt_input_dist, dot interaction (triu order)
+        from dlrm_amd import sharding
+        from dlrm_amd.torchrec_variant import ShardedDLRM
+        if (args.interaction or "dot") != "dot":
+            sys.exit("ERROR: --gpus N --workload mlperf_v2_multihot runs the dot interaction (ShardedDLRM); pass --interaction dot")
+        args.interaction = "dot"
+        shard_plan = sharding.plan(rows, hot_cfg, D, N, B)
+        model = ShardedDLRM(rows, hot_cfg, D, wl["bot"][0], wl["bot"][1:], wl["top"], B, plan=shard_plan).to(device)
+    elif hot_cfg:
         # BASELINE configs[4]: the torchrec trainer's model semantics (triu interaction order, logits, BCEWithLogitsLoss)
         from dlrm_amd.torchrec_variant import DLRM as TorchrecDLRM, DLRM_DCN
         if (args.interaction or "dcn") == "dcn":
@@ -402,7 +436,7 @@ def main():
     model.set_mlp_arith(args.mlp_arith)
     model.overlap_streams = bool(args.overlap) and not args.no_overlap
     model.fuse_emb_interact = bool(args.fuse)
-    model.a2a_chunks = max(args.a2a_chunks, 1) if N > 1 else 1
+    model.a2a_chunks = max(args.a2a_chunks, 1) if (N > 1 and not sharded) else 1
     model.emb_update_mode = {"sorted": ops.UPD_SORTED, "atomic": ops.UPD_ATOMIC, "deterministic": ops.UPD_DETERMINISTIC}[args.emb_update]
     if N > 1:
         wrap = ext_dist.FlatDDP if args.dense_sync == "flat" else ext_dist.DDP
@@ -427,21 +461,26 @@ def main():
     hot = wl.get("hot")
     expand_ms = None
     if hot:
-        if N > 1:
-            sys.exit("ERROR: --workload mlperf_v2_multihot is single-GPU in this round (the 100-hot 40 M-row table needs row-wise "
-                     "sharding to balance, SURVEY §8 f-3)")
-        batches, expand_ms = make_batches(4, B, rows, device, seed=727, hot=hot)
+        batches, expand_ms = make_batches(4, B, rows, device, seed=727, hot=hot,
+                                          local_rows=ext_dist.get_my_slice(B) if sharded else None)
     else:
         batches = make_batches(4, B, rows, device, seed=727)     # every rank reads the whole global batch (reference :1541)
     my_rows = ext_dist.get_my_slice(B) if N > 1 else slice(0, B)
-    local_tables = list(range(len(rows)))[model.local_emb_slice] if N > 1 else list(range(len(rows)))
+    if sharded:
+        local_tables = list(model.tw_mine)           # + a 1/N row range of every row-wise table (accounted below)
+    else:
+        local_tables = list(range(len(rows)))[model.local_emb_slice] if N > 1 else list(range(len(rows)))
 
     one = torch.ones((), dtype=torch.float32, device=device)      # the seed of backward(): E.backward() would launch an ATen fill for it
 
     def eager_step(i):
         X, off, idx, T = batches[i % len(batches)]
-        Z = model(X, off, idx)
-        E = model.loss_fn(Z, T[my_rows])
+        if sharded:                                   # (X, values, None, T): this rank's samples only
+            Z = model(X, off)
+            E = model.loss_fn(Z, T)
+        else:
+            Z = model(X, off, idx)
+            E = model.loss_fn(Z, T[my_rows])
         opt.zero_grad()
         E.backward(one)
         opt.step()
@@ -468,7 +507,13 @@ def main():
         uuids = [None] * N
         torch.distributed.all_gather_object(uuids, uuid)
         dist_info = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
-                     "distinct_gpus": len(set(uuids)), "tables_per_rank": list(model.n_emb_per_rank) if model.n_emb_per_rank else None}
+                     "distinct_gpus": len(set(uuids)),
+                     "tables_per_rank": (shard_plan.tables_per_rank() if sharded else
+                                         (list(model.n_emb_per_rank) if model.n_emb_per_rank else None))}
+        if sharded:
+            dist_info.update({"row_wise_tables": shard_plan.row_wise(), "plan_imbalance": shard_plan.imbalance(),
+                              "reference_block_partition_imbalance": _block_partition_imbalance(shard_plan, N),
+                              "inputs": "per-rank batch slices; ids exchanged by ext_dist.kjt_input_dist (one all-to-all + one all-gather)"})
         if len(set(uuids)) != N and not selftest:
             sys.exit("ERROR: %d ranks share %d GPUs; one process per GPU is required" % (N, len(set(uuids))))
         watchdog(args.hang_timeout, "first training step (RCCL all-to-all + DDP all-reduce for the first time)")
@@ -510,6 +555,9 @@ def main():
     hots = [hot[t] for t in local_tables] if hot else [1] * Tl
     isz = 4 if hot else 8                               # int32 multi-hot ids (torchrec KJT) / int64 (dlrm_s)
     L = sum(hots)                                       # lookups per sample over the local tables
+    if sharded:                                         # row-wise tables: every rank pools the 1/N of the lookups that hit its rows
+        L += sum(hot[t] for t in shard_plan.row_wise()) / N
+        Tl += len(shard_plan.row_wise())
     emb_fwd_bytes = B * (L * (R + isz) + Tl * (R + isz))    # per lookup: row read + index; per bag: pooled row write + offset
     emb_bwd_bytes = B * L * (3 * R + isz)               # per lookup: dV row read + W row read + W row write + index
     bot, top = list(wl["bot"]), list(ln_top)
@@ -610,7 +658,9 @@ def main():
                    "tables": len(rows), "emb_dim": D, "global_batch": B, "table_rows_total": int(sum(rows)),
                    "mlp_bot": "-".join(map(str, bot)), "mlp_top": "-".join(map(str, top)), "optimizer": args.optimizer,
                    "interaction": ("dcn_v2 (3 layers, rank 512)" if dcn else "dot (torchrec triu order)") if hot else "dot",
-                   "loss": "bce_with_logits" if hot else "bce", "parallelism": ("table-wise embeddings x%d + data-parallel MLPs (dense gradients: %s)" % (N, args.dense_sync)) if N > 1 else "single GPU",
+                   "loss": "bce_with_logits" if hot else "bce", "parallelism": (("planned sharding x%d (dlrm_amd.sharding: row-wise tables %s, the rest table-wise longest-first) + data-parallel MLPs (dense gradients: %s), per-rank input slices"
+                                    % (N, shard_plan.row_wise(), args.dense_sync)) if sharded else
+                                   ("table-wise embeddings x%d + data-parallel MLPs (dense gradients: %s)" % (N, args.dense_sync))) if N > 1 else "single GPU",
                    "embedding_update": args.emb_update if graphed is None else "atomic (the HIP-graph path: rocPRIM's sort cannot be replayed, dlrm_amd/graph.py)",
                    "a2a_chunks": model_a2a_chunks,
                    "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "
@@ -717,7 +767,12 @@ def main():
             del gs
         except Exception as e:                       # noqa: BLE001 - diagnostic only
             result["alt_hip_graph"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-    if N > 1:
+    if N > 1 and sharded:
+        result["distributed"] = dist_info
+        if selftest:
+            result["selftest"] = "DLRM_BENCH_SELFTEST_GLOO=1: all ranks on ONE GPU over gloo with host-staged exchanges — control-flow test, NOT a measurement"
+        watchdog(0, "")
+    elif N > 1:
         # ---- the OTHER exchange schedule, same process, same model: never instead of the headline ------------------------
         alt_c = 1 if model_a2a_chunks > 1 else (args.alt_a2a_chunks or {2: 4, 4: 2, 8: 2}.get(N, 2))
         if alt_c == 1 or (B // N) % alt_c == 0:

@@ -225,8 +225,8 @@ static size_t edge_row_floats(int D) {
 
 struct AdaLayout { Layout sort; size_t edge_first, edge_last, total; };
 
-static int ada_layout(size_t L, bool wide, int key_bits, int D, AdaLayout* lo) {
-    int rc = make_layout(L, wide, key_bits, &lo->sort);
+static int ada_layout(size_t L, bool wide, int key_bits, int D, AdaLayout* lo, int n, const int64_t* nnz, const int64_t* rows) {
+    int rc = make_layout(L, wide, key_bits, &lo->sort, n, nnz, rows);
     if (rc) return rc;
     const size_t groups = (L + kG - 1) / kG;
     const size_t row = edge_row_floats(D);
@@ -315,7 +315,7 @@ extern "C" int64_t dlrm_emb_adagrad_workspace_bytes(int T, int D, const int64_t*
         if (L == 0) continue;
         const int row_bits = bits_for(max_rows), key_bits = row_bits + bits_for(n);
         AdaLayout lo;
-        if (ada_layout(L, key_bits > 32, key_bits, D, &lo) != 0) return -1;
+        if (ada_layout(L, key_bits > 32, key_bits, D, &lo, n, nnz_host + t0, rows_host + t0) != 0) return -1;
         if (lo.total > worst) worst = lo.total;
     }
     return (int64_t)worst;
@@ -350,7 +350,7 @@ extern "C" int dlrm_emb_bwd_rowwise_adagrad(int T, int64_t B, int D, void* const
         const int row_bits = bits_for(max_rows), key_bits = row_bits + bits_for(n);
         const bool wide = key_bits > 32;
         AdaLayout lo;
-        int rc = ada_layout(L, wide, key_bits, D, &lo);
+        int rc = ada_layout(L, wide, key_bits, D, &lo, n, nnz_host + t0, rows_host + t0);
         if (rc) return rc;
         if (!workspace || !dlrm_aligned16(workspace) || (size_t)workspace_bytes < lo.total) {
             fprintf(stderr, "libdlrm_hip: dlrm_emb_bwd_rowwise_adagrad: workspace too small (%lld < %zu bytes)\n",

@@ -200,10 +200,71 @@ extern "C" int64_t dlrm_emb_bwd_workspace_bytes(int T, const int64_t* nnz_host, 
         if (L == 0) continue;
         const int row_bits = bits_for(max_rows), key_bits = row_bits + bits_for(n);
         Layout lo;
-        if (make_layout(L, key_bits > 32, key_bits, &lo) != 0) return -1;
+        if (make_layout(L, key_bits > 32, key_bits, &lo, n, nnz_host + t0, rows_host + t0) != 0) return -1;
         if (lo.total > worst) worst = lo.total;
     }
     return (int64_t)worst;
+}
+
+extern "C" int dlrm_emb_sort_kind(int T, const int64_t* nnz_host, const int64_t* rows_host) {
+    if (T <= 0 || !nnz_host || !rows_host || !seg_sort_enabled()) return 0;
+    for (int t0 = 0; t0 < T; t0 += DLRM_MAX_TABLES_PER_LAUNCH) {
+        const int n = (T - t0 < DLRM_MAX_TABLES_PER_LAUNCH) ? T - t0 : DLRM_MAX_TABLES_PER_LAUNCH;
+        long long nz[DLRM_MAX_TABLES_PER_LAUNCH], rw[DLRM_MAX_TABLES_PER_LAUNCH];
+        for (int k = 0; k < n; ++k) { nz[k] = (long long)nnz_host[t0 + k]; rw[k] = (long long)rows_host[t0 + k]; }
+        SegPlan plan;
+        if (!seg_plan(n, nz, rw, &plan)) return 0;
+    }
+    return 1;
+}
+
+namespace {
+template <typename KT>
+__global__ __launch_bounds__(256) void widen_keys_kernel(long long L, const KT* __restrict__ k, unsigned long long* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long long)gridDim.x * 256) out[i] = (unsigned long long)k[i];
+}
+}  // namespace
+
+// The sort of the sort-based updates on its own (what dlrm_emb_bwd_sgd(DLRM_UPD_SORTED) and dlrm_emb_bwd_rowwise_adagrad run first):
+// positions_out[j] = global lookup position (table-major) of the j-th entry in (table, row) order, equal rows in input order;
+// keys_out[j] = table << row_bits | row of that entry (row_bits = bits of the largest table); bag_out[p] = bag of POSITION p
+// (0xFFFFFFFF for a skipped out-of-range lookup).  One launch group only (T <= 32).  Used by the tests to check the sorter itself.
+extern "C" int dlrm_emb_sort_lookups(int T, int64_t B, const int64_t* rows_host, const void* const* indices_host,
+                                     const void* const* offsets_host, const int64_t* nnz_host, int idx_bits, void* workspace,
+                                     int64_t workspace_bytes, uint32_t* positions_out, uint64_t* keys_out, uint32_t* bag_out,
+                                     int* row_bits_out, int64_t* err, void* stream) {
+    if (T <= 0 || T > DLRM_MAX_TABLES_PER_LAUNCH || B <= 0 || !rows_host || !indices_host || !offsets_host || !nnz_host || !positions_out ||
+        !keys_out)
+        return DLRM_E_ARG;
+    if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
+    hipStream_t st = (hipStream_t)stream;
+    int ids[DLRM_MAX_TABLES_PER_LAUNCH];
+    void* wfake[DLRM_MAX_TABLES_PER_LAUNCH];
+    size_t L = 0; long long max_rows = 1;
+    for (int k = 0; k < T; ++k) { ids[k] = k; wfake[k] = nullptr; L += (size_t)nnz_host[k]; if (rows_host[k] > max_rows) max_rows = rows_host[k]; }
+    if (L == 0 || L >= ((size_t)1 << 32)) return DLRM_E_RANGE;
+    const int row_bits = bits_for(max_rows), key_bits = row_bits + bits_for(T);
+    const bool wide = key_bits > 32;
+    if (row_bits_out) *row_bits_out = row_bits;
+    Layout lo;
+    int rc = make_layout(L, wide, key_bits, &lo, T, nnz_host, rows_host);
+    if (rc) return rc;
+    if (!workspace || (size_t)workspace_bytes < lo.total) return DLRM_E_ARG;
+    char* ws = (char*)workspace;
+    SortedArgs sa;
+    rc = wide ? expand_and_sort<unsigned long long>(T, ids, B, wfake, rows_host, indices_host, offsets_host, nnz_host, nullptr, idx_bits, ws, lo,
+                                                    L, row_bits, key_bits, st, &sa, err)
+              : expand_and_sort<unsigned>(T, ids, B, wfake, rows_host, indices_host, offsets_host, nnz_host, nullptr, idx_bits, ws, lo, L, row_bits,
+                                          key_bits, st, &sa, err);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(positions_out, ws + lo.vals_out, L * 4, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess && bag_out) e = hipMemcpyAsync(bag_out, ws + lo.bag_of, L * 4, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    const unsigned nb = (unsigned)((L + 255) / 256 > 2048 ? 2048 : (L + 255) / 256);
+    if (wide) hipLaunchKernelGGL((widen_keys_kernel<unsigned long long>), dim3(nb), dim3(256), 0, st, (long long)L, (const unsigned long long*)(ws + lo.keys_out), (unsigned long long*)keys_out);
+    else      hipLaunchKernelGGL((widen_keys_kernel<unsigned>), dim3(nb), dim3(256), 0, st, (long long)L, (const unsigned*)(ws + lo.keys_out), (unsigned long long*)keys_out);
+    DLRM_LAUNCH_CHECK();
+    return 0;
 }
 
 int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_host, const int64_t* rows_host,
@@ -230,7 +291,7 @@ int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_ho
         const int row_bits = bits_for(max_rows), key_bits = row_bits + bits_for(n);
         const bool wide = key_bits > 32;
         Layout lo;
-        int rc = make_layout(L, wide, key_bits, &lo);
+        int rc = make_layout(L, wide, key_bits, &lo, n, nnz_host + t0, rows_host + t0);
         if (rc) return rc;
         if (!workspace || (size_t)workspace_bytes < lo.total) {
             fprintf(stderr, "libdlrm_hip: dlrm_emb_bwd_sgd(sorted): workspace too small (%lld < %zu bytes)\n",

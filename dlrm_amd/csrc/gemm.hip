@@ -356,14 +356,18 @@ __device__ __forceinline__ Split3 split3(const float (&x)[8]) {
 // each fp32 operand is rounded to the nearest bf16 (ties to even, the rounding torch.bfloat16 conversion uses), ONE
 // v_mfma_f32_32x32x16_bf16 per 16-k step, fp32 accumulation and fp32 results: 16x the fp32 MFMA rate, ~3 significant
 // decimal digits per operand.
-__device__ __forceinline__ unsigned bf16_rne_hi(float a) {               // bf16 bits of a in the UPPER half, lower half junk-free
-    const unsigned u = __float_as_uint(a);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+// (v_cvt_pk_bf16_f32: ONE instruction converts two fp32 values to a packed bf16 pair with round-to-nearest-even — the manual
+// add-0x7fff-and-mask sequence of rounds 1-2 cost ~8 VALU instructions per pair inside the k-loop, which made this path VALU-bound:
+// 289 TFLOP/s = 0.12 of the bf16 MFMA peak, profiles/r03/bench_tb_bf16.json)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
 }
 __device__ __forceinline__ uintx4 round8_bf16(const float (&x)[8]) {
     uintx4 r;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = (bf16_rne_hi(x[2 * i]) >> 16) | bf16_rne_hi(x[2 * i + 1]);
+    for (int i = 0; i < 4; ++i) r[i] = cvt_pk_bf16(x[2 * i], x[2 * i + 1]);
     return r;
 }
 #define MFMA_BF16(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)

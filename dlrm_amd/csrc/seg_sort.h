@@ -1,0 +1,252 @@
+// seg_sort.h — the (table,row) sort of the sort-based embedding updates, written for what the lookups ARE instead of as a
+// general 32-bit radix sort (rocPRIM's onesweep took 4 passes + a histogram + 9 hipMemsetAsync fills, ~150 of the
+// 519 us of the fused EmbeddingBag backward + SGD, and cannot be replayed inside a HIP graph).
+//
+// Reference semantics served: the sparse gradient of EmbeddingBagBackward is consumed row by row IN INPUT ORDER (sparse SGD:
+// `p.add_(coo, alpha=-lr)`, dlrm_s_pytorch.py:1613,1620; row-wise Adagrad coalesces, optim/rwsadagrad.py:117-120), so the update
+// kernels want every table's lookups grouped by row with equal rows in input order: a STABLE sort by (table, row).
+//
+// What is special about the input:
+//   * lookups arrive TABLE-MAJOR (positions base[t] .. base[t] + nnz[t]): the table bits of the key are already sorted, only the
+//     row bits of each table's own segment need sorting, and a table with few rows needs few bits: the 13 Criteo-Terabyte tables
+//     with <= 8192 rows take ONE counting pass, the 40 M-row tables two passes of 13 bits (rocPRIM: four passes of 8 over 31 bits);
+//   * a segment is at most a few global batches long (one lookup per bag in the Criteo data sets).
+//
+// Algorithm: least-significant-digit radix sort, per table segment, digits of up to 13 bits, 1-3 rounds (tables that need fewer
+// rounds join in the last ones; ping-pong buffers chosen so that every table ends in the OUT buffer).  One round = three launches
+// over all participating tables, no memsets, no atomics on global memory, nothing that a HIP graph cannot replay:
+//   seg_hist_kernel     one WAVE per tile of 4096 consecutive entries: digit histogram in LDS -> hist[table][tile][bin]
+//   seg_scan_kernel     one workgroup per table: exclusive prefix over tiles per bin (in place) + exclusive prefix over bins
+//   seg_scatter_kernel  one wave per tile, entries 64 at a time IN ORDER: lanes with equal digits find each other with ballots
+//                       (match-any), the lowest lane of each group advances the digit's cursor in LDS, every entry goes to
+//                       cursor + its rank in the group: stable by construction (rank order inside a 64-entry step, step order
+//                       inside a tile, tile order through the prefix)
+// Segments longer than SEG_MAX_TILES tiles (multi-hot batches with millions of lookups per table) stay with the general sorter.
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int SEG_TILE = 4096;           // entries per wave-tile
+constexpr int SEG_MAX_DBITS = 13;        // 8192 bins: 32 KB of LDS per wave
+constexpr int SEG_MAX_TILES = 64;        // per table segment (262144 lookups)
+constexpr int SEG_MAX_ROUNDS = 3;        // rows < 2^39
+
+struct SegRound {
+    int ntab;                                                // participating tables of this round
+    int tab[DLRM_MAX_TABLES_PER_LAUNCH];                     // their slot in the launch group
+    unsigned tile_start[DLRM_MAX_TABLES_PER_LAUNCH + 1];     // prefix of their tile counts
+    unsigned char dbits[DLRM_MAX_TABLES_PER_LAUNCH];         // digit width of this round
+    unsigned char shift[DLRM_MAX_TABLES_PER_LAUNCH];         // digit position
+    unsigned char first[DLRM_MAX_TABLES_PER_LAUNCH];         // the table's first round: source = IN, value = the position itself
+    unsigned char dst_out[DLRM_MAX_TABLES_PER_LAUNCH];       // destination = OUT (else TMP); a later round's source is the other one
+    unsigned hist_off[DLRM_MAX_TABLES_PER_LAUNCH];           // first counter of the table in the hist buffer  [tiles][bins]
+    unsigned bin_off[DLRM_MAX_TABLES_PER_LAUNCH];            // first counter of the table in the bin-base buffer [bins]
+    long long base[DLRM_MAX_TABLES_PER_LAUNCH];              // first global position of the table's segment
+    long long nnz[DLRM_MAX_TABLES_PER_LAUNCH];
+};
+
+struct SegPlan {
+    int rounds;
+    SegRound round[SEG_MAX_ROUNDS];
+    size_t hist_words, bin_words;                            // buffer sizes (u32 words), the maximum over rounds
+};
+
+static int seg_bits_for(long long n) { int b = 0; while (((long long)1 << b) < n) ++b; return b < 1 ? 1 : b; }
+
+// false: a segment is too long for this sorter (or a table has >= 2^39 rows) -> the caller uses the general sorter
+static bool seg_plan(int n, const long long* nnz, const long long* rows, SegPlan* p) {
+    int passes[DLRM_MAX_TABLES_PER_LAUNCH], rb[DLRM_MAX_TABLES_PER_LAUNCH];
+    int R = 0;
+    for (int k = 0; k < n; ++k) {
+        if (nnz[k] > (long long)SEG_TILE * SEG_MAX_TILES) return false;
+        rb[k] = seg_bits_for(rows[k]);
+        passes[k] = nnz[k] > 0 ? (rb[k] + SEG_MAX_DBITS - 1) / SEG_MAX_DBITS : 0;
+        if (passes[k] > SEG_MAX_ROUNDS) return false;
+        if (passes[k] > R) R = passes[k];
+    }
+    p->rounds = R;
+    p->hist_words = 0; p->bin_words = 0;
+    long long base[DLRM_MAX_TABLES_PER_LAUNCH];
+    long long acc = 0;
+    for (int k = 0; k < n; ++k) { base[k] = acc; acc += nnz[k]; }
+    for (int r = 0; r < R; ++r) {
+        SegRound& q = p->round[r];
+        q.ntab = 0; q.tile_start[0] = 0;
+        size_t hw = 0, bw = 0;
+        for (int k = 0; k < n; ++k) {
+            const int pass = r - (R - passes[k]);             // this table's pass index in round r
+            if (passes[k] == 0 || pass < 0) continue;
+            // digits as even as possible: the first (rb % passes) passes are one bit wider
+            const int lo = rb[k] / passes[k], rem = rb[k] % passes[k];
+            int shift = 0;
+            for (int j = 0; j < pass; ++j) shift += lo + (j < rem ? 1 : 0);
+            const int d = lo + (pass < rem ? 1 : 0);
+            const int i = q.ntab++;
+            const unsigned tiles = (unsigned)((nnz[k] + SEG_TILE - 1) / SEG_TILE);
+            q.tab[i] = k; q.tile_start[i + 1] = q.tile_start[i] + tiles;
+            q.dbits[i] = (unsigned char)d; q.shift[i] = (unsigned char)shift;
+            q.first[i] = (unsigned char)(pass == 0);
+            q.dst_out[i] = (unsigned char)(((R - 1 - r) & 1) == 0);
+            q.hist_off[i] = (unsigned)hw; q.bin_off[i] = (unsigned)bw;
+            q.base[i] = base[k]; q.nnz[i] = nnz[k];
+            hw += (size_t)tiles << d; bw += (size_t)1 << d;
+        }
+        for (int i = q.ntab; i < DLRM_MAX_TABLES_PER_LAUNCH; ++i) {
+            q.tab[i] = 0; q.tile_start[i + 1] = q.tile_start[q.ntab]; q.dbits[i] = 1; q.shift[i] = 0; q.first[i] = 0; q.dst_out[i] = 1;
+            q.hist_off[i] = 0; q.bin_off[i] = 0; q.base[i] = 0; q.nnz[i] = 0;
+        }
+        if (hw > p->hist_words) p->hist_words = hw;
+        if (bw > p->bin_words) p->bin_words = bw;
+    }
+    return true;
+}
+
+// which participating table owns wave-tile `w` (<= 32 entries: a scalar scan of the kernarg)
+__device__ __forceinline__ int seg_find(const SegRound& q, unsigned w) {
+    int i = 0;
+    while (i + 1 < q.ntab && w >= q.tile_start[i + 1]) ++i;
+    return i;
+}
+
+template <typename KT>
+__global__ __launch_bounds__(64) void seg_hist_kernel(SegRound q, const KT* __restrict__ in, const KT* __restrict__ tmp,
+                                                      const KT* __restrict__ out, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[1 << SEG_MAX_DBITS];
+    const int lane = threadIdx.x;
+    const int i = seg_find(q, blockIdx.x);
+    const unsigned tile = blockIdx.x - q.tile_start[i];
+    const int d = q.dbits[i], shift = q.shift[i];
+    const unsigned bins = 1u << d, mask = bins - 1;
+    const KT* __restrict__ src = q.first[i] ? in : (q.dst_out[i] ? tmp : out);
+    for (unsigned b = lane; b < bins; b += 64) h[b] = 0u;
+    const long long s = q.base[i] + (long long)tile * SEG_TILE;
+    long long n = q.nnz[i] - (long long)tile * SEG_TILE; if (n > SEG_TILE) n = SEG_TILE;
+    // (one wave: LDS operations complete in order, no barrier needed between the fill, the adds and the read-out)
+    for (int c = lane; c < (int)n; c += 64) atomicAdd(&h[(unsigned)(src[s + c] >> shift) & mask], 1u);
+    unsigned* __restrict__ dst = hist + q.hist_off[i] + ((size_t)tile << d);
+    for (unsigned b = lane; b < bins; b += 64) dst[b] = h[b];
+}
+
+// per table: hist[tile][bin] -> exclusive prefix over the tiles of every bin (in place), binbase[bin] = exclusive prefix of the bins'
+// totals.  An entry of digit b in tile t then goes to  binbase[b] + hist[t][b] + (its rank among the tile's entries of digit b).
+__global__ __launch_bounds__(1024) void seg_scan_kernel(SegRound q, unsigned* __restrict__ hist, unsigned* __restrict__ binbase) {
+    __shared__ unsigned tot[1 << SEG_MAX_DBITS];
+    __shared__ unsigned wsum[16];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int d = q.dbits[i];
+    const unsigned bins = 1u << d;
+    const unsigned tiles = q.tile_start[i + 1] - q.tile_start[i];
+    unsigned* __restrict__ h = hist + q.hist_off[i];
+    for (unsigned b = tid; b < bins; b += 1024) {
+        unsigned run = 0;
+        for (unsigned t = 0; t < tiles; ++t) {
+            const unsigned c = h[((size_t)t << d) + b];
+            h[((size_t)t << d) + b] = run;
+            run += c;
+        }
+        tot[b] = run;
+    }
+    __syncthreads();
+    // exclusive scan of tot[0..bins): every thread owns PER consecutive bins
+    const unsigned per = (bins + 1023) / 1024;                // 1 .. 8
+    unsigned loc[8], sum = 0;
+#pragma unroll
+    for (unsigned j = 0; j < 8; ++j) {
+        const unsigned b = tid * per + j;
+        loc[j] = (j < per && b < bins) ? tot[b] : 0u;
+        sum += loc[j];
+    }
+    unsigned inc = sum;                                        // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += v;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    unsigned wbase = 0;
+    for (int w = 0; w < (tid >> 6); ++w) wbase += wsum[w];
+    unsigned run = wbase + inc - sum;
+    unsigned* __restrict__ bb = binbase + q.bin_off[i];
+#pragma unroll
+    for (unsigned j = 0; j < 8; ++j) {
+        const unsigned b = tid * per + j;
+        if (j < per && b < bins) { bb[b] = run; run += loc[j]; }
+    }
+}
+
+template <typename KT>
+__global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* __restrict__ kin, const KT* __restrict__ ktmp_r,
+                                                         const KT* __restrict__ kout_r, KT* __restrict__ ktmp, KT* __restrict__ kout,
+                                                         const unsigned* __restrict__ vtmp_r, const unsigned* __restrict__ vout_r,
+                                                         unsigned* __restrict__ vtmp, unsigned* __restrict__ vout,
+                                                         const unsigned* __restrict__ hist, const unsigned* __restrict__ binbase) {
+    __shared__ volatile unsigned cur[1 << SEG_MAX_DBITS];     // (volatile: lanes hand cursors to each other through it, in program order)
+    const int lane = threadIdx.x;
+    const int i = seg_find(q, blockIdx.x);
+    const unsigned tile = blockIdx.x - q.tile_start[i];
+    const int d = q.dbits[i], shift = q.shift[i];
+    const unsigned bins = 1u << d, mask = bins - 1;
+    const bool first = q.first[i] != 0, to_out = q.dst_out[i] != 0;
+    const KT* __restrict__ ksrc = first ? kin : (to_out ? ktmp_r : kout_r);
+    const unsigned* __restrict__ vsrc = to_out ? vtmp_r : vout_r;       // (not read in a table's first round: the value IS the position)
+    KT* __restrict__ kdst = to_out ? kout : ktmp;
+    unsigned* __restrict__ vdst = to_out ? vout : vtmp;
+    const unsigned* __restrict__ h = hist + q.hist_off[i] + ((size_t)tile << d);
+    const unsigned* __restrict__ bb = binbase + q.bin_off[i];
+    for (unsigned b = lane; b < bins; b += 64) cur[b] = bb[b] + h[b];
+    const long long seg = q.base[i];
+    const long long s = seg + (long long)tile * SEG_TILE;
+    long long n = q.nnz[i] - (long long)tile * SEG_TILE; if (n > SEG_TILE) n = SEG_TILE;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int c0 = 0; c0 < (int)n; c0 += 64) {
+        const bool valid = c0 + lane < (int)n;
+        const KT key = valid ? ksrc[s + c0 + lane] : (KT)0;
+        const unsigned val = valid ? (first ? (unsigned)(s + c0 + lane) : vsrc[s + c0 + lane]) : 0u;
+        const unsigned dg = (unsigned)(key >> shift) & mask;
+        // match-any: the set of valid lanes holding my digit
+        unsigned long long same = __ballot(valid);
+        for (int b = 0; b < d; ++b) {
+            const bool bit = (dg >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        const int rank = __popcll(same & below);
+        const int leader = __ffsll((long long)same) - 1;                 // lowest lane of my group (valid lanes only use it)
+        unsigned start = 0u;
+        if (valid && rank == 0) {                                        // one lane per distinct digit: no two leaders share an address
+            start = cur[dg];
+            cur[dg] = start + (unsigned)__popcll(same);
+        }
+        start = __shfl(start, leader < 0 ? 0 : leader, 64);
+        if (valid) {
+            const long long dst = seg + (long long)start + rank;
+            kdst[dst] = key;
+            vdst[dst] = val;
+        }
+    }
+}
+
+// Sorts the n table segments of keys_in (positions are the values) into keys_out / vals_out, stable.  keys_tmp / vals_tmp /
+// hist / binbase are scratch.  Returns 0, or a HIP error code.
+template <typename KT>
+static int seg_sort_run(const SegPlan& p, const KT* keys_in, KT* keys_tmp, KT* keys_out, unsigned* vals_tmp, unsigned* vals_out,
+                        unsigned* hist, unsigned* binbase, hipStream_t st) {
+    for (int r = 0; r < p.rounds; ++r) {
+        const SegRound& q = p.round[r];
+        const unsigned tiles = q.tile_start[q.ntab];
+        if (q.ntab == 0 || tiles == 0) continue;
+        hipLaunchKernelGGL((seg_hist_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out, hist);
+        DLRM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(seg_scan_kernel, dim3((unsigned)q.ntab), dim3(1024), 0, st, q, hist, binbase);
+        DLRM_LAUNCH_CHECK();
+        hipLaunchKernelGGL((seg_scatter_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out,
+                           keys_tmp, keys_out, (const unsigned*)vals_tmp, (const unsigned*)vals_out, vals_tmp, vals_out,
+                           (const unsigned*)hist, (const unsigned*)binbase);
+        DLRM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace

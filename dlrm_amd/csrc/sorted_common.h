@@ -4,6 +4,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include "common.h"
+#include "seg_sort.h"
 
 namespace {
 
@@ -101,7 +102,20 @@ static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 static int bits_for(long long n) { int b = 0; while (((long long)1 << b) < n) ++b; return b < 1 ? 1 : b; }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-struct Layout { size_t keys_in, keys_out, vals_in, vals_out, bag_of, temp, temp_bytes, total; };
+struct Layout {
+    size_t keys_in, keys_out, vals_in, vals_out, bag_of, temp, temp_bytes, total;
+    // the segmented sorter of seg_sort.h (own = true: it handles this group; the rocPRIM temp then stays unused)
+    size_t keys_tmp, vals_tmp, hist, binbase;
+    bool own;
+    SegPlan plan;
+};
+
+// env DLRM_SORT=rocprim forces the general (vendor) sorter: A/B and fallback
+static bool seg_sort_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DLRM_SORT"); v = (e && strcmp(e, "rocprim") == 0) ? 0 : 1; }
+    return v == 1;
+}
 
 template <typename KT>
 static hipError_t sort_temp_bytes(size_t L, int bits, size_t* bytes) {
@@ -110,9 +124,16 @@ static hipError_t sort_temp_bytes(size_t L, int bits, size_t* bytes) {
         nullptr, *bytes, nullptr, nullptr, nullptr, nullptr, L, 0, bits, (hipStream_t)0, false);
 }
 
-static int make_layout(size_t L, bool wide, int bits, Layout* lo) {
+// n / nnz / rows: the tables of the launch group (in launch order) — given, the group is planned for the segmented sorter
+static int make_layout(size_t L, bool wide, int bits, Layout* lo, int n = 0, const int64_t* nnz = nullptr, const int64_t* rows = nullptr) {
     const size_t ksz = wide ? 8 : 4;
     size_t o = 0;
+    lo->own = false;
+    if (n > 0 && n <= DLRM_MAX_TABLES_PER_LAUNCH && nnz && rows && seg_sort_enabled()) {
+        long long nz[DLRM_MAX_TABLES_PER_LAUNCH], rw[DLRM_MAX_TABLES_PER_LAUNCH];
+        for (int k = 0; k < n; ++k) { nz[k] = (long long)nnz[k]; rw[k] = (long long)rows[k]; }
+        lo->own = seg_plan(n, nz, rw, &lo->plan);
+    }
     lo->keys_in = o;  o += align256(L * ksz);
     lo->keys_out = o; o += align256(L * ksz);
     lo->vals_in = o;  o += align256(L * 4);
@@ -122,6 +143,13 @@ static int make_layout(size_t L, bool wide, int bits, Layout* lo) {
                         : sort_temp_bytes<unsigned>(L, bits, &lo->temp_bytes);
     if (e != hipSuccess) return (int)e;
     lo->temp = o; o += align256(lo->temp_bytes);
+    lo->keys_tmp = lo->vals_tmp = lo->hist = lo->binbase = 0;
+    if (lo->own) {
+        lo->keys_tmp = o; o += align256(L * ksz);
+        lo->vals_tmp = o; o += align256(L * 4);
+        lo->hist = o;     o += align256(lo->plan.hist_words * 4);
+        lo->binbase = o;  o += align256(lo->plan.bin_words * 4);
+    }
     lo->total = o;
     return 0;
 }
@@ -172,6 +200,9 @@ static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight
             hipLaunchKernelGGL((expand_kernel<int, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
     }
     DLRM_LAUNCH_CHECK();
+    if (lo.own)         // table-major segments, per-table digit counts: seg_sort.h (graph-replayable: plain kernels, no memsets)
+        return seg_sort_run<KT>(lo.plan, (const KT*)keys_in, (KT*)(ws + lo.keys_tmp), keys_out, (unsigned*)(ws + lo.vals_tmp), vals_out,
+                                (unsigned*)(ws + lo.hist), (unsigned*)(ws + lo.binbase), st);
     size_t tb = lo.temp_bytes;
     hipError_t e = rocprim::radix_sort_pairs(ws + lo.temp, tb, (const KT*)keys_in, keys_out, (const unsigned*)vals_in,
                                              vals_out, L, 0, key_bits, st, false);

@@ -432,6 +432,42 @@ def _host_staged(t: torch.Tensor) -> bool:
     return t.is_cuda and dist.get_backend() == "gloo"       # the 1-GPU test rig: several ranks on one device, gloo rendezvous
 
 
+def _pack_ids(pieces: Sequence[torch.Tensor], like: torch.Tensor) -> torch.Tensor:
+    """concatenation of 1-D id tensors: one strided block-copy launch on the GPU (dlrm_copy_blocks), torch.cat on CPU ranks"""
+    if not pieces:
+        return like.new_empty(0)
+    if not like.is_cuda:
+        return torch.cat(list(pieces))
+    from . import ops
+    out = like.new_empty(sum(p.numel() for p in pieces))
+    dsts, o = [], 0
+    for p in pieces:
+        dsts.append(out[o:o + p.numel()].view(1, -1))
+        o += p.numel()
+    ops.copy_id_blocks([p.view(1, -1) for p in pieces], dsts)
+    return out
+
+
+def _unpack_ids(rv: torch.Tensor, widths: Sequence[int]) -> List[torch.Tensor]:
+    """rv [N, sum(widths)] (one row per source rank) -> for every width w a contiguous [N * w] tensor = that column block of all rows,
+    source-major (= global batch order): one block-copy launch on the GPU, reshape copies on CPU ranks"""
+    outs, o = [], 0
+    if not rv.is_cuda:
+        for w in widths:
+            outs.append(rv[:, o:o + w].reshape(-1))
+            o += w
+        return outs
+    from . import ops
+    N = rv.size(0)
+    srcs = []
+    for w in widths:
+        srcs.append(rv[:, o:o + w])
+        outs.append(rv.new_empty(N * w))
+        o += w
+    ops.copy_id_blocks(srcs, [t.view(N, -1) for t in outs])
+    return outs
+
+
 def kjt_input_dist(values: torch.Tensor, hot: Sequence[int], tw_owner: Sequence[int], rw_tables: Sequence[int]):
     """Every rank holds the ids of ITS batch slice for ALL tables, key-major like the KJT the reference builds per rank
     (`values` = cat over tables t of [Bl * hot[t]] ids, multi_hot_criteo.py:200-214).  Returns, in GLOBAL batch order,
@@ -450,7 +486,7 @@ def kjt_input_dist(values: torch.Tensor, hot: Sequence[int], tw_owner: Sequence[
     piece = lambda t: values[Bl * seg[t]:Bl * seg[t + 1]]
     owned = [[t for t in range(T) if tw_owner[t] == r] for r in range(N)]
     # ---- table-wise: destination-major send buffer
-    send = torch.cat([piece(t) for r in range(N) for t in owned[r]]) if any(owned) else values.new_empty(0)
+    send = _pack_ids([piece(t) for r in range(N) for t in owned[r]], values)
     send_counts = [Bl * sum(hot[t] for t in owned[r]) for r in range(N)]
     mine = owned[me]
     per_src = Bl * sum(hot[t] for t in mine)
@@ -462,16 +498,14 @@ def kjt_input_dist(values: torch.Tensor, hot: Sequence[int], tw_owner: Sequence[
             recv.copy_(h_out)
         else:
             dist.all_to_all_single(recv, send, [per_src] * N, send_counts)
-    tw, o = {}, 0
-    rv = recv.view(N, per_src) if per_src else recv
-    for t in mine:                                             # [N, Bl*h_t] -> [B*h_t]: source-major == global batch order
-        w = Bl * hot[t]
-        tw[t] = rv[:, o:o + w].reshape(-1)
-        o += w
+    tw = {}
+    if per_src:                                                # [N, Bl*h_t] -> [B*h_t]: source-major == global batch order
+        for t, ids in zip(mine, _unpack_ids(recv.view(N, per_src), [Bl * hot[t] for t in mine])):
+            tw[t] = ids
     # ---- row-wise: everybody needs everybody's ids
     rw = {}
     if rw_tables:
-        mine_rw = torch.cat([piece(t) for t in rw_tables])
+        mine_rw = _pack_ids([piece(t) for t in rw_tables], values)
         gathered = values.new_empty(N * mine_rw.numel())
         if _host_staged(values):
             h_out = torch.empty(gathered.shape, dtype=gathered.dtype)
@@ -479,11 +513,8 @@ def kjt_input_dist(values: torch.Tensor, hot: Sequence[int], tw_owner: Sequence[
             gathered.copy_(h_out)
         else:
             dist.all_gather_into_tensor(gathered, mine_rw.contiguous())
-        gv, o = gathered.view(N, -1), 0
-        for t in rw_tables:
-            w = Bl * hot[t]
-            rw[t] = gv[:, o:o + w].reshape(-1)
-            o += w
+        for t, ids in zip(rw_tables, _unpack_ids(gathered.view(N, -1), [Bl * hot[t] for t in rw_tables])):
+            rw[t] = ids
     return tw, rw
 
 

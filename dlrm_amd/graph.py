@@ -9,7 +9,7 @@ The reference loop body (dlrm_s_pytorch.py:1574-1621) is what gets captured, unc
 
 Everything the C ABI enqueues is capture-safe by construction: kernels take table / tensor pointers by value in
 the kernarg segment, nothing allocates or synchronises, scratch buffers come from torch's caching allocator (graph
-private pool during capture) and rocPRIM's radix sort runs entirely on the capture stream.
+private pool during capture) and the segmented sort of the embedding updates is made of plain kernels on the capture stream.
 
 Constraints (checked, never silently worked around):
   * single process (ext_dist.my_size == 1): RCCL collectives and DDP hooks are not captured;
@@ -18,11 +18,11 @@ Constraints (checked, never silently worked around):
   * no autograd graph of an earlier eager step may still be alive at capture time (e.g. a loss tensor the caller kept):
     the autograd engine would synchronise the capture stream with the stream those old nodes were created on, which
     invalidates the capture.  Reduce losses to Python floats (`float(loss)`) or `del` them before the first graphed call;
-  * RESOLVED in round 3 (was "KNOWN ISSUE", profiles/r02/graph_probe.md d): the GPU memory fault at B = 65536 came from replaying
-    rocPRIM's radix sort (sorted embedding update), not from the batch size: tools/probes/graph_sorted_probe.py faults in
-    "sorted" mode with 2000-row tables and is clean in "deterministic" / "atomic" mode.  The graph path switches the model to
-    the atomic update and refuses the (sort-based) row-wise Adagrad; tests/test_gpu_model.py replays 36 full-batch steps with
-    host syncs in between, bit-identical to eager;
+  * the GPU memory fault at B = 65536 of round 1 (profiles/r02/graph_probe.md d) came from replaying rocPRIM's radix sort, not from
+    the batch size (tools/probes/graph_sorted_probe.py).  The sort-based updates now run on the library's own segmented sorter
+    (csrc/seg_sort.h) whenever every table segment holds <= 262144 lookups — then the graph keeps the sorted update and the fused
+    row-wise Adagrad; otherwise it switches SGD to the atomic update and refuses the Adagrad update (GraphedTrainStep.
+    _settle_sort_mode).  tests/test_gpu_model.py replays 36 full-batch steps with host syncs in between, bit-identical to eager;
   * learning rates are baked into kernel arguments at capture time: when a scheduler changes a param group's lr the
     step is re-captured (correct, but a schedule that changes lr every step gains nothing from replay).
 """
@@ -95,16 +95,12 @@ class GraphedTrainStep:
             if float(g.get("lr_decay", 0.0) or 0.0) != 0.0:
                 raise RuntimeError("dlrm_amd.graph: lr_decay != 0 changes the step size every step; a captured graph cannot "
                                    "follow it (use the eager step)")
-        if getattr(model, "emb_update_mode", None) == ops.UPD_SORTED:
-            # rocPRIM's onesweep radix sort (the sorted update and the row-wise Adagrad update run on it) ends in a memory-aperture
-            # violation when REPLAYED from a HIP graph on ROCm 7.2 — even with 2000-row tables, while the deterministic and the
-            # atomic update replay cleanly for 30+ steps with host syncs in between (tools/probes/graph_sorted_probe.py; this was
-            # the "TB-shape graph fault" of profiles/r02/graph_probe.md).  The graph path therefore runs the atomic update:
-            # LDS pre-reduction for tiny tables + hardware fp32 atomics, the right choice at the launch-bound shapes graphs are for.
-            model.emb_update_mode = ops.UPD_ATOMIC
-        if any(type(optimizer).__name__ == n for n in ("RWSAdagrad", "FusedRWSAdagrad")):
-            raise RuntimeError("dlrm_amd.graph: the fused row-wise Adagrad update sorts with rocPRIM, which cannot be replayed from a "
-                               "HIP graph on this ROCm (tools/probes/graph_sorted_probe.py); use the eager step")
+        # Sort-based updates (DLRM_UPD_SORTED, the fused row-wise Adagrad): rocPRIM's onesweep radix sort ends in a memory-aperture
+        # violation when REPLAYED from a HIP graph on ROCm 7.2 (tools/probes/graph_sorted_probe.py; the "TB-shape graph fault" of
+        # profiles/r02/graph_probe.md).  Since round 3 of the build the library sorts table segments of up to 262144 lookups with its
+        # own kernels (csrc/seg_sort.h: no memsets, no vendor code, replayable); whether THIS step's shapes are covered is only known
+        # when the first batch arrives — decided in _settle_sort_mode().
+        self._sort_checked = False
         # the captured step is single-stream: a replayed graph has no launch gaps to hide, and the side-stream overlap
         # of the eager path (DLRM_Net.overlap_streams) would put cross-stream joins into the capture
         model.overlap_streams = False
@@ -119,6 +115,31 @@ class GraphedTrainStep:
         self._eager_calls = 0
         self._replayed = False
         self.serialize = _os.environ.get("DLRM_GTS_SERIALIZE", "1") == "1"
+
+    def _settle_sort_mode(self, lS_o, lS_i) -> None:
+        """First batch: keep the sort-based embedding update only if every table segment goes through the library's own segmented
+        sorter (ops.sort_is_graph_safe); otherwise SGD falls back to the atomic update and the row-wise Adagrad is refused."""
+        if self._sort_checked:
+            return
+        self._sort_checked = True
+        model, optimizer = self.model, self.optimizer
+        adagrad = any(type(optimizer).__name__ == n for n in ("RWSAdagrad", "FusedRWSAdagrad"))
+        if not adagrad and getattr(model, "emb_update_mode", None) != ops.UPD_SORTED:
+            return
+        safe = False
+        try:
+            safe = ops.sort_is_graph_safe([e.weight for e in model.emb_l], ops.BagBatch(lS_o, lS_i, None))
+        except Exception:                                    # noqa: BLE001 - models without plain emb_l tables: be conservative
+            safe = False
+        if _os.environ.get("DLRM_GRAPH_SORTED", "1") == "0":
+            safe = False
+        if safe:
+            return
+        if adagrad:
+            raise RuntimeError("dlrm_amd.graph: this batch needs the general (rocPRIM) sorter for the fused row-wise Adagrad update "
+                               "(a table segment of more than 262144 lookups), which cannot be replayed from a HIP graph on this ROCm "
+                               "(tools/probes/graph_sorted_probe.py); use the eager step")
+        model.emb_update_mode = ops.UPD_ATOMIC               # LDS pre-reduction for tiny tables + hardware fp32 atomics
 
     # one eager training step on the static buffers (the reference loop body)
     def _eager(self):
@@ -176,6 +197,7 @@ class GraphedTrainStep:
             torch.cuda.current_stream(X.device).synchronize()
             self._replayed = False
         if self.static is None:
+            self._settle_sort_mode(lS_o, lS_i)
             self.static = (X.clone(), _clone_struct(lS_o), _clone_struct(lS_i), T.clone())
         else:
             xs, os_, is_, ts = self.static

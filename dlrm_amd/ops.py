@@ -336,6 +336,35 @@ def _emb_workspace(need: int, device) -> torch.Tensor:
     return ws
 
 
+def sort_is_graph_safe(weights: Sequence[torch.Tensor], bags: BagBatch) -> bool:
+    """True when the sort-based embedding updates of these shapes run entirely on the library's own segmented sorter
+    (csrc/seg_sort.h: plain kernels, replayable inside a HIP graph); False when a table segment needs the general sorter."""
+    _, _, rows = _weights_desc(weights)
+    return _lib.load().dlrm_emb_sort_kind(bags.T, bags._nnz, rows) == 1
+
+
+def sort_lookups(rows: Sequence[int], bags: BagBatch):
+    """The (table, row) sort of the sort-based updates on its own (dlrm_emb_sort_lookups; bags.T <= 32): returns
+    (positions uint32-as-int64 [L], keys int64 [L] = table << row_bits | row, bag_of int64 [L] (-1: skipped lookup), row_bits)."""
+    lib = _lib.load()
+    dev = bags.keep[0].device
+    rows_a = _lib.i64_array([int(r) for r in rows])
+    need = lib.dlrm_emb_bwd_workspace_bytes(bags.T, bags._nnz, rows_a)
+    if need < 0:
+        raise RuntimeError("dlrm_amd: dlrm_emb_bwd_workspace_bytes failed")
+    ws = _emb_workspace(need, dev)
+    L = int(sum(bags.nnz))
+    pos = torch.empty(L, dtype=torch.int32, device=dev)
+    keys = torch.empty(L, dtype=torch.int64, device=dev)
+    bag_of = torch.empty(L, dtype=torch.int32, device=dev)
+    rb = C.c_int(0)
+    rc = lib.dlrm_emb_sort_lookups(bags.T, bags.B, rows_a, bags._idx, bags._off, bags._nnz, bags.idx_bits, C.c_void_p(ws.data_ptr()),
+                                   ws.numel(), C.c_void_p(pos.data_ptr()), C.c_void_p(keys.data_ptr()), C.c_void_p(bag_of.data_ptr()),
+                                   C.byref(rb), C.c_void_p(_err_block(dev).data_ptr()), _stream(pos))
+    _lib.check(rc, "dlrm_emb_sort_lookups")
+    return pos.long() & 0xFFFFFFFF, keys, bag_of.long(), rb.value
+
+
 def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Tensor, lr: float,
                 mode: int = UPD_SORTED) -> None:
     """Fused EmbeddingBag backward + sparse SGD: W_t[idx] -= lr * dout[bag, t*D:(t+1)*D] (in place)."""
@@ -821,6 +850,19 @@ def copy_blocks(srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor]) -> N
                               _lib.ptr_array([b_.data_ptr() for b_ in dsts]), _lib.i64_array([_ld(b_) for b_ in dsts]),
                               widths, _stream())
     _lib.check(rc, "dlrm_copy_blocks")
+
+
+def copy_id_blocks(srcs: Sequence[torch.Tensor], dsts: Sequence[torch.Tensor]) -> None:
+    """copy_blocks for integer id tensors (int32 / int64, 2-D [M, w_k] views whose rows are contiguous): the id re-layouts of the
+    sharded input distribution (ext_dist.kjt_input_dist: destination-major send buffer, source-major -> global-batch-order unpack)
+    as ONE strided block-copy launch instead of torch.cat / reshape copies.  Ids travel as 32-bit words."""
+    def words(t):
+        if t.dtype not in (torch.int32, torch.int64) or t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
+            raise RuntimeError("dlrm_amd: copy_id_blocks needs 2-D int32 / int64 tensors with contiguous rows")
+        return (t.view(torch.int32) if t.dtype == torch.int64 else t).view(torch.float32)
+    pairs = [(words(a_), words(b_)) for a_, b_ in zip(srcs, dsts) if a_.numel()]
+    if pairs:
+        copy_blocks([a_ for a_, _ in pairs], [b_ for _, b_ in pairs])
 
 
 def bce_elementwise(p: torch.Tensor, target: torch.Tensor) -> torch.Tensor:

@@ -87,6 +87,18 @@ int dlrm_emb_fwd(int T, int64_t B, int D,
  *        dlrm_emb_bwd_workspace_bytes(...) bytes (may be NULL for the other modes).
  */
 int64_t dlrm_emb_bwd_workspace_bytes(int T, const int64_t* nnz_host, const int64_t* rows_host);
+/* Which sorter the sort-based updates (DLRM_UPD_SORTED, dlrm_emb_bwd_rowwise_adagrad) will use for these table shapes:
+ *   1 = the segmented per-table radix sort of csrc/seg_sort.h for every launch group: plain kernels only, replayable inside a HIP graph;
+ *   0 = at least one group (a table segment of more than 262144 lookups, or >= 2^39 rows) goes to the general sorter (rocPRIM),
+ *       which must not be captured into a HIP graph on ROCm 7.2 (tools/probes/graph_sorted_probe.py). */
+int     dlrm_emb_sort_kind(int T, const int64_t* nnz_host, const int64_t* rows_host);
+/* The sort itself (one launch group, T <= 32): positions_out[j] = global lookup position (table-major) of the j-th entry in
+ * (table, row) order, equal rows in input order; keys_out[j] = table << *row_bits_out | row; bag_out[p] (nullable) = bag of position p
+ * (0xFFFFFFFF: skipped out-of-range lookup).  workspace as dlrm_emb_bwd_workspace_bytes.  For tests and tools. */
+int     dlrm_emb_sort_lookups(int T, int64_t B, const int64_t* rows_host, const void* const* indices_host,
+                              const void* const* offsets_host, const int64_t* nnz_host, int idx_bits, void* workspace,
+                              int64_t workspace_bytes, uint32_t* positions_out, uint64_t* keys_out, uint32_t* bag_out,
+                              int* row_bits_out, int64_t* err, void* stream);
 int dlrm_emb_bwd_sgd(int T, int64_t B, int D,
                      void* const* weight_host, const int64_t* rows_host,
                      const void* const* indices_host, const void* const* offsets_host,

@@ -230,6 +230,71 @@ def test_kjt_input_dist_and_row_wise_collectives(size):
         assert np.array_equal(results[r]["gx"], np.repeat(((g // Bl + 1) * g).reshape(-1, 1), 3, axis=1))
 
 
+def _kjt_mlperf_worker(rank, size, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank))
+    from dlrm_amd import ext_dist
+    from dlrm_amd import sharding as S
+    ext_dist.init_distributed(rank=rank, local_rank=rank, size=size, use_gpu=False, backend="gloo")
+    plan = S.plan(MLPERF_ROWS, MLPERF_HOT, 128, size, 65536)            # the plan bench.py --gpus N --workload mlperf_v2_multihot builds
+    owner = [-1] * 26
+    for sh in plan.shards:
+        if sh.kind == "table":
+            owner[sh.table] = sh.rank
+    rw_tables = plan.row_wise()
+    Bl = 3
+    # id of (table t, global sample g, slot j): unique, so any mis-routed element is visible
+    vals = []
+    for t, h in enumerate(MLPERF_HOT):
+        for b in range(Bl):
+            g = rank * Bl + b
+            vals += [1000000 * t + 1000 * g + j for j in range(h)]
+    tw, rw = ext_dist.kjt_input_dist(torch.tensor(vals, dtype=torch.int64), MLPERF_HOT, owner, rw_tables)
+    # row-wise pooling: rank r owns rows [lo, hi) of table 20; its partial sum of a [B, 2] block = the ids of ITS range, summed per sample
+    lo, hi = [s_ for s_ in plan.shards if s_.table == rw_tables[0]][0].row_ranges[rank]
+    ids = rw[rw_tables[0]].view(Bl * size, -1) % MLPERF_ROWS[rw_tables[0]]
+    part = torch.where((ids >= lo) & (ids < hi), ids, torch.zeros_like(ids)).sum(1, keepdim=True).double().repeat(1, 2)
+    y = ext_dist.reduce_scatter_rows(part)
+    q.put((rank, {"tw": {t: v.numpy().copy() for t, v in tw.items()}, "rw": {t: v.numpy().copy() for t, v in rw.items()},
+                  "y": y.numpy().copy(), "owner": owner, "rw_tables": rw_tables}))
+    ext_dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_kjt_input_dist_at_the_mlperf_v2_plan_on_eight_ranks():
+    """the input distribution and the row-wise reduce-scatter at the plan the 8-GPU benchmark uses — 26 MLPerf-v2
+    tables, multi-hot sizes 3,2,1,...,100,27,... (214 ids per sample), tables 20 and 21 row-wise over all 8 ranks, the other 24
+    table-wise longest-first — on 8 gloo ranks: every table-wise owner receives the whole batch's ids of its tables in global
+    order, every rank receives the row-wise tables' ids, and the per-range partial sums of a row-wise table add up to the full sum."""
+    size = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_kjt_mlperf_worker, args=(r, size, port, q)) for r in range(size)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(size))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    Bl = 3
+    B = Bl * size
+    owner, rw_tables = results[0]["owner"], results[0]["rw_tables"]
+    assert rw_tables == [20, 21] and all(o >= 0 for t, o in enumerate(owner) if t not in rw_tables)
+    want = lambda t: np.asarray([1000000 * t + 1000 * g + j for g in range(B) for j in range(MLPERF_HOT[t])], dtype=np.int64)
+    seen = set()
+    for r in range(size):
+        assert sorted(results[r]["tw"]) == [t for t in range(26) if owner[t] == r]
+        for t, v in results[r]["tw"].items():
+            assert np.array_equal(v, want(t)), (r, t)
+            seen.add(t)
+        assert sorted(results[r]["rw"]) == rw_tables
+        for t in rw_tables:
+            assert np.array_equal(results[r]["rw"][t], want(t)), (r, t)
+        full = (want(20).reshape(B, -1) % MLPERF_ROWS[20]).sum(1)[r * Bl:(r + 1) * Bl].astype(np.float64)
+        assert np.array_equal(results[r]["y"], np.repeat(full.reshape(-1, 1), 2, axis=1)), r
+    assert len(seen) == 24
+
+
 def _flat_ddp_worker(rank, size, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size), LOCAL_RANK=str(rank))
     from dlrm_amd import ext_dist

@@ -153,6 +153,53 @@ def test_emb_bwd_sgd_sorted_large_tables_bit_exact(D, idx_dtype):
         np.testing.assert_allclose(got, want[t], rtol=1e-5, atol=1e-5)
 
 
+CRITEO_TB_ROWS = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155,
+                  4, 976, 14, 39979771, 25641295, 39664984, 585935, 12972, 108, 36]
+
+
+@pytest.mark.parametrize("case", ["criteo_onehot", "ragged_hot_rows_int32", "wide_keys_three_rounds", "tiny_tables_many_tiles",
+                                  "long_segment_general_sorter", "single_lookup"])
+def test_lookup_sort_is_stable_and_exact(case):
+    """The (table, row) sort in front of the sort-based updates (csrc/seg_sort.h; dlrm_emb_sort_lookups) against numpy's stable
+    argsort of the same keys — positions, keys and the bag of every position, exactly: one-hot Criteo tables (1- and 2-round tables
+    mixed), ragged multi-hot bags with hot rows and an empty table (int32), 64-bit keys over three rounds, segments of many tiles
+    over 1- and 2-row tables (every cursor hit by every lane), and a segment too long for the segmented sorter (general sorter)."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(len(case))
+    idx_dtype = torch.int64
+    if case == "criteo_onehot":
+        rows, B = CRITEO_TB_ROWS, 5000
+        bags = [(np.arange(B, dtype=np.int64), rng.integers(0, n, size=B).astype(np.int64)) for n in rows]
+    elif case == "ragged_hot_rows_int32":
+        rows, B, idx_dtype = [3, 40, 9, 5000, 100003], 3000, torch.int32
+        bags = [ragged(rng, B, n, 6) for n in rows]
+        bags[2] = (np.zeros(B, dtype=np.int64), np.zeros(0, dtype=np.int64))
+        bags[4][1][::3] = 77                                           # a hot row in a big table
+    elif case == "wide_keys_three_rounds":
+        rows, B = [1 << 34, 5, 1 << 27], 2000
+        bags = [ragged(rng, B, n, 3, empty_frac=0.0) for n in rows]
+    elif case == "tiny_tables_many_tiles":
+        rows, B = [1, 2, 70000], 70000
+        bags = [(np.arange(B, dtype=np.int64), rng.integers(0, n, size=B).astype(np.int64)) for n in rows]
+    elif case == "long_segment_general_sorter":
+        rows, B = [1000, 50], 300000
+        bags = [(np.arange(B, dtype=np.int64), rng.integers(0, n, size=B).astype(np.int64)) for n in rows]
+    else:
+        rows, B = [7], 1
+        bags = [(np.zeros(1, dtype=np.int64), np.asarray([5], dtype=np.int64))]
+    bb = ops.BagBatch([to_dev(o, idx_dtype) for o, _ in bags], [to_dev(i, idx_dtype) for _, i in bags])
+    pos, keys, bag_of, rb = ops.sort_lookups(rows, bb)
+    torch.cuda.synchronize()
+    assert rb == max(1, int(np.ceil(np.log2(max(rows))))) or (1 << rb) >= max(rows)
+    want_keys = np.concatenate([(np.int64(t) << rb) | i for t, (_, i) in enumerate(bags)]) if sum(len(i) for _, i in bags) else np.zeros(0, np.int64)
+    order = np.argsort(want_keys, kind="stable")
+    assert np.array_equal(pos.cpu().numpy(), order), case
+    assert np.array_equal(keys.cpu().numpy(), want_keys[order]), case
+    want_bag = np.concatenate([np.searchsorted(o, np.arange(len(i)), side="right") - 1 for o, i in bags])
+    assert np.array_equal(bag_of.cpu().numpy(), want_bag), case
+    ops.check_index_errors(sync=True)
+
+
 # ------------------------------------------------------------------------------------------ interaction
 @pytest.mark.parametrize("F,D,itself", [(4, 16, False), (27, 128, False), (27, 16, False), (6, 12, True), (2, 2, False),
                                         (9, 64, False), (33, 32, False), (49, 8, True),
