@@ -108,6 +108,8 @@ def parse():
     ap.add_argument("--cpu-row-cap", type=int, default=4000000, help="row cap of the baseline legs' tables (SURVEY 8d: 4 M)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed iterations of the CPU baseline (median reported)")
     ap.add_argument("--cpu-warmup", type=int, default=3)
+    ap.add_argument("--cpu-budget", type=float, default=90.0, help="seconds of host time the CPU baseline leg may take (thread-count "
+                                                                     "probes + warm-up + as many of --cpu-steps as fit, at least 3)")
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
     ap.add_argument("--a2a-chunks", type=int, default=int(os.environ.get("DLRM_A2A_CHUNKS", "1")),
                     help="N > 1: schedule of the HEADLINE measurement. 1 (default) = the reference schedule: one all-to-all per "
@@ -201,7 +203,8 @@ def baseline_legs(state, args, device):
     import contextlib
     from oracle import ref_baseline
     with contextlib.redirect_stdout(sys.stderr):        # the reference prints at import ("Unable to import mlperf_logging"): stdout carries ONE JSON line
-        out = ref_baseline.run(state, args.lr, cpu_warmup=args.cpu_warmup, cpu_steps=args.cpu_steps, gpu_device=device)
+        out = ref_baseline.run(state, args.lr, cpu_warmup=args.cpu_warmup, cpu_steps=args.cpu_steps, gpu_device=device,
+                               cpu_budget_s=args.cpu_budget)
     if out is not None:
         cpu, stock = out
         return {"cpu_baseline": cpu, "stock_gpu_baseline": stock}
@@ -213,12 +216,14 @@ def baseline_legs(state, args, device):
     m = TorchPortDLRM(params, sigmoid_top=len(state["ln_top"]) - 2, loss="bce", lr=args.lr)
     X, off, idx, T = state["batch"]
     off, idx = list(off), list(idx)
-    times = []
+    times, t_begin = [], time.time()
     for it in range(args.cpu_warmup + args.cpu_steps):
         t0 = time.time()
         m.train_step(X, off, idx, T)
         if it >= args.cpu_warmup:
             times.append((time.time() - t0) * 1e3)
+        if len(times) >= 3 and time.time() - t_begin > args.cpu_budget:
+            break
     med = float(np.median(times))
     B = X.shape[0]
     torch.set_num_threads(default_threads)

@@ -85,12 +85,18 @@ def run_on_gpu(device, interaction: str = "dot", arith: str = "f32", check_param
         pre = "" if variant == "bench" else "cond."
         acc0 = 0.0 if variant == "bench" else float(meta["conditioned_initial_accumulator_value"])
         np.random.seed(meta["seed_init"])
-        if interaction == "dcn":
-            model = DLRM_DCN(rows, D, meta["bot"][0], meta["bot"][1:], meta["top"], dcn_num_layers=3, dcn_low_rank_dim=512)
-        else:
-            model = DLRM(rows, D, meta["bot"][0], meta["bot"][1:], meta["top"])
+        import dlrm_amd.dlrm_net as _net
+        saved_init = _net._EMB_INIT_DEVICE
+        _net.set_embedding_init(None)            # the fixture's tables are numpy draws (bench.py allocates its 104 GB of tables on the device)
+        try:
+            if interaction == "dcn":
+                model = DLRM_DCN(rows, D, meta["bot"][0], meta["bot"][1:], meta["top"], dcn_num_layers=3, dcn_low_rank_dim=512)
+            else:
+                model = DLRM(rows, D, meta["bot"][0], meta["bot"][1:], meta["top"])
+        finally:
+            _net.set_embedding_init(saved_init)
         for k, v in model.state_dict().items():
-            if _sha(v.numpy()) != dig[f"init.{k}"]:
+            if _sha(v.cpu().numpy()) != dig[f"init.{k}"]:
                 raise AssertionError(f"golden_v2: initial {k} differs from the fixture's")
         model = model.to(device)
         model.set_mlp_arith(arith)

@@ -375,6 +375,6 @@ def test_reference_baseline_leg_runs_the_compiled_reference_and_agrees_with_the_
     params = {f"emb_l.{k}.weight": t.clone() for k, t in enumerate(tables)}
     params.update({k: v.clone() for k, v in mlp.items()})
     port = TorchPortDLRM(params, sigmoid_top=len(ln_top) - 2, loss="bce", lr=0.5)
-    for _ in range(3):
+    for _ in range(cpu["iterations_run"]):
         loss, _ = port.train_step(X, list(off), list(idx), T)
     assert abs(loss - cpu["final_loss"]) <= 1e-6 * abs(loss), (loss, cpu["final_loss"])
