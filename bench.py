@@ -627,6 +627,19 @@ def main():
     else:
         result_extra = {}
 
+    mode_of = {"sorted": ops.UPD_SORTED, "atomic": ops.UPD_ATOMIC, "deterministic": ops.UPD_DETERMINISTIC}
+    lookup_sort = None
+    if args.emb_update == "sorted" or args.optimizer == "rwsadagrad":
+        try:
+            if sharded:
+                lookup_sort = "per shard (csrc/seg_sort.h where a shard's segments hold <= 262144 lookups)"
+            else:
+                own = ops.sort_is_graph_safe([e.weight for e in model.emb_l], ops.BagBatch(batches[0][1], batches[0][2]))
+                lookup_sort = ("segmented radix sort of csrc/seg_sort.h (the library's own kernels, HIP-graph replayable)" if own else
+                               "rocPRIM radix_sort_pairs (a table segment exceeds 262144 lookups, or DLRM_SORT=rocprim)")
+        except Exception as e:                            # noqa: BLE001 - a label, never allowed to break the line
+            lookup_sort = "unknown (%s)" % type(e).__name__
+
     def roof(n):
         k = kernels[n]
         t = pmc["kernels"].get(n) if pmc else None
@@ -666,7 +679,9 @@ def main():
                    "loss": "bce_with_logits" if hot else "bce", "parallelism": (("planned sharding x%d (dlrm_amd.sharding: row-wise tables %s, the rest table-wise longest-first) + data-parallel MLPs (dense gradients: %s), per-rank input slices"
                                     % (N, shard_plan.row_wise(), args.dense_sync)) if sharded else
                                    ("table-wise embeddings x%d + data-parallel MLPs (dense gradients: %s)" % (N, args.dense_sync))) if N > 1 else "single GPU",
-                   "embedding_update": args.emb_update if graphed is None else "atomic (the HIP-graph path: rocPRIM's sort cannot be replayed, dlrm_amd/graph.py)",
+                   "embedding_update": (args.emb_update if model.emb_update_mode == mode_of[args.emb_update] else
+                                        "atomic (the HIP-graph path fell back: a table segment needs the general sorter, which cannot be replayed; dlrm_amd/graph.py)"),
+                   "lookup_sort": lookup_sort,
                    "a2a_chunks": model_a2a_chunks,
                    "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "
                                              "(no pooled-embedding buffer)") if (args.fuse and N == 1 and not hot) else "two kernels (dlrm_emb_fwd, dlrm_interact_*)",

@@ -16,8 +16,9 @@
 // rounds join in the last ones; ping-pong buffers chosen so that every table ends in the OUT buffer).  One round = three launches
 // over all participating tables, no memsets, no atomics on global memory, nothing that a HIP graph cannot replay:
 //   seg_hist_kernel     one WAVE per tile of 4096 consecutive entries: digit histogram in LDS -> hist[table][tile][bin]
-//   seg_scan_kernel     one workgroup per table: exclusive prefix over tiles per bin (in place) + exclusive prefix over bins
-//   seg_scatter_kernel  one wave per tile, entries 64 at a time IN ORDER: lanes with equal digits find each other with ballots
+//   seg_colscan_kernel  one thread per (table, bin): exclusive prefix over the table's tiles (in place) + the bin's total
+//   seg_scatter_kernel  one wave per tile (its 4096 keys prefetched into registers); it turns the bins' totals into the bins' start
+//                       positions itself (prefix scan in LDS), then takes its entries 64 at a time IN ORDER: lanes with equal digits find each other with ballots
 //                       (match-any), the lowest lane of each group advances the digit's cursor in LDS, every entry goes to
 //                       cursor + its rank in the group: stable by construction (rank order inside a 64-entry step, step order
 //                       inside a tile, tile order through the prefix)
@@ -36,6 +37,7 @@ struct SegRound {
     int ntab;                                                // participating tables of this round
     int tab[DLRM_MAX_TABLES_PER_LAUNCH];                     // their slot in the launch group
     unsigned tile_start[DLRM_MAX_TABLES_PER_LAUNCH + 1];     // prefix of their tile counts
+    unsigned scan_start[DLRM_MAX_TABLES_PER_LAUNCH + 1];     // prefix of their 256-bin blocks (grid of seg_colscan_kernel)
     unsigned char dbits[DLRM_MAX_TABLES_PER_LAUNCH];         // digit width of this round
     unsigned char shift[DLRM_MAX_TABLES_PER_LAUNCH];         // digit position
     unsigned char first[DLRM_MAX_TABLES_PER_LAUNCH];         // the table's first round: source = IN, value = the position itself
@@ -72,7 +74,7 @@ static bool seg_plan(int n, const long long* nnz, const long long* rows, SegPlan
     for (int k = 0; k < n; ++k) { base[k] = acc; acc += nnz[k]; }
     for (int r = 0; r < R; ++r) {
         SegRound& q = p->round[r];
-        q.ntab = 0; q.tile_start[0] = 0;
+        q.ntab = 0; q.tile_start[0] = 0; q.scan_start[0] = 0;
         size_t hw = 0, bw = 0;
         for (int k = 0; k < n; ++k) {
             const int pass = r - (R - passes[k]);             // this table's pass index in round r
@@ -85,6 +87,7 @@ static bool seg_plan(int n, const long long* nnz, const long long* rows, SegPlan
             const int i = q.ntab++;
             const unsigned tiles = (unsigned)((nnz[k] + SEG_TILE - 1) / SEG_TILE);
             q.tab[i] = k; q.tile_start[i + 1] = q.tile_start[i] + tiles;
+            q.scan_start[i + 1] = q.scan_start[i] + (((unsigned)1 << d) + 255) / 256;
             q.dbits[i] = (unsigned char)d; q.shift[i] = (unsigned char)shift;
             q.first[i] = (unsigned char)(pass == 0);
             q.dst_out[i] = (unsigned char)(((R - 1 - r) & 1) == 0);
@@ -93,7 +96,7 @@ static bool seg_plan(int n, const long long* nnz, const long long* rows, SegPlan
             hw += (size_t)tiles << d; bw += (size_t)1 << d;
         }
         for (int i = q.ntab; i < DLRM_MAX_TABLES_PER_LAUNCH; ++i) {
-            q.tab[i] = 0; q.tile_start[i + 1] = q.tile_start[q.ntab]; q.dbits[i] = 1; q.shift[i] = 0; q.first[i] = 0; q.dst_out[i] = 1;
+            q.tab[i] = 0; q.tile_start[i + 1] = q.tile_start[q.ntab]; q.scan_start[i + 1] = q.scan_start[q.ntab]; q.dbits[i] = 1; q.shift[i] = 0; q.first[i] = 0; q.dst_out[i] = 1;
             q.hist_off[i] = 0; q.bin_off[i] = 0; q.base[i] = 0; q.nnz[i] = 0;
         }
         if (hw > p->hist_words) p->hist_words = hw;
@@ -109,6 +112,11 @@ __device__ __forceinline__ int seg_find(const SegRound& q, unsigned w) {
     return i;
 }
 
+constexpr int SEG_CHUNKS = SEG_TILE / 64;     // 64-entry steps per tile: a lane keeps its SEG_CHUNKS keys of the tile in registers
+
+// All loads of a tile are issued up front (SEG_CHUNKS independent, coalesced loads per lane): a wave that fetched one 64-entry step
+// at a time paid a full memory round trip per step — 64 dependent round trips per tile, ~0.2 ms per pass on Criteo-Terabyte shapes
+// (profiles/round3: the first version of this sorter was slower than rocPRIM for exactly that reason).
 template <typename KT>
 __global__ __launch_bounds__(64) void seg_hist_kernel(SegRound q, const KT* __restrict__ in, const KT* __restrict__ tmp,
                                                       const KT* __restrict__ out, unsigned* __restrict__ hist) {
@@ -119,70 +127,58 @@ __global__ __launch_bounds__(64) void seg_hist_kernel(SegRound q, const KT* __re
     const int d = q.dbits[i], shift = q.shift[i];
     const unsigned bins = 1u << d, mask = bins - 1;
     const KT* __restrict__ src = q.first[i] ? in : (q.dst_out[i] ? tmp : out);
-    for (unsigned b = lane; b < bins; b += 64) h[b] = 0u;
     const long long s = q.base[i] + (long long)tile * SEG_TILE;
-    long long n = q.nnz[i] - (long long)tile * SEG_TILE; if (n > SEG_TILE) n = SEG_TILE;
-    // (one wave: LDS operations complete in order, no barrier needed between the fill, the adds and the read-out)
-    for (int c = lane; c < (int)n; c += 64) atomicAdd(&h[(unsigned)(src[s + c] >> shift) & mask], 1u);
+    long long nn = q.nnz[i] - (long long)tile * SEG_TILE; if (nn > SEG_TILE) nn = SEG_TILE;
+    const int n = (int)nn;
+    KT k[SEG_CHUNKS];
+    // (indices past the tile's end are clamped to its last entry, not predicated: 64 unconditional loads in straight-line code)
+#pragma unroll
+    for (int j = 0; j < SEG_CHUNKS; ++j) { const int e = j * 64 + lane; k[j] = src[s + (e < n ? e : n - 1)]; }
+    for (unsigned b = lane; b < bins; b += 64) h[b] = 0u;
+    // (one wave: its LDS operations complete in order, no barrier needed between the fill, the adds and the read-out)
+#pragma unroll
+    for (int j = 0; j < SEG_CHUNKS; ++j)
+        if (j * 64 + lane < n) atomicAdd(&h[(unsigned)(k[j] >> shift) & mask], 1u);
     unsigned* __restrict__ dst = hist + q.hist_off[i] + ((size_t)tile << d);
     for (unsigned b = lane; b < bins; b += 64) dst[b] = h[b];
 }
 
-// per table: hist[tile][bin] -> exclusive prefix over the tiles of every bin (in place), binbase[bin] = exclusive prefix of the bins'
-// totals.  An entry of digit b in tile t then goes to  binbase[b] + hist[t][b] + (its rank among the tile's entries of digit b).
-__global__ __launch_bounds__(1024) void seg_scan_kernel(SegRound q, unsigned* __restrict__ hist, unsigned* __restrict__ binbase) {
-    __shared__ unsigned tot[1 << SEG_MAX_DBITS];
-    __shared__ unsigned wsum[16];
-    const int i = blockIdx.x, tid = threadIdx.x;
+// one thread per (table, bin): hist[tile][bin] -> exclusive prefix over the table's tiles (in place), tot[bin] = the bin's total.
+// Neighbouring threads own neighbouring bins (coalesced), the tiles' counts are fetched 16 at a time (independent loads).
+__global__ __launch_bounds__(256) void seg_colscan_kernel(SegRound q, unsigned* __restrict__ hist, unsigned* __restrict__ tot) {
+    int i = 0;
+    while (i + 1 < q.ntab && blockIdx.x >= q.scan_start[i + 1]) ++i;
     const int d = q.dbits[i];
     const unsigned bins = 1u << d;
+    const unsigned b = (blockIdx.x - q.scan_start[i]) * 256 + threadIdx.x;
+    if (b >= bins) return;
     const unsigned tiles = q.tile_start[i + 1] - q.tile_start[i];
-    unsigned* __restrict__ h = hist + q.hist_off[i];
-    for (unsigned b = tid; b < bins; b += 1024) {
-        unsigned run = 0;
-        for (unsigned t = 0; t < tiles; ++t) {
-            const unsigned c = h[((size_t)t << d) + b];
-            h[((size_t)t << d) + b] = run;
-            run += c;
-        }
-        tot[b] = run;
-    }
-    __syncthreads();
-    // exclusive scan of tot[0..bins): every thread owns PER consecutive bins
-    const unsigned per = (bins + 1023) / 1024;                // 1 .. 8
-    unsigned loc[8], sum = 0;
+    unsigned* __restrict__ h = hist + q.hist_off[i] + b;
+    unsigned run = 0;
+    for (unsigned t0 = 0; t0 < tiles; t0 += 16) {
+        unsigned c[16];
 #pragma unroll
-    for (unsigned j = 0; j < 8; ++j) {
-        const unsigned b = tid * per + j;
-        loc[j] = (j < per && b < bins) ? tot[b] : 0u;
-        sum += loc[j];
-    }
-    unsigned inc = sum;                                        // inclusive scan over the wave
+        for (int u = 0; u < 16; ++u) c[u] = (t0 + u < tiles) ? h[(size_t)(t0 + u) << d] : 0u;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned v = __shfl_up(inc, o, 64);
-        if ((tid & 63) >= o) inc += v;
+        for (int u = 0; u < 16; ++u)
+            if (t0 + u < tiles) { h[(size_t)(t0 + u) << d] = run; run += c[u]; }
     }
-    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-    __syncthreads();
-    unsigned wbase = 0;
-    for (int w = 0; w < (tid >> 6); ++w) wbase += wsum[w];
-    unsigned run = wbase + inc - sum;
-    unsigned* __restrict__ bb = binbase + q.bin_off[i];
-#pragma unroll
-    for (unsigned j = 0; j < 8; ++j) {
-        const unsigned b = tid * per + j;
-        if (j < per && b < bins) { bb[b] = run; run += loc[j]; }
-    }
+    tot[q.bin_off[i] + b] = run;
 }
+
+// cursor array in LDS, padded so that lane l's run of `per` consecutive bins (the bin-prefix scan below) starts in bank l: element e
+// lives at e + (e >> lp), per = 2^lp bins per lane
+__host__ __device__ __forceinline__ unsigned seg_slot(unsigned e, int lp) { return e + (e >> lp); }
 
 template <typename KT>
 __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* __restrict__ kin, const KT* __restrict__ ktmp_r,
                                                          const KT* __restrict__ kout_r, KT* __restrict__ ktmp, KT* __restrict__ kout,
                                                          const unsigned* __restrict__ vtmp_r, const unsigned* __restrict__ vout_r,
                                                          unsigned* __restrict__ vtmp, unsigned* __restrict__ vout,
-                                                         const unsigned* __restrict__ hist, const unsigned* __restrict__ binbase) {
-    __shared__ volatile unsigned cur[1 << SEG_MAX_DBITS];     // (volatile: lanes hand cursors to each other through it, in program order)
+                                                         const unsigned* __restrict__ hist, const unsigned* __restrict__ tot) {
+    // lanes hand cursors to each other through this array.  One wave: its LDS instructions execute in program order; the
+    // __builtin_amdgcn_wave_barrier() calls below keep the COMPILER from moving LDS accesses across the hand-over points
+    __shared__ unsigned cur[(1 << SEG_MAX_DBITS) + 64 + 64];
     const int lane = threadIdx.x;
     const int i = seg_find(q, blockIdx.x);
     const unsigned tile = blockIdx.x - q.tile_start[i];
@@ -193,18 +189,57 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
     const unsigned* __restrict__ vsrc = to_out ? vtmp_r : vout_r;       // (not read in a table's first round: the value IS the position)
     KT* __restrict__ kdst = to_out ? kout : ktmp;
     unsigned* __restrict__ vdst = to_out ? vout : vtmp;
-    const unsigned* __restrict__ h = hist + q.hist_off[i] + ((size_t)tile << d);
-    const unsigned* __restrict__ bb = binbase + q.bin_off[i];
-    for (unsigned b = lane; b < bins; b += 64) cur[b] = bb[b] + h[b];
     const long long seg = q.base[i];
     const long long s = seg + (long long)tile * SEG_TILE;
-    long long n = q.nnz[i] - (long long)tile * SEG_TILE; if (n > SEG_TILE) n = SEG_TILE;
+    long long nn = q.nnz[i] - (long long)tile * SEG_TILE; if (nn > SEG_TILE) nn = SEG_TILE;
+    const int n = (int)nn;
+    // ---- the whole tile into registers: SEG_CHUNKS independent loads per lane (and as many for the values after the first round)
+    KT k[SEG_CHUNKS];
+    unsigned v[SEG_CHUNKS];
+    // (indices past the tile's end are clamped to its last entry, not predicated: unconditional loads in straight-line code)
+#pragma unroll
+    for (int j = 0; j < SEG_CHUNKS; ++j) { const int e = j * 64 + lane; k[j] = ksrc[s + (e < n ? e : n - 1)]; }
+    if (first) {
+#pragma unroll
+        for (int j = 0; j < SEG_CHUNKS; ++j) v[j] = (unsigned)(s + j * 64 + lane);
+    } else {
+#pragma unroll
+        for (int j = 0; j < SEG_CHUNKS; ++j) { const int e = j * 64 + lane; v[j] = vsrc[s + (e < n ? e : n - 1)]; }
+    }
+    // ---- cursors: exclusive prefix of the bins' totals over the bins (this wave scans them itself, in LDS) + this tile's offset
+    const int lp = d > 6 ? d - 6 : 0;                  // per = 2^lp bins per lane (1 when bins <= 64)
+    const unsigned per = 1u << lp;
+    const unsigned* __restrict__ tt = tot + q.bin_off[i];
+    for (unsigned b = lane; b < bins; b += 64) cur[seg_slot(b, lp)] = tt[b];
+    __builtin_amdgcn_wave_barrier();
+    unsigned sum = 0;
+    const unsigned b0 = (unsigned)lane * per;
+    if (b0 < bins)
+        for (unsigned e = 0; e < per; ++e) sum += cur[seg_slot(b0 + e, lp)];
+    unsigned inc = sum;                                 // inclusive scan of the lanes' sums
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+    unsigned run = inc - sum;
+    if (b0 < bins)
+        for (unsigned e = 0; e < per; ++e) {
+            const unsigned t_ = cur[seg_slot(b0 + e, lp)];
+            cur[seg_slot(b0 + e, lp)] = run;
+            run += t_;
+        }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned* __restrict__ h = hist + q.hist_off[i] + ((size_t)tile << d);
+    for (unsigned b = lane; b < bins; b += 64) cur[seg_slot(b, lp)] += h[b];
+    __builtin_amdgcn_wave_barrier();
+    // ---- 64 entries at a time, in order
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int c0 = 0; c0 < (int)n; c0 += 64) {
-        const bool valid = c0 + lane < (int)n;
-        const KT key = valid ? ksrc[s + c0 + lane] : (KT)0;
-        const unsigned val = valid ? (first ? (unsigned)(s + c0 + lane) : vsrc[s + c0 + lane]) : 0u;
-        const unsigned dg = (unsigned)(key >> shift) & mask;
+#pragma unroll
+    for (int j = 0; j < SEG_CHUNKS; ++j) {
+        if (j * 64 >= n) break;
+        const bool valid = j * 64 + lane < n;
+        const unsigned dg = (unsigned)(k[j] >> shift) & mask;
         // match-any: the set of valid lanes holding my digit
         unsigned long long same = __ballot(valid);
         for (int b = 0; b < d; ++b) {
@@ -216,14 +251,15 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
         const int leader = __ffsll((long long)same) - 1;                 // lowest lane of my group (valid lanes only use it)
         unsigned start = 0u;
         if (valid && rank == 0) {                                        // one lane per distinct digit: no two leaders share an address
-            start = cur[dg];
-            cur[dg] = start + (unsigned)__popcll(same);
+            start = cur[seg_slot(dg, lp)];
+            cur[seg_slot(dg, lp)] = start + (unsigned)__popcll(same);
         }
+        __builtin_amdgcn_wave_barrier();
         start = __shfl(start, leader < 0 ? 0 : leader, 64);
         if (valid) {
             const long long dst = seg + (long long)start + rank;
-            kdst[dst] = key;
-            vdst[dst] = val;
+            kdst[dst] = k[j];
+            vdst[dst] = v[j];
         }
     }
 }
@@ -239,7 +275,7 @@ static int seg_sort_run(const SegPlan& p, const KT* keys_in, KT* keys_tmp, KT* k
         if (q.ntab == 0 || tiles == 0) continue;
         hipLaunchKernelGGL((seg_hist_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out, hist);
         DLRM_LAUNCH_CHECK();
-        hipLaunchKernelGGL(seg_scan_kernel, dim3((unsigned)q.ntab), dim3(1024), 0, st, q, hist, binbase);
+        hipLaunchKernelGGL(seg_colscan_kernel, dim3(q.scan_start[q.ntab]), dim3(256), 0, st, q, hist, binbase);
         DLRM_LAUNCH_CHECK();
         hipLaunchKernelGGL((seg_scatter_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out,
                            keys_tmp, keys_out, (const unsigned*)vals_tmp, (const unsigned*)vals_out, vals_tmp, vals_out,
