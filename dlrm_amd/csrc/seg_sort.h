@@ -175,7 +175,8 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
                                                          const KT* __restrict__ kout_r, KT* __restrict__ ktmp, KT* __restrict__ kout,
                                                          const unsigned* __restrict__ vtmp_r, const unsigned* __restrict__ vout_r,
                                                          unsigned* __restrict__ vtmp, unsigned* __restrict__ vout,
-                                                         const unsigned* __restrict__ hist, const unsigned* __restrict__ tot) {
+                                                         const unsigned* __restrict__ hist, const unsigned* __restrict__ tot, int dbg) {
+    // dbg (env DLRM_SEG_DEBUG, timing only — WRONG results): 1 no scattered stores, 2 no match-any ballots, 4 no LDS cursor hand-over
     // lanes hand cursors to each other through this array.  One wave: its LDS instructions execute in program order; the
     // __builtin_amdgcn_wave_barrier() calls below keep the COMPILER from moving LDS accesses across the hand-over points
     __shared__ unsigned cur[(1 << SEG_MAX_DBITS) + 64 + 64];
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
         const unsigned dg = (unsigned)(k[j] >> shift) & mask;
         // match-any: the set of valid lanes holding my digit
         unsigned long long same = __ballot(valid);
+        if (!(dbg & 2))
         for (int b = 0; b < d; ++b) {
             const bool bit = (dg >> b) & 1u;
             const unsigned long long bal = __ballot(bit);
@@ -250,22 +252,29 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
         const int rank = __popcll(same & below);
         const int leader = __ffsll((long long)same) - 1;                 // lowest lane of my group (valid lanes only use it)
         unsigned start = 0u;
-        if (valid && rank == 0) {                                        // one lane per distinct digit: no two leaders share an address
+        if (valid && rank == 0 && !(dbg & 4)) {                          // one lane per distinct digit: no two leaders share an address
             start = cur[seg_slot(dg, lp)];
             cur[seg_slot(dg, lp)] = start + (unsigned)__popcll(same);
         }
         __builtin_amdgcn_wave_barrier();
         start = __shfl(start, leader < 0 ? 0 : leader, 64);
-        if (valid) {
+        if (valid && !(dbg & 1)) {
             const long long dst = seg + (long long)start + rank;
             kdst[dst] = k[j];
             vdst[dst] = v[j];
         }
+        if ((dbg & 1) && start + rank + k[j] + v[j] == 0x7fffffffu) kdst[0] = 0;   // keeps the values live
     }
 }
 
 // Sorts the n table segments of keys_in (positions are the values) into keys_out / vals_out, stable.  keys_tmp / vals_tmp /
 // hist / binbase are scratch.  Returns 0, or a HIP error code.
+static int seg_debug() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DLRM_SEG_DEBUG"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 template <typename KT>
 static int seg_sort_run(const SegPlan& p, const KT* keys_in, KT* keys_tmp, KT* keys_out, unsigned* vals_tmp, unsigned* vals_out,
                         unsigned* hist, unsigned* binbase, hipStream_t st) {
@@ -279,7 +288,7 @@ static int seg_sort_run(const SegPlan& p, const KT* keys_in, KT* keys_tmp, KT* k
         DLRM_LAUNCH_CHECK();
         hipLaunchKernelGGL((seg_scatter_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out,
                            keys_tmp, keys_out, (const unsigned*)vals_tmp, (const unsigned*)vals_out, vals_tmp, vals_out,
-                           (const unsigned*)hist, (const unsigned*)binbase);
+                           (const unsigned*)hist, (const unsigned*)binbase, seg_debug());
         DLRM_LAUNCH_CHECK();
     }
     return 0;
