@@ -140,6 +140,7 @@ __global__ __launch_bounds__(64) void seg_hist_kernel(SegRound q, const KT* __re
     for (int j = 0; j < SEG_CHUNKS; ++j)
         if (j * 64 + lane < n) atomicAdd(&h[(unsigned)(k[j] >> shift) & mask], 1u);
     unsigned* __restrict__ dst = hist + q.hist_off[i] + ((size_t)tile << d);
+#pragma unroll 8
     for (unsigned b = lane; b < bins; b += 64) dst[b] = h[b];
 }
 
@@ -170,40 +171,26 @@ __global__ __launch_bounds__(256) void seg_colscan_kernel(SegRound q, unsigned* 
 // lives at e + (e >> lp), per = 2^lp bins per lane
 __host__ __device__ __forceinline__ unsigned seg_slot(unsigned e, int lp) { return e + (e >> lp); }
 
-template <typename KT>
-__global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* __restrict__ kin, const KT* __restrict__ ktmp_r,
-                                                         const KT* __restrict__ kout_r, KT* __restrict__ ktmp, KT* __restrict__ kout,
-                                                         const unsigned* __restrict__ vtmp_r, const unsigned* __restrict__ vout_r,
-                                                         unsigned* __restrict__ vtmp, unsigned* __restrict__ vout,
-                                                         const unsigned* __restrict__ hist, const unsigned* __restrict__ tot, int dbg) {
-    // dbg (env DLRM_SEG_DEBUG, timing only — WRONG results): 1 no scattered stores, 2 no match-any ballots, 4 no LDS cursor hand-over
-    // lanes hand cursors to each other through this array.  One wave: its LDS instructions execute in program order; the
-    // __builtin_amdgcn_wave_barrier() calls below keep the COMPILER from moving LDS accesses across the hand-over points
-    __shared__ unsigned cur[(1 << SEG_MAX_DBITS) + 64 + 64];
+// one tile of one table: prefetch, cursors, ordered scatter.  FIRST = the table's first round (source IN, value = position: no value loads)
+template <typename KT, bool FIRST>
+__device__ __forceinline__ void seg_scatter_tile(const SegRound& q, int i, unsigned tile, const KT* __restrict__ ksrc,
+                                                 const unsigned* __restrict__ vsrc, KT* __restrict__ kdst, unsigned* __restrict__ vdst,
+                                                 const unsigned* __restrict__ hist, const unsigned* __restrict__ tot, int dbg,
+                                                 unsigned* cur, unsigned char* claim) {
     const int lane = threadIdx.x;
-    const int i = seg_find(q, blockIdx.x);
-    const unsigned tile = blockIdx.x - q.tile_start[i];
     const int d = q.dbits[i], shift = q.shift[i];
     const unsigned bins = 1u << d, mask = bins - 1;
-    const bool first = q.first[i] != 0, to_out = q.dst_out[i] != 0;
-    const KT* __restrict__ ksrc = first ? kin : (to_out ? ktmp_r : kout_r);
-    const unsigned* __restrict__ vsrc = to_out ? vtmp_r : vout_r;       // (not read in a table's first round: the value IS the position)
-    KT* __restrict__ kdst = to_out ? kout : ktmp;
-    unsigned* __restrict__ vdst = to_out ? vout : vtmp;
     const long long seg = q.base[i];
     const long long s = seg + (long long)tile * SEG_TILE;
     long long nn = q.nnz[i] - (long long)tile * SEG_TILE; if (nn > SEG_TILE) nn = SEG_TILE;
     const int n = (int)nn;
-    // ---- the whole tile into registers: SEG_CHUNKS independent loads per lane (and as many for the values after the first round)
+    // ---- the whole tile into registers: SEG_CHUNKS independent loads per lane (and as many for the values after the first round);
+    // indices past the tile's end are clamped to its last entry, not predicated: unconditional loads in straight-line code
     KT k[SEG_CHUNKS];
-    unsigned v[SEG_CHUNKS];
-    // (indices past the tile's end are clamped to its last entry, not predicated: unconditional loads in straight-line code)
+    unsigned v[FIRST ? 1 : SEG_CHUNKS];
 #pragma unroll
     for (int j = 0; j < SEG_CHUNKS; ++j) { const int e = j * 64 + lane; k[j] = ksrc[s + (e < n ? e : n - 1)]; }
-    if (first) {
-#pragma unroll
-        for (int j = 0; j < SEG_CHUNKS; ++j) v[j] = (unsigned)(s + j * 64 + lane);
-    } else {
+    if constexpr (!FIRST) {
 #pragma unroll
         for (int j = 0; j < SEG_CHUNKS; ++j) { const int e = j * 64 + lane; v[j] = vsrc[s + (e < n ? e : n - 1)]; }
     }
@@ -211,7 +198,15 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
     const int lp = d > 6 ? d - 6 : 0;                  // per = 2^lp bins per lane (1 when bins <= 64)
     const unsigned per = 1u << lp;
     const unsigned* __restrict__ tt = tot + q.bin_off[i];
-    for (unsigned b = lane; b < bins; b += 64) cur[seg_slot(b, lp)] = tt[b];
+    // (16 independent loads per lane before the first LDS store: a load-then-store loop pays one memory round trip per iteration,
+    // 128 of them for 8192 bins — that alone was ~25 us of this kernel's first version)
+    for (unsigned bb0 = 0; bb0 < bins; bb0 += 64 * 16) {
+        unsigned t_[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const unsigned b = bb0 + u * 64 + lane; t_[u] = tt[b < bins ? b : bins - 1]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const unsigned b = bb0 + u * 64 + lane; if (b < bins) cur[seg_slot(b, lp)] = t_[u]; }
+    }
     __builtin_amdgcn_wave_barrier();
     unsigned sum = 0;
     const unsigned b0 = (unsigned)lane * per;
@@ -232,7 +227,13 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
         }
     __builtin_amdgcn_wave_barrier();
     const unsigned* __restrict__ h = hist + q.hist_off[i] + ((size_t)tile << d);
-    for (unsigned b = lane; b < bins; b += 64) cur[seg_slot(b, lp)] += h[b];
+    for (unsigned bb0 = 0; bb0 < bins; bb0 += 64 * 16) {
+        unsigned t_[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const unsigned b = bb0 + u * 64 + lane; t_[u] = h[b < bins ? b : bins - 1]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const unsigned b = bb0 + u * 64 + lane; if (b < bins) cur[seg_slot(b, lp)] += t_[u]; }
+    }
     __builtin_amdgcn_wave_barrier();
     // ---- 64 entries at a time, in order
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -241,13 +242,21 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
         if (j * 64 >= n) break;
         const bool valid = j * 64 + lane < n;
         const unsigned dg = (unsigned)(k[j] >> shift) & mask;
-        // match-any: the set of valid lanes holding my digit
+        // match-any: the set of valid lanes holding my digit.  Bitwise over the d <= 13 digit bits it took 13 ballots per step (62 of
+        // the first version's 172 us per sort); instead every lane writes its number into the digit's CLAIM byte — lanes of one digit
+        // hit one address and exactly one write survives — reads it back, and the lanes are matched on that 6-bit winner number.
         unsigned long long same = __ballot(valid);
-        if (!(dbg & 2))
-        for (int b = 0; b < d; ++b) {
-            const bool bit = (dg >> b) & 1u;
-            const unsigned long long bal = __ballot(bit);
-            same &= bit ? bal : ~bal;
+        if (!(dbg & 2)) {
+            if (valid) claim[dg] = (unsigned char)lane;
+            __builtin_amdgcn_wave_barrier();
+            const unsigned w = valid ? (unsigned)claim[dg] : 64u;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const bool bit = (w >> b) & 1u;
+                const unsigned long long bal = __ballot(bit);
+                same &= bit ? bal : ~bal;
+            }
         }
         const int rank = __popcll(same & below);
         const int leader = __ffsll((long long)same) - 1;                 // lowest lane of my group (valid lanes only use it)
@@ -258,17 +267,38 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
         }
         __builtin_amdgcn_wave_barrier();
         start = __shfl(start, leader < 0 ? 0 : leader, 64);
+        const unsigned val = FIRST ? (unsigned)(s + j * 64 + lane) : v[FIRST ? 0 : j];
         if (valid && !(dbg & 1)) {
             const long long dst = seg + (long long)start + rank;
             kdst[dst] = k[j];
-            vdst[dst] = v[j];
+            vdst[dst] = val;
         }
-        if ((dbg & 1) && start + rank + k[j] + v[j] == 0x7fffffffu) kdst[0] = 0;   // keeps the values live
+        if ((dbg & 1) && start + rank + k[j] + val == 0x7fffffffu) kdst[0] = 0;   // keeps the values live
     }
 }
 
-// Sorts the n table segments of keys_in (positions are the values) into keys_out / vals_out, stable.  keys_tmp / vals_tmp /
-// hist / binbase are scratch.  Returns 0, or a HIP error code.
+template <typename KT>
+__global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* __restrict__ kin, const KT* __restrict__ ktmp_r,
+                                                         const KT* __restrict__ kout_r, KT* __restrict__ ktmp, KT* __restrict__ kout,
+                                                         const unsigned* __restrict__ vtmp_r, const unsigned* __restrict__ vout_r,
+                                                         unsigned* __restrict__ vtmp, unsigned* __restrict__ vout,
+                                                         const unsigned* __restrict__ hist, const unsigned* __restrict__ tot, int dbg) {
+    // dbg (env DLRM_SEG_DEBUG, timing only — WRONG results): 1 no scattered stores, 2 no match-any, 4 no LDS cursor hand-over.
+    // Lanes hand cursors to each other through `cur`.  One wave: its LDS instructions execute in program order; the
+    // __builtin_amdgcn_wave_barrier() calls keep the COMPILER from moving LDS accesses across the hand-over points.
+    __shared__ unsigned cur[(1 << SEG_MAX_DBITS) + 64 + 64];
+    __shared__ unsigned char claim[1 << SEG_MAX_DBITS];     // per digit: the lane that claimed it in the current step (match-any label)
+    const int i = seg_find(q, blockIdx.x);
+    const unsigned tile = blockIdx.x - q.tile_start[i];
+    const bool to_out = q.dst_out[i] != 0;
+    KT* __restrict__ kdst = to_out ? kout : ktmp;
+    unsigned* __restrict__ vdst = to_out ? vout : vtmp;
+    if (q.first[i])
+        seg_scatter_tile<KT, true>(q, i, tile, kin, nullptr, kdst, vdst, hist, tot, dbg, cur, claim);
+    else
+        seg_scatter_tile<KT, false>(q, i, tile, to_out ? ktmp_r : kout_r, to_out ? vtmp_r : vout_r, kdst, vdst, hist, tot, dbg, cur, claim);
+}
+
 static int seg_debug() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("DLRM_SEG_DEBUG"); v = e ? atoi(e) : 0; }
