@@ -17,8 +17,9 @@
 // over all participating tables, no memsets, no atomics on global memory, nothing that a HIP graph cannot replay:
 //   seg_hist_kernel     one WAVE per tile of 4096 consecutive entries: digit histogram in LDS -> hist[table][tile][bin]
 //   seg_colscan_kernel  one thread per (table, bin): exclusive prefix over the table's tiles (in place) + the bin's total
-//   seg_scatter_kernel  one wave per tile (its 4096 keys prefetched into registers); it turns the bins' totals into the bins' start
-//                       positions itself (prefix scan in LDS), then takes its entries 64 at a time IN ORDER: lanes with equal digits find each other with ballots
+//   seg_binscan_kernel  one workgroup per table: exclusive prefix of the bins' totals = first position of every digit
+//   seg_scatter_kernel  one wave per tile (its 4096 keys prefetched into registers, the start positions of ITS digits gathered), entries
+//                       taken 64 at a time IN ORDER: lanes with equal digits find each other through a claim byte per digit + 6 ballots
 //                       (match-any), the lowest lane of each group advances the digit's cursor in LDS, every entry goes to
 //                       cursor + its rank in the group: stable by construction (rank order inside a 64-entry step, step order
 //                       inside a tile, tile order through the prefix)
@@ -167,9 +168,36 @@ __global__ __launch_bounds__(256) void seg_colscan_kernel(SegRound q, unsigned* 
     tot[q.bin_off[i] + b] = run;
 }
 
-// cursor array in LDS, padded so that lane l's run of `per` consecutive bins (the bin-prefix scan below) starts in bank l: element e
-// lives at e + (e >> lp), per = 2^lp bins per lane
-__host__ __device__ __forceinline__ unsigned seg_slot(unsigned e, int lp) { return e + (e >> lp); }
+// per table: tot[bin] -> exclusive prefix over the bins (in place): the first position of every digit inside the table's segment
+__global__ __launch_bounds__(1024) void seg_binscan_kernel(SegRound q, unsigned* __restrict__ tot) {
+    __shared__ unsigned wsum[16];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const unsigned bins = 1u << q.dbits[i];
+    unsigned* __restrict__ t = tot + q.bin_off[i];
+    const unsigned per = (bins + 1023) / 1024;                // 1 .. 8 consecutive bins per thread
+    unsigned loc[8], sum = 0;
+#pragma unroll
+    for (unsigned j = 0; j < 8; ++j) {
+        const unsigned b = tid * per + j;
+        loc[j] = (j < per && b < bins) ? t[b] : 0u;
+        sum += loc[j];
+    }
+    unsigned inc = sum;                                        // inclusive scan over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += v;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    unsigned run = inc - sum;
+    for (int w = 0; w < (tid >> 6); ++w) run += wsum[w];
+#pragma unroll
+    for (unsigned j = 0; j < 8; ++j) {
+        const unsigned b = tid * per + j;
+        if (j < per && b < bins) { t[b] = run; run += loc[j]; }
+    }
+}
 
 // one tile of one table: prefetch, cursors, ordered scatter.  FIRST = the table's first round (source IN, value = position: no value loads)
 template <typename KT, bool FIRST>
@@ -194,46 +222,19 @@ __device__ __forceinline__ void seg_scatter_tile(const SegRound& q, int i, unsig
 #pragma unroll
         for (int j = 0; j < SEG_CHUNKS; ++j) { const int e = j * 64 + lane; v[j] = vsrc[s + (e < n ? e : n - 1)]; }
     }
-    // ---- cursors: exclusive prefix of the bins' totals over the bins (this wave scans them itself, in LDS) + this tile's offset
-    const int lp = d > 6 ? d - 6 : 0;                  // per = 2^lp bins per lane (1 when bins <= 64)
-    const unsigned per = 1u << lp;
+    // ---- where the tile's entries of digit g start:  first[g] (seg_binscan_kernel) + entries of g in the earlier tiles (seg_colscan_kernel),
+    // GATHERED for the digits this lane actually holds (SEG_CHUNKS independent 4-byte reads from each array) — a tile of 4096 entries
+    // touches at most 4096 of up to 8192 bins, and loading + prefix-scanning all of them per tile cost more than the scatter itself
+    // (35 of 49 us, profiles/round3).  LDS keeps only the running COUNT of every digit inside this tile.
     const unsigned* __restrict__ tt = tot + q.bin_off[i];
-    // (16 independent loads per lane before the first LDS store: a load-then-store loop pays one memory round trip per iteration,
-    // 128 of them for 8192 bins — that alone was ~25 us of this kernel's first version)
-    for (unsigned bb0 = 0; bb0 < bins; bb0 += 64 * 16) {
-        unsigned t_[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { const unsigned b = bb0 + u * 64 + lane; t_[u] = tt[b < bins ? b : bins - 1]; }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { const unsigned b = bb0 + u * 64 + lane; if (b < bins) cur[seg_slot(b, lp)] = t_[u]; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    unsigned sum = 0;
-    const unsigned b0 = (unsigned)lane * per;
-    if (b0 < bins)
-        for (unsigned e = 0; e < per; ++e) sum += cur[seg_slot(b0 + e, lp)];
-    unsigned inc = sum;                                 // inclusive scan of the lanes' sums
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned up = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += up;
-    }
-    unsigned run = inc - sum;
-    if (b0 < bins)
-        for (unsigned e = 0; e < per; ++e) {
-            const unsigned t_ = cur[seg_slot(b0 + e, lp)];
-            cur[seg_slot(b0 + e, lp)] = run;
-            run += t_;
-        }
-    __builtin_amdgcn_wave_barrier();
     const unsigned* __restrict__ h = hist + q.hist_off[i] + ((size_t)tile << d);
-    for (unsigned bb0 = 0; bb0 < bins; bb0 += 64 * 16) {
-        unsigned t_[16];
+    unsigned off[SEG_CHUNKS];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const unsigned b = bb0 + u * 64 + lane; t_[u] = h[b < bins ? b : bins - 1]; }
+    for (int j = 0; j < SEG_CHUNKS; ++j) { const unsigned dg = (unsigned)(k[j] >> shift) & mask; off[j] = tt[dg]; }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const unsigned b = bb0 + u * 64 + lane; if (b < bins) cur[seg_slot(b, lp)] += t_[u]; }
-    }
+    for (int j = 0; j < SEG_CHUNKS; ++j) { const unsigned dg = (unsigned)(k[j] >> shift) & mask; off[j] += h[dg]; }
+#pragma unroll 16
+    for (unsigned b = lane; b < bins; b += 64) cur[b] = 0u;
     __builtin_amdgcn_wave_barrier();
     // ---- 64 entries at a time, in order
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -262,11 +263,11 @@ __device__ __forceinline__ void seg_scatter_tile(const SegRound& q, int i, unsig
         const int leader = __ffsll((long long)same) - 1;                 // lowest lane of my group (valid lanes only use it)
         unsigned start = 0u;
         if (valid && rank == 0 && !(dbg & 4)) {                          // one lane per distinct digit: no two leaders share an address
-            start = cur[seg_slot(dg, lp)];
-            cur[seg_slot(dg, lp)] = start + (unsigned)__popcll(same);
+            start = cur[dg];
+            cur[dg] = start + (unsigned)__popcll(same);
         }
         __builtin_amdgcn_wave_barrier();
-        start = __shfl(start, leader < 0 ? 0 : leader, 64);
+        start = off[j] + __shfl(start, leader < 0 ? 0 : leader, 64);    // (off[j] is the same for every lane of the group)
         const unsigned val = FIRST ? (unsigned)(s + j * 64 + lane) : v[FIRST ? 0 : j];
         if (valid && !(dbg & 1)) {
             const long long dst = seg + (long long)start + rank;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
     // dbg (env DLRM_SEG_DEBUG, timing only — WRONG results): 1 no scattered stores, 2 no match-any, 4 no LDS cursor hand-over.
     // Lanes hand cursors to each other through `cur`.  One wave: its LDS instructions execute in program order; the
     // __builtin_amdgcn_wave_barrier() calls keep the COMPILER from moving LDS accesses across the hand-over points.
-    __shared__ unsigned cur[(1 << SEG_MAX_DBITS) + 64 + 64];
+    __shared__ unsigned cur[1 << SEG_MAX_DBITS];            // per digit: entries of it placed so far in this tile
     __shared__ unsigned char claim[1 << SEG_MAX_DBITS];     // per digit: the lane that claimed it in the current step (match-any label)
     const int i = seg_find(q, blockIdx.x);
     const unsigned tile = blockIdx.x - q.tile_start[i];
@@ -315,6 +316,8 @@ static int seg_sort_run(const SegPlan& p, const KT* keys_in, KT* keys_tmp, KT* k
         hipLaunchKernelGGL((seg_hist_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out, hist);
         DLRM_LAUNCH_CHECK();
         hipLaunchKernelGGL(seg_colscan_kernel, dim3(q.scan_start[q.ntab]), dim3(256), 0, st, q, hist, binbase);
+        DLRM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(seg_binscan_kernel, dim3((unsigned)q.ntab), dim3(1024), 0, st, q, binbase);
         DLRM_LAUNCH_CHECK();
         hipLaunchKernelGGL((seg_scatter_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out,
                            keys_tmp, keys_out, (const unsigned*)vals_tmp, (const unsigned*)vals_out, vals_tmp, vals_out,
