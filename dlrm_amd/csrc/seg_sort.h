@@ -15,10 +15,10 @@
 // Algorithm: least-significant-digit radix sort, per table segment, digits of up to 13 bits, 1-3 rounds (tables that need fewer
 // rounds join in the last ones; ping-pong buffers chosen so that every table ends in the OUT buffer).  One round = three launches
 // over all participating tables, no memsets, no atomics on global memory, nothing that a HIP graph cannot replay:
-//   seg_hist_kernel     one WAVE per tile of 4096 consecutive entries: digit histogram in LDS -> hist[table][tile][bin]
+//   seg_hist_kernel     one WAVE per tile of 2048 consecutive entries: digit histogram in LDS -> hist[table][tile][bin]
 //   seg_colscan_kernel  one thread per (table, bin): exclusive prefix over the table's tiles (in place) + the bin's total
 //   seg_binscan_kernel  one workgroup per table: exclusive prefix of the bins' totals = first position of every digit
-//   seg_scatter_kernel  one wave per tile (its 4096 keys prefetched into registers, the start positions of ITS digits gathered), entries
+//   seg_scatter_kernel  one wave per tile (its 2048 keys prefetched into registers, the start positions of ITS digits gathered), entries
 //                       taken 64 at a time IN ORDER: lanes with equal digits find each other through a claim byte per digit + 6 ballots
 //                       (match-any), the lowest lane of each group advances the digit's cursor in LDS, every entry goes to
 //                       cursor + its rank in the group: stable by construction (rank order inside a 64-entry step, step order
@@ -29,9 +29,9 @@
 
 namespace {
 
-constexpr int SEG_TILE = 4096;           // entries per wave-tile
+constexpr int SEG_TILE = 2048;           // entries per wave-tile (measured at Criteo-Terabyte shapes: 4096 -> 134 us per sort, 2048 -> 120 us)
 constexpr int SEG_MAX_DBITS = 13;        // 8192 bins: 32 KB of LDS per wave
-constexpr int SEG_MAX_TILES = 64;        // per table segment (262144 lookups)
+constexpr int SEG_MAX_TILES = 128;       // per table segment (262144 lookups)
 constexpr int SEG_MAX_ROUNDS = 3;        // rows < 2^39
 
 struct SegRound {
@@ -223,8 +223,8 @@ __device__ __forceinline__ void seg_scatter_tile(const SegRound& q, int i, unsig
         for (int j = 0; j < SEG_CHUNKS; ++j) { const int e = j * 64 + lane; v[j] = vsrc[s + (e < n ? e : n - 1)]; }
     }
     // ---- where the tile's entries of digit g start:  first[g] (seg_binscan_kernel) + entries of g in the earlier tiles (seg_colscan_kernel),
-    // GATHERED for the digits this lane actually holds (SEG_CHUNKS independent 4-byte reads from each array) — a tile of 4096 entries
-    // touches at most 4096 of up to 8192 bins, and loading + prefix-scanning all of them per tile cost more than the scatter itself
+    // GATHERED for the digits this lane actually holds (SEG_CHUNKS independent 4-byte reads from each array) — a tile of 2048 entries
+    // touches at most 2048 of up to 8192 bins, and loading + prefix-scanning all of them per tile cost more than the scatter itself
     // (35 of 49 us, profiles/round3).  LDS keeps only the running COUNT of every digit inside this tile.
     const unsigned* __restrict__ tt = tot + q.bin_off[i];
     const unsigned* __restrict__ h = hist + q.hist_off[i] + ((size_t)tile << d);
