@@ -59,6 +59,8 @@ struct GemmArgs {
     unsigned* bits_out;
     const unsigned* bits_in;
     long long bits_nblk;           // 64-column blocks per row band = ceil(N / 64)
+    // bf16-storage GEMMs (ARITH = 3): a second, bf16 copy of the result (what the next GEMM of the tower reads); C may then be null
+    unsigned short* Cb; long long ldcb;
 };
 
 template <bool KC>
@@ -416,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     constexpr int TN = 2;
     constexpr bool A_IL = FRAG && !A_KC, B_IL = FRAG && !B_KC;      // operand's sub-tiles interleaved (see above)
     static_assert(!FRAG || ARITH == 0, "vector fragments are implemented for the native fp32 main loop");
+    static_assert(ARITH != 3 || (A_KC && B_KC), "bf16-storage operands are k-contiguous (the data gradient reads a transposed weight copy)");
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
     constexpr int A_BYTES = BMt * BK3 * 4, B_BYTES = BNt * BK3 * 4, STAGE = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     // latency for the matrix cores (measured: 1083 us with the in-epilogue read vs 984 us without a mask on the
     // 1024x1024 layer).  The 8 row segments of the first 32-row band are requested while the last two k-tiles are
     // still being multiplied, band b+1 is requested before band b is transposed and stored.
-    constexpr bool MASKED = A_KC && !B_KC;
+    constexpr bool MASKED = (A_KC && !B_KC) || ARITH == 3;      // (bf16 storage: forward and data gradient share the <KC, KC> instance)
     const int c4 = (lane & 15) * 4;
     const long long nb = n0 + wn * 64 + c4;
     const bool full_n = nb + 3 < g.N;
@@ -616,6 +619,23 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
                 for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].w, fa[tm].w, acc[tm][tn], 0, 0, 0);
             if constexpr (!A_KC && !B_KC && !FRAG) __builtin_amdgcn_s_setprio(0);
         }
+        } else if constexpr (ARITH == 3) {
+            // bf16 STORAGE: the operands already are bf16 in memory.  A k-contiguous bf16 row tile is, byte for byte, the fp32 tile
+            // image with half as many "floats" per row — the same DMA plan, the same XOR swizzle, the same ds_read_b128 — and the
+            // 16 bytes a lane reads (fp32 k-quad 2j + h of its row) are exactly the 8 consecutive bf16 k-values
+            // 16j + 8h .. + 7 that v_mfma_f32_32x32x16_bf16 wants from it: one MFMA per (sub-tile pair, j), nothing converted in the loop.
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uintx4 fa[TM], fb[TN];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[t] = *(const uintx4*)(ldsb + cur + fa_off[j] + t * 32 * 64);
+#pragma unroll
+                for (int t = 0; t < TN; ++t) fb[t] = *(const uintx4*)(ldsb + cur + fb_off[j] + t * 32 * 64);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = MFMA_BF16(fb[tn], fa[tm], acc[tm][tn]);
+            }
         } else {
             // 32x32x16 bf16 operand: lane supplies row (lane & 31), k = 8*(lane>>5) + 0..7 -> the whole 16-k tile is one step
             Split3 sb[TN];
@@ -768,6 +788,15 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
                     if (!((wv >> (31 - (it * 4 + 3))) & 1u)) v.w = 0.f;
                 }
             }
+            if constexpr (ARITH == 3) {
+                // bf16 storage (host guarantees N % 4 == 0 and aligned outputs): the fp32 result for the consumers that need it (weight
+                // gradient, matrix-vector layer, interaction) and/or its bf16 rounding for the next GEMM of the tower
+                if (g.C) *(float4*)c = v;
+                if (g.Cb) {
+                    uint2 pk; pk.x = cvt_pk_bf16(v.x, v.y); pk.y = cvt_pk_bf16(v.z, v.w);
+                    *(uint2*)(g.Cb + m * g.ldcb + nb) = pk;
+                }
+            } else
             if (g.vecC && full_n) {
                 if constexpr (MASKED) {
                     if (g.mask && !use_bits) {
@@ -883,6 +912,35 @@ __global__ __launch_bounds__(256) void relu_bits_kernel(long long M, int N, cons
             v = (v << 1) | ((m < M && n < N && Y[m * ldy + n] > 0.f) ? 1u : 0u);
         }
         bits[w] = v;
+    }
+}
+
+// fp32 -> bf16 copies for the bf16-storage tower: dst[m, n] = bf16(src[m, n]) (round to nearest even), zero for N <= n < Npad
+__global__ __launch_bounds__(256) void cast_bf16_kernel(long long M, int N, int Npad, const float* __restrict__ src, long long lds_,
+                                                        unsigned short* __restrict__ dst, long long ldd) {
+    const int np2 = Npad / 2;
+    const long long total = M * np2;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long m = e / np2;
+        const int n = (int)(e - m * np2) * 2;
+        const float a = n < N ? src[m * lds_ + n] : 0.f, b = n + 1 < N ? src[m * lds_ + n + 1] : 0.f;
+        *(unsigned*)(dst + m * ldd + n) = cvt_pk_bf16(a, b);
+    }
+}
+// transposed copy (weights: dstT[c, r] = bf16(src[r, c]), zero for R <= r < Rpad): 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void cast_bf16_t_kernel(int R, int C, int Rpad, const float* __restrict__ src, long long lds_,
+                                                          unsigned short* __restrict__ dstT, long long ldd) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(long long)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < Rpad) dstT[(long long)c * ldd + r] = (unsigned short)(cvt_pk_bf16(tile[tx][i], 0.f) & 0xffffu);
     }
 }
 
@@ -1017,6 +1075,52 @@ extern "C" int dlrm_linear_fwd(int64_t M, int N, int K, const float* X, int64_t 
     const int rc = launch_gemm<true, true>(g, 1, (hipStream_t)stream, arith, &fast);
     if (rc == 0 && relu_bits && !fast) return relu_bits_from(M, N, Y, ldy, relu_bits, (hipStream_t)stream);
     return rc;
+}
+
+extern "C" int dlrm_cast_bf16(int64_t M, int N, int Npad, const float* src, int64_t lds_, uint16_t* dst, int64_t ldd, void* stream) {
+    if (M <= 0 || N <= 0 || Npad < N || (Npad & 1) || !src || !dst || lds_ < N || ldd < Npad || (ldd & 1) || (((uintptr_t)dst) & 3u)) return DLRM_E_ARG;
+    long long nb = (M * (Npad / 2) + 255) / 256; if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (long long)M, N, Npad, src, (long long)lds_,
+                       (unsigned short*)dst, (long long)ldd);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_cast_bf16_transposed(int R, int C, int Rpad, const float* src, int64_t lds_, uint16_t* dstT, int64_t ldd, void* stream) {
+    if (R <= 0 || C <= 0 || Rpad < R || !src || !dstT || lds_ < C || ldd < Rpad) return DLRM_E_ARG;
+    dim3 grid((unsigned)((C + 31) / 32), (unsigned)((Rpad + 31) / 32));
+    hipLaunchKernelGGL(cast_bf16_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, R, C, Rpad, src, (long long)lds_, (unsigned short*)dstT,
+                       (long long)ldd);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// C[M, N] (fp32, nullable) and / or Cb[M, N] (bf16, nullable) = epilogue(A[M, K] . B[N, K]^T), A and B bf16 in memory, fp32 accumulation:
+//   forward        A = X, B = W:    + bias, activation, optional ReLU sign bits OUT (relu_bits_out)
+//   data gradient  A = dY, B = W^T: result masked by the previous layer's ReLU sign bits (relu_bits_in)
+// Preconditions (DLRM_E_ALIGN otherwise — the caller falls back to the fp32-storage kernels): K % 32 == 0, N % 4 == 0, 16-byte aligned
+// operand rows (lda, ldb % 8 == 0), 16-byte aligned fp32 rows (ldc % 4 == 0), 8-byte aligned bf16 rows (ldcb % 4 == 0).
+extern "C" int dlrm_gemm_bf16(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
+                              int act, uint64_t* relu_bits_out, const uint64_t* relu_bits_in, float* C, int64_t ldc, uint16_t* Cb,
+                              int64_t ldcb, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !Cb)) return DLRM_E_ARG;
+    if (lda < K || ldb < K || (C && ldc < N) || (Cb && ldcb < N)) return DLRM_E_ARG;
+    if (act < DLRM_ACT_NONE || act > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
+    if (relu_bits_out && act != DLRM_ACT_RELU) return DLRM_E_MODE;
+    if (K % 32 || N % 4 || lda % 8 || ldb % 8 || !dlrm_aligned16(A) || !dlrm_aligned16(B) || (C && (!dlrm_aligned16(C) || ldc % 4)) ||
+        (Cb && ((((uintptr_t)Cb) & 7u) || ldcb % 4)))
+        return DLRM_E_ALIGN;
+    GemmArgs g = {};
+    g.M = M; g.N = N; g.K = K / 2;                    // in units of one fp32 word = two bf16 values
+    g.A = (const float*)A; g.lda = lda / 2; g.B = (const float*)B; g.ldb = ldb / 2;
+    g.C = C; g.ldc = ldc; g.Cb = (unsigned short*)Cb; g.ldcb = ldcb;
+    g.vecA = 1; g.vecB = 1; g.vecC = 1;
+    g.kchunk = g.K;
+    g.bias = bias; g.act = act;
+    g.bits_out = (unsigned*)relu_bits_out; g.bits_in = (const unsigned*)relu_bits_in; g.bits_nblk = ((long long)N + 63) / 64;
+    const long long wg256 = ((M + 255) / 256) * ((N + 127) / 128);
+    const bool big = M >= 256 && wg256 > 384 && wg256 <= 512;
+    return big ? launch_gemm3<true, true, 4, 3>(g, 1, (hipStream_t)stream) : launch_gemm3<true, true, 2, 3>(g, 1, (hipStream_t)stream);
 }
 
 extern "C" int64_t dlrm_relu_bits_bytes(int64_t M, int N) {

@@ -489,116 +489,6 @@ __global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, Gath
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// forward, D = 128, "register prefetch" variant (opt-in: DLRM_INTERACT_FWD=pf; the LDS-DMA kernel above stays the default).
-//
-// MEASURED (profiles/r03/ceilings.md, same box, alternating runs): 0.249 ms vs 0.239 ms for the DMA kernel — twice the
-// waves and twice the bytes in flight do NOT help, i.e. the DMA kernel is not latency-bound as its occupancy suggests:
-// it moves 1.03 GB (88 % reads) at 4.6 TB/s, which is what mixed read/write streams reach on this part (float4 copy
-// 4.7-4.9 TB/s, 7:1 read:write 3.7-3.9 TB/s, pure reads 6.3 TB/s: tools/probes/hbm_peak.hip).  Kept for reproducing that.
-//
-// What limited interact_fwd_dma_kernel (profiles/r03: 4.6 TB/s, PMC traffic == algorithmic bytes, so no wasted
-// traffic): two 16-KiB images per wave = 129 KiB of LDS per workgroup => ONE wave per SIMD with ONE sample (13.8 KB) in
-// flight behind the one being multiplied: 256 CUs x 4 waves x 13.8 KB = 14 MB in flight, which at ~3 us of loaded HBM
-// latency is exactly the 4.6 TB/s it ran at (Little's law), and nothing else on the SIMD hides the wait.
-// Here a wave keeps ONE LDS image and prefetches the next sample into registers (NI float4 per lane, loaded with the
-// same source-side swizzle the DMA used, so the image layout and the MFMA code are unchanged); 75 KiB of LDS per
-// workgroup => two workgroups per CU, two waves per SIMD: twice the bytes in flight and a second wave to issue MFMAs
-// while the first waits.  (Two samples ahead would need 2 x 56 + 42 address registers: it spills at 256 VGPRs.)  The R row is assembled in a wave-private LDS row and written as 16-byte segments (30 x 64 B
-// coalesced stores instead of 351 predicated 4-byte ones).
-// ---------------------------------------------------------------------------------------------
-constexpr int IFWD_ROW_BYTES = 2560;     // staged output row: up to 640 floats (F = 32 with self pairs: 128 + 528 -> 656 > 640 falls back)
-
-template <int NI>
-__device__ __forceinline__ void pf_load(floatx4 (&buf)[NI], const gfloatx4* (&src)[NI], const unsigned (&step)[NI], bool valid) {
-    if (!valid) return;                 // wave-uniform: no next sample
-#pragma unroll
-    for (int c = 0; c < NI; ++c) {      // lanes of the masked-off row (odd F) read feature 0 instead (valid memory, never stored)
-        buf[c] = *src[c];
-        src[c] = (const gfloatx4*)((const __attribute__((address_space(1))) char*)src[c] + step[c]);
-    }
-}
-
-template <int NI>       // NI = ceil(F / 2)
-__global__ __launch_bounds__(256, 2) void interact_fwd_pf_kernel(FeatArgs fa, long long B, int F, int self,
-                                                                 float* __restrict__ R, long long ldr) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    long long* tp = (long long*)lds;
-    long long* tl = tp + DLRM_MAX_FEATURES;
-    char* img = (char*)(tl + DLRM_MAX_FEATURES) + (size_t)wave * (IDMA_IMG + IFWD_ROW_BYTES);
-    float* orow = (float*)(img + IDMA_IMG);
-
-    table_to_lds(fa, tp, tl, F);
-    for (int e = lane; e < (IDMA_IMG + IFWD_ROW_BYTES) / 16; e += 64) ((float4*)img)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-
-    const long long b_stride = (long long)gridDim.x * 4;
-    long long b = (long long)blockIdx.x * 4 + wave;
-    if (b >= B) return;
-    // per-lane source of its 16 bytes in each of the sample's NI row-pair chunks (same plan as the DMA kernel)
-    const gfloatx4* src[NI];
-    unsigned step[NI];                 // bytes between this wave's consecutive samples (< 4 GiB: checked by the host)
-    const bool last_on = 2 * (NI - 1) + (lane >> 5) < F;     // only the last row pair can be half empty (odd F)
-#pragma unroll
-    for (int c = 0; c < NI; ++c) {
-        const int row = 2 * c + (lane >> 5);
-        const int quad = (lane & 31) ^ (row & 15);
-        const int rr = (c < NI - 1 || last_on) ? row : 0;
-        src[c] = (const gfloatx4*)((const gfloat*)tp[rr] + b * tl[rr] + 4 * quad);
-        step[c] = (unsigned)(b_stride * tl[rr] * 4);
-    }
-
-    const int g = lane >> 4, li = lane & 15;
-    const int P = (self & 1) ? F * (F + 1) / 2 : F * (F - 1) / 2;
-    const int NB = (F + 15) >> 4;
-    const int W4 = (int)(ldr >> 2);                          // float4 segments of one R row (ldr % 4 == 0 on this path)
-
-    floatx4 p0[NI];
-    pf_load<NI>(p0, src, step, true);
-    for (; b < B; b += b_stride) {
-        // ---- sample b: registers -> image (the previous sample's fragment reads are older LDS operations of this wave),
-        // then the NEXT sample's loads go out and stay in flight while this one is multiplied
-#pragma unroll
-        for (int c = 0; c < NI - 1; ++c) *(floatx4*)(img + c * 1024 + lane * 16) = p0[c];
-        if (last_on) *(floatx4*)(img + (NI - 1) * 1024 + lane * 16) = p0[NI - 1];
-        pf_load<NI>(p0, src, step, b + b_stride < B);
-        for (int r = 0; r < NB; ++r) {
-            for (int c = 0; c <= r; ++c) {
-                floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                const char* ap = img + (16 * r + li) * (IDMA_D * 4);
-                const char* bp = img + (16 * c + li) * (IDMA_D * 4);
-#pragma unroll
-                for (int s_ = 0; s_ < IDMA_D / 16; ++s_) {
-                    const int q = ((4 * s_ + g) ^ li) * 16;      // (row & 15) == li for both operands
-                    const float4 av = *(const float4*)(ap + q);
-                    const float4 bv = *(const float4*)(bp + q);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
-                }
-                const floatx4 acc = acc0 + acc1;
-                const int j = 16 * c + li;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = 16 * r + 4 * g + q;
-                    if (i < F && ((self & 1) ? (j <= i) : (j < i))) orow[pair_pos(i, j, F, self)] = acc[q];
-                }
-            }
-        }
-        // ---- R[b] = [x | pairs | zero padding] in 16-byte segments: x from image row 0 (row & 15 == 0: un-swizzled), the rest
-        // from the staged row (its tail beyond P stays zero from the initial clear)
-        float* Rb = R + b * ldr;
-        for (int e = lane; e < W4; e += 64) {
-            const float4 v = (e < IDMA_D / 4) ? *(const float4*)(img + e * 16) : *(const float4*)((const char*)orow + (e - IDMA_D / 4) * 16);
-            *(float4*)(Rb + 4 * e) = v;
-        }
-    }
-}
-
-
 // backward, D = 128: dT = (dZ + dZ^T) · T per sample, T by LDS-DMA (same images as the forward kernel), the
 // dR row by LDS-DMA too.  The symmetric S = dZ + dZ^T is never materialised: the 16x16x4 MFMA A fragment of a
 // lane is S[16r + li][4kk + g], whose source position inside the dR row depends only on the lane -> 4*NB*NB LDS
@@ -858,31 +748,6 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
             case 13: FWD_G(13); break; case 14: FWD_G(14); break; case 15: FWD_G(15); break; default: FWD_G(16); break;
         }
 #undef FWD_G
-        DLRM_LAUNCH_CHECK();
-        return 0;
-    }
-    static int fwd_variant = -1;      // env DLRM_INTERACT_FWD=pf: the register-prefetch kernel instead of the LDS-DMA one (0 = pf, 1 = dma)
-    if (fwd_variant < 0) { const char* e = getenv("DLRM_INTERACT_FWD"); fwd_variant = (e && !strcmp(e, "pf")) ? 0 : 1; }
-    int64_t max_ld = 0;
-    for (int f = 0; f < F; ++f) if (feat_ld_host[f] > max_ld) max_ld = feat_ld_host[f];
-    if (fwd_variant == 0 && interact_dma_ok(F, D, vec) && dlrm_aligned16(R) && ldr % 4 == 0 && (ldr - D) * 4 <= IFWD_ROW_BYTES &&
-        max_ld * 2048 * 4 < (1LL << 32)) {
-        const size_t lds = 2 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * (size_t)(IDMA_IMG + IFWD_ROW_BYTES);   // 75 KiB: two workgroups per CU
-        int64_t nb = (B + 3) / 4; if (nb > 512) nb = 512;
-        const int ni = (F + 1) / 2;
-#define FWD_PF(NIV)                                                                                          \
-        do {                                                                                                 \
-            (void)hipFuncSetAttribute((const void*)interact_fwd_pf_kernel<NIV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL(interact_fwd_pf_kernel<NIV>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, fa, \
-                               (long long)B, F, self_interaction & 3, R, (long long)ldr);                \
-        } while (0)
-        switch (ni) {
-            case 1: FWD_PF(1); break;   case 2: FWD_PF(2); break;   case 3: FWD_PF(3); break;   case 4: FWD_PF(4); break;
-            case 5: FWD_PF(5); break;   case 6: FWD_PF(6); break;   case 7: FWD_PF(7); break;   case 8: FWD_PF(8); break;
-            case 9: FWD_PF(9); break;   case 10: FWD_PF(10); break; case 11: FWD_PF(11); break; case 12: FWD_PF(12); break;
-            case 13: FWD_PF(13); break; case 14: FWD_PF(14); break; case 15: FWD_PF(15); break; default: FWD_PF(16); break;
-        }
-#undef FWD_PF
         DLRM_LAUNCH_CHECK();
         return 0;
     }

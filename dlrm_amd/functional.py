@@ -28,6 +28,9 @@ OVERLAP_WGRAD = os.environ.get("DLRM_OVERLAP_WGRAD", "0") == "1"
 # hidden ReLU layers store 1 sign bit per activation for the next layer's data-gradient epilogue (DLRM_RELU_BITS=0: the
 # epilogue re-reads the fp32 activation instead)
 RELU_BITS = os.environ.get("DLRM_RELU_BITS", "1") == "1"
+# arith "bf16": activations / weights are also kept as bf16 copies and the GEMMs read those (dlrm_gemm_bf16) instead of rounding fp32
+# operands inside the k-loop (DLRM_BF16_STORAGE=0: the in-loop rounding of rounds 1-2; results are bit-identical)
+BF16_STORAGE = os.environ.get("DLRM_BF16_STORAGE", "1") == "1"
 _side_streams = {}
 
 
@@ -75,6 +78,10 @@ def _grad_out(p: torch.Tensor) -> torch.Tensor:
         return torch.empty_like(p)
     ARENA_BUSY.add(key)
     return v
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
 
 
 def _round4(n: int) -> int:
@@ -136,6 +143,12 @@ class MLPFunction(Function):
             raise RuntimeError("dlrm_amd: MLP input width %d does not match the first layer (%d)" % (x.size(1), K0))
         cur = x
         need_bits = RELU_BITS and any(ctx.needs_input_grad)          # a forward that will be differentiated (Function.forward itself runs grad-free)
+        # arith "bf16" with bf16 STORAGE (default; DLRM_BF16_STORAGE=0 restores the in-loop rounding of rounds 1-2): every GEMM layer reads a
+        # bf16 copy of its input and of its weight (dlrm_gemm_bf16: no conversion in the k-loop) and writes its activation twice — fp32
+        # (what the weight gradient, the matrix-vector layer and the interaction read) and bf16 (what the next GEMM reads).  Same operand
+        # rounding and accumulation order as the in-loop path: results are bit-identical to it.
+        store16 = BF16_STORAGE and arith == ops.arith_code("bf16")
+        cur16 = None                                                  # bf16 copy of `cur`, [M, round32(width)], when a layer produced one
         outs, bits = [], []
         for i in range(L):
             W, b = params[2 * i], params[2 * i + 1]
@@ -149,7 +162,18 @@ class MLPFunction(Function):
             # hidden ReLU layers also store their sign bits (1 bit per element): the data-gradient GEMM of the NEXT layer reads
             # those instead of this fp32 activation for its fused ReLU derivative
             rb = ops.relu_bits_alloc(M, N, x.device) if (i < L - 1 and acts[i] == ACT_RELU and need_bits) else None
-            ops.linear_fwd(cur, W, b, acts[i], y, arith, relu_bits=rb)
+            if store16 and N % 4 == 0 and _ld(y) % 4 == 0 and y.data_ptr() % 16 == 0:
+                Kb = ops.round32(W.size(1))
+                a16 = cur16 if (cur16 is not None and cur16.size(1) == Kb) else ops.cast_bf16(cur, Kb, category="linear_fwd")
+                w16 = ops.cast_bf16(W, Kb, category="linear_fwd")
+                # the bf16 copy of this activation, if the NEXT layer is a GEMM that can take it as it is (width a multiple of 32)
+                nxt = i + 1 < L and params[2 * (i + 1)].size(0) % 4 == 0 and N % 32 == 0
+                y16 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if nxt else None
+                ops.gemm_bf16(a16, w16, b, acts[i], y, y16, relu_bits_out=rb, category="linear_fwd")
+                cur16 = y16
+            else:
+                ops.linear_fwd(cur, W, b, acts[i], y, arith, relu_bits=rb)
+                cur16 = None
             outs.append(y)
             bits.append(rb)
             cur = y
@@ -183,6 +207,8 @@ class MLPFunction(Function):
         main = torch.cuda.current_stream()
         side = _side_stream(x.device) if OVERLAP_WGRAD else None
         keep = []                                          # tensors the side stream reads stay alive until the join
+        store16 = BF16_STORAGE and arith == ops.arith_code("bf16")
+        dZ16 = None                                        # bf16 copy of dZ when the previous data-gradient GEMM produced one
         for i in range(L - 1, -1, -1):
             W = params[2 * i] if not (i == 0 and W0p is not None) else W0p
             X_i = x if i == 0 else outs[i - 1]
@@ -198,14 +224,32 @@ class MLPFunction(Function):
             else:
                 ops.linear_bwd_weight(dZ, X_i, dW, db, arith=arith)
             grads[2 * i], grads[2 * i + 1] = dW, db
-            if i > 0:
-                dprev = alloc2d(M, W.size(1), x)
+            need_dx = i > 0 or ctx.needs_input_grad[0]
+            if not need_dx:
+                continue
+            N_i, K_i = W.size(0), W.size(1)
+            mask_act = acts[i - 1] if i > 0 else ACT_NONE
+            rbits = ctx.bits[i - 1] if i > 0 else None
+            dprev = alloc2d(M, K_i, x)
+            ok16 = (store16 and N_i % 32 == 0 and K_i % 4 == 0 and _ld(dprev) % 4 == 0
+                    and (mask_act == ACT_NONE or (mask_act == ACT_RELU and rbits is not None)))
+            if ok16:
+                # bf16 storage: dX = dZ . W as a <k-contiguous, k-contiguous> GEMM over a transposed bf16 copy of W; the gradient is
+                # written in fp32 (the next weight gradient reads it) and in bf16 (the next data gradient reads it)
+                a16 = dZ16 if dZ16 is not None else ops.cast_bf16(dZ, N_i, category="linear_bwd_data")
+                wT16 = ops.cast_bf16_transposed(W, N_i, category="linear_bwd_data")
+                want16 = i > 0 and K_i % 32 == 0 and (i - 1 > 0 or ctx.needs_input_grad[0])
+                d16 = torch.empty((M, K_i), dtype=torch.bfloat16, device=x.device) if want16 else None
+                ops.gemm_bf16(a16, wT16, None, ACT_NONE, dprev, d16, relu_bits_in=rbits, category="linear_bwd_data")
+                dZ16 = d16
+            else:
                 # dgrad GEMM with the previous layer's activation derivative fused into the epilogue
-                ops.linear_bwd_data(dZ, W, X_i, acts[i - 1], dprev, arith, relu_bits=ctx.bits[i - 1])
+                ops.linear_bwd_data(dZ, W, X_i if i > 0 else None, mask_act, dprev, arith, relu_bits=rbits)
+                dZ16 = None
+            if i > 0:
                 dZ = dprev
-            elif ctx.needs_input_grad[0]:
-                dX = alloc2d(M, W.size(1), x)
-                ops.linear_bwd_data(dZ, W, None, ACT_NONE, dX, arith)
+            else:
+                dX = dprev
                 if dX.size(1) != ctx.in_width:
                     dX = dX[:, :ctx.in_width]
         if side is not None:

@@ -606,6 +606,64 @@ def linear_bwd_data(dY: torch.Tensor, W: torch.Tensor, Xact: Optional[torch.Tens
     return dX
 
 
+# ---- bf16-storage tower (dlrm_cast_bf16 / dlrm_gemm_bf16, include/dlrm_hip.h) -------------------------------------------------
+def round32(n: int) -> int:
+    return (n + 31) & ~31
+
+
+def cast_bf16(src: torch.Tensor, Npad: Optional[int] = None, category: str = "cast_bf16") -> torch.Tensor:
+    """[M, N] fp32 -> contiguous [M, Npad] bf16 (round to nearest even; zero columns N..Npad-1)"""
+    lib = _lib.load()
+    _req(src, "src", ndim=2)
+    M, N = src.shape
+    Npad = N + (N & 1) if Npad is None else int(Npad)
+    dst = torch.empty((M, Npad), dtype=torch.bfloat16, device=src.device)
+    with _timed(category):
+        rc = lib.dlrm_cast_bf16(M, N, Npad, C.c_void_p(src.data_ptr()), _ld(src), C.c_void_p(dst.data_ptr()), Npad, _stream(dst))
+    _lib.check(rc, "dlrm_cast_bf16")
+    return dst
+
+
+def cast_bf16_transposed(src: torch.Tensor, Rpad: Optional[int] = None, category: str = "cast_bf16") -> torch.Tensor:
+    """[R, C] fp32 -> contiguous [C, Rpad] bf16 = its transpose (zero columns R..Rpad-1): W^T for the data-gradient GEMM"""
+    lib = _lib.load()
+    _req(src, "src", ndim=2)
+    R, Cc = src.shape
+    Rpad = R if Rpad is None else int(Rpad)
+    dst = torch.empty((Cc, Rpad), dtype=torch.bfloat16, device=src.device)
+    with _timed(category):
+        rc = lib.dlrm_cast_bf16_transposed(R, Cc, Rpad, C.c_void_p(src.data_ptr()), _ld(src), C.c_void_p(dst.data_ptr()), Rpad, _stream(dst))
+    _lib.check(rc, "dlrm_cast_bf16_transposed")
+    return dst
+
+
+def gemm_bf16(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], act: int, Cf: Optional[torch.Tensor],
+              Cb: Optional[torch.Tensor], relu_bits_out: Optional[torch.Tensor] = None, relu_bits_in: Optional[torch.Tensor] = None,
+              category: str = "linear_fwd") -> None:
+    """Cf (fp32) and/or Cb (bf16) [M, N] = epilogue(A[M, K] @ B[N, K]^T) with bf16 operands in memory (dlrm_gemm_bf16)."""
+    lib = _lib.load()
+    for t, name in ((A, "A"), (B, "B")):
+        if t.dtype != torch.bfloat16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError(f"dlrm_amd: gemm_bf16 operand {name} must be a 2-D bf16 GPU tensor with contiguous rows")
+    M, K = A.shape
+    N = B.size(0)
+    if B.size(1) != K:
+        raise RuntimeError("dlrm_amd: gemm_bf16 reduction lengths differ")
+    if Cf is not None:
+        _req(Cf, "C", ndim=2)
+    if Cb is not None and (Cb.dtype != torch.bfloat16 or tuple(Cb.shape) != (M, N) or Cb.stride(1) != 1):
+        raise RuntimeError("dlrm_amd: gemm_bf16 bf16 output must be [M, N] bf16 with contiguous rows")
+    out = Cf if Cf is not None else Cb
+    with _timed(category):
+        rc = lib.dlrm_gemm_bf16(M, N, K, C.c_void_p(A.data_ptr()), A.stride(0), C.c_void_p(B.data_ptr()), B.stride(0),
+                                C.c_void_p(bias.data_ptr()) if bias is not None else None, int(act),
+                                C.c_void_p(relu_bits_out.data_ptr()) if relu_bits_out is not None else None,
+                                C.c_void_p(relu_bits_in.data_ptr()) if relu_bits_in is not None else None,
+                                C.c_void_p(Cf.data_ptr()) if Cf is not None else None, _ld(Cf) if Cf is not None else 0,
+                                C.c_void_p(Cb.data_ptr()) if Cb is not None else None, Cb.stride(0) if Cb is not None else 0, _stream(out))
+    _lib.check(rc, "dlrm_gemm_bf16")
+
+
 _wgrad_ws = {}   # (device, stream) -> cached split-K workspace (kernels of one stream are ordered, so one slab set suffices)
 
 

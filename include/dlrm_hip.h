@@ -210,6 +210,21 @@ int dlrm_interact_bwd_gather(int64_t B, int F, int D, const void* const* feat_ho
  * (mb * ceil(N/64) + nb) * 64; bit 31 - (4*it + c) of word l is element (row 32*mb + 4*it + l/16, column 64*nb + 4*(l%16) + c),
  * it < 8, c < 4 (the lane geometry of the GEMM epilogues: lane l of a wave owns word l, shifts its 32 signs in with one
  * compare + add-with-carry each, and the block moves as ONE coalesced 4-byte access per lane). */
+/* bf16-STORAGE tower (BASELINE.json configs[4] "bf16 MLP on MFMA"; torchrec_dlrm/dlrm_main.py:302,526 runs its MLPs reduced-precision):
+ * activations and weights are kept as bf16 copies in HBM and v_mfma_f32_32x32x16_bf16 reads them without any conversion in the loop.
+ *   dlrm_cast_bf16            dst[m, n] = bf16(src[m, n]) (nearest even), zero for N <= n < Npad        (inputs, weights)
+ *   dlrm_cast_bf16_transposed dstT[c, r] = bf16(src[r, c]), zero for R <= r < Rpad                        (W^T for the data gradient)
+ *   dlrm_gemm_bf16            C (fp32, nullable) and/or Cb (bf16, nullable) [M, N] = epilogue(A[M, K] . B[N, K]^T), fp32 accumulation:
+ *                             forward  A = X,  B = W   : + bias, activation, ReLU sign bits OUT (relu_bits_out, nullable)
+ *                             dgrad    A = dY, B = W^T : masked by the previous layer's ReLU sign bits (relu_bits_in, nullable)
+ *                             needs K % 32 == 0, N % 4 == 0, lda/ldb % 8 == 0, 16-byte aligned rows; DLRM_E_ALIGN otherwise.
+ * Results equal DLRM_ARITH_BF16 of dlrm_linear_fwd / _bwd_data bit for bit (same operand rounding, same accumulation order); the
+ * weight gradient keeps reading the fp32 copies through dlrm_linear_bwd_weight(arith = DLRM_ARITH_BF16). */
+int dlrm_cast_bf16(int64_t M, int N, int Npad, const float* src, int64_t lds, uint16_t* dst, int64_t ldd, void* stream);
+int dlrm_cast_bf16_transposed(int R, int C, int Rpad, const float* src, int64_t lds, uint16_t* dstT, int64_t ldd, void* stream);
+int dlrm_gemm_bf16(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, int act,
+                   uint64_t* relu_bits_out, const uint64_t* relu_bits_in, float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, void* stream);
+
 int64_t dlrm_relu_bits_bytes(int64_t M, int N);
 int dlrm_linear_fwd(int64_t M, int N, int K,
                     const float* X, int64_t ldx, const float* W, int64_t ldw,

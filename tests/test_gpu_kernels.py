@@ -387,6 +387,70 @@ def test_linear_bf16_arithmetic(M, N, K):
     assert 1e-4 < err < 0.1, err
 
 
+def test_bf16_casts_are_round_to_nearest_even_and_padded():
+    """dlrm_cast_bf16 / dlrm_cast_bf16_transposed against torch's fp32 -> bfloat16 conversion (round to nearest even), including the
+    zero padding columns and odd shapes"""
+    from dlrm_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for M, N, Np in ((300, 13, 32), (65, 479, 480), (1000, 256, 256), (7, 1, 2)):
+        x = (torch.randn(M, N, generator=g) * 3).to(dev())
+        x[0, 0] = 1.00390625          # exactly half way between two bf16 values: ties to even
+        got = ops.cast_bf16(x, Np)
+        want = torch.zeros(M, Np, dtype=torch.bfloat16, device=dev())
+        want[:, :N] = x.to(torch.bfloat16)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (M, N, Np)
+    for R, C_, Rp in ((1024, 480, 1024), (100, 37, 128), (1, 256, 32)):
+        w = torch.randn(R, C_, generator=g).to(dev())
+        got = ops.cast_bf16_transposed(w, Rp)
+        want = torch.zeros(C_, Rp, dtype=torch.bfloat16, device=dev())
+        want[:, :R] = w.t().to(torch.bfloat16)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (R, C_, Rp)
+
+
+@pytest.mark.parametrize("ln,B", [([13, 512, 256, 128], 4096), ([479, 1024, 1024, 512, 256, 1], 2048), ([13, 64, 40, 16], 300), ([96, 64, 32], 129)])
+def test_bf16_storage_tower_is_bit_identical_to_in_loop_rounding(ln, B):
+    """arith "bf16" with bf16 STORAGE (dlrm_gemm_bf16: activations / weights read as bf16 copies, nothing converted in the k-loop, the
+    data gradient over a transposed bf16 weight copy) against the in-loop rounding path of rounds 1-2 (dlrm_linear_fwd / _bwd_data with
+    DLRM_ARITH_BF16): same operand rounding, same accumulation order -> outputs, input gradient and every parameter gradient equal
+    bit for bit; and both within bf16 tolerance of an fp64 reference."""
+    from dlrm_amd import functional, ops
+    from dlrm_amd.functional import MLPFunction
+    rng = np.random.default_rng(sum(ln))
+    L = len(ln) - 1
+    params = []
+    for i in range(L):
+        params += [to_dev((rng.standard_normal((ln[i + 1], ln[i])) * np.sqrt(2 / (ln[i] + ln[i + 1]))).astype(np.float32)).requires_grad_(True),
+                   to_dev((rng.standard_normal(ln[i + 1]) * 0.1).astype(np.float32)).requires_grad_(True)]
+    acts = tuple([ops.ACT_RELU] * (L - 1) + [ops.ACT_SIGMOID if ln[-1] == 1 else ops.ACT_RELU])
+    x0 = to_dev(rng.random((B, ln[0])).astype(np.float32))
+    dy = to_dev(rng.standard_normal((B, ln[-1])).astype(np.float32))
+    results = []
+    saved = functional.BF16_STORAGE
+    try:
+        for storage in (False, True):
+            functional.BF16_STORAGE = storage
+            x = x0.clone().requires_grad_(True)
+            for p in params:
+                p.grad = None
+            y = MLPFunction.apply(x, acts, None, ops.arith_code("bf16"), *params)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            results.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in params]))
+    finally:
+        functional.BF16_STORAGE = saved
+    (y0, dx0, g0), (y1, dx1, g1) = results
+    assert torch.equal(y0, y1), float((y0 - y1).abs().max())
+    assert torch.equal(dx0, dx1), float((dx0 - dx1).abs().max())
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    # and the arithmetic is what it claims to be: bf16 operands, fp32 accumulation
+    h = x0.double().cpu().numpy()
+    for i in range(L):
+        h = h @ params[2 * i].detach().double().cpu().numpy().T + params[2 * i + 1].detach().double().cpu().numpy()
+        h = 1 / (1 + np.exp(-h)) if acts[i] == ops.ACT_SIGMOID else np.maximum(h, 0)
+    np.testing.assert_allclose(y1.cpu().numpy(), h, rtol=6e-2, atol=6e-2 * float(np.abs(h).max()))
+
+
 @pytest.mark.parametrize("M,N,K0", [(5000, 512, 13), (300, 64, 479), (4096, 1024, 479), (33, 8, 5), (8192, 128, 14)])
 def test_linear_weight_gradient_of_padded_input(M, N, K0):
     """First MLP layers run on a zero-padded input (13 -> 16 dense features, 479 -> 480 interaction outputs):
