@@ -691,8 +691,10 @@ def main():
                    "launch": "HIP graph replay of the captured step (dlrm_amd.graph)" if graphed is not None else "eager (one C-ABI call per kernel)",
                    "mlp_arith": {"f32": "f32: native fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                                  "bf16x6": "bf16x6: fp32 operands split exactly into 3 bf16 terms in-kernel, 6 bf16 MFMA products, fp32 accumulate",
-                                 "bf16": "bf16: MLP operands rounded to bf16 in-kernel, one bf16 MFMA per 16-k step, fp32 accumulate "
-                                         "(reduced precision: NOT the headline configuration)"}[args.mlp_arith]},
+                                 "bf16": "bf16: forward / data-gradient GEMMs read bf16 copies of activations and weights (dlrm_gemm_bf16, nothing converted "
+                                         "in the k-loop; activations written in fp32 + bf16), weight gradient rounds its fp32 operands in the loop; one "
+                                         "v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate, fp32 master weights (reduced precision: NOT the headline "
+                                         "configuration)"}[args.mlp_arith]},
         "final_loss": final_loss,
         "parity_check": parity,
         "kernel_timing": "HIP events on the launch stream, one per change of launch category (a run of consecutive launches of one category "

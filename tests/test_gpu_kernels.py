@@ -407,12 +407,14 @@ def test_bf16_casts_are_round_to_nearest_even_and_padded():
         assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (R, C_, Rp)
 
 
-@pytest.mark.parametrize("ln,B", [([13, 512, 256, 128], 4096), ([479, 1024, 1024, 512, 256, 1], 2048), ([13, 64, 40, 16], 300), ([96, 64, 32], 129)])
+@pytest.mark.parametrize("ln,B", [([13, 512, 256, 128], 4096), ([479, 1024, 1024, 512, 256, 1], 2048), ([13, 64, 48, 16], 300), ([96, 64, 32], 129)])
 def test_bf16_storage_tower_is_bit_identical_to_in_loop_rounding(ln, B):
     """arith "bf16" with bf16 STORAGE (dlrm_gemm_bf16: activations / weights read as bf16 copies, nothing converted in the k-loop, the
     data gradient over a transposed bf16 weight copy) against the in-loop rounding path of rounds 1-2 (dlrm_linear_fwd / _bwd_data with
     DLRM_ARITH_BF16): same operand rounding, same accumulation order -> outputs, input gradient and every parameter gradient equal
-    bit for bit; and both within bf16 tolerance of an fp64 reference."""
+    bit for bit; and both within bf16 tolerance of an fp64 reference.  (Layer widths are multiples of 16: for other widths the in-loop
+    path falls back to the any-shape fp32 kernel and is MORE precise than bf16, so there is nothing to be identical to; 48 exercises
+    the zero padding of a reduction length to the next multiple of 32.)"""
     from dlrm_amd import functional, ops
     from dlrm_amd.functional import MLPFunction
     rng = np.random.default_rng(sum(ln))
