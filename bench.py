@@ -296,8 +296,8 @@ def parity_check_v2(args, device, interaction):
 # kernel category -> the sources its kernels are compiled from: PMC traffic measured on an older version of ANY of them is stale
 KERNEL_SOURCES = {
     "emb_fwd": ["emb.hip", "common.h"],
-    "emb_bwd_sgd": ["emb_sorted.hip", "sorted_common.h", "common.h"],
-    "emb_bwd_adagrad": ["adagrad.hip", "sorted_common.h", "common.h"],
+    "emb_bwd_sgd": ["emb_sorted.hip", "sorted_common.h", "seg_sort.h", "common.h"],
+    "emb_bwd_adagrad": ["adagrad.hip", "sorted_common.h", "seg_sort.h", "common.h"],
     "interact_fwd": ["interact.hip", "common.h"], "interact_bwd": ["interact.hip", "common.h"],
     "linear_fwd": ["gemm.hip", "gemv.hip", "common.h"], "linear_bwd_data": ["gemm.hip", "gemv.hip", "common.h"],
     "linear_bwd_weight": ["gemm.hip", "gemv.hip", "smallk.hip", "common.h"],
@@ -612,8 +612,8 @@ def main():
     kname = {"linear_fwd": "gemm3_kernel<KC,KC> (Y = X*W^T + bias, act; LDS-DMA ring, 256x128x16 tiles)",
              "linear_bwd_data": "gemm3_kernel<KC,KS> (dX = dY*W, previous layer's act' fused in the epilogue)",
              "linear_bwd_weight": "gemm3_kernel<KS,KS> (dW = dY^T*X split over the batch + bias-grad row sums) + splitk_reduce_kernel",
-             "emb_bwd_adagrad": "expand + rocprim radix sort + adagrad_groups_kernel + adagrad_fixup_kernel",
-             "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "expand + rocprim radix sort + sorted_update_kernel" if args.emb_update == "sorted" else "emb_bwd_sgd_{atomic,lds}_kernel",
+             "emb_bwd_adagrad": "expand + lookup sort (seg_sort.h, or rocPRIM for segments > 262144 lookups) + adagrad_groups_kernel + adagrad_fixup_kernel",
+             "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "expand + segmented radix sort (seg_hist / seg_colscan / seg_binscan / seg_scatter, csrc/seg_sort.h) + sorted_update_kernel" if args.emb_update == "sorted" else "emb_bwd_sgd_{atomic,lds}_kernel",
              "interact_fwd": "interact_fwd_dma_kernel", "interact_bwd": "interact_bwd_dma_kernel",
              "emb_interact_fwd": "interact_fwd_dma_kernel<gather>: one-hot embedding lookups fetched by the interaction kernel (K1 + K6 fused)",
              "emb_interact_bwd": "interact_bwd_dma_kernel<gather>"}

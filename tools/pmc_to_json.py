@@ -11,7 +11,8 @@ import sys
 
 CATS = {
     "emb_fwd": ["emb_fwd_kernel"],
-    "emb_bwd_sgd": ["expand_kernel", "rocprim::", "sorted_update_kernel"],
+    "emb_bwd_sgd": ["expand_kernel", "rocprim::", "seg_hist_kernel", "seg_colscan_kernel", "seg_binscan_kernel", "seg_scatter_kernel",
+                    "sorted_update_kernel"],
     "interact_fwd": ["interact_fwd"],
     "interact_bwd": ["interact_bwd"],
     "linear_fwd": ["gemm3_kernel<true, true", "gemm_f32_kernel<true, true"],
