@@ -126,12 +126,18 @@ class GraphedTrainStep:
         adagrad = any(type(optimizer).__name__ == n for n in ("RWSAdagrad", "FusedRWSAdagrad"))
         if not adagrad and getattr(model, "emb_update_mode", None) != ops.UPD_SORTED:
             return
-        safe = False
+        safe, lookups = False, 0
         try:
-            safe = ops.sort_is_graph_safe([e.weight for e in model.emb_l], ops.BagBatch(lS_o, lS_i, None))
+            bags = ops.BagBatch(lS_o, lS_i, None)
+            safe = ops.sort_is_graph_safe([e.weight for e in model.emb_l], bags)
+            lookups = int(sum(bags.nnz))
         except Exception:                                    # noqa: BLE001 - models without plain emb_l tables: be conservative
             safe = False
-        if _os.environ.get("DLRM_GRAPH_SORTED", "1") == "0":
+        # DLRM_GRAPH_SORTED: "1" keep the sorted update whenever it is replayable, "0" never, default "auto": keep it for batches of
+        # >= 2^19 lookups (Criteo-Terabyte: 1.7 M) and take the atomic update for launch-bound batches, where the sort's nine small
+        # launches cost more than its rows save (Criteo-Kaggle shapes, 53 k lookups: 0.83 ms sorted vs atomic, profiles/round3)
+        pref = _os.environ.get("DLRM_GRAPH_SORTED", "auto")
+        if pref == "0" or (pref == "auto" and not adagrad and lookups < (1 << 19)):
             safe = False
         if safe:
             return

@@ -106,7 +106,7 @@ def test_rwsadagrad_training_matches_reference_golden():
 
 
 @pytest.mark.parametrize("update", ["deterministic", "sorted"])
-def test_graphed_step_equals_eager_step(update):
+def test_graphed_step_equals_eager_step(update, monkeypatch):
     """The whole-step HIP graph (dlrm_amd.graph) replays exactly the kernels of the eager step: same losses, same
     parameters, bit for bit (deterministic embedding update), over more steps than the warm-up + capture.
     "sorted": the sort-based update stays in the captured step (the library's own segmented sorter replays; rocPRIM's did not) —
@@ -114,6 +114,7 @@ def test_graphed_step_equals_eager_step(update):
     import dlrm_amd
     from dlrm_amd.graph import GraphedTrainStep
     from dlrm_amd.optim import FusedSGD
+    monkeypatch.setenv("DLRM_GRAPH_SORTED", "1")      # (default "auto" takes the atomic update for a batch this small)
     d, meta = load_golden("config1_b128")
     device = torch.device("cuda:0")
     batches = [(torch.from_numpy(X).to(device), [torch.from_numpy(o).to(device) for o in lS_o],

@@ -47,12 +47,12 @@ timeout 300 python bench.py --steps 20 --warmup 5 $FLAGS --mlp-arith bf16 > $OUT
 timeout 300 python bench.py --steps 20 --warmup 5 $FLAGS --graph > $OUT/bench_tb_graph.json 2> /dev/null
 timeout 300 python bench.py --workload criteo_kaggle --steps 50 --warmup 10 $FLAGS > $OUT/bench_kaggle_eager.json 2> /dev/null
 timeout 300 python bench.py --workload criteo_kaggle --steps 50 --warmup 10 $FLAGS --graph > $OUT/bench_kaggle_graph.json 2> /dev/null
-DLRM_GRAPH_SORTED=0 timeout 300 python bench.py --workload criteo_kaggle --steps 50 --warmup 10 $FLAGS --graph > $OUT/bench_kaggle_graph_atomic.json 2> /dev/null
+DLRM_GRAPH_SORTED=1 timeout 300 python bench.py --workload criteo_kaggle --steps 50 --warmup 10 $FLAGS --graph > $OUT/bench_kaggle_graph_sorted.json 2> /dev/null
 timeout 600 python bench.py --workload mlperf_v2_multihot --interaction dot --steps 10 --warmup 3 > $OUT/bench_mlperf_v2_dot.json 2> $OUT/bench_mlperf_v2_dot.err
 timeout 600 python bench.py --workload mlperf_v2_multihot --steps 10 --warmup 3 > $OUT/bench_mlperf_v2_dcn.json 2> $OUT/bench_mlperf_v2_dcn.err
 python - <<PY
 import json
-for n in ("bench_tb_rwsadagrad","bench_tb_bf16","bench_tb_graph","bench_kaggle_eager","bench_kaggle_graph","bench_kaggle_graph_atomic","bench_mlperf_v2_dot","bench_mlperf_v2_dcn"):
+for n in ("bench_tb_rwsadagrad","bench_tb_bf16","bench_tb_graph","bench_kaggle_eager","bench_kaggle_graph","bench_kaggle_graph_sorted","bench_mlperf_v2_dot","bench_mlperf_v2_dcn"):
     try:
         d=json.load(open("$OUT/%s.json" % n)); p=d.get("parity_check") or {}
         print("%-28s ms %.3f  update=%s parity=%s" % (n, d["ms_per_step"], d["config"]["embedding_update"][:20], p.get("pass")))
