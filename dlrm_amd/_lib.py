@@ -58,8 +58,6 @@ SIGNATURES = {
     "dlrm_linear_bwd_weight_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "dlrm_linear_bwd_weight": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
     "dlrm_linear_bwd_weight_padded": (_i32, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
-    "dlrm_linear_bwd_weight_deferred": (_i32, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp, _vp]),
-    "dlrm_splitk_reduce_multi": (_i32, [_i32, _vp, _vp]),
     "dlrm_pad_cols": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_act_bwd": (_i32, [_i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     "dlrm_loss_workspace_bytes": (_i64, [_i64]),
@@ -87,13 +85,6 @@ SIGNATURES = {
     "dlrm_clamp": (_i32, [_i64, _vp, _f32, _f32, _vp, _vp]),
     "dlrm_clamp_bwd": (_i32, [_i64, _vp, _f32, _f32, _vp, _vp, _vp]),
 }
-
-class SplitkDesc(C.Structure):
-    """dlrm_splitk_desc of include/dlrm_hip.h"""
-    _fields_ = [("valid", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("splits", C.c_int32), ("accumulate", C.c_int32),
-                ("vec4", C.c_int32), ("part", C.c_void_p), ("ldp", C.c_int64), ("slab", C.c_int64), ("dW", C.c_void_p),
-                ("lddw", C.c_int64), ("rs_part", C.c_void_p), ("dbias", C.c_void_p)]
-
 
 _ERR = {-1: "DLRM_E_ARG (null pointer / bad size)", -2: "DLRM_E_ALIGN", -3: "DLRM_E_RANGE (compiled limit exceeded)",
         -4: "DLRM_E_MODE (unknown mode / not implemented)"}

@@ -868,51 +868,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int N, int K, int sp
     }
 }
 
-// the slab reductions of SEVERAL weight gradients in one launch (blockIdx.y = layer): a tower's backward pass queues one record
-// per layer (dlrm_linear_bwd_weight_deferred) and reduces them together — seven ~15 us launches per step become two
-struct SplitkMultiArgs { dlrm_splitk_desc d[DLRM_MAX_SPLITK_DESCS]; };
-
-__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(SplitkMultiArgs a) {
-    const dlrm_splitk_desc& d = a.d[blockIdx.y];
-    const int N = d.N, K = d.K, splits = d.splits;
-    const float* __restrict__ part = d.part;
-    float* __restrict__ dW = d.dW;
-    if (d.rs_part) {
-        for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < N; n += (long long)gridDim.x * 256) {
-            float acc = d.accumulate ? d.dbias[n] : 0.f;
-#pragma unroll 8
-            for (int s_ = 0; s_ < splits; ++s_) acc += d.rs_part[(long long)s_ * N + n];
-            d.dbias[n] = acc;
-        }
-    }
-    if (d.vec4) {
-        const int kq = K / 4;
-        const long long total = (long long)N * kq;
-        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-            const long long n = e / kq;
-            const int k = (int)(e - n * kq) * 4;
-            const float* p = part + n * d.ldp + k;
-            float* o = dW + n * d.lddw + k;
-            float4 acc = d.accumulate ? *(const float4*)o : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-            for (int s_ = 0; s_ < splits; ++s_) {
-                const float4 v = *(const float4*)(p + (long long)s_ * d.slab);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
-            *(float4*)o = acc;
-        }
-    } else {
-        const long long total = (long long)N * K;
-        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-            const long long n = e / K;
-            const int k = (int)(e - n * K);
-            float acc = d.accumulate ? dW[n * d.lddw + k] : 0.f;
-            for (int s_ = 0; s_ < splits; ++s_) acc += part[n * d.ldp + k + (long long)s_ * d.slab];
-            dW[n * d.lddw + k] = acc;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // dZ = dY ⊙ act'(Y), dbias += colsum(dZ)   (tower outputs whose dY does not come from a dgrad GEMM)
 // ---------------------------------------------------------------------------------------------
@@ -1238,8 +1193,7 @@ extern "C" int64_t dlrm_linear_bwd_weight_workspace_bytes(int64_t M, int N, int 
 static int linear_bwd_weight_impl(int64_t M, int N, int K, int K_store, const float* dY, int64_t lddy,
                                   const float* X, int64_t ldx, float* dW, int64_t lddw,
                                   float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
-                                  int arith, void* stream, dlrm_splitk_desc* defer = nullptr) {
-    if (defer) defer->valid = 0;
+                                  int arith, void* stream) {
     if (!arith_ok(arith)) return DLRM_E_MODE;
     if (M <= 0 || N <= 0 || K <= 0 || K_store <= 0 || K_store > K || !dY || !X || !dW) return DLRM_E_ARG;
     if (lddy < N || ldx < K || lddw < K_store) return DLRM_E_ARG;
@@ -1278,12 +1232,6 @@ static int linear_bwd_weight_impl(int64_t M, int N, int K, int K_store, const fl
         int rc = launch_gemm<false, false>(g, splits, st, arith);
         if (rc) return rc;
         const bool v4 = dlrm_aligned16(dW) && lddw % 4 == 0 && K_store % 4 == 0;
-        if (defer) {            // the caller reduces the slabs of several layers in one launch (dlrm_splitk_reduce_multi)
-            defer->valid = 1; defer->N = N; defer->K = K_store; defer->splits = splits; defer->accumulate = accumulate ? 1 : 0; defer->vec4 = v4 ? 1 : 0;
-            defer->part = (const float*)workspace; defer->ldp = ldp; defer->slab = slab; defer->dW = dW; defer->lddw = lddw;
-            defer->rs_part = rs_part; defer->dbias = dbias;
-            return 0;
-        }
         const long long items = (long long)N * (v4 ? K_store / 4 : K_store);
         int blocks = (int)((items + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
         if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, N, K_store, splits, (const float*)workspace,
@@ -1315,34 +1263,6 @@ extern "C" int dlrm_linear_bwd_weight_padded(int64_t M, int N, int K, int K_stor
                                              float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
                                              int arith, void* stream) {
     return linear_bwd_weight_impl(M, N, K, K_store, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, arith, stream);
-}
-
-extern "C" int dlrm_linear_bwd_weight_deferred(int64_t M, int N, int K, int K_store, const float* dY, int64_t lddy,
-                                               const float* X, int64_t ldx, float* dW, int64_t lddw,
-                                               float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
-                                               int arith, dlrm_splitk_desc* desc, void* stream) {
-    if (!desc) return DLRM_E_ARG;
-    return linear_bwd_weight_impl(M, N, K, K_store, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, arith, stream, desc);
-}
-
-extern "C" int dlrm_splitk_reduce_multi(int n, const dlrm_splitk_desc* descs, void* stream) {
-    if (n < 0 || (n > 0 && !descs)) return DLRM_E_ARG;
-    for (int k0 = 0; k0 < n; k0 += DLRM_MAX_SPLITK_DESCS) {
-        const int m = (n - k0 < DLRM_MAX_SPLITK_DESCS) ? n - k0 : DLRM_MAX_SPLITK_DESCS;
-        SplitkMultiArgs a = {};
-        long long most = 1;
-        for (int k = 0; k < m; ++k) {
-            const dlrm_splitk_desc& d = descs[k0 + k];
-            if (!d.valid || d.N <= 0 || d.K <= 0 || d.splits <= 0 || !d.part || !d.dW) return DLRM_E_ARG;
-            a.d[k] = d;
-            const long long items = (long long)d.N * (d.vec4 ? d.K / 4 : d.K);
-            if (items > most) most = items;
-        }
-        long long bx = (most + 255) / 256; if (bx > 1024) bx = 1024;
-        hipLaunchKernelGGL(splitk_reduce_multi_kernel, dim3((unsigned)bx, (unsigned)m), dim3(256), 0, (hipStream_t)stream, a);
-        DLRM_LAUNCH_CHECK();
-    }
-    return 0;
 }
 
 extern "C" int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, const float* Y,

@@ -31,9 +31,6 @@ RELU_BITS = os.environ.get("DLRM_RELU_BITS", "1") == "1"
 # arith "bf16": activations / weights are also kept as bf16 copies and the GEMMs read those (dlrm_gemm_bf16) instead of rounding fp32
 # operands inside the k-loop (DLRM_BF16_STORAGE=0: the in-loop rounding of rounds 1-2; results are bit-identical)
 BF16_STORAGE = os.environ.get("DLRM_BF16_STORAGE", "1") == "1"
-# the split-K slab reductions of a tower's weight gradients run as one launch at the end of its backward pass (DLRM_DEFER_SPLITK=0: one
-# ~15 us launch per layer, as in rounds 1-2)
-DEFER_SPLITK = os.environ.get("DLRM_DEFER_SPLITK", "1") == "1"
 _side_streams = {}
 
 
@@ -212,8 +209,6 @@ class MLPFunction(Function):
         keep = []                                          # tensors the side stream reads stay alive until the join
         store16 = BF16_STORAGE and arith == ops.arith_code("bf16")
         dZ16 = None                                        # bf16 copy of dZ when the previous data-gradient GEMM produced one
-        # the split-K slab reductions of all layers are queued and run as ONE launch after the loop (DLRM_DEFER_SPLITK=0: one per layer)
-        queued = [] if DEFER_SPLITK else None
         for i in range(L - 1, -1, -1):
             W = params[2 * i] if not (i == 0 and W0p is not None) else W0p
             X_i = x if i == 0 else outs[i - 1]
@@ -224,10 +219,10 @@ class MLPFunction(Function):
             if side is not None:
                 side.wait_event(main.record_event())
                 with torch.cuda.stream(side):
-                    ops.linear_bwd_weight(dZ, X_i, dW, db, arith=arith, deferred=queued)  # dW and db (row sums of dZ^T) in one GEMM
+                    ops.linear_bwd_weight(dZ, X_i, dW, db, arith=arith)  # dW and db (row sums of dZ^T) in one GEMM
                 keep.append(dZ)
             else:
-                ops.linear_bwd_weight(dZ, X_i, dW, db, arith=arith, deferred=queued)
+                ops.linear_bwd_weight(dZ, X_i, dW, db, arith=arith)
             grads[2 * i], grads[2 * i + 1] = dW, db
             need_dx = i > 0 or ctx.needs_input_grad[0]
             if not need_dx:
@@ -257,12 +252,6 @@ class MLPFunction(Function):
                 dX = dprev
                 if dX.size(1) != ctx.in_width:
                     dX = dX[:, :ctx.in_width]
-        if queued:
-            if side is not None:
-                with torch.cuda.stream(side):
-                    ops.splitk_reduce_multi(queued)
-            else:
-                ops.splitk_reduce_multi(queued)
         if side is not None:
             main.wait_stream(side)
             del keep

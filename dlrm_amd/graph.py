@@ -184,7 +184,7 @@ class GraphedTrainStep:
         self._lrs = self._current_lrs()
         # the graph holds raw pointers into the cached scratch workspaces: pin those tensors so that a later, larger
         # request elsewhere (which replaces the cache entry) cannot free memory the replays still use
-        self._pinned_ws = [w for k_, w in list(ops._emb_ws.items()) + list(ops._wgrad_ws.items()) if k_[0] == dev]
+        self._pinned_ws = [w for (d_, _), w in list(ops._emb_ws.items()) + list(ops._wgrad_ws.items()) if d_ == dev]
         self.captures += 1
         torch.cuda.current_stream(dev).wait_stream(self.stream)
 

@@ -667,11 +667,10 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], ac
 _wgrad_ws = {}   # (device, stream) -> cached split-K workspace (kernels of one stream are ordered, so one slab set suffices)
 
 
-def _wgrad_workspace(need: int, device, slot: int = -1) -> Optional[torch.Tensor]:
-    """slot >= 0: a workspace of its own (deferred slab reductions keep every layer's slabs alive until the tower's one reduction)"""
+def _wgrad_workspace(need: int, device) -> Optional[torch.Tensor]:
     if need <= 0:
         return None
-    key = (device, torch.cuda.current_stream().cuda_stream, slot)
+    key = (device, torch.cuda.current_stream().cuda_stream)
     ws = _wgrad_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(int(need), dtype=torch.uint8, device=device)
@@ -680,13 +679,10 @@ def _wgrad_workspace(need: int, device, slot: int = -1) -> Optional[torch.Tensor
 
 
 def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor] = None,
-                      accumulate: bool = False, use_workspace: bool = True, arith=_lib.ARITH_F32,
-                      deferred: Optional[list] = None) -> torch.Tensor:
+                      accumulate: bool = False, use_workspace: bool = True, arith=_lib.ARITH_F32) -> torch.Tensor:
     """dW = dY^T @ X and (optionally) dbias = column sums of dY, one GEMM (+ the split-K slab reduction).
     dW may be NARROWER than X (dW [N, K_store], X [M, K >= K_store]): the extra columns of X are alignment padding
-    (zeros) and their gradient is dropped.  use_workspace=False exercises the atomic-accumulation variant.
-    deferred: a list — the split-K GEMM runs into a workspace of its own and the slab reduction is NOT launched; its record is
-    appended to the list and `splitk_reduce_multi(list)` reduces the slabs of all queued layers in one launch (same result)."""
+    (zeros) and their gradient is dropped.  use_workspace=False exercises the atomic-accumulation variant."""
     lib = _lib.load()
     _req(dY, "dY", ndim=2); _req(X, "X", ndim=2); _req(dW, "dW", ndim=2)
     M, N = dY.shape
@@ -698,18 +694,6 @@ def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias
         _req(dbias, "dbias", ndim=1)
         if dbias.numel() != N:
             raise RuntimeError("dlrm_amd: linear_bwd_weight dbias size mismatch")
-    if deferred is not None:
-        ws = _wgrad_workspace(lib.dlrm_linear_bwd_weight_workspace_bytes(M, N, K), dY.device, slot=len(deferred))
-        desc = _lib.SplitkDesc()
-        with _timed("linear_bwd_weight"):
-            rc = lib.dlrm_linear_bwd_weight_deferred(M, N, K, K_store, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(X.data_ptr()), _ld(X),
-                                                     C.c_void_p(dW.data_ptr()), _ld(dW),
-                                                     C.c_void_p(dbias.data_ptr()) if dbias is not None else None, int(bool(accumulate)),
-                                                     C.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
-                                                     arith_code(arith), C.byref(desc), _stream(dW))
-        _lib.check(rc, "dlrm_linear_bwd_weight_deferred")
-        deferred.append(desc if desc.valid else None)      # (None keeps the slot numbering = one workspace per layer)
-        return dW
     ws = _wgrad_workspace(lib.dlrm_linear_bwd_weight_workspace_bytes(M, N, K), dY.device) if use_workspace else None
     with _timed("linear_bwd_weight"):
         common = (C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(X.data_ptr()), _ld(X),
@@ -724,17 +708,6 @@ def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias
             rc = lib.dlrm_linear_bwd_weight_padded(M, N, K, K_store, *common)
     _lib.check(rc, "dlrm_linear_bwd_weight")
     return dW
-
-
-def splitk_reduce_multi(deferred: list) -> None:
-    """the slab reductions queued by linear_bwd_weight(..., deferred=list), one launch (dlrm_splitk_reduce_multi)"""
-    descs = [d for d in deferred if d is not None]
-    if not descs:
-        return
-    arr = (_lib.SplitkDesc * len(descs))(*descs)
-    with _timed("linear_bwd_weight"):
-        rc = _lib.load().dlrm_splitk_reduce_multi(len(descs), C.cast(arr, C.c_void_p), _stream())
-    _lib.check(rc, "dlrm_splitk_reduce_multi")
 
 
 def pad_cols(src: torch.Tensor, Kp: int) -> torch.Tensor:

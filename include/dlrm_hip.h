@@ -251,22 +251,6 @@ int dlrm_linear_bwd_data(int64_t M, int N, int K,
  * split-K partial slabs, summed in a fixed order by a second kernel (deterministic dW).  NULL / too small:
  * the k-slices accumulate into dW with fp32 atomics instead (correct, slower, order-dependent rounding). */
 int64_t dlrm_linear_bwd_weight_workspace_bytes(int64_t M, int N, int K);
-/* Deferred slab reduction: dlrm_linear_bwd_weight_deferred runs the split-K GEMM of one layer into ITS OWN workspace and, instead of
- * launching the slab reduction, fills *desc (valid = 1); dlrm_splitk_reduce_multi then reduces the slabs of up to
- * DLRM_MAX_SPLITK_DESCS layers in ONE launch (same fixed summation order: results identical to dlrm_linear_bwd_weight).  When the
- * layer does not take the slab path (matrix-vector layer, K <= 16, no workspace) the call completes the gradient itself and
- * leaves desc->valid = 0.  The workspace must stay untouched until the multi reduction has run. */
-#define DLRM_MAX_SPLITK_DESCS 16
-typedef struct {
-    int32_t valid, N, K, splits, accumulate, vec4;
-    const float* part; int64_t ldp, slab;        /* slabs [splits][N][ldp] */
-    float* dW; int64_t lddw;
-    const float* rs_part; float* dbias;           /* bias-gradient partials [splits][N] (nullable) */
-} dlrm_splitk_desc;
-int dlrm_linear_bwd_weight_deferred(int64_t M, int N, int K, int K_store, const float* dY, int64_t lddy, const float* X, int64_t ldx,
-                                    float* dW, int64_t lddw, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
-                                    int arith, dlrm_splitk_desc* desc, void* stream);
-int dlrm_splitk_reduce_multi(int n, const dlrm_splitk_desc* descs, void* stream);
 int dlrm_linear_bwd_weight(int64_t M, int N, int K,
                            const float* dY, int64_t lddy, const float* X, int64_t ldx,
                            float* dW, int64_t lddw, float* dbias, int accumulate,

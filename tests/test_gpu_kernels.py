@@ -387,31 +387,6 @@ def test_linear_bf16_arithmetic(M, N, K):
     assert 1e-4 < err < 0.1, err
 
 
-def test_deferred_split_k_reduction_equals_the_per_layer_one():
-    """dlrm_linear_bwd_weight_deferred + dlrm_splitk_reduce_multi (one slab reduction launch for all layers of a tower) against
-    dlrm_linear_bwd_weight layer by layer: same slabs, same fixed summation order -> dW and db bit-identical; layers that do not take
-    the slab path (matrix-vector layer, K <= 16) complete inside the deferred call."""
-    from dlrm_amd import ops
-    rng = np.random.default_rng(21)
-    M = 8192
-    layers = [(1024, 480), (512, 1024), (256, 512), (1, 256), (512, 16), (128, 256)]
-    queued, got, want = [], [], []
-    keep = []
-    for N, K in layers:
-        dY = to_dev(rng.standard_normal((M, N)).astype(np.float32))
-        X = to_dev(rng.standard_normal((M, K)).astype(np.float32))
-        dW0, db0 = torch.empty(N, K, device=dev()), torch.empty(N, device=dev())
-        dW1, db1 = torch.full((N, K), 7.0, device=dev()), torch.full((N,), 7.0, device=dev())
-        ops.linear_bwd_weight(dY, X, dW0, db0)
-        ops.linear_bwd_weight(dY, X, dW1, db1, deferred=queued)
-        want.append((dW0, db0)); got.append((dW1, db1)); keep += [dY, X]
-    assert sum(d is not None for d in queued) >= 4 and len(queued) == len(layers)
-    ops.splitk_reduce_multi(queued)
-    torch.cuda.synchronize()
-    for (a, b), (c, d_), (N, K) in zip(want, got, layers):
-        assert torch.equal(a, c) and torch.equal(b, d_), (N, K)
-
-
 def test_bf16_casts_are_round_to_nearest_even_and_padded():
     """dlrm_cast_bf16 / dlrm_cast_bf16_transposed against torch's fp32 -> bfloat16 conversion (round to nearest even), including the
     zero padding columns and odd shapes"""
