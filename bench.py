@@ -634,7 +634,10 @@ def main():
             if sharded:
                 lookup_sort = "per shard (csrc/seg_sort.h where a shard's segments hold <= 262144 lookups)"
             else:
-                own = ops.sort_is_graph_safe([e.weight for e in model.emb_l], ops.BagBatch(batches[0][1], batches[0][2]))
+                o_, i_ = batches[0][1], batches[0][2]
+                if N > 1:                                     # table-wise shards: this rank sorts the lookups of its own tables only
+                    o_, i_ = o_[model.local_emb_slice], i_[model.local_emb_slice]
+                own = ops.sort_is_graph_safe([e.weight for e in model.emb_l], ops.BagBatch(o_, i_))
                 lookup_sort = ("segmented radix sort of csrc/seg_sort.h (the library's own kernels, HIP-graph replayable)" if own else
                                "rocPRIM radix_sort_pairs (a table segment exceeds 262144 lookups, or DLRM_SORT=rocprim)")
         except Exception as e:                            # noqa: BLE001 - a label, never allowed to break the line

@@ -339,6 +339,8 @@ def _emb_workspace(need: int, device) -> torch.Tensor:
 def sort_is_graph_safe(weights: Sequence[torch.Tensor], bags: BagBatch) -> bool:
     """True when the sort-based embedding updates of these shapes run entirely on the library's own segmented sorter
     (csrc/seg_sort.h: plain kernels, replayable inside a HIP graph); False when a table segment needs the general sorter."""
+    if len(weights) != bags.T:
+        raise RuntimeError("dlrm_amd: sort_is_graph_safe needs one table per bag list")
     _, _, rows = _weights_desc(weights)
     return _lib.load().dlrm_emb_sort_kind(bags.T, bags._nnz, rows) == 1
 
