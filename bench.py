@@ -108,7 +108,7 @@ def parse():
     ap.add_argument("--cpu-row-cap", type=int, default=4000000, help="row cap of the baseline legs' tables (SURVEY 8d: 4 M)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed iterations of the CPU baseline (median reported)")
     ap.add_argument("--cpu-warmup", type=int, default=3)
-    ap.add_argument("--cpu-budget", type=float, default=90.0, help="seconds of host time the CPU baseline leg may take (thread-count "
+    ap.add_argument("--cpu-budget", type=float, default=130.0, help="seconds of host time the CPU baseline leg may take (thread-count "
                                                                      "probes + warm-up + as many of --cpu-steps as fit, at least 3)")
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
     ap.add_argument("--a2a-chunks", type=int, default=int(os.environ.get("DLRM_A2A_CHUNKS", "1")),

@@ -93,7 +93,7 @@ def time_loop(ref, model, batch, lr, use_gpu, device, warmup, steps):
     return times, loss
 
 
-def run(state, lr, cpu_warmup=3, cpu_steps=10, gpu_warmup=3, gpu_steps=10, gpu_device=None, cpu_budget_s=90.0):
+def run(state, lr, cpu_warmup=3, cpu_steps=10, gpu_warmup=3, gpu_steps=10, gpu_device=None, cpu_budget_s=130.0):
     """state: m_spa, ln_bot, ln_top, tables (list of CPU fp32 [rows, D]), mlp (state_dict names -> CPU tensors), batch
     (X [B,13] f32, lS_o [T,B] i64, lS_i [T,B] i64, T [B,1] f32; CPU), row_cap.  Returns (cpu_baseline, stock_gpu_baseline) or None
     when oracle/_ref is absent.
