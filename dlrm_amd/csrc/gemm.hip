@@ -957,7 +957,12 @@ static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
         if (dbg < 0) { const char* e = getenv("DLRM_GEMM_DEBUG"); dbg = e ? atoi(e) : 0; }
         g.debug = dbg;
     }
-    const size_t lds = (size_t)NSTAGE3 * (BMt + BNt) * BK3 * 4;     // 72 KiB (TM=4) / 48 KiB (TM=2)
+    size_t lds = (size_t)NSTAGE3 * (BMt + BNt) * BK3 * 4;           // 72 KiB (TM=4) / 48 KiB (TM=2)
+    {   // tuning aid (env DLRM_GEMM_LDS_PAD, bytes): extra dynamic LDS per workgroup = fewer resident workgroups per CU (occupancy probe)
+        static int pad = -1;
+        if (pad < 0) { const char* e = getenv("DLRM_GEMM_LDS_PAD"); pad = e ? atoi(e) : 0; }
+        lds += (size_t)pad;
+    }
     static bool attr_done[DLRM_MAX_DEVICES] = {};      // the attribute is per (function, device)
     const int dev = dlrm_current_device();
     if (!attr_done[dev]) {
