@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_batches, load_golden, params_with_prefix
+from conftest import GOLDEN, ROOT, golden_batches, load_golden, params_with_prefix
 from oracle import oracle as O
 
 # cat_wbce_clamp: "cat" interaction + --loss-threshold clamp + --loss-function=wbce (the remaining --arch-* surface)
@@ -378,3 +378,34 @@ def test_reference_baseline_leg_runs_the_compiled_reference_and_agrees_with_the_
     for _ in range(cpu["iterations_run"]):
         loss, _ = port.train_step(X, list(off), list(idx), T)
     assert abs(loss - cpu["final_loss"]) <= 1e-6 * abs(loss), (loss, cpu["final_loss"])
+
+
+def test_mlperf_v2_fixture_agrees_with_the_numpy_oracle_at_step_0():
+    """tests/golden/mlperf_v2_dot_b65536.npz was produced by a torch-operator composition of the torchrec model (oracle/make_golden_v2.py);
+    the repo's other restatement of the same published model — oracle.OracleDLRM (numpy + the C oracle, pair_order="triu", logits,
+    BCEWithLogits) — must give the same step-0 logits on the regenerated inputs and initial parameters: two independent
+    restatements of the (unpinnable, third-party) torchrec semantics agree at the benchmark's own scale, 214 lookups per sample."""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import make_golden_v2 as G
+    from dlrm_amd.torchrec_variant import DLRM
+    z = np.load(os.path.join(GOLDEN, "mlperf_v2_dot_b65536.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    rows, hot, B = meta["rows"], meta["hot"], meta["B"]
+    (X, ids, values, off_l, lab), = G.make_inputs(rows, hot, B, 1)
+    for tag, a in (("X", X), ("ids", ids), ("values", values), ("off", off_l), ("labels", lab)):
+        assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:32] == meta["digests"][f"s0.{tag}"], tag
+    np.random.seed(meta["seed_init"])
+    shell = DLRM(rows, meta["D"], meta["bot"][0], meta["bot"][1:], meta["top"])
+    init = {k: v.detach().numpy().copy() for k, v in shell.state_dict().items()}
+    ref = O.OracleDLRM(init, pair_order="triu", final_top_act_none=True, loss="bce_logits")
+    # the forward is per sample: the first 4096 samples are enough (and keep this test at seconds; the GPU test covers all 65536)
+    n = 4096
+    off = [off_l[t][:n].astype(np.int64) for t in range(len(rows))]
+    idx, o = [], 0
+    for h in hot:
+        idx.append(values[o:o + n * h].astype(np.int64))
+        o += B * h
+    logits = ref.forward(X[:n], off, idx)
+    np.testing.assert_allclose(logits.reshape(-1), z["s0.logits"][:n], rtol=2e-5, atol=2e-6)
