@@ -112,12 +112,20 @@ def test_multi_rank_training_matches_reference_multi_rank_run(fixture, chunks, d
 # ---------------------------------------------------------------------------------------------------------------------
 # planned sharding (table-wise + row-wise), non-replicated key-major inputs
 # ---------------------------------------------------------------------------------------------------------------------
-_SH = dict(rows=[50, 7, 3000, 11, 400], hot=[3, 1, 7, 2, 1], D=16, dense_in=13, dense=[32, 16], over=[48, 24, 1], B=32, lr=0.2)
+_SH2 = dict(rows=[50, 7, 3000, 11, 400], hot=[3, 1, 7, 2, 1], D=16, dense_in=13, dense=[32, 16], over=[48, 24, 1], B=32, lr=0.2)
+# 4 ranks: nine tables, the 9-hot 3000-row table row-wise over all four ranks, two table-wise tables on every rank
+_SH4 = dict(rows=[50, 7, 3000, 11, 400, 23, 90, 64, 31], hot=[3, 1, 9, 2, 1, 2, 1, 2, 1], D=16, dense_in=13, dense=[32, 16], over=[48, 24, 1],
+            B=32, lr=0.2)
+_SH = _SH2
 
 
-def _sharded_inputs(step):
+def _sh(size):
+    return _SH4 if size == 4 else _SH2
+
+
+def _sharded_inputs(step, size=2):
     rng = np.random.default_rng(100 + step)
-    c = _SH
+    c = _sh(size)
     X = rng.random((c["B"], c["dense_in"])).astype(np.float32)
     ids = [rng.integers(0, n, size=(c["B"], h)).astype(np.int32) for n, h in zip(c["rows"], c["hot"])]    # [B, h_t] per table
     labels = rng.integers(0, 2, size=c["B"]).astype(np.float32)
@@ -131,8 +139,8 @@ def _sharded_worker(rank, size, port, q, full_init):
     from dlrm_amd.torchrec_variant import DLRMTrain, ShardedDLRM
     ext_dist.init_distributed(rank=rank, local_rank=0, size=size, use_gpu=True, backend="gloo")
     dev = torch.device("cuda:0")
-    c = _SH
-    # force one row-wise table (3000 rows, 7-hot) plus planned table-wise placement of the rest
+    c = _sh(size)
+    # force one row-wise table (3000 rows, 7- / 9-hot) plus planned table-wise placement of the rest
     plan = sharding.plan(c["rows"], c["hot"], c["D"], size, c["B"], row_wise_threshold=0.6)
     assert plan.row_wise() == [2], plan
     np.random.seed(1)
@@ -149,7 +157,7 @@ def _sharded_worker(rank, size, port, q, full_init):
     sl = slice(rank * Bl, (rank + 1) * Bl)
     res = {}
     for s in range(2):
-        X, ids, labels = _sharded_inputs(s)
+        X, ids, labels = _sharded_inputs(s, size)
         values = torch.from_numpy(np.concatenate([i[sl].reshape(-1) for i in ids])).to(dev)       # key-major ids of MY samples only
         loss, (_, logits, _) = _train_step(train, torch.from_numpy(X[sl]).to(dev), values, torch.from_numpy(labels[sl]).to(dev))
         res[f"s{s}.logits"] = logits.cpu().numpy()
@@ -179,14 +187,14 @@ def _train_step(train, dense, values, labels):
     return loss, (loss.detach(), logits.detach(), labels)
 
 
-def test_sharded_dlrm_two_ranks_matches_single_process_oracle():
-    """ShardedDLRM on 2 ranks (one MI355X, gloo rendezvous): table-wise + one ROW-WISE table, each rank feeding only its half of
+@pytest.mark.parametrize("size", [2, 4])
+def test_sharded_dlrm_ranks_match_single_process_oracle(size):
+    """ShardedDLRM on 2 and 4 ranks (one MI355X, gloo rendezvous): table-wise + one ROW-WISE table, each rank feeding only its slice of
     the batch — against the single-process oracle on the whole batch: logits of every rank's slice, per-rank losses (mean over
     the local slice), and after two steps the embedding shards (the reference's N x embedding-gradient behaviour: oracle
     emb_lr_scale = N) and the DDP-averaged top tower."""
     from oracle import oracle as O
-    c = _SH
-    size = 2
+    c = _sh(size)
     rng = np.random.default_rng(9)
     T = len(c["rows"])
     F = T + 1
@@ -211,7 +219,7 @@ def test_sharded_dlrm_two_ranks_matches_single_process_oracle():
     ref = O.OracleDLRM(full, pair_order="triu", final_top_act_none=True, loss="bce_logits")
     Bl = c["B"] // size
     for s in range(2):
-        X, ids, labels = _sharded_inputs(s)
+        X, ids, labels = _sharded_inputs(s, size)
         off = [np.arange(c["B"], dtype=np.int64) * h for h in c["hot"]]
         idx = [i.reshape(-1).astype(np.int64) for i in ids]
         # the distributed loss is the mean over each rank's slice; the global-mean step with emb lr x N reproduces its updates
@@ -232,7 +240,7 @@ def test_sharded_dlrm_two_ranks_matches_single_process_oracle():
                 seen.add((t, lo))
             elif k.startswith("final.top_l."):
                 np.testing.assert_allclose(v, ref.p[k[len("final."):]], rtol=1e-4, atol=5e-6, err_msg=k)
-    assert len({t for t, _ in seen}) == T and len([1 for t, _ in seen if t == 2]) == 2      # the row-wise table came back in two shards
+    assert len({t for t, _ in seen}) == T and len([1 for t, _ in seen if t == 2]) == size   # the row-wise table came back in one shard per rank
 
 
 # ---------------------------------------------------------------------------------------------------------------------
