@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libdlrm_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED, UPD_PRESORTED = 0, 1, 2, 3
+UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED = 0, 1, 2
 ARITH_F32, ARITH_BF16X6, ARITH_BF16 = 0, 1, 2
 
 _lock = threading.Lock()

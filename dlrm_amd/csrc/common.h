@@ -62,7 +62,7 @@ int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_ho
                                  const void* const* indices_host, const void* const* offsets_host,
                                  const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
                                  const float* dout, int64_t dout_ld, float lr, void* workspace,
-                                 int64_t workspace_bytes, int64_t* err, void* stream, bool presorted);
+                                 int64_t workspace_bytes, int64_t* err, void* stream);
 
 // gemv.hip: the N == 1 MLP layer as HBM-streaming kernels; each returns 0 when it handled the call and
 // DLRM_GEMV_NOT_HANDLED when the shape/alignment is outside its fast path (the caller then uses the GEMM kernels).

@@ -534,11 +534,10 @@ extern "C" int dlrm_emb_bwd_sgd(int T, int64_t B, int D, void* const* weight_hos
                           nnz_host, idx_bits);
     if (rc) return rc;
     if (!dout || dout_ld < (int64_t)T * D) return DLRM_E_ARG;
-    if (mode != DLRM_UPD_ATOMIC && mode != DLRM_UPD_DETERMINISTIC && mode != DLRM_UPD_SORTED && mode != DLRM_UPD_PRESORTED) return DLRM_E_MODE;
-    if (mode == DLRM_UPD_SORTED || mode == DLRM_UPD_PRESORTED)
+    if (mode != DLRM_UPD_ATOMIC && mode != DLRM_UPD_DETERMINISTIC && mode != DLRM_UPD_SORTED) return DLRM_E_MODE;
+    if (mode == DLRM_UPD_SORTED)
         return dlrm_emb_bwd_sgd_sorted_impl(T, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host,
-                                            psw_host, idx_bits, dout, dout_ld, lr, workspace, workspace_bytes, err, stream,
-                                            mode == DLRM_UPD_PRESORTED);
+                                            psw_host, idx_bits, dout, dout_ld, lr, workspace, workspace_bytes, err, stream);
     hipStream_t st = (hipStream_t)stream;
     const float neg_lr = -lr;
     dim3 block(256, 1, 1);

@@ -140,10 +140,10 @@ static int run_sorted(int n, const int* ids, int64_t B, int D, void* const* weig
                       const void* const* indices_host, const void* const* offsets_host, const int64_t* nnz_host,
                       const void* const* psw_host, int idx_bits, const float* dout, int64_t dout_ld, float neg_lr,
                       char* ws, const Layout& lo, size_t L, int row_bits, int key_bits, bool vec_ok, hipStream_t st,
-                      int64_t* err, bool presorted) {
+                      int64_t* err) {
     SortedArgs sa;
     int rc0 = expand_and_sort<KT>(n, ids, B, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host, idx_bits,
-                                  ws, lo, L, row_bits, key_bits, st, &sa, err, presorted);
+                                  ws, lo, L, row_bits, key_bits, st, &sa, err);
     if (rc0) return rc0;
     const KT* keys_out = (const KT*)(ws + lo.keys_out);
     const unsigned* vals_out = (const unsigned*)(ws + lo.vals_out);
@@ -233,8 +233,9 @@ extern "C" int dlrm_emb_sort_lookups(int T, int64_t B, const int64_t* rows_host,
                                      const void* const* offsets_host, const int64_t* nnz_host, int idx_bits, void* workspace,
                                      int64_t workspace_bytes, uint32_t* positions_out, uint64_t* keys_out, uint32_t* bag_out,
                                      int* row_bits_out, int64_t* err, void* stream) {
-    if (T <= 0 || T > DLRM_MAX_TABLES_PER_LAUNCH || B <= 0 || !rows_host || !indices_host || !offsets_host || !nnz_host) return DLRM_E_ARG;
-    if ((positions_out == nullptr) != (keys_out == nullptr)) return DLRM_E_ARG;
+    if (T <= 0 || T > DLRM_MAX_TABLES_PER_LAUNCH || B <= 0 || !rows_host || !indices_host || !offsets_host || !nnz_host || !positions_out ||
+        !keys_out)
+        return DLRM_E_ARG;
     if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
     hipStream_t st = (hipStream_t)stream;
     int ids[DLRM_MAX_TABLES_PER_LAUNCH];
@@ -256,7 +257,6 @@ extern "C" int dlrm_emb_sort_lookups(int T, int64_t B, const int64_t* rows_host,
               : expand_and_sort<unsigned>(T, ids, B, wfake, rows_host, indices_host, offsets_host, nnz_host, nullptr, idx_bits, ws, lo, L, row_bits,
                                           key_bits, st, &sa, err);
     if (rc) return rc;
-    if (!positions_out) return 0;        // pre-sort only: the workspace is handed to dlrm_emb_bwd_sgd(DLRM_UPD_PRESORTED) as it is
     hipError_t e = hipMemcpyAsync(positions_out, ws + lo.vals_out, L * 4, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess && bag_out) e = hipMemcpyAsync(bag_out, ws + lo.bag_of, L * 4, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return (int)e;
@@ -271,9 +271,8 @@ int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_ho
                                  const void* const* indices_host, const void* const* offsets_host,
                                  const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
                                  const float* dout, int64_t dout_ld, float lr, void* workspace,
-                                 int64_t workspace_bytes, int64_t* err, void* stream, bool presorted) {
+                                 int64_t workspace_bytes, int64_t* err, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (presorted && T > DLRM_MAX_TABLES_PER_LAUNCH) return DLRM_E_RANGE;      // (one launch group: the workspace holds one sorted list)
     bool vec_ok = dlrm_aligned16(dout) && (dout_ld % 4 == 0);
     for (int t = 0; t < T; ++t) vec_ok = vec_ok && dlrm_aligned16(weight_host[t]);
     for (int t0 = 0; t0 < T; t0 += DLRM_MAX_TABLES_PER_LAUNCH) {
@@ -301,9 +300,9 @@ int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_ho
         }
         rc = wide ? run_sorted<unsigned long long>(n, ids, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host,
                                                    psw_host, idx_bits, dout, dout_ld, -lr, (char*)workspace, lo, L, row_bits,
-                                                   key_bits, vec_ok, st, err, presorted)
+                                                   key_bits, vec_ok, st, err)
                   : run_sorted<unsigned>(n, ids, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host,
-                                         idx_bits, dout, dout_ld, -lr, (char*)workspace, lo, L, row_bits, key_bits, vec_ok, st, err, presorted);
+                                         idx_bits, dout, dout_ld, -lr, (char*)workspace, lo, L, row_bits, key_bits, vec_ok, st, err);
         if (rc) return rc;
     }
     return 0;

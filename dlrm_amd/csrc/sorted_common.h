@@ -162,7 +162,7 @@ template <typename KT>
 static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight_host, const int64_t* rows_host,
                            const void* const* indices_host, const void* const* offsets_host, const int64_t* nnz_host,
                            const void* const* psw_host, int idx_bits, char* ws, const Layout& lo, size_t L, int row_bits,
-                           int key_bits, hipStream_t st, SortedArgs* sa_out, int64_t* err, bool presorted = false) {
+                           int key_bits, hipStream_t st, SortedArgs* sa_out, int64_t* err) {
     EmbArgs a;
     a.err = (long long*)err;
     SortedArgs& sa = *sa_out;
@@ -175,9 +175,6 @@ static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight
         sa.w[k] = a.w[k]; sa.psw[k] = a.psw[k]; sa.slot[k] = t; sa.base[k] = base;
         if (k < n) base += nnz_host[t];
     }
-    // presorted: `ws` already holds keys_out / vals_out / bag_of for exactly these lookups (dlrm_emb_sort_lookups ran earlier, e.g. on a
-    // side stream beside the forward / backward GEMMs): only the kernel arguments are filled in
-    if (presorted) return 0;
     KT* keys_in = (KT*)(ws + lo.keys_in);
     KT* keys_out = (KT*)(ws + lo.keys_out);
     unsigned* vals_in = (unsigned*)(ws + lo.vals_in);

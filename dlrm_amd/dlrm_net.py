@@ -208,10 +208,6 @@ class DLRM_Net(nn.Module):
         # buffer is never written or re-read.  Bit-identical results, but measured slower than the two kernels in this round
         # (profiles/r03/ceilings.md), hence off by default.
         self.fuse_emb_interact = os.environ.get("DLRM_FUSE_EMB_INTERACT", "0") == "1"
-        # DLRM_PRESORT=1 (experiment): the (table, row) sort of the sorted fused update depends on the indices only — it is issued on the
-        # side stream right after the lookups of the forward pass (ops.emb_presort) and runs beside the interaction / top-MLP kernels; the
-        # update then consumes the sorted list (DLRM_UPD_PRESORTED).  Same result.
-        self.presort_lookups = os.environ.get("DLRM_PRESORT", "0") == "1"
         self._bound_optimizer = None        # weakref to the optimizer that owns the tables (learnt at its first step)
         self._side_keep: list = []          # tensors the side stream still reads (released at the join)
         # > 1: the pooled-embedding all-to-all of the distributed forward is pipelined in that many batch chunks (opt-in)
@@ -322,18 +318,7 @@ class DLRM_Net(nn.Module):
         """[B, T*D] pooled embeddings of all given tables, one kernel launch."""
         bags = self._bags(lS_o, lS_i, v_W_l)
         ws = self._emb_weights(emb_l)
-        out = EmbeddingBagsFunction.apply(self._stash_embedding_grad, bags, out_slot, *ws, *self._pool_weights(v_W_l, ws[0].device))
-        if (self.presort_lookups and self.fused_emb_update and self.emb_update_mode == ops.UPD_SORTED and torch.is_grad_enabled()
-                and ws[0].is_cuda and ws[0].requires_grad):
-            dev = ws[0].device
-            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-            if main != side:
-                ops.timer_mark()
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    ops.emb_presort(ws, bags)
-                ops.timer_mark()
-        return out
+        return EmbeddingBagsFunction.apply(self._stash_embedding_grad, bags, out_slot, *ws, *self._pool_weights(v_W_l, ws[0].device))
 
     def apply_emb(self, lS_o, lS_i, emb_l, v_W_l):
         """Reference-shaped result: a list with one [B, D] tensor per table (dlrm_s_pytorch.py:407-462)."""

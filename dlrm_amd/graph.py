@@ -104,7 +104,6 @@ class GraphedTrainStep:
         # the captured step is single-stream: a replayed graph has no launch gaps to hide, and the side-stream overlap
         # of the eager path (DLRM_Net.overlap_streams) would put cross-stream joins into the capture
         model.overlap_streams = False
-        model.presort_lookups = False        # (a side-stream pre-sort would put cross-stream joins into the capture as well)
         self.warmup = max(int(warmup), 1)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.stream: Optional[torch.cuda.Stream] = None

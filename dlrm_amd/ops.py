@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, UPD_ATOMIC, UPD_DETERMINISTIC, UPD_PRESORTED, UPD_SORTED  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED  # noqa: F401
 
 
 def _stream(t: Optional[torch.Tensor] = None) -> C.c_void_p:
@@ -186,7 +186,6 @@ class BagBatch:
         if len(lS_o) != T:
             raise RuntimeError("dlrm_amd: offsets / indices table counts differ")
         self.T = T
-        self.presorted = None     # (workspace, event) of emb_presort: consumed by the sorted fused update of these bags
         self.ignore_oob = False   # True: out-of-range ids are expected (row-wise shards: ids of other ranks' rows) — skipped, not reported
         self.keep = []  # keep tensors alive while kernels may still read them
         if isinstance(lS_i, torch.Tensor) and isinstance(lS_o, torch.Tensor) and lS_i.dim() == 2 and lS_o.dim() == 2:
@@ -368,30 +367,6 @@ def sort_lookups(rows: Sequence[int], bags: BagBatch):
     return pos.long() & 0xFFFFFFFF, keys, bag_of.long(), rb.value
 
 
-def emb_presort(weights: Sequence[torch.Tensor], bags: BagBatch) -> bool:
-    """Run the (table, row) sort of these bags NOW, on the current stream, into a workspace of its own (dlrm_emb_sort_lookups without
-    outputs); the sorted SGD update of the same bags later consumes it (DLRM_UPD_PRESORTED) after waiting for the recorded event.
-    The sort depends on the indices only: DLRM_Net issues it on the side stream during the forward pass, where its ~0.14 ms of small
-    latency-bound kernels run beside the GEMMs instead of on the critical path of the update.  False when not applicable."""
-    if bags.T > 32 or bags.presorted is not None or bags.ignore_oob:
-        return False
-    lib = _lib.load()
-    _, _, rows = _weights_desc(weights)
-    need = lib.dlrm_emb_bwd_workspace_bytes(bags.T, bags._nnz, rows)
-    if need <= 0:
-        return False
-    dev = weights[0].device
-    ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
-    with _timed("emb_presort"):
-        rc = lib.dlrm_emb_sort_lookups(bags.T, bags.B, rows, bags._idx, bags._off, bags._nnz, bags.idx_bits, C.c_void_p(ws.data_ptr()),
-                                       ws.numel(), None, None, None, None, C.c_void_p(_err_block(dev).data_ptr()), _stream(ws))
-    _lib.check(rc, "dlrm_emb_sort_lookups")
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
-    bags.presorted = (ws, ev)
-    return True
-
-
 def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Tensor, lr: float,
                 mode: int = UPD_SORTED) -> None:
     """Fused EmbeddingBag backward + sparse SGD: W_t[idx] -= lr * dout[bag, t*D:(t+1)*D] (in place)."""
@@ -401,14 +376,7 @@ def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Ten
     if dout.size(0) != bags.B or dout.size(1) < bags.T * D or len(weights) != bags.T:
         raise RuntimeError("dlrm_amd: emb_bwd_sgd shape mismatch")
     ws_ptr, ws_bytes = None, 0
-    if mode == UPD_SORTED and bags.presorted is not None:
-        ws, ev = bags.presorted                       # sorted earlier (emb_presort): wait for it, consume it, release it
-        bags.presorted = None
-        torch.cuda.current_stream(dout.device).wait_event(ev)
-        ws.record_stream(torch.cuda.current_stream(dout.device))
-        mode = UPD_PRESORTED
-        ws_ptr, ws_bytes = C.c_void_p(ws.data_ptr()), ws.numel()
-    elif mode == UPD_SORTED:
+    if mode == UPD_SORTED:
         need = lib.dlrm_emb_bwd_workspace_bytes(bags.T, bags._nnz, rows)
         if need < 0:
             raise RuntimeError("dlrm_amd: dlrm_emb_bwd_workspace_bytes failed")

@@ -44,8 +44,6 @@ extern "C" {
 /* embedding-update modes */
 #define DLRM_UPD_ATOMIC        0  /* fast: LDS pre-reduction for tiny tables + HW fp32 atomics */
 #define DLRM_UPD_DETERMINISTIC 1  /* exact: per-row in-input-order FMA chain (bit-exact vs torch sparse SGD) */
-#define DLRM_UPD_PRESORTED     3  /* DLRM_UPD_SORTED on a workspace that dlrm_emb_sort_lookups (outputs NULL) already filled for exactly these lookups:
-                                     the sort depends on the indices only and can run early, beside other work (T <= 32) */
 #define DLRM_UPD_SORTED        2  /* fast: lookups radix-sorted by (table,row), plain read-modify-write per row run;
                                      needs workspace (dlrm_emb_bwd_workspace_bytes); atomics only where a run straddles chunks */
 
@@ -96,9 +94,7 @@ int64_t dlrm_emb_bwd_workspace_bytes(int T, const int64_t* nnz_host, const int64
 int     dlrm_emb_sort_kind(int T, const int64_t* nnz_host, const int64_t* rows_host);
 /* The sort itself (one launch group, T <= 32): positions_out[j] = global lookup position (table-major) of the j-th entry in
  * (table, row) order, equal rows in input order; keys_out[j] = table << *row_bits_out | row; bag_out[p] (nullable) = bag of position p
- * (0xFFFFFFFF: skipped out-of-range lookup).  workspace as dlrm_emb_bwd_workspace_bytes.  For tests and tools — and, with
- * positions_out = keys_out = bag_out = NULL, the PRE-SORT: the workspace then holds the sorted list for dlrm_emb_bwd_sgd(mode =
- * DLRM_UPD_PRESORTED) on the same lookups. */
+ * (0xFFFFFFFF: skipped out-of-range lookup).  workspace as dlrm_emb_bwd_workspace_bytes.  For tests and tools. */
 int     dlrm_emb_sort_lookups(int T, int64_t B, const int64_t* rows_host, const void* const* indices_host,
                               const void* const* offsets_host, const int64_t* nnz_host, int idx_bits, void* workspace,
                               int64_t workspace_bytes, uint32_t* positions_out, uint64_t* keys_out, uint32_t* bag_out,

@@ -274,15 +274,6 @@ def test_terabyte_full_batch_matches_reference_golden(arith, overlap, fuse):
     assert len(rel) == 3 and max(rel) <= 1e-5, rel
 
 
-def test_presorted_lookups_on_the_side_stream_match_reference_golden(monkeypatch):
-    """DLRM_PRESORT=1: the lookup sort of the sorted fused update issued during the forward pass on the side stream (ops.emb_presort) and
-    consumed by the update (DLRM_UPD_PRESORTED) — same 3 reference steps at the full batch, same bars (every check of run_on_gpu)."""
-    import golden_tb
-    monkeypatch.setenv("DLRM_PRESORT", "1")
-    rel = golden_tb.run_on_gpu(torch.device("cuda:0"))
-    assert max(rel) <= 1e-5, rel
-
-
 def test_terabyte_full_batch_hbm_resident_tables_match_reference_golden():
     """the same 3 reference training steps at B = 65536 with the seven big tables capped at 4 M rows instead of
     2000 (fixture terabyte_b65536_cap4m: 14.5 GB of tables, 22-bit row keys, rows looked up 0-3 times per batch) — the sorted
