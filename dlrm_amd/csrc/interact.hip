@@ -44,10 +44,9 @@ struct FeatArgs {
 // "gather" mode of the D = 128 kernels: a feature whose idx[f] != NULL is NOT a [B, D] matrix but a one-hot EmbeddingBag —
 // row b of the feature is table row idx[f][b] (p[f] = table base, ld[f] = D).  The pooled-embedding buffer between
 // dlrm_emb_fwd and the interaction (a 852 MB write + 852 MB read at Criteo-Terabyte shapes) then never exists.
-// MEASURED (profiles/r03/ceilings.md): bit-identical, but SLOWER than the two kernels — forward 0.64 ms vs 0.30 + 0.24, backward
-// 0.87 vs 0.38: one sample per wave in flight is enough for the plain interaction (13.8 KB contiguous per sample) and far too
-// little for 26 random 512-byte rows out of 96 GB (DRAM row + TLB misses; dlrm_emb_fwd hides them with 8 waves per SIMD x 4 bags).
-// Opt-in (DLRM_Net.fuse_emb_interact) until the gather gets a deeper software pipeline.
+// Round 2's version was SLOWER than the two kernels (forward 0.64 ms vs 0.30 + 0.24, backward 0.87 vs 0.38): its row selectors came in
+// through ordinary loads, whose first use drains the whole VM queue beside an LDS-DMA in flight.  They now arrive by LDS-DMA themselves,
+// three samples ahead (see "gather mode" below).
 struct GatherArgs {
     const void* idx[DLRM_MAX_FEATURES];     // NULL: plain feature matrix
     const void* off[DLRM_MAX_FEATURES];     // bag starts of that table: verified to be 0, 1, 2, ... (one lookup per bag)
@@ -331,71 +330,82 @@ __device__ __forceinline__ void dma_issue(DmaPlan& pl, unsigned lds_img) {
     }
 }
 
-// gather mode: per lane and DMA chunk, the byte address of "row selector 0" and the byte stride per selector; the selector
-// of sample b is b itself for a plain feature and idx[f][b] for a gathered one
+// ---- gather mode -------------------------------------------------------------------------------------------------------
+// The row selector of feature f for sample b is b itself for a plain feature and idx[f][b] for a gathered one.  Selectors never
+// travel through registers on their way in: an ordinary global_load beside an LDS-DMA in flight makes the compiler drain the
+// whole VM queue at its first use (round 2's version did exactly that: 0.64 ms for the fused forward).  Lane l of ONE
+// `global_load_lds_dword` fetches the low (l < 32) or high (l >= 32) dword of idx[l & 31][b] into a 256-byte LDS slot, a second
+// one the bag start off[l & 31][b] (verified to equal b: one lookup per bag); both are issued three samples ahead, so by the
+// time a sample's rows are addressed its selectors are older than everything the counted wait leaves in flight.
+constexpr int GSEL_SLOT = 512;                          // idx dwords [64] | off dwords [64]
+constexpr int GSEL_WAVE_BYTES = 3 * GSEL_SLOT;          // ring of three samples per wave
+constexpr int GDR_BYTES = 2048;                         // dR row image in gather mode (dlrm_interact_gather_ok bounds the row)
+
+__device__ __forceinline__ void glds4_v(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 template <int NI>
-struct GatherPlan {
-    const char* base[NI];
-    unsigned stride[NI];
+struct GatherCtx {
+    const char* base[NI];        // per DMA chunk: byte address of selector 0 of this lane's row, incl. the lane's swizzled 16 bytes
+    unsigned stride[NI];         // bytes per selector
     bool on[NI];
+    const char* qsrc;            // this lane's dword of idx[lane & 31][0] / off[lane & 31][0]
+    const char* osrc;
+    long long rows;              // of feature lane & 31; < 0: plain feature (selector = the sample number) or no feature
+    int esz;                     // bytes per index
 };
 
 template <int NI>
-__device__ __forceinline__ void gather_plan_init(GatherPlan<NI>& gp, const long long* tp, const long long* tl, int F, int lane) {
+__device__ __forceinline__ void gather_ctx_init(GatherCtx<NI>& gc, const long long* tp, const long long* tl, const long long* tq,
+                                                const long long* to, const long long* tr, int F, int lane, int idx_bits) {
 #pragma unroll
     for (int c = 0; c < NI; ++c) {
         const int row = 2 * c + (lane >> 5);
         const int quad = (lane & 31) ^ (row & 15);
-        gp.on[c] = row < F;
-        const int rr = gp.on[c] ? row : 0;
-        gp.base[c] = (const char*)tp[rr] + 16 * quad;
-        gp.stride[c] = (unsigned)(tl[rr] * 4);
+        gc.on[c] = row < F;
+        const int rr = gc.on[c] ? row : 0;
+        gc.base[c] = (const char*)tp[rr] + 16 * quad;
+        gc.stride[c] = (unsigned)(tl[rr] * 4);
     }
+    const int f = lane & 31, ff = f < F ? f : 0;
+    const int hi = (idx_bits == 64) ? 4 * (lane >> 5) : 0;
+    gc.qsrc = (const char*)tq[ff] + hi;
+    gc.osrc = (const char*)to[ff] + hi;
+    gc.rows = f < F ? tr[f] : -1;
+    gc.esz = idx_bits >> 3;
 }
 
-// row selectors of sample b for this lane's chunks: ONLY the loads (index + bag start; wave-half-uniform addresses, served as
-// broadcasts) — nothing here may consume them, or the compiler's wait would also drain the DMA issued just before
+// selectors of sample s (any s < B: the caller clamps look-ahead past the end) -> LDS slot; two VM operations
 template <int NI>
-__device__ __forceinline__ void gather_fetch(long long (&sel)[NI], long long (&chk)[NI], const long long* tq, const long long* to,
-                                             int F, int lane, long long b, int idx_bits) {
-    // unconditional loads (plain features carry a valid dummy index pointer, see fill_gather); 32-bit values are kept as raw
-    // zero-extended bits — sign extension would be a USE of the loaded register and stall right here
-    typedef __attribute__((address_space(1))) long long gll;
-    typedef __attribute__((address_space(1))) unsigned guint;
-    if (idx_bits == 64) {
-#pragma unroll
-        for (int c = 0; c < NI; ++c) {
-            const int row = 2 * c + (lane >> 5), rr = row < F ? row : 0;
-            sel[c] = ((const gll*)tq[rr])[b]; chk[c] = ((const gll*)to[rr])[b];
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < NI; ++c) {
-            const int row = 2 * c + (lane >> 5), rr = row < F ? row : 0;
-            sel[c] = (long long)((const guint*)tq[rr])[b]; chk[c] = (long long)((const guint*)to[rr])[b];
-        }
-    }
+__device__ __forceinline__ void gather_sel_issue(const GatherCtx<NI>& gc, long long s, unsigned slot_lds) {
+    glds4_v(gc.qsrc + s * gc.esz, slot_lds);
+    glds4_v(gc.osrc + s * gc.esz, slot_lds + 256);
 }
 
-// issue the DMA of sample b from its (by now loaded) selectors.  Verifies the one-hot layout (bag start of b == b) and the index
-// range; a violation is reported and row 0 is read instead.
+// rows of sample s from its (landed) selector slot -> image; NI VM operations.  Verifies the one-lookup-per-bag layout and the
+// index range in the lane that owns the feature; a violation is reported and row 0 is read instead.
 template <int NI>
-__device__ __forceinline__ void gather_issue(const GatherPlan<NI>& gp, const long long (&sel)[NI], const long long (&chk)[NI],
-                                             const long long* tr, int lane, long long b, int idx_bits, long long* err,
-                                             unsigned lds_img) {
+__device__ __forceinline__ void gather_rows_issue(const GatherCtx<NI>& gc, const char* slot, long long s, int lane, int idx_bits,
+                                                  long long* err, unsigned img_lds) {
+    const int f = lane & 31;
+    const unsigned lo = *(const unsigned*)(slot + 4 * f), hi = *(const unsigned*)(slot + 128 + 4 * f);
+    const unsigned olo = *(const unsigned*)(slot + 256 + 4 * f), ohi = *(const unsigned*)(slot + 384 + 4 * f);
+    unsigned idu = (unsigned)s;
+    if (gc.rows >= 0) {
+        long long id = idx_bits == 64 ? (long long)(((unsigned long long)hi << 32) | lo) : (long long)(int)lo;
+        const long long o = idx_bits == 64 ? (long long)(((unsigned long long)ohi << 32) | olo) : (long long)(int)olo;
+        if (o != s) dlrm_report_bad_index(err, f - 1, -(o + 1), -1);                    // not a one-lookup-per-bag batch (rows = -1 marks it)
+        if (!dlrm_index_ok(id, gc.rows)) { dlrm_report_bad_index(err, f - 1, id, gc.rows); id = 0; }
+        idu = (unsigned)id;
+    }
 #pragma unroll
     for (int c = 0; c < NI; ++c) {
-        if (!gp.on[c]) continue;
-        const int row = 2 * c + (lane >> 5);
-        const long long rows = tr[row];                          // < 0: plain feature (selector = the sample number)
-        long long id = b;
-        if (rows >= 0) {
-            id = idx_bits == 64 ? sel[c] : (long long)(int)sel[c];
-            const long long o = idx_bits == 64 ? chk[c] : (long long)(int)chk[c];
-            if (o != b) dlrm_report_bad_index(err, row - 1, -(o + 1), -1);               // not a one-lookup-per-bag batch (rows = -1 marks it)
-            if (!dlrm_index_ok(id, rows)) { dlrm_report_bad_index(err, row - 1, id, rows); id = 0; }
-        }
-        glds16_v(gp.base[c] + id * (long long)gp.stride[c], lds_img + c * 1024);
+        const unsigned a = __builtin_amdgcn_readlane(idu, 2 * c), b2 = __builtin_amdgcn_readlane(idu, (2 * c + 1) & 31);
+        const unsigned mine = (lane >> 5) ? b2 : a;
+        if (gc.on[c]) glds16_v(gc.base[c] + (unsigned long long)mine * gc.stride[c], img_lds + c * 1024);
     }
 }
 
@@ -422,13 +432,21 @@ __global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, Gath
     long long b = (long long)blockIdx.x * 4 + wave;
     if (b >= B) return;
     DmaPlan pl;
-    GatherPlan<NI> gp;
-    long long sel[NI], chk[NI];
+    GatherCtx<NI> gc;
+    // gather mode: the wave's ring of three selector slots lives behind the images
+    const char* sel0 = (const char*)(tr + DLRM_MAX_FEATURES) + (size_t)4 * 2 * IDMA_IMG + (size_t)wave * GSEL_WAVE_BYTES;
+    const unsigned sel0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)sel0;
+    int sl = 0;                                             // slot of the current sample's selectors
     if constexpr (GATHER) {
-        gather_plan_init<NI>(gp, tp, tl, F, lane);
-        gather_fetch<NI>(sel, chk, tq, to, F, lane, b, ga.idx_bits);
-        gather_issue<NI>(gp, sel, chk, tr, lane, b, ga.idx_bits, ga.err, img0_lds);
-        if (b + b_stride < B) gather_fetch<NI>(sel, chk, tq, to, F, lane, b + b_stride, ga.idx_bits);
+        gather_ctx_init<NI>(gc, tp, tl, tq, to, tr, F, lane, ga.idx_bits);
+        const long long last = B - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const long long s = b + k * b_stride;
+            gather_sel_issue<NI>(gc, s < B ? s : last, sel0_lds + k * GSEL_SLOT);
+        }
+        wait_vmcnt_i<0>();
+        gather_rows_issue<NI>(gc, sel0, b, lane, ga.idx_bits, ga.err, img0_lds);
     } else {
         dma_plan_init(pl, tp, tl, F, lane, b, b_stride);
     }
@@ -441,13 +459,17 @@ __global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, Gath
     for (; b < B; b += b_stride) {
         const bool more = b + b_stride < B;
         if constexpr (GATHER) {
-            // everything issued so far has landed: this sample's rows (DMA) and the NEXT sample's row selectors (registers);
-            // the next sample's rows go out now and stay in flight while this one is multiplied, the selectors after it follow
-            wait_vmcnt_i<0>();
+            // the next sample's selectors landed with the previous wait (they are older than the rows it retired): its rows go out
+            // now, the selectors three samples ahead take the slot this sample's selectors just left, and the counted wait leaves
+            // exactly those NI + 2 operations in flight while this sample is multiplied
             if (more) {
-                gather_issue<NI>(gp, sel, chk, tr, lane, b + b_stride, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IDMA_IMG);
-                if (b + 2 * b_stride < B) gather_fetch<NI>(sel, chk, tq, to, F, lane, b + 2 * b_stride, ga.idx_bits);
-            }
+                const int sl1 = sl == 2 ? 0 : sl + 1;
+                gather_rows_issue<NI>(gc, sel0 + sl1 * GSEL_SLOT, b + b_stride, lane, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IDMA_IMG);
+                const long long s3 = b + 3 * b_stride;
+                gather_sel_issue<NI>(gc, s3 < B ? s3 : B - 1, sel0_lds + sl * GSEL_SLOT);
+                wait_vmcnt_i<NI + 2>();
+                sl = sl1;
+            } else wait_vmcnt_i<0>();
         } else {
             if (more) { dma_issue<NI>(pl, img0_lds + (cur ^ 1) * IDMA_IMG); wait_vmcnt_i<NI>(); }
             else wait_vmcnt_i<0>();
@@ -511,24 +533,27 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
     long long* tq = dl + DLRM_MAX_FEATURES;                 // gather mode only
     long long* to = tq + DLRM_MAX_FEATURES;
     long long* tr = to + DLRM_MAX_FEATURES;
-    char* img0 = (char*)(tr + DLRM_MAX_FEATURES) + (size_t)wave * (2 * IDMA_IMG + 2 * IDMA_DR_BYTES);
+    constexpr int DRB = GATHER ? GDR_BYTES : IDMA_DR_BYTES;      // dR row image
+    char* img0 = (char*)(tr + DLRM_MAX_FEATURES) + (size_t)wave * (2 * IDMA_IMG + 2 * DRB);
     char* drow0 = img0 + 2 * IDMA_IMG;
     const unsigned img0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)img0;
     const unsigned drow0_lds = img0_lds + 2 * IDMA_IMG;
+    // gather mode: the wave's ring of three selector slots lives behind all the images
+    const char* sel0 = (const char*)(tr + DLRM_MAX_FEATURES) + (size_t)4 * (2 * IDMA_IMG + 2 * DRB) + (size_t)wave * GSEL_WAVE_BYTES;
+    const unsigned sel0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)sel0;
 
     table_to_lds(fa, tp, tl, F);
     table_to_lds(da, dp, dl, F);
     if constexpr (GATHER) gather_to_lds(ga, tq, to, tr, F);
-    for (int e = lane; e < (2 * IDMA_IMG + 2 * IDMA_DR_BYTES) / 16; e += 64) ((float4*)img0)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = lane; e < (2 * IDMA_IMG + 2 * DRB) / 16; e += 64) ((float4*)img0)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
     const long long b_stride = (long long)gridDim.x * 4;
     long long b = (long long)blockIdx.x * 4 + wave;
     if (b >= B) return;
     DmaPlan pl;
-    GatherPlan<NI> gp;
-    long long sel[NI], chk[NI];
-    if constexpr (GATHER) gather_plan_init<NI>(gp, tp, tl, F, lane);
+    GatherCtx<NI> gc;
+    if constexpr (GATHER) gather_ctx_init<NI>(gc, tp, tl, tq, to, tr, F, lane, ga.idx_bits);
     else dma_plan_init(pl, tp, tl, F, lane, b, b_stride);
     // dR row: lane covers bytes [1024*c + 16*lane, +16) of the row, c < nr; lanes past the row pitch are masked
     const int nr = __builtin_amdgcn_readfirstlane((int)((ldr * 4 + 1023) / 1024));
@@ -572,11 +597,16 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
             ostep[r][q] = b_stride * dl[ii] * 4;
         }
 
-    int cur = 0;
+    int cur = 0, sl = 0;
     if constexpr (GATHER) {
-        gather_fetch<NI>(sel, chk, tq, to, F, lane, b, ga.idx_bits);
-        gather_issue<NI>(gp, sel, chk, tr, lane, b, ga.idx_bits, ga.err, img0_lds);
-        if (b + b_stride < B) gather_fetch<NI>(sel, chk, tq, to, F, lane, b + b_stride, ga.idx_bits);
+        const long long last = B - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const long long s = b + k * b_stride;
+            gather_sel_issue<NI>(gc, s < B ? s : last, sel0_lds + k * GSEL_SLOT);
+        }
+        wait_vmcnt_i<0>();
+        gather_rows_issue<NI>(gc, sel0, b, lane, ga.idx_bits, ga.err, img0_lds);
     } else {
         dma_issue<NI>(pl, img0_lds);
     }
@@ -584,19 +614,24 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
     for (; b < B; b += b_stride) {
         const bool more = b + b_stride < B;
         if constexpr (GATHER) {
-            wait_vmcnt_i<0>();         // this sample's rows + dR row have landed, so have the next sample's row selectors
+            // same schedule as the forward kernel: rows + dR row of the next sample and the selectors three samples ahead stay in
+            // flight (NI + nr + 2 operations) while this sample is multiplied
             if (more) {
-                gather_issue<NI>(gp, sel, chk, tr, lane, b + b_stride, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IDMA_IMG);
-                issue_dr(drow0_lds + (cur ^ 1) * IDMA_DR_BYTES);
-                if (b + 2 * b_stride < B) gather_fetch<NI>(sel, chk, tq, to, F, lane, b + 2 * b_stride, ga.idx_bits);
-            }
+                const int sl1 = sl == 2 ? 0 : sl + 1;
+                gather_rows_issue<NI>(gc, sel0 + sl1 * GSEL_SLOT, b + b_stride, lane, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IDMA_IMG);
+                issue_dr(drow0_lds + (cur ^ 1) * DRB);
+                const long long s3 = b + 3 * b_stride;
+                gather_sel_issue<NI>(gc, s3 < B ? s3 : B - 1, sel0_lds + sl * GSEL_SLOT);
+                wait_vmcnt_rt(NI + nr + 2);
+                sl = sl1;
+            } else wait_vmcnt_i<0>();
         } else if (more) {
             dma_issue<NI>(pl, img0_lds + (cur ^ 1) * IDMA_IMG);
-            issue_dr(drow0_lds + (cur ^ 1) * IDMA_DR_BYTES);
+            issue_dr(drow0_lds + (cur ^ 1) * DRB);
             wait_vmcnt_rt(NI + nr);
         } else wait_vmcnt_i<0>();
         const char* my = img0 + cur * IDMA_IMG;
-        const char* dr = drow0 + cur * IDMA_DR_BYTES;
+        const char* dr = drow0 + cur * DRB;
         float aS[NB][4 * NB];
 #pragma unroll
         for (int r = 0; r < NB; ++r)
@@ -683,13 +718,17 @@ static int fill_gather(GatherArgs& ga, int F, const void* const* gidx, const voi
     for (int f = 0; f < DLRM_MAX_FEATURES; ++f) {
         const bool g = gidx && f < F && gidx[f];
         if (g && (!goff || !goff[f] || !grows || grows[f] <= 0)) return DLRM_E_ARG;
+        if (g && grows[f] > 0xFFFFFFFFLL) return DLRM_E_RANGE;          // row selectors travel as 32-bit values inside the kernels
         // plain features: a valid dummy pointer (their loads are unconditional and ignored) and rows = -1
         ga.idx[f] = g ? gidx[f] : any_idx; ga.off[f] = g ? goff[f] : any_off; ga.rows[f] = g ? grows[f] : -1;
     }
     return 0;
 }
 
-extern "C" int dlrm_interact_gather_ok(int F, int D) { return (D == IDMA_D && F >= 1 && F <= IDMA_ROWS) ? 1 : 0; }
+// F <= 27: the dR row (D + F (F + 1) / 2 floats with self pairs, padded to 4) must fit the 2 KiB image of the gather backward
+extern "C" int dlrm_interact_gather_ok(int F, int D) {
+    return (D == IDMA_D && F >= 1 && F <= IDMA_ROWS && 4 * ((IDMA_D + F * (F + 1) / 2 + 3) & ~3) <= GDR_BYTES) ? 1 : 0;
+}
 
 static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
                              const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
@@ -731,8 +770,8 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
     rc = fill_gather(ga, F, gidx, goff, grows, idx_bits, err);
     if (rc) return rc;
     if (gidx) {          // gathered features exist only in the D = 128 LDS-DMA kernel
-        if (!(D == IDMA_D && F <= IDMA_ROWS && vec && dlrm_aligned16(R) && ldr % 4 == 0)) return DLRM_E_MODE;
-        const size_t lds = 5 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * 2 * (size_t)IDMA_IMG;
+        if (!(dlrm_interact_gather_ok(F, D) && vec && dlrm_aligned16(R) && ldr % 4 == 0)) return DLRM_E_MODE;
+        const size_t lds = 5 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * 2 * (size_t)IDMA_IMG + 4 * (size_t)GSEL_WAVE_BYTES;
         int64_t nb = (B + 3) / 4; if (nb > 256) nb = 256;
         const int ni = (F + 1) / 2;
 #define FWD_G(NIV)                                                                                           \
@@ -832,11 +871,13 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
         GatherArgs ga;
         rc = fill_gather(ga, F, gidx, goff, grows, idx_bits, err);
         if (rc) return rc;
-        const bool dma_path = (gidx ? (D == IDMA_D && F <= IDMA_ROWS && vec) : interact_dma_ok(F, D, vec)) && dvec && dlrm_aligned16(dR) &&
-                              ldr % 4 == 0 && ldr * 4 <= IDMA_DR_BYTES;
+        const bool dma_path = (gidx ? (dlrm_interact_gather_ok(F, D) && vec) : interact_dma_ok(F, D, vec)) && dvec && dlrm_aligned16(dR) &&
+                              ldr % 4 == 0 && ldr * 4 <= (gidx ? GDR_BYTES : IDMA_DR_BYTES);
         if (gidx && !dma_path) return DLRM_E_MODE;
         if (dma_path) {
-            const size_t lds_dma = 7 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * (2 * (size_t)IDMA_IMG + 2 * (size_t)IDMA_DR_BYTES);
+            const size_t lds_dma = 7 * DLRM_MAX_FEATURES * sizeof(long long) +
+                                   (gidx ? 4 * (2 * (size_t)IDMA_IMG + 2 * (size_t)GDR_BYTES + (size_t)GSEL_WAVE_BYTES)
+                                         : 4 * (2 * (size_t)IDMA_IMG + 2 * (size_t)IDMA_DR_BYTES));
             int64_t nb = (B + 3) / 4; if (nb > 256) nb = 256;
             const int ni = (F + 1) / 2;
 #define BWD_DMA(NIV)                                                                                         \

@@ -177,7 +177,7 @@ int dlrm_interact_bwd(int64_t B, int F, int D,
  *   offsets_host[f] : the table's bag starts; the kernels verify offsets[b] == b (one lookup per bag) — a violation, or an
  *                     index outside [0, rows_host[f]), is reported through `err` ({1, table, index, rows}; rows = -1 marks a
  *                     bag-layout violation) and row 0 is read instead.
- * Available when dlrm_interact_gather_ok(F, D) (D = 128, F <= 32, 16-byte aligned operands); otherwise DLRM_E_MODE and the
+ * Available when dlrm_interact_gather_ok(F, D) (D = 128, F <= 27, tables of < 2^32 rows, 16-byte aligned operands); otherwise DLRM_E_MODE and the
  * caller runs the two kernels.  The backward writes dfeat rows exactly like dlrm_interact_bwd (the gradient of a gathered
  * feature is the dout operand of dlrm_emb_bwd_*). */
 int dlrm_interact_gather_ok(int F, int D);

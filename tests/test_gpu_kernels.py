@@ -684,7 +684,8 @@ def test_emb_bwd_coo_is_the_reference_sparse_gradient():
 
 
 @pytest.mark.parametrize("T,B,idx_dtype,itself", [(26, 5000, torch.int64, False), (26, 4099, torch.int32, False), (3, 777, torch.int64, True),
-                                                  (31, 300, torch.int64, False), (7, 64, torch.int32, True)])
+                                                  (26, 300, torch.int64, True), (7, 64, torch.int32, True), (2, 5, torch.int64, False),
+                                                  (26, 65536, torch.int64, False)])
 def test_gather_interaction_is_bit_identical_to_the_two_kernels(T, B, idx_dtype, itself):
     """dlrm_interact_fwd_gather / _bwd_gather (one lookup per bag, D = 128: the interaction kernel fetches the embedding rows
     itself) against dlrm_emb_fwd + dlrm_interact_fwd / _bwd: the SAME bits for R, dx and the embedding-row gradients; a
@@ -718,7 +719,7 @@ def test_gather_interaction_is_bit_identical_to_the_two_kernels(T, B, idx_dtype,
     assert torch.equal(d0[:, :D], dx) and torch.equal(d0[:, D:], dE)
     ops.check_index_errors(sync=True)
     # violations are reported
-    bad_off = off.clone(); bad_off[T - 1, 5] = 4
+    bad_off = off.clone(); bad_off[T - 1, min(5, B - 1)] = min(5, B - 1) - 1
     ops.interact_fwd_gather(x, Ws, ops.BagBatch(bad_off, idx), D, itself, R1)
     with pytest.raises(IndexError, match="one-lookup-per-bag"):
         ops.check_index_errors(sync=True)
@@ -726,6 +727,12 @@ def test_gather_interaction_is_bit_identical_to_the_two_kernels(T, B, idx_dtype,
     ops.interact_fwd_gather(x, Ws, ops.BagBatch(off, bad_idx), D, itself, R1)
     with pytest.raises(IndexError, match="out of range"):
         ops.check_index_errors(sync=True)
+    if idx_dtype == torch.int64:                       # the selectors travel as two dwords: the high one counts
+        bad_idx = idx.clone(); bad_idx[T - 1, B - 1] = (1 << 32) + 1
+        ops.interact_bwd_gather(x, Ws, ops.BagBatch(off, bad_idx), D, itself, dR, dx, dE)
+        with pytest.raises(IndexError, match="out of range"):
+            ops.check_index_errors(sync=True)
+    assert not ops.gather_ok(29, 128) and ops.gather_ok(27, 128)      # the dR row of F > 27 (with self pairs) exceeds the gather backward's image
 
 
 # ------------------------------------------------------------------------------------------ config 5 inputs: Multihot
