@@ -81,10 +81,13 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-alt-overlap", action="store_true", help="do not also measure the 2-stream schedule (profiling runs: keeps the "
                                                                     "rocprofv3 / PMC statistics to the single-stream headline steps)")
-    ap.add_argument("--fuse", action="store_true",
-                    help="N = 1, one lookup per bag, D = 128: the interaction kernels fetch the embedding rows themselves and the "
-                         "pooled-embedding buffer never exists (DLRM_Net.fuse_emb_interact; bit-identical results, measured slower "
-                         "than the two kernels in round 3: opt-in)")
+    ap.add_argument("--no-fuse", dest="fuse", action="store_false", default=True,
+                    help="run the embedding lookups and the interaction as two kernels.  Default (N = 1, one lookup per bag, D = 128, as "
+                         "in DLRM_Net): the interaction kernels fetch the embedding rows themselves and the pooled-embedding buffer never "
+                         "exists (DLRM_Net.fuse_emb_interact; bit-identical results); the two-kernel step is measured in the same run as "
+                         "alt_two_kernel_lookup")
+    ap.add_argument("--fuse", dest="fuse", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-alt-fuse", action="store_true", help="do not also measure the two-kernel lookup + interaction step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the pre-run check of this exact configuration against the golden fixture of the live reference")
@@ -299,6 +302,7 @@ KERNEL_SOURCES = {
     "emb_bwd_sgd": ["emb_sorted.hip", "sorted_common.h", "seg_sort.h", "common.h"],
     "emb_bwd_adagrad": ["adagrad.hip", "sorted_common.h", "seg_sort.h", "common.h"],
     "interact_fwd": ["interact.hip", "common.h"], "interact_bwd": ["interact.hip", "common.h"],
+    "emb_interact_fwd": ["interact.hip", "common.h"], "emb_interact_bwd": ["interact.hip", "common.h"],
     "linear_fwd": ["gemm.hip", "gemv.hip", "common.h"], "linear_bwd_data": ["gemm.hip", "gemv.hip", "common.h"],
     "linear_bwd_weight": ["gemm.hip", "gemv.hip", "smallk.hip", "common.h"],
 }
@@ -752,6 +756,21 @@ def main():
                                    "final_loss": float(loss_alt.detach()),
                                    "note": "opt-in (--mlp-arith bf16x6); parity-tested at the fp32 tolerances"}
         del loss_alt
+    if N == 1 and graphed is None and not hot and args.fuse and getattr(model, "fuse_emb_interact", False) and not args.no_alt_fuse:
+        # the same step with the lookups and the interaction as two kernels (rounds 1-2's forward; what multi-hot and distributed runs launch)
+        model.fuse_emb_interact = False
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss_u = step(i)
+        torch.cuda.synchronize()
+        dtu = (time.perf_counter() - t0) / args.steps
+        model.fuse_emb_interact = True
+        result["alt_two_kernel_lookup"] = {"value": B / dtu, "unit": "samples/s", "ms_per_step": dtu * 1e3, "final_loss": float(loss_u.detach()),
+                                           "note": "--no-fuse: dlrm_emb_fwd + dlrm_interact_fwd / _bwd through the pooled-embedding buffer; bit-identical results"}
+        del loss_u
     if N == 1 and graphed is None and not hot and not (args.overlap and not args.no_overlap) and not args.no_alt_overlap:
         # the same step on two HIP streams (embedding kernels beside the bottom-MLP GEMMs): beside the headline, never instead
         model.overlap_streams = True

@@ -410,7 +410,7 @@ __device__ __forceinline__ void gather_rows_issue(const GatherCtx<NI>& gc, const
 }
 
 template <int NI, bool GATHER>       // NI = ceil(F / 2)
-__global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, GatherArgs ga, long long B, int F, int self,
+__global__ __launch_bounds__(320) void interact_fwd_dma_kernel(FeatArgs fa, GatherArgs ga, long long B, int F, int self,
                                                                float* __restrict__ R, long long ldr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -420,21 +420,26 @@ __global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, Gath
     long long* tq = tl + DLRM_MAX_FEATURES;                 // gather mode only (the LDS is reserved either way)
     long long* to = tq + DLRM_MAX_FEATURES;
     long long* tr = to + DLRM_MAX_FEATURES;
-    char* img0 = (char*)(tr + DLRM_MAX_FEATURES) + (size_t)wave * 2 * IDMA_IMG;
+    // images hold 2 NI rows (not 32): five waves' double buffers fit the 160 KiB for F <= 28.  The second 16-row tile then reads up to
+    // four rows past its image — the next image or the selector slots behind the last one (always allocated): those rows only
+    // feed outputs that are never stored (i, j >= F)
+    constexpr int IMGB = 2 * NI * IDMA_D * 4;
+    const int W = __builtin_amdgcn_readfirstlane((int)(blockDim.x >> 6));
+    char* img0 = (char*)(tr + DLRM_MAX_FEATURES) + (size_t)wave * 2 * IMGB;
     const unsigned img0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)img0;
 
     table_to_lds(fa, tp, tl, F);
     if constexpr (GATHER) gather_to_lds(ga, tq, to, tr, F);
-    for (int e = lane; e < 2 * IDMA_IMG / 16; e += 64) ((float4*)img0)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = lane; e < 2 * IMGB / 16; e += 64) ((float4*)img0)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    const long long b_stride = (long long)gridDim.x * 4;
-    long long b = (long long)blockIdx.x * 4 + wave;
+    const long long b_stride = (long long)gridDim.x * W;
+    long long b = (long long)blockIdx.x * W + wave;
     if (b >= B) return;
     DmaPlan pl;
     GatherCtx<NI> gc;
     // gather mode: the wave's ring of three selector slots lives behind the images
-    const char* sel0 = (const char*)(tr + DLRM_MAX_FEATURES) + (size_t)4 * 2 * IDMA_IMG + (size_t)wave * GSEL_WAVE_BYTES;
+    const char* sel0 = (const char*)(tr + DLRM_MAX_FEATURES) + (size_t)W * 2 * IMGB + (size_t)wave * GSEL_WAVE_BYTES;
     const unsigned sel0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)sel0;
     int sl = 0;                                             // slot of the current sample's selectors
     if constexpr (GATHER) {
@@ -453,55 +458,78 @@ __global__ __launch_bounds__(256) void interact_fwd_dma_kernel(FeatArgs fa, Gath
 
     const int g = lane >> 4, li = lane & 15;
     const int P = (self & 1) ? F * (F + 1) / 2 : F * (F - 1) / 2;
-    const int NB = (F + 15) >> 4;
+    constexpr int NB = (2 * NI + 15) / 16;                  // 16-row tiles of the image (F <= 2 NI)
+    const int dbg = self >> 6;                              // timing-only switches (interact_debug)
+    // where this lane's four results of tile pair (r, c) go inside the R row (float index; -1 = not part of the output):
+    // output row i = 16 r + 4 g + q, column j = 16 c + li — a function of the lane only, computed once
+    int opos[NB * (NB + 1) / 2][4];
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 16 * r + 4 * g + q, j = 16 * c + li;
+                const bool ok = i < F && ((self & 1) ? (j <= i) : (j < i));
+                opos[r * (r + 1) / 2 + c][q] = ok ? IDMA_D + pair_pos(i, j, F, self) : -1;
+            }
+    constexpr int NPAIR = NB * (NB + 1) / 2;
     int cur = 0;
     if constexpr (!GATHER) dma_issue<NI>(pl, img0_lds);
     for (; b < B; b += b_stride) {
-        const bool more = b + b_stride < B;
+        const bool more = b + b_stride < B && !(dbg & 1);
         if constexpr (GATHER) {
             // the next sample's selectors landed with the previous wait (they are older than the rows it retired): its rows go out
             // now, the selectors three samples ahead take the slot this sample's selectors just left, and the counted wait leaves
             // exactly those NI + 2 operations in flight while this sample is multiplied
             if (more) {
                 const int sl1 = sl == 2 ? 0 : sl + 1;
-                gather_rows_issue<NI>(gc, sel0 + sl1 * GSEL_SLOT, b + b_stride, lane, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IDMA_IMG);
+                gather_rows_issue<NI>(gc, sel0 + sl1 * GSEL_SLOT, b + b_stride, lane, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IMGB);
                 const long long s3 = b + 3 * b_stride;
                 gather_sel_issue<NI>(gc, s3 < B ? s3 : B - 1, sel0_lds + sl * GSEL_SLOT);
                 wait_vmcnt_i<NI + 2>();
                 sl = sl1;
-            } else wait_vmcnt_i<0>();
+            } else if (!(dbg & 1)) wait_vmcnt_i<0>();
         } else {
-            if (more) { dma_issue<NI>(pl, img0_lds + (cur ^ 1) * IDMA_IMG); wait_vmcnt_i<NI>(); }
-            else wait_vmcnt_i<0>();
+            if (more) { dma_issue<NI>(pl, img0_lds + (cur ^ 1) * IMGB); wait_vmcnt_i<NI>(); }
+            else if (!(dbg & 1)) wait_vmcnt_i<0>();
         }
-        const char* my = img0 + cur * IDMA_IMG;
-        float* Rb = R + b * ldr;
-        for (int r = 0; r < NB; ++r) {
-            for (int c = 0; c <= r; ++c) {
-                floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                const char* ap = my + (16 * r + li) * (IDMA_D * 4);
-                const char* bp = my + (16 * c + li) * (IDMA_D * 4);
+        if (dbg & 2) { cur ^= 1; continue; }
+        const char* my = img0 + cur * IMGB;
+        // fragments of image rows li and 16 + li for the eight 16-wide k-steps: the three tile pairs of the lower triangle
+        // ((0,0), (1,0), (1,1)) multiply these two row sets with each other, so 16 ds_read_b128 feed all 96 MFMAs of the sample
+        float4 fr[NB][IDMA_D / 16];
 #pragma unroll
-                for (int s = 0; s < IDMA_D / 16; ++s) {
-                    const int q = ((4 * s + g) ^ li) * 16;      // (row & 15) == li for both operands
-                    const float4 av = *(const float4*)(ap + q);
-                    const float4 bv = *(const float4*)(bp + q);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc1, 0, 0, 0);
-                }
-                const floatx4 acc = acc0 + acc1;
-                const int j = 16 * c + li;
+        for (int r = 0; r < NB; ++r)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = 16 * r + 4 * g + q;
-                    if (i < F && ((self & 1) ? (j <= i) : (j < i))) {
-                        const int p = pair_pos(i, j, F, self);
-                        Rb[IDMA_D + p] = acc[q];
+            for (int s = 0; s < IDMA_D / 16; ++s)
+                fr[r][s] = *(const float4*)(my + (16 * r + li) * (IDMA_D * 4) + (((4 * s + g) ^ li) * 16));      // (row & 15) == li
+        // the tile pairs advance together, one k-substep at a time: consecutive MFMAs are independent, the two accumulators of a
+        // pair (even / odd substeps, summed at the end — the summation order of every version of this kernel) are three issues apart
+        floatx4 acc[NPAIR][2];
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) { acc[p][0] = (floatx4){0.f, 0.f, 0.f, 0.f}; acc[p][1] = (floatx4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < IDMA_D / 16; ++s) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int r = 0; r < NB; ++r)
+#pragma unroll
+                    for (int c = 0; c <= r; ++c) {
+                        const float av = e == 0 ? fr[r][s].x : e == 1 ? fr[r][s].y : e == 2 ? fr[r][s].z : fr[r][s].w;
+                        const float bv = e == 0 ? fr[c][s].x : e == 1 ? fr[c][s].y : e == 2 ? fr[c][s].z : fr[c][s].w;
+                        acc[r * (r + 1) / 2 + c][e & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[r * (r + 1) / 2 + c][e & 1], 0, 0, 0);
                     }
-                }
             }
+        }
+        float* Rb = R + b * ldr;
+#pragma unroll
+        for (int p = 0; p < NPAIR; ++p) {
+            const floatx4 sum = acc[p][0] + acc[p][1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (opos[p][q] >= 0 && !(dbg & 4)) Rb[opos[p][q]] = sum[q];
         }
         // R[:, 0:D] = x (row 0 of the image, un-swizzled: row & 15 == 0), then the alignment padding
         if (lane < 32) *(float4*)(Rb + 4 * lane) = *(const float4*)(my + lane * 16);
@@ -701,6 +729,27 @@ static bool interact_dma_ok(int F, int D, int vec) {
     return !off && D == IDMA_D && F >= 1 && F <= IDMA_ROWS && vec;
 }
 
+// tuning aid (env DLRM_INTERACT_DEBUG, D = 128 forward kernels): 1 = no DMA and no waits in the sample loop (compute + stores only),
+// 2 = no multiplication and no stores (DMA only), 4 = no stores — WRONG results, timing only
+static int interact_debug() {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("DLRM_INTERACT_DEBUG"); dbg = e ? (atoi(e) & 7) : 0; }
+    return dbg;
+}
+
+// forward D = 128 kernels: waves per workgroup (one workgroup per CU) and its LDS — tables, two 2 NI-row images per wave, the selector
+// slots (gather mode; in plain mode they are the slack the second 16-row tile may read into)
+static size_t fwd_dma_lds(int ni, int W) {
+    return 5 * DLRM_MAX_FEATURES * sizeof(long long) + (size_t)W * (2 * (size_t)(2 * ni * IDMA_D * 4) + GSEL_WAVE_BYTES) + 2048;
+}
+static int fwd_dma_waves(int ni) {
+    static int forced = -1;      // env DLRM_INTERACT_WAVES (tuning aid)
+    if (forced < 0) { const char* e = getenv("DLRM_INTERACT_WAVES"); forced = e ? atoi(e) : 0; }
+    int W = (forced >= 1 && forced <= 5) ? forced : 4;      // five waves fit F <= 28 but two of them then share a SIMD: 245 vs 211 us measured
+    while (W > 1 && fwd_dma_lds(ni, W) > 160 * 1024) --W;
+    return W;
+}
+
 static int pick_grid(int64_t B) {
     // 4 samples per workgroup pass; ~2 resident workgroups per CU x 256 CUs x 4 oversubscription
     int64_t nb = (B + 3) / 4;
@@ -771,14 +820,15 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
     if (rc) return rc;
     if (gidx) {          // gathered features exist only in the D = 128 LDS-DMA kernel
         if (!(dlrm_interact_gather_ok(F, D) && vec && dlrm_aligned16(R) && ldr % 4 == 0)) return DLRM_E_MODE;
-        const size_t lds = 5 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * 2 * (size_t)IDMA_IMG + 4 * (size_t)GSEL_WAVE_BYTES;
-        int64_t nb = (B + 3) / 4; if (nb > 256) nb = 256;
         const int ni = (F + 1) / 2;
+        const int W = fwd_dma_waves(ni);
+        const size_t lds = fwd_dma_lds(ni, W);
+        int64_t nb = (B + W - 1) / W; if (nb > 256) nb = 256;
 #define FWD_G(NIV)                                                                                           \
         do {                                                                                                 \
             (void)hipFuncSetAttribute((const void*)interact_fwd_dma_kernel<NIV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((interact_fwd_dma_kernel<NIV, true>), dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, fa, ga, \
-                               (long long)B, F, self_interaction & 3, R, (long long)ldr);                \
+            hipLaunchKernelGGL((interact_fwd_dma_kernel<NIV, true>), dim3((unsigned)nb), dim3(64 * W), lds, (hipStream_t)stream, fa, ga, \
+                               (long long)B, F, (self_interaction & 3) | (interact_debug() << 6), R, (long long)ldr); \
         } while (0)
         switch (ni) {
             case 1: FWD_G(1); break;   case 2: FWD_G(2); break;   case 3: FWD_G(3); break;   case 4: FWD_G(4); break;
@@ -791,14 +841,15 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
         return 0;
     }
     if (interact_dma_ok(F, D, vec) && dlrm_aligned16(R) && ldr % 4 == 0) {
-        const size_t lds = 5 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * 2 * (size_t)IDMA_IMG;   // 130.5 KiB: one workgroup per CU
-        int64_t nb = (B + 3) / 4; if (nb > 256) nb = 256;
         const int ni = (F + 1) / 2;
+        const int W = fwd_dma_waves(ni);
+        const size_t lds = fwd_dma_lds(ni, W);                                                      // one workgroup per CU
+        int64_t nb = (B + W - 1) / W; if (nb > 256) nb = 256;
 #define FWD_DMA(NIV)                                                                                         \
         do {                                                                                                 \
             (void)hipFuncSetAttribute((const void*)interact_fwd_dma_kernel<NIV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((interact_fwd_dma_kernel<NIV, false>), dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, fa, ga, \
-                               (long long)B, F, self_interaction & 3, R, (long long)ldr);                \
+            hipLaunchKernelGGL((interact_fwd_dma_kernel<NIV, false>), dim3((unsigned)nb), dim3(64 * W), lds, (hipStream_t)stream, fa, ga, \
+                               (long long)B, F, (self_interaction & 3) | (interact_debug() << 6), R, (long long)ldr); \
         } while (0)
         switch (ni) {
             case 1: FWD_DMA(1); break;   case 2: FWD_DMA(2); break;   case 3: FWD_DMA(3); break;   case 4: FWD_DMA(4); break;

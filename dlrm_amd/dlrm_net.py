@@ -203,11 +203,13 @@ class DLRM_Net(nn.Module):
         # optimizer step.  Same kernels, same arithmetic, same results; optimizer.step() returns with the caller's stream
         # ordered after the update.
         self.overlap_streams = os.environ.get("DLRM_OVERLAP", "0") == "1"
-        # OPT-IN (DLRM_FUSE_EMB_INTERACT=1): single-process forward with ONE lookup per bag (the Criteo data sets) and D = 128 — the
-        # interaction kernels gather the embedding rows themselves (dlrm_interact_fwd_gather): apply_emb's pooled-embedding
-        # buffer is never written or re-read.  Bit-identical results, but measured slower than the two kernels in this round
-        # (profiles/r03/ceilings.md), hence off by default.
-        self.fuse_emb_interact = os.environ.get("DLRM_FUSE_EMB_INTERACT", "0") == "1"
+        # Single-process forward with ONE lookup per bag (the Criteo data sets; DLRM_FUSE_EMB_INTERACT=0 turns it off), D = 128 and at most
+        # 26 tables: the interaction kernels gather the embedding rows themselves (dlrm_interact_fwd_gather / _bwd_gather) and
+        # apply_emb's pooled-embedding buffer is never written or re-read — bit-identical results, forward 0.21 ms instead of 0.34 +
+        # 0.26 at Criteo-Terabyte shapes (profiles/round3).  Taken when every table has exactly B lookups; the kernels verify that the
+        # bag starts are 0, 1, 2, ... (what nnz == B means for every input the reference's loaders and generators produce: each of their
+        # bags has at least one lookup) and report a violation through the index-error block, like an out-of-range index.
+        self.fuse_emb_interact = os.environ.get("DLRM_FUSE_EMB_INTERACT", "1") == "1"
         self._bound_optimizer = None        # weakref to the optimizer that owns the tables (learnt at its first step)
         self._side_keep: list = []          # tensors the side stream still reads (released at the join)
         # > 1: the pooled-embedding all-to-all of the distributed forward is pipelined in that many batch chunks (opt-in)

@@ -117,7 +117,7 @@ def run_on_gpu(device, arith="f32", mode=None, steps=None, check=True, name="ter
             sd[k].copy_(torch.from_numpy(fx.init.pop(k)))          # (popped: the host copy of a 2 GB table is released at once)
     model.emb_update_mode = ops.UPD_SORTED if mode is None else mode
     model.set_mlp_arith(arith)
-    model.fuse_emb_interact = bool(fuse)      # opt-in: lookups fetched by the interaction kernels instead of two kernels
+    model.fuse_emb_interact = bool(fuse)      # lookups fetched by the interaction kernels (the product default) instead of two kernels
     model.overlap_streams = bool(overlap)     # embedding kernels on a side stream beside the bottom-MLP GEMMs (bench default)
     opt = FusedSGD(model.parameters(), lr=meta["lr"])
     rel = []

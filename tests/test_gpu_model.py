@@ -267,7 +267,7 @@ def test_terabyte_full_batch_matches_reference_golden(arith, overlap, fuse):
     """BASELINE.json configs[2] — the configuration the headline samples/s is quoted on — against 3 training steps of the
     live reference at the full batch (B = 65536, 26 tables, D = 128, towers 13-512-256-128 / 479-1024-1024-512-256-1, lr 1.0,
     rows capped at 2000): loss within 1e-5 relative at every step (north_star), predictions rtol 2e-5, parameters rtol 1e-4.
-    "bench-default" = bench.py's default 2-stream schedule ("fused-gather-interaction" adds the opt-in DLRM_Net.fuse_emb_interact): embedding lookups / fused update on a side HIP stream beside the
+    "bench-default" = bench.py's default 2-stream schedule ("fused-gather-interaction" = DLRM_Net.fuse_emb_interact, the default since round 3; the other cases run the two kernels): embedding lookups / fused update on a side HIP stream beside the
     bottom-MLP GEMMs (from the second step on the update is launched during backward) — same kernels, same results."""
     import golden_tb
     rel = golden_tb.run_on_gpu(torch.device("cuda:0"), arith=arith, overlap=overlap, fuse=fuse)

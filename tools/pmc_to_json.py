@@ -13,14 +13,26 @@ CATS = {
     "emb_fwd": ["emb_fwd_kernel"],
     "emb_bwd_sgd": ["expand_kernel", "rocprim::", "seg_hist_kernel", "seg_colscan_kernel", "seg_binscan_kernel", "seg_scatter_kernel",
                     "sorted_update_kernel"],
-    "interact_fwd": ["interact_fwd"],
+    "interact_fwd": ["interact_fwd"],                                  # (the gather instantiations <NI, true> are split off below)
     "interact_bwd": ["interact_bwd"],
+    "emb_interact_fwd": ["interact_fwd_dma_kernel<"],
+    "emb_interact_bwd": ["interact_bwd_dma_kernel<"],
     "linear_fwd": ["gemm3_kernel<true, true", "gemm_f32_kernel<true, true"],
     "linear_bwd_data": ["gemm3_kernel<true, false", "gemm_f32_kernel<true, false"],
     "linear_bwd_weight": ["gemm3_kernel<false, false", "gemm_f32_kernel<false, false", "splitk_reduce_kernel"],
 }
-CALLS_PER_STEP = {"emb_fwd": 1, "emb_bwd_sgd": 1, "interact_fwd": 1, "interact_bwd": 1, "linear_fwd": 8, "linear_bwd_data": 7,
-                  "linear_bwd_weight": 8}
+CALLS_PER_STEP = {"emb_fwd": 1, "emb_bwd_sgd": 1, "interact_fwd": 1, "interact_bwd": 1, "emb_interact_fwd": 1, "emb_interact_bwd": 1,
+                  "linear_fwd": 8, "linear_bwd_data": 7, "linear_bwd_weight": 8}
+
+
+def in_cat(cat, pats, kernel):
+    """fused lookup + interaction = the <NI, true> instantiations of the LDS-DMA interaction kernels"""
+    gather = "_dma_kernel<" in kernel and kernel.split("_dma_kernel<", 1)[1].split(">", 1)[0].replace(" ", "").endswith(",true")
+    if cat.startswith("emb_interact"):
+        return gather and any(p in kernel for p in pats)
+    if cat.startswith("interact"):
+        return not gather and any(p in kernel for p in pats)
+    return any(p in kernel for p in pats)
 
 
 def load(path):
@@ -46,8 +58,8 @@ def main():
         out["git_head"] = None
     fetch, write = load(f"{src}/pmc_FETCH_SIZE.csv"), load(f"{src}/pmc_WRITE_SIZE.csv")
     for cat, pats in CATS.items():
-        f_kb = sum(c * v for k, c, v in fetch if any(p in k for p in pats)) / steps
-        w_kb = sum(c * v for k, c, v in write if any(p in k for p in pats)) / steps
+        f_kb = sum(c * v for k, c, v in fetch if in_cat(cat, pats, k)) / steps
+        w_kb = sum(c * v for k, c, v in write if in_cat(cat, pats, k)) / steps
         n = CALLS_PER_STEP[cat]
         out["kernels"][cat] = {"fetch_raw_bytes": f_kb * 1024 / n, "fetch_bytes": 2 * f_kb * 1024 / n,
                                "write_bytes": w_kb * 1024 / n, "traffic_bytes": (2 * f_kb + w_kb) * 1024 / n,
