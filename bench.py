@@ -691,7 +691,7 @@ def main():
                    "lookup_sort": lookup_sort,
                    "a2a_chunks": model_a2a_chunks,
                    "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "
-                                             "(no pooled-embedding buffer)") if (args.fuse and N == 1 and not hot) else "two kernels (dlrm_emb_fwd, dlrm_interact_*)",
+                                             "(no pooled-embedding buffer)") if "emb_interact_fwd" in kernels else "two kernels (dlrm_emb_fwd, dlrm_interact_*)",
                    "streams": ("single stream" if (not args.overlap or args.no_overlap or graphed is not None) else
                                "2 HIP streams: embedding lookups / fused sparse update on a side stream beside the bottom-MLP GEMMs "
                                "(per-kernel event times then overlap: their sum exceeds the step time)"),
