@@ -274,7 +274,8 @@ def test_terabyte_full_batch_matches_reference_golden(arith, overlap, fuse):
     assert len(rel) == 3 and max(rel) <= 1e-5, rel
 
 
-def test_terabyte_full_batch_hbm_resident_tables_match_reference_golden():
+@pytest.mark.parametrize("fuse", [True, False], ids=["fused-lookups", "two-kernels"])
+def test_terabyte_full_batch_hbm_resident_tables_match_reference_golden(fuse):
     """the same 3 reference training steps at B = 65536 with the seven big tables capped at 4 M rows instead of
     2000 (fixture terabyte_b65536_cap4m: 14.5 GB of tables, 22-bit row keys, rows looked up 0-3 times per batch) — the sorted
     update's long-key / few-duplicates regime and the lookups' HBM-resident regime pinned to the live reference: losses 1e-5,
@@ -283,7 +284,7 @@ def test_terabyte_full_batch_hbm_resident_tables_match_reference_golden():
     import psutil
     if psutil.virtual_memory().available < 24e9:
         pytest.skip("needs ~16 GB of host RAM to regenerate the reference's initial tables")
-    rel = golden_tb.run_on_gpu(torch.device("cuda:0"), name="terabyte_b65536_cap4m")
+    rel = golden_tb.run_on_gpu(torch.device("cuda:0"), name="terabyte_b65536_cap4m", fuse=fuse)      # fuse = the product default (bench.py)
     assert max(rel) <= 1e-5, rel
 
 
