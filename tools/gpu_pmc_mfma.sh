@@ -2,7 +2,7 @@
 # MFMA-pipe and LDS counters of the step's kernels (separate passes, kernel-trace only): SQ_VALU_MFMA_BUSY_CYCLES vs GRBM_GUI_ACTIVE,
 # SQ_LDS_BANK_CONFLICT vs SQ_LDS_IDX_ACTIVE
 OUT=gpurun_out/${1:-pmcm}; mkdir -p $OUT; export TMPDIR=/tmp
-FLAGS="--no-cpu-baseline --no-alt-arith --no-parity-check --no-alt-overlap --no-kernel-timers"
+FLAGS="--no-cpu-baseline --no-alt-arith --no-parity-check --no-alt-overlap --no-alt-fuse --no-kernel-timers"
 cd /tmp
 for c in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   tag=$(echo $c | cut -d' ' -f1)
