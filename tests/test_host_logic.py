@@ -312,3 +312,36 @@ def test_dense_sync_environment_switch_resolves_ddp_to_the_flat_wrapper():
         e.update(env)
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == want, (r.stdout, r.stderr[-500:])
+
+
+def test_fused_lookup_defaults_and_pmc_categories(monkeypatch):
+    """The fused lookup + interaction path is the product default (DLRM_FUSE_EMB_INTERACT=0 and bench.py --no-fuse turn it off), and the
+    PMC folding tool books the <NI, true> instantiations of the LDS-DMA interaction kernels under emb_interact_*, never under interact_*."""
+    import importlib
+    import sys as _sys
+    import numpy as _np
+    import dlrm_amd
+    ln = _np.asarray([10, 20])
+    kw = dict(m_spa=4, ln_emb=ln, ln_bot=_np.asarray([3, 4]), ln_top=_np.asarray([4 + 3, 2, 1]), arch_interaction_op="dot")
+    _np.random.seed(0)
+    assert dlrm_amd.DLRM_Net(**kw).fuse_emb_interact is True
+    monkeypatch.setenv("DLRM_FUSE_EMB_INTERACT", "0")
+    assert dlrm_amd.DLRM_Net(**kw).fuse_emb_interact is False
+    monkeypatch.delenv("DLRM_FUSE_EMB_INTERACT")
+
+    tools = os.path.join(ROOT, "tools")
+    _sys.path.insert(0, tools)
+    try:
+        p2j = importlib.import_module("pmc_to_json")
+    finally:
+        _sys.path.remove(tools)
+    fused, plain = "interact_fwd_dma_kernel<14, true>", "interact_fwd_dma_kernel<14, false>"
+    assert p2j.in_cat("emb_interact_fwd", p2j.CATS["emb_interact_fwd"], fused) and not p2j.in_cat("interact_fwd", p2j.CATS["interact_fwd"], fused)
+    assert p2j.in_cat("interact_fwd", p2j.CATS["interact_fwd"], plain) and not p2j.in_cat("emb_interact_fwd", p2j.CATS["emb_interact_fwd"], plain)
+    assert p2j.in_cat("interact_bwd", p2j.CATS["interact_bwd"], "interact_bwd_kernel<2>") and p2j.in_cat("emb_fwd", p2j.CATS["emb_fwd"], "emb_fwd_kernel<4, 32, 1, long long, 2>")
+
+    monkeypatch.setattr(_sys, "argv", ["bench.py"])
+    bench = importlib.import_module("bench")
+    assert bench.parse().fuse is True
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--no-fuse"])
+    assert bench.parse().fuse is False
