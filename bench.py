@@ -445,6 +445,8 @@ def main():
     model.set_mlp_arith(args.mlp_arith)
     model.overlap_streams = bool(args.overlap) and not args.no_overlap
     model.fuse_emb_interact = bool(args.fuse)
+    # (what DLRM_Net.sequential_forward checks: dot interaction, one lookup per bag, D = 128, at most 26 tables, single process)
+    fused_active = bool(args.fuse) and N == 1 and not hot_cfg and int(D) == 128 and len(rows) + 1 <= 27
     model.a2a_chunks = max(args.a2a_chunks, 1) if (N > 1 and not sharded) else 1
     model.emb_update_mode = {"sorted": ops.UPD_SORTED, "atomic": ops.UPD_ATOMIC, "deterministic": ops.UPD_DETERMINISTIC}[args.emb_update]
     if N > 1:
@@ -691,7 +693,7 @@ def main():
                    "lookup_sort": lookup_sort,
                    "a2a_chunks": model_a2a_chunks,
                    "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "
-                                             "(no pooled-embedding buffer)") if "emb_interact_fwd" in kernels else "two kernels (dlrm_emb_fwd, dlrm_interact_*)",
+                                             "(no pooled-embedding buffer)") if fused_active else "two kernels (dlrm_emb_fwd, dlrm_interact_*)",
                    "streams": ("single stream" if (not args.overlap or args.no_overlap or graphed is not None) else
                                "2 HIP streams: embedding lookups / fused sparse update on a side stream beside the bottom-MLP GEMMs "
                                "(per-kernel event times then overlap: their sum exceeds the step time)"),

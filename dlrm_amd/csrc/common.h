@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/dlrm_hip.h"
 
 #define DLRM_WAVE 64
@@ -26,6 +27,15 @@
 static inline int dlrm_current_device() { int d = 0; (void)hipGetDevice(&d); return (d >= 0 && d < DLRM_MAX_DEVICES) ? d : 0; }
 
 static inline bool dlrm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// timing-only tuning switches (DLRM_GEMM_DEBUG, DLRM_INTERACT_DEBUG, DLRM_SEG_DEBUG) make kernels skip work: results are WRONG.
+// Reading one that is set says so on stderr, once per switch.
+static inline int dlrm_debug_env(const char* name, int mask) {
+    const char* e = getenv(name);
+    const int v = e ? (atoi(e) & mask) : 0;
+    if (v) fprintf(stderr, "libdlrm_hip: %s=%d is a tuning switch: its timing-only bits make kernels skip work and their results are WRONG\n", name, v);
+    return v;
+}
 
 __device__ __forceinline__ float dlrm_wave_sum(float v) {
 #pragma unroll
