@@ -331,8 +331,42 @@ def load_pmc_traffic():
     return d
 
 
+def self_launch_command(args, argv, port=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): the command line this file re-executes
+    itself under — one rank per GPU, the reference's own launch pattern (README.md:345-346, torch.distributed.launch -> .run)."""
+    port = port or int(os.environ.get("MASTER_PORT", 29500 + os.getpid() % 2000))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def resolve_world(args, argv=None, environ=None):
+    """Decide how many ranks this invocation is.  Returns ("run", N) for a rank (or the single process) that measures, ("exec", cmd)
+    when `--gpus N > 1` was given WITHOUT a launcher: the caller re-executes under torch.distributed.run.  A launcher whose
+    WORLD_SIZE disagrees with --gpus is an ERROR (exit 2), never a line with a different n_gpus than asked for."""
+    environ = os.environ if environ is None else environ
+    argv = sys.argv[1:] if argv is None else argv
+    ws = environ.get("WORLD_SIZE")
+    if ws is None:
+        if args.gpus > 1:
+            if environ.get("DLRM_BENCH_NO_SELF_LAUNCH", "0") == "1":
+                cmd = self_launch_command(args, argv)
+                sys.exit("ERROR: --gpus %d needs one process per GPU; launch as:\n  %s" % (args.gpus, " ".join(cmd)))
+            return "exec", self_launch_command(args, argv)
+        return "run", 1
+    world = int(ws)
+    if world != args.gpus:
+        print(f"ERROR: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; refusing to print a line for a GPU count "
+              f"that was not asked for", file=sys.stderr)
+        sys.exit(2)
+    return "run", world
+
+
 def main():
     args = parse()
+    what, val = resolve_world(args)
+    if what == "exec":
+        print("[bench] --gpus %d without a launcher: re-executing as %s" % (args.gpus, " ".join(val)), file=sys.stderr, flush=True)
+        os.execv(val[0], val)
     if os.environ.get("DLRM_BENCH_WATCHDOG"):       # debugging aid: dump every thread's Python stack after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DLRM_BENCH_WATCHDOG"]), repeat=False, exit=False)
@@ -351,10 +385,7 @@ def main():
         wl["batch"] = args.batch
     if args.row_cap:
         wl["rows"] = [min(r, args.row_cap) for r in wl["rows"]]
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    N = world
+    N = val
 
     import dlrm_amd
     from dlrm_amd import ext_dist, ops
@@ -476,6 +507,11 @@ def main():
                                           local_rows=ext_dist.get_my_slice(B) if sharded else None)
     else:
         batches = make_batches(4, B, rows, device, seed=727)     # every rank reads the whole global batch (reference :1541)
+        if N == 1:
+            # the fused lookup + interaction path proves "one lookup per bag" once per offsets tensor (one device pass + one stream
+            # synchronisation, ops.offsets_are_iota): paid here for the four resident batches, whatever --warmup is
+            for b_ in batches:
+                ops.offsets_are_iota(b_[1])
     my_rows = ext_dist.get_my_slice(B) if N > 1 else slice(0, B)
     if sharded:
         local_tables = list(model.tw_mine)           # + a 1/N row range of every row-wise table (accounted below)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "dlrm_interact_fwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _vp]),
     "dlrm_interact_bwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _pp, _pi64, _vp]),
     "dlrm_interact_gather_ok": (_i32, [_i32, _i32]),
+    "dlrm_offsets_are_iota": (_i32, [_i32, _i64, _pp, _i32, _vp, _vp]),
     "dlrm_interact_fwd_gather": (_i32, [_i64, _i32, _i32, _pp, _pi64, _pp, _pp, _pi64, _i32, _i32, _vp, _i64, _vp, _vp]),
     "dlrm_interact_bwd_gather": (_i32, [_i64, _i32, _i32, _pp, _pi64, _pp, _pp, _pi64, _i32, _i32, _vp, _i64, _pp, _pi64, _vp, _vp]),
     "dlrm_relu_bits_bytes": (_i64, [_i64, _i32]),

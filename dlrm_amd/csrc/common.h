@@ -29,13 +29,20 @@ static inline int dlrm_current_device() { int d = 0; (void)hipGetDevice(&d); ret
 static inline bool dlrm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // timing-only tuning switches (DLRM_GEMM_DEBUG, DLRM_INTERACT_DEBUG, DLRM_SEG_DEBUG) make kernels skip work: results are WRONG.
-// Reading one that is set says so on stderr, once per switch.
+// They exist ONLY in a tuning build (`make TUNING=1` -> -DDLRM_TUNING, tools/probes/): the product library never reads these
+// environment variables — the function folds to the constant 0, so no environment can turn a kernel of the shipped library into
+// a no-op (tests/test_host_logic.py checks that the names are absent from the binary).
+#ifdef DLRM_TUNING
 static inline int dlrm_debug_env(const char* name, int mask) {
     const char* e = getenv(name);
     const int v = e ? (atoi(e) & mask) : 0;
     if (v) fprintf(stderr, "libdlrm_hip: %s=%d is a tuning switch: its timing-only bits make kernels skip work and their results are WRONG\n", name, v);
     return v;
 }
+#define DLRM_DEBUG_ENV(name, mask) dlrm_debug_env(name, mask)
+#else
+#define DLRM_DEBUG_ENV(name, mask) 0
+#endif
 
 __device__ __forceinline__ float dlrm_wave_sum(float v) {
 #pragma unroll

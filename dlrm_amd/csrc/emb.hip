@@ -685,3 +685,38 @@ extern "C" int dlrm_emb_psw_grad(int T, int64_t B, int D, const void* const* wei
     }
     return 0;
 }
+
+// -------------------------------------------------------------------------------------------
+// "one lookup per bag" proof for the fused lookup + interaction path (dlrm_interact_*_gather): offsets_t[b] == b for every table
+// and bag.  nnz == B alone does not prove it (an empty bag plus a two-lookup bag also sum to B, and EmbeddingBag accepts that:
+// dlrm_s_pytorch.py:453-457).  One coalesced pass over T*B offsets; *violations (device-visible, e.g. pinned host memory) receives the
+// number of bags whose start differs from their number — the caller synchronises the stream and reads it.
+// -------------------------------------------------------------------------------------------
+namespace {
+struct IotaArgs { const void* off[DLRM_MAX_TABLES_PER_LAUNCH]; };
+template <typename IdxT>
+__global__ __launch_bounds__(256) void offsets_iota_kernel(IotaArgs a, long long B, int* __restrict__ violations) {
+    const IdxT* off = (const IdxT*)a.off[blockIdx.y];
+    int bad = 0;
+    for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < B; b += (long long)gridDim.x * 256)
+        bad += ((long long)off[b] != b);
+    if (__any(bad != 0)) atomicAdd(violations, bad);
+}
+}  // namespace
+
+extern "C" int dlrm_offsets_are_iota(int T, int64_t B, const void* const* offsets_host, int idx_bits, int32_t* violations, void* stream) {
+    if (T <= 0 || B <= 0 || !offsets_host || !violations) return DLRM_E_ARG;
+    if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
+    hipStream_t st = (hipStream_t)stream;
+    for (int t0 = 0; t0 < T; t0 += DLRM_MAX_TABLES_PER_LAUNCH) {
+        const int n = (T - t0 < DLRM_MAX_TABLES_PER_LAUNCH) ? T - t0 : DLRM_MAX_TABLES_PER_LAUNCH;
+        IotaArgs a = {};
+        for (int k = 0; k < n; ++k) { if (!offsets_host[t0 + k]) return DLRM_E_ARG; a.off[k] = offsets_host[t0 + k]; }
+        long long nb = (B + 255) / 256; if (nb > 256) nb = 256;
+        dim3 grid((unsigned)nb, (unsigned)n, 1), block(256);
+        if (idx_bits == 64) hipLaunchKernelGGL(offsets_iota_kernel<long long>, grid, block, 0, st, a, (long long)B, violations);
+        else                hipLaunchKernelGGL(offsets_iota_kernel<int>, grid, block, 0, st, a, (long long)B, violations);
+        DLRM_LAUNCH_CHECK();
+    }
+    return 0;
+}

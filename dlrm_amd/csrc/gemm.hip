@@ -954,7 +954,7 @@ static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     g.tiles_n = (int)((g.N + BNt - 1) / BNt);
     {   // tuning aid (env DLRM_GEMM_DEBUG): 1 no DMA refill in the k-loop, 2 no wait + barrier, 4 no epilogue — WRONG results, timing only
         static int dbg = -1;
-        if (dbg < 0) dbg = dlrm_debug_env("DLRM_GEMM_DEBUG", 0x7fffffff);
+        if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_GEMM_DEBUG", 0x7fffffff);
         g.debug = dbg;
     }
     size_t lds = (size_t)NSTAGE3 * (BMt + BNt) * BK3 * 4;           // 72 KiB (TM=4) / 48 KiB (TM=2)
@@ -1023,7 +1023,7 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
     g.tiles_m = (int)((g.M + BM - 1) / BM);
     g.tiles_n = (int)((g.N + BN - 1) / BN);
     static int dbg = -1;
-    if (dbg < 0) dbg = dlrm_debug_env("DLRM_GEMM_DEBUG", 0x7fffffff);
+    if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_GEMM_DEBUG", 0x7fffffff);
     g.debug = dbg;
     const size_t lds = 2 * 2 * TILE_F * sizeof(float);   // 73,728 B: two workgroups per CU
     static bool attr_done[DLRM_MAX_DEVICES] = {};

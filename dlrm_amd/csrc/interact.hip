@@ -733,7 +733,7 @@ static bool interact_dma_ok(int F, int D, int vec) {
 // 2 = no multiplication and no stores (DMA only), 4 = no stores — WRONG results, timing only
 static int interact_debug() {
     static int dbg = -1;
-    if (dbg < 0) dbg = dlrm_debug_env("DLRM_INTERACT_DEBUG", 7);
+    if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_INTERACT_DEBUG", 7);
     return dbg;
 }
 

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
 
 static int seg_debug() {
     static int v = -1;
-    if (v < 0) v = dlrm_debug_env("DLRM_SEG_DEBUG", 0x7fffffff);
+    if (v < 0) v = DLRM_DEBUG_ENV("DLRM_SEG_DEBUG", 0x7fffffff);
     return v;
 }
 

@@ -206,9 +206,10 @@ class DLRM_Net(nn.Module):
         # Single-process forward with ONE lookup per bag (the Criteo data sets; DLRM_FUSE_EMB_INTERACT=0 turns it off), D = 128 and at most
         # 26 tables: the interaction kernels gather the embedding rows themselves (dlrm_interact_fwd_gather / _bwd_gather) and
         # apply_emb's pooled-embedding buffer is never written or re-read — bit-identical results, forward 0.21 ms instead of 0.34 +
-        # 0.26 at Criteo-Terabyte shapes (profiles/round3).  Taken when every table has exactly B lookups; the kernels verify that the
-        # bag starts are 0, 1, 2, ... (what nnz == B means for every input the reference's loaders and generators produce: each of their
-        # bags has at least one lookup) and report a violation through the index-error block, like an out-of-range index.
+        # 0.26 at Criteo-Terabyte shapes (profiles/round3).  Taken when every table has exactly B lookups AND the bag starts are proven
+        # to be 0, 1, 2, ... (ops.offsets_are_iota: one device pass + one synchronisation per distinct offsets tensor object, cached;
+        # a ragged batch with nnz == B — an empty bag next to a two-lookup bag — takes the two kernels like every other multi-hot
+        # input).  The kernels still verify the bag starts themselves and report a violation through the index-error block.
         self.fuse_emb_interact = os.environ.get("DLRM_FUSE_EMB_INTERACT", "1") == "1"
         self._bound_optimizer = None        # weakref to the optimizer that owns the tables (learnt at its first step)
         self._side_keep: list = []          # tensors the side stream still reads (released at the join)
@@ -460,7 +461,11 @@ class DLRM_Net(nn.Module):
         if (self.fuse_emb_interact and self.arch_interaction_op == "dot" and dense_x.is_cuda and ops.gather_ok(1 + T, D)
                 and not any(w is not None for w in (self.v_W_l or []))):
             bags = self._bags(lS_o, lS_i, None)
-            if all(n == B for n in bags.nnz) and all(e.weight.data_ptr() % 16 == 0 for e in self.emb_l):
+            # nnz == B does not prove one lookup per bag (an empty bag next to a two-lookup bag is legal EmbeddingBag input and the
+            # reference computes it): ops.offsets_are_iota proves offsets == arange(B) on the device, once per offsets tensor
+            # object (None = undecided, only while a HIP graph is being captured: GraphedTrainStep proves every incoming batch).
+            if (all(n == B for n in bags.nnz) and all(e.weight.data_ptr() % 16 == 0 for e in self.emb_l)
+                    and ops.offsets_are_iota(lS_o) is not False):
                 x = self.apply_mlp(dense_x, self.bot_l)
                 z = GatherInteractFunction.apply(self._stash_embedding_grad, D, self._interaction_mode(), bags, x,
                                                  *self._emb_weights(self.emb_l))

@@ -147,6 +147,26 @@ class GraphedTrainStep:
                                "(tools/probes/graph_sorted_probe.py); use the eager step")
         model.emb_update_mode = ops.UPD_ATOMIC               # LDS pre-reduction for tiny tables + hardware fp32 atomics
 
+    def _prove_one_lookup_per_bag(self, lS_o, lS_i) -> None:
+        """The fused lookup + interaction kernels are only valid for offsets == arange(B).  Eager steps prove that per offsets tensor
+        (ops.offsets_are_iota); inside a capture nothing can synchronise and the static offsets buffer is rewritten before every
+        replay, so the proof is made HERE, on the caller's tensors, before they are copied.  A batch that fails it turns the fused
+        path off for this model and drops the captured graph (the next call re-captures with the two kernels)."""
+        model = self.model
+        if not getattr(model, "fuse_emb_interact", False):
+            return
+        n_i = lS_i.size(-1) if isinstance(lS_i, torch.Tensor) else None
+        n_o = lS_o.size(-1) if isinstance(lS_o, torch.Tensor) else None
+        if isinstance(lS_i, torch.Tensor) != isinstance(lS_o, torch.Tensor) or (n_i is not None and n_i != n_o):
+            return                              # not the one-lookup shape: sequential_forward will not take the fused path
+        if n_i is None and any(i.numel() != o.numel() for i, o in zip(lS_i, lS_o)):
+            return
+        if ops.offsets_are_iota(lS_o) is False:
+            model.fuse_emb_interact = False
+            if self.graph is not None:
+                self.graph.reset()
+                self.graph = None
+
     # one eager training step on the static buffers (the reference loop body)
     def _eager(self):
         X, lS_o, lS_i, T = self.static
@@ -202,6 +222,7 @@ class GraphedTrainStep:
             # sizes the replay has finished long before the host gets here.
             torch.cuda.current_stream(X.device).synchronize()
             self._replayed = False
+        self._prove_one_lookup_per_bag(lS_o, lS_i)
         if self.static is None:
             self._settle_sort_mode(lS_o, lS_i)
             self.static = (X.clone(), _clone_struct(lS_o), _clone_struct(lS_i), T.clone())

@@ -481,6 +481,77 @@ def gather_ok(F: int, D: int) -> bool:
     return bool(_lib.load().dlrm_interact_gather_ok(F, D))
 
 
+# --- "one lookup per bag" proof for the fused lookup + interaction path -------------------------------------------------------
+# nnz == B does not prove offsets == arange(B): EmbeddingBag accepts an empty bag next to a two-lookup bag (dlrm_s_pytorch.py:453-457)
+# and the reference computes that input correctly.  The proof is one pass over the offsets on the device + ONE stream
+# synchronisation, paid once per distinct offsets tensor: the verdict is cached on the tensor OBJECT (weak reference, so a recycled
+# address can never alias) together with its in-place version counter.
+_iota_cache: dict = {}          # id(tensor) -> (weakref, _version, verdict)
+_iota_flags: dict = {}          # device index -> pinned host int32[1]
+IOTA_STATS = {"checked": 0, "cached": 0}
+
+
+def _iota_cached(t: torch.Tensor):
+    e = _iota_cache.get(id(t))
+    if e is not None and e[0]() is t and e[1] == t._version:
+        return e[2]
+    return None
+
+
+def _iota_remember(t: torch.Tensor, verdict: bool) -> None:
+    import weakref
+    if len(_iota_cache) > 256:
+        for k in [k for k, e in _iota_cache.items() if e[0]() is None]:
+            del _iota_cache[k]
+        if len(_iota_cache) > 256:
+            _iota_cache.clear()
+    _iota_cache[id(t)] = (weakref.ref(t), t._version, verdict)
+
+
+def offsets_are_iota(lS_o):
+    """True iff every table's bag starts are 0, 1, ..., B-1 (with nnz == B: exactly one lookup per bag).  `lS_o` is what the caller
+    passed to the module (a stacked [T, B] tensor or a list of [B] tensors): the verdict is remembered per tensor object.  While a HIP
+    graph is being captured no synchronisation is possible: returns None (undecided) unless every tensor is already cached —
+    GraphedTrainStep proves it on the incoming batch before every replay instead."""
+    srcs = [lS_o] if isinstance(lS_o, torch.Tensor) else list(lS_o)
+    verdicts = [_iota_cached(t) for t in srcs]
+    if all(v is not None for v in verdicts):
+        IOTA_STATS["cached"] += 1
+        return all(verdicts)
+    dev = srcs[0].device
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    ptrs, keep = [], []
+    for t in srcs:
+        if not t.is_cuda or t.dtype not in (torch.int64, torch.int32) or t.dtype != srcs[0].dtype:
+            raise RuntimeError("dlrm_amd: offsets must be int32/int64 GPU tensors of one dtype")
+        if t.dim() == 2:
+            if t.stride(1) != 1 and t.size(1) > 1:
+                t = t.contiguous()
+            ptrs += [t.data_ptr() + k * t.stride(0) * t.element_size() for k in range(t.size(0))]
+        else:
+            t = t.contiguous()
+            ptrs.append(t.data_ptr())
+        keep.append(t)
+    B = srcs[0].size(-1)
+    flag = _iota_flags.get(dev.index)
+    if flag is None:
+        flag = _iota_flags[dev.index] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    flag[0] = 0
+    st = torch.cuda.current_stream(dev)
+    rc = _lib.load().dlrm_offsets_are_iota(len(ptrs), B, _lib.ptr_array(ptrs), 64 if srcs[0].dtype == torch.int64 else 32,
+                                           C.c_void_p(flag.data_ptr()), C.c_void_p(st.cuda_stream))
+    _lib.check(rc, "dlrm_offsets_are_iota")
+    st.synchronize()
+    ok = int(flag[0]) == 0
+    IOTA_STATS["checked"] += 1
+    # one verdict for the whole set: each tensor of a list is remembered with it (a False verdict of the set is re-examined only if
+    # the same objects come back, and then it is False again)
+    for t in srcs:
+        _iota_remember(t, ok)
+    return ok
+
+
 def _gather_desc(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: BagBatch, D: int):
     """feature 0 = the [B, D] block x, features 1..T = the tables addressed through the bags' indices"""
     if bags.T != len(weights) or any(n != bags.B for n in bags.nnz):

@@ -181,6 +181,11 @@ int dlrm_interact_bwd(int64_t B, int F, int D,
  * caller runs the two kernels.  The backward writes dfeat rows exactly like dlrm_interact_bwd (the gradient of a gathered
  * feature is the dout operand of dlrm_emb_bwd_*). */
 int dlrm_interact_gather_ok(int F, int D);
+/* The proof the caller owes before taking that path: offsets_host[t][b] == b for all T tables and B bags ("one lookup per bag";
+ * nnz == B alone does not prove it — EmbeddingBag accepts an empty bag next to a two-lookup bag, dlrm_s_pytorch.py:453-457).  Adds the
+ * number of bags whose start differs from their number to *violations (DEVICE-VISIBLE int32, zeroed by the caller; pinned host memory
+ * lets the caller read it after synchronising `stream`). */
+int dlrm_offsets_are_iota(int T, int64_t B, const void* const* offsets_host, int idx_bits, int32_t* violations, void* stream);
 int dlrm_interact_fwd_gather(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
                              const void* const* index_host, const void* const* offsets_host, const int64_t* rows_host,
                              int idx_bits, int self_interaction, float* R, int64_t ldr, int64_t* err, void* stream);

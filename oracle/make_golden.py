@@ -484,6 +484,136 @@ def capture_terabyte(ref, dp, name="terabyte_b65536", row_cap=2000, B=65536, ste
 
 
 # ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[3] AT ITS OWN SHAPES: the reference's 8-rank run (gloo, CPU) of the MLPerf Criteo-Terabyte model —
+# 26 tables table-wise over 8 ranks ([4,4,3,3,3,3,3,3]), D = 128, towers 13-512-256-128 / 479-1024-1024-512-256-1, GLOBAL batch
+# 65536 (8192 per rank), rows capped (dlrm_s_pytorch.py:528-585, extend_distributed.py:541-576, README.md:345-346)
+# ---------------------------------------------------------------------------------------------
+def _dist_tb_worker(rank, size, port, meta, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    ref, dp, ext = import_reference()
+    sys.path.insert(0, os.path.dirname(OUT))
+    import golden_tb
+    init, rs = golden_tb.regen_init(meta)
+    batches = golden_tb.regen_batches(meta, rs)
+    ext.init_distributed(rank=rank, local_rank=rank, size=size, use_gpu=False, backend="gloo")
+    ln_emb, ln_bot, ln_top = (np.asarray(meta[k]) for k in ("ln_emb", "ln_bot", "ln_top"))
+    np.random.seed(1)
+    model = ref.DLRM_Net(meta["m_spa"], ln_emb, ln_bot, ln_top, arch_interaction_op="dot", sigmoid_top=ln_top.size - 2,
+                         loss_function="bce")
+    with torch.no_grad():
+        for j, g in enumerate(model.local_emb_indices):
+            model.emb_l[j].weight.copy_(torch.from_numpy(init[f"emb_l.{g}.weight"]))
+        for name, p in model.bot_l.named_parameters():
+            p.copy_(torch.from_numpy(init[f"bot_l.{name}"]))
+        for name, p in model.top_l.named_parameters():
+            p.copy_(torch.from_numpy(init[f"top_l.{name}"]))
+    model.bot_l = ext.DDP(model.bot_l)
+    model.top_l = ext.DDP(model.top_l)
+    lr = meta["lr"]
+    opt = torch.optim.SGD([{"params": [p for emb in model.emb_l for p in emb.parameters()], "lr": lr},
+                           {"params": model.bot_l.parameters(), "lr": lr}, {"params": model.top_l.parameters(), "lr": lr}], lr=lr)
+    res = {}
+    for s, (X, off, idx, T) in enumerate(batches):
+        Z = model(torch.from_numpy(X), torch.from_numpy(off), [torch.from_numpy(i) for i in idx])
+        Tl = torch.from_numpy(T)[ext.get_my_slice(T.shape[0])]
+        E = model.loss_fn(Z, Tl)
+        res[f"s{s}.Z"] = Z.detach().numpy().copy()
+        res[f"s{s}.loss"] = np.float64(E.detach().numpy())
+        opt.zero_grad()
+        E.backward()
+        if s == 0 and rank == 0:
+            res["s0.top8_weight_grad"] = model.top_l.module[8].weight.grad.numpy().copy()      # AFTER the DDP all-reduce (mean)
+            res["s0.bot0_bias_grad"] = model.bot_l.module[0].bias.grad.numpy().copy()
+        opt.step()
+    for j, g in enumerate(model.local_emb_indices):
+        v = model.emb_l[j].weight.detach().numpy()
+        res[f"final_head.emb_l.{g}.weight"] = v[:48].copy()
+        res[f"final_tail.emb_l.{g}.weight"] = v[-48:].copy()
+        res[f"final_colsum.emb_l.{g}.weight"] = v.astype(np.float64).sum(0)
+        res[f"final_touched.emb_l.{g}.weight"] = v[batches[0][2][g][:64]].copy()
+    if rank == 0:
+        for tower, mod in (("bot_l", model.bot_l.module), ("top_l", model.top_l.module)):
+            for name, p in mod.named_parameters():
+                v = p.detach().numpy()
+                if v.ndim == 2 and v.size > 70000:
+                    # large matrices: every 8th row, plus fp64 row and column sums of the whole matrix (every element is covered)
+                    res[f"final_rows8.{tower}.{name}"] = v[::8].copy()
+                    res[f"final_colsum.{tower}.{name}"] = v.astype(np.float64).sum(0)
+                    res[f"final_rowsum.{tower}.{name}"] = v.astype(np.float64).sum(1)
+                else:
+                    res[f"final.{tower}.{name}"] = v.copy()
+    res["local_emb_indices"] = np.asarray(list(model.local_emb_indices))
+    q.put((rank, res))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def capture_distributed_tb(name="dist8_tb", size=8, row_cap=2000, B=65536, steps=2, lr=0.5, seed=321, port=29651):
+    """Inputs and initial parameters are NOT stored (as in capture_terabyte): the fixture holds the seed, the generator state and the
+    digests; tests/golden_tb.py regenerates and verifies them.  Stored: every rank's predictions and loss per step, rank 0's two
+    step-0 gradients after the DDP all-reduce, the final towers (small tensors whole; large matrices as every 8th row + fp64 row/column
+    sums) and head / tail / looked-up rows + fp64 column sums of every final table from the rank that owns it."""
+    import time
+    import torch.multiprocessing as mp
+    ref, dp, ext = import_reference()
+    ln_emb = np.asarray([min(n, row_cap) for n in CRITEO_TB_ROWS])
+    ln_bot = np.asarray([13, 512, 256, 128])
+    m_spa = 128
+    F = ln_emb.size + 1
+    ln_top = np.asarray([F * (F - 1) // 2 + m_spa, 1024, 1024, 512, 256, 1])
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    model = ref.DLRM_Net(m_spa, ln_emb, ln_bot, ln_top, arch_interaction_op="dot", arch_interaction_itself=False,
+                         sigmoid_bot=-1, sigmoid_top=ln_top.size - 2, loss_function="bce")
+    out, digests = {}, {}
+    for k, v in model.state_dict().items():
+        digests[f"init.{k}"] = _sha(v.detach().numpy())
+    st = np.random.get_state()
+    out["rng_after_init.keys"] = np.asarray(st[1], dtype=np.uint32)
+    out["rng_after_init.pos_gauss"] = np.asarray([st[2], st[3]], dtype=np.int64)
+    out["rng_after_init.cached"] = np.asarray([st[4]], dtype=np.float64)
+    t0 = time.time()
+    batches = [gen_batch(dp, 13, ln_emb, B, 1, True, True) for _ in range(steps)]
+    print(f"{name}: reference generator {time.time() - t0:.0f} s")
+    for s, (X, lS_o, lS_i, T) in enumerate(batches):
+        digests[f"s{s}.X"] = _sha(X.numpy())
+        digests[f"s{s}.T"] = _sha(T.numpy())
+        digests[f"s{s}.idx"] = _sha(np.stack([i.numpy().astype(np.int64) for i in lS_i]))
+        digests[f"s{s}.off"] = _sha(np.stack([o.numpy().astype(np.int64) for o in lS_o]))
+    meta = dict(name=name, size=size, m_spa=m_spa, ln_emb=ln_emb.tolist(), ln_bot=ln_bot.tolist(), ln_top=ln_top.tolist(), B=B,
+                steps=steps, lr=lr, loss="bce", itself=False, sigmoid_top=int(ln_top.size - 2), seed=seed, row_cap=row_cap,
+                num_idx=1, fixed=True, digests=digests, torch=torch.__version__, numpy=np.__version__,
+                reference="facebookresearch/dlrm @ /root/reference: DLRM_Net.distributed_forward + extend_distributed on 8 gloo ranks "
+                          "(README.md:345-346 launch pattern, bench/run_and_time.sh:17 shapes)")
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    out["losses"] = np.zeros(0)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)      # (provisional: the workers regenerate through golden_tb.regen_*)
+    del model, batches
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    t0 = time.time()
+    procs = [ctx.Process(target=_dist_tb_worker, args=(r, size, port, meta, q)) for r in range(size)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=3600) for _ in range(size))
+    for p in procs:
+        p.join(120)
+    print(f"{name}: reference {size}-rank training {time.time() - t0:.0f} s")
+    for r, res in results.items():
+        for k, v in res.items():
+            out[f"rank{r}.{k}"] = np.asarray(v)
+    out["losses"] = np.asarray([[float(results[r][f"s{s}.loss"]) for s in range(steps)] for r in range(size)])
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(name, "rank losses", out["losses"].tolist())
+    sys.path.insert(0, os.path.dirname(OUT))
+    import golden_tb
+    golden_tb.load(name)        # digests + RNG state of the vectorised regeneration
+    print(f"{name}: regeneration verified")
+
+
+# ---------------------------------------------------------------------------------------------
 # BASELINE.json configs[4] inputs: the reference's Multihot class (torchrec_dlrm/multi_hot.py:27-175)
 # ---------------------------------------------------------------------------------------------
 def import_multihot():
@@ -592,6 +722,9 @@ def main(which):
     if which in ("all", "dist8"):
         # the real Criteo split: 26 tables over 8 ranks -> [4,4,3,3,3,3,3,3] (extend_distributed.py:47-62), B = 64 -> 8 per rank
         capture_distributed("dist8_t26", size=8, ln_emb=[5 + (7 * k) % 23 for k in range(26)], B=64, top_mid=16, port=29641)
+    if which == "dist8tb":
+        # not part of "all": the reference's 8-rank run at the full Terabyte shapes takes a few minutes of host time
+        capture_distributed_tb()
     if which == "all":
         capture_multihot()
         capture_metrics()

@@ -239,6 +239,63 @@ def test_interact_fwd_bwd(F, D, itself, B):
     np.testing.assert_allclose(dE.cpu().numpy().reshape(B, F - 1, D), dwant[:, 1:, :], rtol=1e-5, atol=2 * atol)
 
 
+@pytest.mark.parametrize("widths", [[4, 4, 3, 3, 3, 3, 3, 3], [13, 13], [1] * 26, [7, 7, 6, 6]],
+                         ids=["config4_8ranks", "2ranks", "26ranks", "4ranks"])
+@pytest.mark.parametrize("B", [8192, 333])
+def test_interact_fwd_bwd_over_all_to_all_blocks(widths, B):
+    """BASELINE configs[3] at its OWN shapes: after the forward all-to-all a rank's interaction reads the bottom-MLP output
+    plus one receive block per peer (dlrm_s_pytorch.py:528-585; 26 tables over 8 ranks = widths 4,4,3,3,3,3,3,3,
+    extend_distributed.py:47-62), each block its own allocation with its own leading dimension, D = 128, B/N = 8192 rows;
+    the backward writes each block's gradient into a strided chunk of the reverse exchange's send buffer.  Checked directly
+    against the oracle (dlrm_s_pytorch.py:483-504), forward and backward."""
+    from dlrm_amd import ops
+    D, T = 128, sum(widths)
+    F = T + 1
+    rng = np.random.default_rng(B + len(widths))
+    feat = rng.standard_normal((B, F, D)).astype(np.float32)
+    want = O.interact_fwd(feat, False)
+    Wd = want.shape[1]
+    ldr = (Wd + 3) & ~3
+    # x lives inside a wider activation buffer (row pitch > D); every receive block has its own pitch: block j is padded by
+    # 4 * (j % 3) floats so that no two consecutive blocks share a leading dimension
+    xbuf = torch.full((B, D + 8), -7.0, device=dev())
+    x = xbuf[:, :D]
+    x.copy_(to_dev(feat[:, 0, :]))
+    blocks, t0 = [x], 1
+    for j, w in enumerate(widths):
+        buf = torch.full((B, w * D + 4 * (j % 3)), -9.0, device=dev())
+        blk = buf[:, :w * D]
+        blk.copy_(to_dev(feat[:, t0:t0 + w, :].reshape(B, w * D)))
+        blocks.append(blk)
+        t0 += w
+    R = torch.full((B, ldr), 3.0, device=dev())
+    ops.interact_fwd(blocks, D, False, R)
+    torch.cuda.synchronize()
+    got = R.cpu().numpy()
+    atol = 3e-5
+    np.testing.assert_allclose(got[:, :Wd], want, rtol=1e-5, atol=atol)
+    assert np.array_equal(got[:, :D], feat[:, 0, :])
+    assert np.all(got[:, Wd:] == 0)
+    # backward: the gradient of block j lands in a column chunk of ONE flat send buffer [B, T*D + pad] (the layout
+    # ext_dist's reverse all-to-all sends in place), the gradient of x in its own strided buffer
+    dR = rng.standard_normal((B, Wd)).astype(np.float32)
+    dwant = O.interact_bwd(feat, dR, False)
+    dRd = torch.zeros((B, ldr), device=dev())
+    dRd[:, :Wd] = to_dev(dR)
+    dxbuf = torch.full((B, D + 4), 5.0, device=dev())
+    send = torch.full((B, T * D + 12), 6.0, device=dev())
+    dblocks, c0 = [dxbuf[:, :D]], 0
+    for w in widths:
+        dblocks.append(send[:, c0:c0 + w * D])
+        c0 += w * D
+    ops.interact_bwd(blocks, D, False, dRd, dblocks)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dxbuf[:, :D].cpu().numpy(), dwant[:, 0, :], rtol=1e-5, atol=2 * atol)
+    np.testing.assert_allclose(send[:, :T * D].cpu().numpy().reshape(B, T, D), dwant[:, 1:, :], rtol=1e-5, atol=2 * atol)
+    assert torch.all(dxbuf[:, D:] == 5.0) and torch.all(send[:, T * D:] == 6.0)      # nothing written outside the chunks
+    assert torch.all(xbuf[:, D:] == -7.0)
+
+
 # ------------------------------------------------------------------------------------------ MLP layers
 @pytest.mark.parametrize("M,N,K,act", [(128, 512, 13, 1), (300, 16, 512, 1), (257, 1024, 479, 1), (64, 1, 256, 2),
                                        (1, 3, 2, 0), (513, 130, 36, 1), (1000, 128, 256, 1),
@@ -711,6 +768,16 @@ def test_gather_interaction_is_bit_identical_to_the_two_kernels(T, B, idx_dtype,
     R1 = torch.full((B, ldr), 7.0, device=dev())
     ops.interact_fwd_gather(x, Ws, bags, D, itself, R1)
     assert torch.equal(R0, R1)
+    # ... and DIRECTLY against the oracle (O.emb_fwd + O.interact_fwd, dlrm_s_pytorch.py:407-462, 483-504): this test stands on its
+    # own, whatever else ran before it
+    idx_np = idx.cpu().numpy().astype(np.int64)
+    Bo = min(B, 6000)
+    feat_o = np.empty((Bo, F, D), dtype=np.float32)
+    feat_o[:, 0] = x.cpu().numpy()[:Bo]
+    for t in range(T):
+        feat_o[:, 1 + t] = O.emb_fwd(Ws[t].cpu().numpy(), idx_np[t, :Bo], np.arange(Bo, dtype=np.int64))
+    want = O.interact_fwd(feat_o, itself)
+    np.testing.assert_allclose(R1.cpu().numpy()[:Bo, :W_], want, rtol=1e-5, atol=3e-5)
     dR = to_dev(rng.standard_normal((B, ldr)).astype(np.float32))
     d0 = torch.empty((B, F * D), device=dev())
     ops.interact_bwd([feat[:, :D], feat[:, D:]], D, itself, dR, [d0[:, :D], d0[:, D:]])
@@ -718,6 +785,9 @@ def test_gather_interaction_is_bit_identical_to_the_two_kernels(T, B, idx_dtype,
     ops.interact_bwd_gather(x, Ws, bags, D, itself, dR, dx, dE)
     assert torch.equal(d0[:, :D], dx) and torch.equal(d0[:, D:], dE)
     ops.check_index_errors(sync=True)
+    dwant = O.interact_bwd(feat_o, dR.cpu().numpy()[:Bo, :W_], itself)
+    np.testing.assert_allclose(dx.cpu().numpy()[:Bo], dwant[:, 0, :], rtol=1e-5, atol=6e-5)
+    np.testing.assert_allclose(dE.cpu().numpy()[:Bo].reshape(Bo, T, D), dwant[:, 1:, :], rtol=1e-5, atol=6e-5)
     # violations are reported
     bad_off = off.clone(); bad_off[T - 1, min(5, B - 1)] = min(5, B - 1) - 1
     ops.interact_fwd_gather(x, Ws, ops.BagBatch(bad_off, idx), D, itself, R1)

