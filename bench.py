@@ -104,6 +104,8 @@ def parse():
                     help="N > 1: gradient all-reduce of the data-parallel MLP towers: torch DistributedDataParallel (the reference, "
                          "dlrm_s_pytorch.py:1329-1336; default) or dlrm_amd.ext_dist.FlatDDP (one flat buffer the weight-gradient GEMMs "
                          "write into, one collective per tower); the other one is measured in the same run as alt_dense_sync")
+    ap.add_argument("--no-box-calibration", action="store_true", help="skip the in-run MFMA / HBM probes (profiling runs: keeps the probe "
+                    "kernels out of the trace); frac_of_measured_peak then falls back to the guide's constants")
     ap.add_argument("--no-kernel-timers", action="store_true", help="no per-kernel HIP events in the timed region (no roofline)")
     ap.add_argument("--timer-every", type=int, default=4,
                     help="per-kernel HIP events are recorded on every n-th step of the timed region (an event is a queue barrier, "
@@ -131,6 +133,56 @@ def parse():
                     help="f32: native fp32 MFMA; bf16x6: exact 3-term bf16 split of the fp32 operands, 6 bf16 MFMA products, "
                          "fp32 accumulation (fp32 round-off class)")
     return ap.parse_args()
+
+
+def measure_box(device, quick=False):
+    """In-run calibration of THIS box (boxes of the pool differ by up to 6 %): what its matrix pipes and its HBM sustain
+    right now, measured with the library's own probes (dlrm_calib_mfma / dlrm_calib_hbm_copy, ~50 ms each) and HIP events on the
+    current stream.  `frac_of_measured_peak` of every kernel category is priced against these numbers, so a slow-box line and a
+    fast-box line of the same commit agree; `frac` stays priced against the spec peaks of MI355X_MICROARCH.md."""
+    import ctypes as C
+    from dlrm_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    scratch = torch.zeros(4, dtype=torch.float32, device=device)
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = {"cu_count": cus}
+    for kind, key, iters in ((0, "mfma_f32_tflops", 4000 if quick else 15000), (1, "mfma_bf16_tflops", 8000 if quick else 30000)):
+        flop = C.c_double(0.0)
+        _lib.check(lib.dlrm_calib_mfma(kind, 200, C.c_void_p(scratch.data_ptr()), C.byref(flop), st), "dlrm_calib_mfma")     # warm
+        torch.cuda.synchronize(device)
+        e0.record()
+        _lib.check(lib.dlrm_calib_mfma(kind, iters, C.c_void_p(scratch.data_ptr()), C.byref(flop), st), "dlrm_calib_mfma")
+        e1.record()
+        torch.cuda.synchronize(device)
+        out[key] = flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    out["mfma_clock_mhz"] = out["mfma_f32_tflops"] * 1e12 / (cus * 256.0) / 1e6      # 256 fp32 MFMA FLOP per clock per CU
+    nbytes = 1 << 30
+    a = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    b = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    a.zero_(); b.zero_()
+    reps = 25 if quick else 100
+    for r in range(reps + 2):
+        if r == 2:
+            torch.cuda.synchronize(device)
+            e0.record()
+        _lib.check(lib.dlrm_calib_hbm_copy(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), nbytes, st), "dlrm_calib_hbm_copy")
+    e1.record()
+    torch.cuda.synchronize(device)
+    out["hbm_copy_gbps"] = 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    return out
+
+
+def merge_box(b0, b1):
+    """mean of the calibration before and after the timed region (+ the two readings, so drift inside a run is visible)"""
+    box = {k: (0.5 * (b0[k] + b1[k]) if isinstance(b0[k], float) else b0[k]) for k in b0}
+    box["before"] = {k: round(v, 2) for k, v in b0.items() if isinstance(v, float)}
+    box["after"] = {k: round(v, 2) for k, v in b1.items() if isinstance(v, float)}
+    box["note"] = ("measured in this run by dlrm_calib_mfma / dlrm_calib_hbm_copy right before and right after the timed region "
+                   "(mean); frac_of_measured_peak is priced against these, frac against the spec peaks")
+    return box
 
 
 def make_batches(n, B, rows, device, seed, hot=None, local_rows=None):
@@ -569,6 +621,9 @@ def main():
         if i == 0 and N > 1:
             torch.cuda.synchronize()
             watchdog(args.hang_timeout + 20 * (args.warmup + args.steps), "warm-up + timed region")
+    box0 = measure_box(device) if not args.no_box_calibration else None
+    if box0 is not None:
+        step(args.warmup)                # one more untimed step: the timed region starts from the step's own steady state, not the probe's
     if N > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -590,6 +645,7 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+    box = merge_box(box0, measure_box(device)) if box0 is not None else None
     ms = dt / args.steps * 1e3
     value = B / (dt / args.steps)
     final_loss = float(loss.detach())
@@ -623,6 +679,10 @@ def main():
     gi_bwd_bytes = B * (Tl * (R + 2 * isz) + D * 4 + (D + F * (F - 1) // 2) * 4 + (1 + Tl) * R)
 
     mfma_peak, mfma_issue_ratio, mfma_measured = ARITH_PEAK[args.mlp_arith]
+    hbm_measured = MEASURED_HBM_GBS
+    if box is not None:
+        mfma_measured = {"f32": box["mfma_f32_tflops"], "bf16": box["mfma_bf16_tflops"], "bf16x6": box["mfma_bf16_tflops"] / 6.0}[args.mlp_arith]
+        hbm_measured = box["hbm_copy_gbps"]
     kernels = {}
     for name, work, unit, peak, bound in (
             ("emb_fwd", emb_fwd_bytes, "GB/s", HBM_PEAK_GBS, "hbm"),
@@ -643,7 +703,7 @@ def main():
         ach = work / (per_step_ms * 1e-3) / scale
         kernels[name] = {"ms_per_step": per_step_ms, "launches_per_step": k["calls"] / max(timed_steps, 1),
                          "avg_launch_ms": k["avg_ms"], "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                         "frac": ach / peak, "frac_of_measured_peak": ach / (MEASURED_HBM_GBS if unit == "GB/s" else mfma_measured),
+                         "frac": ach / peak, "frac_of_measured_peak": ach / (hbm_measured if unit == "GB/s" else mfma_measured),
                          "algorithmic_work_per_step": work}
     for name in ("act_bwd", "bce_loss", "sgd_dense"):
         if name in ksum:
@@ -697,7 +757,11 @@ def main():
                     (pmc["_file"], k["algorithmic_work_per_step"] // max(int(round(k["launches_per_step"])), 1)))
         else:
             note = ("HBM bytes per call from rocprofv3 PMC passes (%s; source hashes match HEAD)" % pmc["_file"]) if t else None
-        measured_peak = MEASURED_HBM_GBS if k["unit"] == "GB/s" else mfma_measured
+        measured_peak = hbm_measured if k["unit"] == "GB/s" else mfma_measured
+        # the whole per-category table travels INSIDE `roofline` (the driver's record keeps this object): [ms per step, frac of the
+        # spec peak, frac of this box's measured peak]; categories without an algorithmic-work figure carry None fractions
+        by_cat = {c: [round(v["ms_per_step"], 4), round(v["frac"], 4) if "frac" in v else None,
+                      round(v["frac_of_measured_peak"], 4) if "frac_of_measured_peak" in v else None] for c, v in kernels.items()}
         return {"kernel": kname.get(n, n), "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
                 "peak_note": None if k["unit"] == "GB/s" else
                 {"f32": "dense fp32 MFMA peak", "bf16": "dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)",
@@ -705,7 +769,8 @@ def main():
                 "unit": k["unit"], "frac": k["frac"],
                 "frac_of_measured_peak": k["achieved"] / measured_peak, "measured_peak": measured_peak,
                 "traffic": t["traffic_bytes"] if (t and not stale) else None, "traffic_note": note,
-                "avg_launch_ms": k["avg_launch_ms"], "ms_per_step": k["ms_per_step"]}
+                "avg_launch_ms": k["avg_launch_ms"], "ms_per_step": k["ms_per_step"],
+                "by_category": by_cat, "by_category_columns": ["ms_per_step", "frac", "frac_of_measured_peak"], "box": box}
 
     result = {
         "metric": "samples/sec (global batch) + embedding HBM GB/s, Criteo-TB config",
@@ -741,6 +806,7 @@ def main():
                                          "v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate, fp32 master weights (reduced precision: NOT the headline "
                                          "configuration)"}[args.mlp_arith]},
         "final_loss": final_loss,
+        "box": box,
         "parity_check": parity,
         "kernel_timing": "HIP events on the launch stream, one per change of launch category (a run of consecutive launches of one category "
                          "is one event pair; dlrm_amd.ops.KernelTimers), on %d of the %d timed steps" % (timed_steps, args.steps),
@@ -773,7 +839,7 @@ def main():
         result["embedding_kernel_standalone"] = {"kernel": "emb_fwd_kernel (dlrm_emb_fwd, all tables in one launch), measured outside the step: "
                                                            "the step itself runs the lookups inside the interaction kernels",
                                                  "ms": ems, "achieved": ach, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS,
-                                                 "frac_of_measured_peak": ach / MEASURED_HBM_GBS, "algorithmic_bytes": emb_fwd_bytes}
+                                                 "frac_of_measured_peak": ach / hbm_measured, "algorithmic_bytes": emb_fwd_bytes}
         result["embedding_hbm_gbps"]["fwd"] = ach
         result["embedding_hbm_gbps"]["fwd_fused_with_interaction"] = kernels.get("emb_interact_fwd", {}).get("achieved")
         del out0

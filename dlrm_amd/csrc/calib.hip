@@ -1,0 +1,66 @@
+// calib.hip — in-run calibration of the box bench.py is measuring on: boxes of the pool differ by up to 6 % in what their
+// matrix pipes and HBM sustain, so a roofline fraction against a constant says nothing about whether a slow line is a slow box or a
+// regression.  Two probes, ~50 ms each, timed by the caller with HIP events on `stream`:
+//   dlrm_calib_mfma       back-to-back v_mfma_f32_32x32x2_f32 (kind 0) or v_mfma_f32_32x32x16_bf16 (kind 1) on every SIMD, no memory
+//                         traffic -> the matrix rate this chip sustains at its power budget (and the implied clock);
+//   dlrm_calib_hbm_copy   float4 grid-stride copy src -> dst (the access pattern MI355X_MICROARCH.md quotes 6.29 TB/s for).
+// Not on the training path; nothing here is called by the model.
+#include "common.h"
+
+namespace {
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int KIND>
+__global__ __launch_bounds__(256) void calib_mfma_kernel(float* out, int iters, float a, float b) {
+    floatx16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8 av, bv;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { av[r] = (__bf16)a; bv[r] = (__bf16)b; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (KIND == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                else           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
+            }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 123.456f) out[0] = s;          // never true: keeps the accumulators live
+}
+
+__global__ __launch_bounds__(256) void calib_copy_kernel(const float4* __restrict__ a, float4* __restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
+}
+}  // namespace
+
+extern "C" int dlrm_calib_mfma(int kind, int iters, float* scratch, double* flop_out, void* stream) {
+    if (iters <= 0 || !scratch || !flop_out || (kind != 0 && kind != 1)) return DLRM_E_ARG;
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, dlrm_current_device());
+    if (e != hipSuccess) return (int)e;
+    const int grid = p.multiProcessorCount * 2;                 // 2 waves per SIMD
+    if (kind == 0) hipLaunchKernelGGL(calib_mfma_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, scratch, iters, 1.0f, 2.0f);
+    else           hipLaunchKernelGGL(calib_mfma_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, scratch, iters, 1.0f, 2.0f);
+    DLRM_LAUNCH_CHECK();
+    // per wave and iteration: 64 MFMAs of 32 x 32 x {2, 16} multiply-adds
+    *flop_out = (double)grid * 4.0 * iters * 64.0 * (2.0 * 32 * 32 * (kind == 0 ? 2 : 16));
+    return 0;
+}
+
+extern "C" int dlrm_calib_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream) {
+    if (!src || !dst || bytes < 16 || (bytes & 15)) return DLRM_E_ARG;
+    if (!dlrm_aligned16(src) || !dlrm_aligned16(dst)) return DLRM_E_ALIGN;
+    hipLaunchKernelGGL(calib_copy_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, (size_t)(bytes / 16));
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
