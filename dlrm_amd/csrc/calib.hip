@@ -3,7 +3,7 @@
 // regression.  Two probes, ~50 ms each, timed by the caller with HIP events on `stream`:
 //   dlrm_calib_mfma       back-to-back v_mfma_f32_32x32x2_f32 (kind 0) or v_mfma_f32_32x32x16_bf16 (kind 1) on every SIMD, no memory
 //                         traffic -> the matrix rate this chip sustains at its power budget (and the implied clock);
-//   dlrm_calib_hbm_copy   float4 grid-stride copy src -> dst (the access pattern MI355X_MICROARCH.md quotes 6.29 TB/s for).
+//   dlrm_calib_hbm_copy   float4 copy src -> dst, one float4 per thread (the access pattern MI355X_MICROARCH.md quotes 6.29 TB/s for).
 // Not on the training path; nothing here is called by the model.
 #include "common.h"
 
@@ -38,8 +38,11 @@ __global__ __launch_bounds__(256) void calib_mfma_kernel(float* out, int iters, 
     if (s == 123.456f) out[0] = s;          // never true: keeps the accumulators live
 }
 
+// ONE float4 per thread, no loop: the fastest of the copy shapes swept on the box (tools/probes/hbm_copy_sweep.hip, profiles/round4: 6.18 TB/s
+// vs 4.2-5.7 TB/s for grid-stride loops of any unroll / grid, 5.17 TB/s for hipMemcpyAsync) — the "float4 copy" MI355X_MICROARCH.md quotes
 __global__ __launch_bounds__(256) void calib_copy_kernel(const float4* __restrict__ a, float4* __restrict__ b, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b[i] = a[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) b[i] = a[i];
 }
 }  // namespace
 
@@ -60,7 +63,9 @@ extern "C" int dlrm_calib_mfma(int kind, int iters, float* scratch, double* flop
 extern "C" int dlrm_calib_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream) {
     if (!src || !dst || bytes < 16 || (bytes & 15)) return DLRM_E_ARG;
     if (!dlrm_aligned16(src) || !dlrm_aligned16(dst)) return DLRM_E_ALIGN;
-    hipLaunchKernelGGL(calib_copy_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, (size_t)(bytes / 16));
+    const size_t n = (size_t)(bytes / 16);
+    if ((n + 255) / 256 > 0x7fffffffull) return DLRM_E_RANGE;
+    hipLaunchKernelGGL(calib_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n);
     DLRM_LAUNCH_CHECK();
     return 0;
 }

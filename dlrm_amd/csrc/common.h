@@ -50,6 +50,26 @@ __device__ __forceinline__ float dlrm_wave_sum(float v) {
     return v;
 }
 
+// Zero fill as a KERNEL, never hipMemsetAsync: a memset node inside a captured HIP graph replays unreliably on ROCm 7.2 (the bias gradient
+// of a small layer came back inf on the second replay of a whole-step graph when a host synchronisation preceded the capture —
+// tools/probes/graph_prove_probe2.py; rocPRIM's memsets are why its sort cannot be replayed either).  rows x cols floats at pitch ld.
+namespace {
+__global__ __launch_bounds__(256) void dlrm_zero2d_kernel(float* __restrict__ p, long long ld, long long cols, long long total) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / cols;
+        p[r * ld + (e - r * cols)] = 0.f;
+    }
+}
+}  // namespace
+static inline int dlrm_zero2d(float* p, long long ld, long long cols, long long rows, hipStream_t st) {
+    const long long total = rows * cols;
+    if (total <= 0) return 0;
+    long long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(dlrm_zero2d_kernel, dim3((unsigned)nb), dim3(256), 0, st, p, ld, cols, total);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // Tables are passed to the embedding kernels BY VALUE in the kernarg segment (no H2D copy of a
 // pointer table, HIP-graph friendly).  32 tables x 6 x 8 B = 1.5 KiB.
 #define DLRM_MAX_TABLES_PER_LAUNCH 32
@@ -97,3 +117,7 @@ int64_t dlrm_smallk_bwd_weight_workspace_bytes(int64_t M, int N, int K);
 int dlrm_smallk_bwd_weight(int64_t M, int N, int K, int K_store, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,
                            int64_t lddw, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
                            hipStream_t st);
+
+// gemm_bf16.hip: the bf16-shaped (256 x 256 x 64, four phases per k-tile) GEMM; 0 = handled, DLRM_GEMV_NOT_HANDLED = outside its preconditions
+int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, int act,
+                          uint64_t* relu_bits_out, const uint64_t* relu_bits_in, float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, hipStream_t st);

@@ -667,8 +667,8 @@ extern "C" int dlrm_emb_psw_grad(int T, int64_t B, int D, const void* const* wei
     hipStream_t st = (hipStream_t)stream;
     for (int t = 0; t < T; ++t) {                    // dvW is an OUTPUT: zeroed here, then accumulated with atomics
         if (!dvw_host[t]) return DLRM_E_ARG;
-        hipError_t e = hipMemsetAsync(dvw_host[t], 0, (size_t)rows_host[t] * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
+        const int e = dlrm_zero2d((float*)dvw_host[t], rows_host[t], rows_host[t], 1, st);      // a kernel, not a memset node (common.h)
+        if (e) return e;
     }
     for (int t0 = 0; t0 < T; t0 += DLRM_MAX_TABLES_PER_LAUNCH) {
         const int n = (T - t0 < DLRM_MAX_TABLES_PER_LAUNCH) ? T - t0 : DLRM_MAX_TABLES_PER_LAUNCH;

@@ -1115,6 +1115,10 @@ extern "C" int dlrm_gemm_bf16(int64_t M, int N, int K, const uint16_t* A, int64_
     if (K % 32 || N % 4 || lda % 8 || ldb % 8 || !dlrm_aligned16(A) || !dlrm_aligned16(B) || (C && (!dlrm_aligned16(C) || ldc % 4)) ||
         (Cb && ((((uintptr_t)Cb) & 7u) || ldcb % 4)))
         return DLRM_E_ALIGN;
+    {   // the bf16-shaped kernel (gemm_bf16.hip: 256 x 256 x 64 tile, four phases per k-tile) wherever its preconditions hold
+        const int rc = dlrm_gemm_bf16_phased(M, N, K, A, lda, B, ldb, bias, act, relu_bits_out, relu_bits_in, C, ldc, Cb, ldcb, (hipStream_t)stream);
+        if (rc != DLRM_GEMV_NOT_HANDLED) return rc;
+    }
     GemmArgs g = {};
     g.M = M; g.N = N; g.K = K / 2;                    // in units of one fp32 word = two bf16 values
     g.A = (const float*)A; g.lda = lda / 2; g.B = (const float*)B; g.ldb = ldb / 2;
@@ -1248,10 +1252,10 @@ static int linear_bwd_weight_impl(int64_t M, int N, int K, int K_store, const fl
     }
     g.atomic_out = (splits > 1 || accumulate) ? 1 : 0;
     if (!accumulate) {
-        hipError_t e = hipSuccess;
-        if (g.atomic_out) e = hipMemset2DAsync(dW, (size_t)lddw * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)N, st);
-        if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)N * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
+        int e = 0;                            // zeroed by kernels (no memset nodes in a captured step, common.h)
+        if (g.atomic_out) e = dlrm_zero2d(dW, lddw, K, N, st);
+        if (e == 0 && dbias) e = dlrm_zero2d(dbias, N, N, 1, st);
+        if (e) return e;
     }
     return launch_gemm<false, false>(g, splits, st, arith);
 }

@@ -1,0 +1,290 @@
+// gemm_bf16.hip — the bf16-SHAPED GEMM of the bf16 MLP towers (BASELINE.json configs[4], "bf16 MLP on MFMA";
+// torchrec_dlrm/README.MD:177-194, dlrm_main.py:526,598-619) for gfx950.
+//
+//   C[M, N] (fp32, optional) / Cb[M, N] (bf16, optional) = epilogue( A[M, K] . B[N, K]^T ),   A and B bf16, k contiguous
+//     forward        A = X,  B = W      + bias, activation, ReLU sign bits OUT
+//     data gradient  A = dY, B = W^T    masked by the previous layer's ReLU sign bits IN
+//
+// Why a second kernel beside gemm3_kernel<.., ARITH = 3> (gemm.hip): that one reuses the fp32-shaped pipeline — a 256 x 128 tile, one
+// barrier and six LDS-DMA issues per 32 k for 16 MFMAs — and sits at 0.08-0.15 of the bf16 matrix peak (profiles/round3).  At bf16 rates
+// a 256 x 128 x 32 step is 512 MFMA cycles per wave: the barrier, the DMA issue and the fragment reads all have to hide under it, which a
+// load-all-then-multiply body cannot do.  This kernel is shaped for the bf16 pipe:
+//   * tile 256 x 256 x 64, 8 waves (2 x 4) of 128 x 64 = 4 x 2 sub-tiles of v_mfma_f32_32x32x16_bf16 (128 accumulator registers),
+//     one workgroup per CU (two waves per SIMD), 128 KiB of LDS = 2 k-tiles x (A 32 KiB + B 32 KiB): 128 FLOP per staged byte;
+//   * FOUR PHASES per k-tile, each = one quadrant (64 x 32 x 64: 8 MFMAs = 256 matrix-pipe cycles) of the wave tile:
+//         LOAD  : ds_read_b128 of the quadrant's NEW fragments (8 A + 4 B, 4 B, 8 A, 4 B), 2 LDS-DMA issues of the NEXT k-tile, counted vmcnt
+//         s_barrier
+//         MATH  : 8 MFMAs at raised priority
+//         s_barrier
+//     the two wave halves (rows 0-127 / 128-255 of the tile; one wave of each half per SIMD) run ONE BARRIER APART, so on every SIMD
+//     one wave multiplies while the other reads fragments and issues DMA — fragment reads of phase p+1 under the MFMAs of phase p;
+//   * the next k-tile is staged in four 16 KiB pieces in the ORDER OF FIRST USE (A rows of the first two sub-tile rows, B columns of the
+//     first sub-tile column, B second column, A last two rows), one piece per phase: every piece is issued >= 3 phases before its first
+//     read and its slot is rewritten >= 2 phases after its last read; `s_waitcnt vmcnt(4)` leaves two pieces in flight across every barrier;
+//   * LDS image per operand and k-half: [256 rows][64 B] with the 16-byte slots XOR-swizzled through the SOURCE address (the DMA
+//     destination is lane-linear) — the image gemm3_kernel uses, conflict-free for the 32-row x 16-byte fragment reads;
+//   * epilogue as in gemm3_kernel: accumulators hold the TRANSPOSED sub-tiles, bands pass through wave-private LDS and leave as 16-byte
+//     (fp32) / 8-byte (bf16) row segments; bias, activation, sign bits out (one 4-byte word per lane and 32 x 64 block), sign-bit mask in.
+// Preconditions (checked by the host; otherwise the caller keeps gemm3_kernel): K % 64 == 0, N % 4 == 0, N >= 192, M >= 256, 16-byte aligned
+// operand rows.  Rows / columns past the matrix edge are clamped to a valid address and never stored.
+#include "common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+struct BfArgs {
+    long long M, N, K;                       // K in bf16 elements, multiple of 64
+    const unsigned short* A; long long lda;  // elements
+    const unsigned short* B; long long ldb;
+    float* C; long long ldc;                 // nullable
+    unsigned short* Cb; long long ldcb;      // nullable
+    const float* bias; int act;
+    unsigned* bits_out; const unsigned* bits_in; long long bits_nblk;
+    int tiles_m, tiles_n;
+};
+
+constexpr int PBM = 256, PBN = 256, PBK = 64;
+constexpr int OP_BYTES = 2 * 256 * 64;            // one operand of one k-tile: [2 k-halves][256 rows][64 B] = 32 KiB
+constexpr int KHALF_BYTES = 256 * 64;             // 16 KiB
+constexpr int STAGE_BYTES = 2 * OP_BYTES;         // 64 KiB
+constexpr int P_EPI_LD = 64 + 4;
+
+__device__ __forceinline__ void p_glds16(unsigned voff, const void* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void p_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void p_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned p_cvt_pk_bf16(float lo, float hi) {
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float p_act(float v, int act) {
+    if (act == DLRM_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == DLRM_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+#define P_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
+
+// MASKED: the result is multiplied by the previous layer's ReLU derivative, read from its sign bits (data gradient)
+__global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    const char* ldsb = (const char*)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;              // wave row (its half of the tile's rows), wave column
+    const int l31 = lane & 31, h = lane >> 5;
+
+    // workgroups go to the 8 XCDs round-robin in dispatch order: every XCD gets a contiguous range of tiles (the tiles_n tiles of one A
+    // row panel meet in one L2)
+    int id;
+    {
+        const int nwg = g.tiles_m * g.tiles_n, lin = (int)blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, local = lin >> 3;
+        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int tile_m = __builtin_amdgcn_readfirstlane(id / g.tiles_n), tile_n = __builtin_amdgcn_readfirstlane(id - tile_m * g.tiles_n);
+    const long long m0 = (long long)tile_m * PBM, n0 = (long long)tile_n * PBN;
+    const int nk = (int)(g.K / PBK);
+
+    // ---- DMA plan.  A piece = 128 tile rows x 64 k = 16 chunks of 1 KiB (16 rows x 64 B of one k-half); wave w moves chunks w and w + 8
+    // of every piece: k-half = w & 1, row group (16 rows) = (w >> 1) and (w >> 1) + 4.
+    //   piece 0 (A0): A rows {0..63, 128..191}      piece 1 (B0): B rows {64 c + 0..31,  c = 0..3}
+    //   piece 3 (A1): A rows {64..127, 192..255}    piece 2 (B1): B rows {64 c + 32..63, c = 0..3}
+    unsigned voff[4][2], dst[4][2];
+    {
+        const int kh = wave & 1;
+        const int srow = lane >> 2, sslot = (lane & 3) ^ ((lane >> 4) & 3);     // source k-slot of the lane's 16 bytes (XOR swizzle, see gemm.hip dma_offset)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rg = (wave >> 1) + 4 * i;                              // 0..7: sixteen-row group inside the piece
+                int row;                                                         // tile row of the chunk's first row
+                if (p == 0)      row = (rg >> 2) * 128 + (rg & 3) * 16;
+                else if (p == 3) row = (rg >> 2) * 128 + 64 + (rg & 3) * 16;
+                else if (p == 1) row = (rg >> 1) * 64 + (rg & 1) * 16;
+                else             row = (rg >> 1) * 64 + 32 + (rg & 1) * 16;
+                const bool isA = (p == 0 || p == 3);
+                const long long r0 = isA ? m0 : n0, rmax = isA ? g.M : g.N, ld = isA ? g.lda : g.ldb;
+                long long rgl = r0 + row + srow; if (rgl > rmax - 1) rgl = rmax - 1;
+                voff[p][i] = (unsigned)(((rgl - r0) * ld + kh * 32 + sslot * 8) * 2);
+                dst[p][i] = lds_base + (isA ? 0 : OP_BYTES) + kh * KHALF_BYTES + row * 64;
+            }
+    }
+    const char* baseA = (const char*)(g.A + m0 * g.lda);
+    const char* baseB = (const char*)(g.B + n0 * g.ldb);
+
+#define P_ISSUE(piece, stage_off)                                                                                   \
+    do {                                                                                                            \
+        const char* sb_ = ((piece) == 0 || (piece) == 3) ? baseA : baseB;                                           \
+        p_glds16(voff[piece][0], sb_, dst[piece][0] + (stage_off));                                                 \
+        p_glds16(voff[piece][1], sb_, dst[piece][1] + (stage_off));                                                 \
+    } while (0)
+
+    // ---- fragment read offsets inside an operand image: lane (l31, h) reads row l31 of a 32-row sub-tile, 16-byte slot (2 jj + h) of k-half kh
+    unsigned fa_off[2], fb_off[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const unsigned sl = (unsigned)(((2 * jj + h) ^ ((l31 >> 2) & 3)) * 16);
+        fa_off[jj] = (unsigned)((wr * 128 + l31) * 64) + sl;
+        fb_off[jj] = (unsigned)OP_BYTES + (unsigned)((wc * 64 + l31) * 64) + sl;
+    }
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- prologue: the whole first k-tile, in the order of first use; its first two pieces have landed before anyone reads
+    P_ISSUE(0, 0); P_ISSUE(1, 0); P_ISSUE(2, 0); P_ISSUE(3, 0);
+    baseA += PBK * 2; baseB += PBK * 2;
+    p_wait_vmcnt<4>();
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // the second wave half runs one barrier behind the first
+
+    uintx4 fa[2][4], fb[4];                             // fragments of the current quadrant: A [2 sub-tile rows][4 k-steps], B [4 k-steps]
+    unsigned cur = 0;                                   // byte offset of the stage being multiplied
+#define P_READ_A(half)                                                                                              \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
+            fa[t][j] = *(const uintx4*)(ldsb + cur + fa_off[j & 1] + (j >> 1) * KHALF_BYTES + ((half) * 2 + t) * 2048);
+#define P_READ_B(tn)                                                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
+            fb[j] = *(const uintx4*)(ldsb + cur + fb_off[j & 1] + (j >> 1) * KHALF_BYTES + (tn) * 2048);
+#define P_MATH(half, tn)                                                                                            \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                               \
+            acc[(half) * 2 + t][tn] = P_MFMA(fb[j], fa[t][j], acc[(half) * 2 + t][tn]);                             \
+        __builtin_amdgcn_s_setprio(0);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                               \
+        asm volatile("" ::: "memory");
+    // MORE = 1: one piece of the next k-tile is issued per phase and two pieces stay in flight across the barrier; the last k-tile
+    // (MORE = 0, peeled) only drains
+#define P_STAGE(piece, MORE)                                                                                        \
+        if (MORE) { P_ISSUE(piece, nxt); p_wait_vmcnt<4>(); } else p_wait_vmcnt<0>();
+#define P_KTILE(MORE)                                                                                               \
+    {                                                                                                               \
+        const unsigned nxt = cur ^ (unsigned)STAGE_BYTES;                                                           \
+        /* phase 1: quadrant (rows 0-63, cols 0-31) */                                                             \
+        P_READ_A(0) P_READ_B(0) P_STAGE(0, MORE) P_MATH(0, 0)                                                       \
+        /* phase 2: (rows 0-63, cols 32-63) */                                                                     \
+        P_READ_B(1) P_STAGE(1, MORE) P_MATH(0, 1)                                                                   \
+        /* phase 3: (rows 64-127, cols 32-63) */                                                                   \
+        P_READ_A(1) P_STAGE(2, MORE) P_MATH(1, 1)                                                                   \
+        /* phase 4: (rows 64-127, cols 0-31) */                                                                    \
+        P_READ_B(0) P_STAGE(3, MORE) P_MATH(1, 0)                                                                   \
+        if (MORE) { baseA += PBK * 2; baseB += PBK * 2; }                                                           \
+        cur = nxt;                                                                                                  \
+    }
+    for (int kt = 0; kt + 1 < nk; ++kt) P_KTILE(1)
+    P_KTILE(0)
+#undef P_KTILE
+#undef P_READ_A
+#undef P_READ_B
+#undef P_MATH
+#undef P_STAGE
+#undef P_ISSUE
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // the first half waits for the second: the tile buffers become epilogue staging
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue (gemm3_kernel's, for a 128 x 64 wave tile): one 32-row band at a time through wave-private LDS.
+    // Transposed C/D layout of the 32x32 MFMA: lane owns m_local = lane & 31 and n_local = 8 q + 4 (lane >> 5) + {0..3}, q = reg >> 2.
+    const int c4 = (lane & 15) * 4;
+    const long long nb = n0 + wc * 64 + c4;
+    unsigned mkb[4] = {0u, 0u, 0u, 0u};
+    if (g.bits_in) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long mb = (m0 + wr * 128 + i * 32) >> 5, nbk = (n0 + wc * 64) >> 6, last_band = (g.M - 1) >> 5;
+            mkb[i] = (nbk < g.bits_nblk) ? g.bits_in[((mb < last_band ? mb : last_band) * g.bits_nblk + nbk) * 64 + lane] : 0u;
+        }
+    }
+    float* S = lds + wave * (32 * P_EPI_LD);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias && nb < g.N) bv = *(const float4*)(g.bias + nb);      // N % 4 == 0 and nb % 4 == 0: the quad is inside the bias vector
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        unsigned myword = 0u;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
+                *(float4*)__builtin_assume_aligned(S + l31 * P_EPI_LD + tn * 32 + 8 * q + 4 * h, 16) = v;
+            }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + (lane >> 4);
+            const long long m = m0 + wr * 128 + tm * 32 + row;
+            const bool live = m < g.M && nb < g.N;
+            float4 v = *(const float4*)__builtin_assume_aligned(S + row * P_EPI_LD + c4, 16);
+            v.x = p_act(v.x + bv.x, g.act); v.y = p_act(v.y + bv.y, g.act);
+            v.z = p_act(v.z + bv.z, g.act); v.w = p_act(v.w + bv.w, g.act);
+            if (g.bits_out) {           // word = 2*word + (v > 0): compare into VCC, add-with-carry (layout: dlrm_relu_bits_bytes, dlrm_hip.h)
+                asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                             "v_cmp_lt_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                             "v_cmp_lt_f32 vcc, 0, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                             "v_cmp_lt_f32 vcc, 0, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                             : "+v"(myword) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "vcc");
+            }
+            if (!live) continue;
+            if (g.bits_in) {
+                const unsigned wv = mkb[tm];
+                if (!((wv >> (31 - (it * 4 + 0))) & 1u)) v.x = 0.f;
+                if (!((wv >> (31 - (it * 4 + 1))) & 1u)) v.y = 0.f;
+                if (!((wv >> (31 - (it * 4 + 2))) & 1u)) v.z = 0.f;
+                if (!((wv >> (31 - (it * 4 + 3))) & 1u)) v.w = 0.f;
+            }
+            if (g.C) *(float4*)(g.C + m * g.ldc + nb) = v;
+            if (g.Cb) {
+                uint2 pk; pk.x = p_cvt_pk_bf16(v.x, v.y); pk.y = p_cvt_pk_bf16(v.z, v.w);
+                *(uint2*)(g.Cb + m * g.ldcb + nb) = pk;
+            }
+        }
+        if (g.bits_out) {
+            const long long mb = (m0 + wr * 128 + tm * 32) >> 5, nbk = (n0 + wc * 64) >> 6;
+            if (mb <= ((g.M - 1) >> 5) && nbk < g.bits_nblk) g.bits_out[(mb * g.bits_nblk + nbk) * 64 + lane] = myword;
+        }
+    }
+}
+
+}  // namespace
+
+// returns 0 when the phased kernel took the call, DLRM_GEMV_NOT_HANDLED when the shape is outside its preconditions (the caller keeps gemm3_kernel)
+int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, int act,
+                          uint64_t* relu_bits_out, const uint64_t* relu_bits_in, float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, hipStream_t st) {
+    static int enabled = -1;           // DLRM_BF16_PHASED=0: keep the fp32-shaped kernel everywhere (A/B runs)
+    if (enabled < 0) { const char* e = getenv("DLRM_BF16_PHASED"); enabled = e ? atoi(e) : 1; }
+    if (!enabled || K % PBK || N % 4 || N < 192 || M < 256 || lda % 8 || ldb % 8) return DLRM_GEMV_NOT_HANDLED;
+    if (bias && !dlrm_aligned16(bias)) return DLRM_GEMV_NOT_HANDLED;
+    BfArgs g = {};
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.Cb = Cb; g.ldcb = ldcb;
+    g.bias = bias; g.act = act;
+    g.bits_out = (unsigned*)relu_bits_out; g.bits_in = (const unsigned*)relu_bits_in; g.bits_nblk = ((long long)N + 63) / 64;
+    g.tiles_m = (int)((M + PBM - 1) / PBM); g.tiles_n = (int)((N + PBN - 1) / PBN);
+    const size_t lds = 2 * STAGE_BYTES;                 // 128 KiB: one workgroup per CU
+    static bool attr_done[DLRM_MAX_DEVICES] = {};
+    const int dev = dlrm_current_device();
+    if (!attr_done[dev]) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_phased_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_phased_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), lds, st, g);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}

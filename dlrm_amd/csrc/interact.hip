@@ -740,7 +740,12 @@ static int interact_debug() {
 // forward D = 128 kernels: waves per workgroup (one workgroup per CU) and its LDS — tables, two 2 NI-row images per wave, the selector
 // slots (gather mode; in plain mode they are the slack the second 16-row tile may read into)
 static size_t fwd_dma_lds(int ni, int W) {
-    return 5 * DLRM_MAX_FEATURES * sizeof(long long) + (size_t)W * (2 * (size_t)(2 * ni * IDMA_D * 4) + GSEL_WAVE_BYTES) + 2048;
+    // a 16-row fragment tile of the LAST wave's last image reads up to (16 * tiles - 2 NI) rows of 512 B past the image: what lies behind
+    // it are the W selector slots and this slack — sized from the over-read, not assumed (with DLRM_INTERACT_WAVES <= 3 and few features
+    // the selector slots alone were smaller than the over-read: out-of-bounds LDS reads whose values were discarded)
+    const size_t over = (size_t)(16 * ((2 * ni + 15) / 16) - 2 * ni) * IDMA_D * 4, sel = (size_t)W * GSEL_WAVE_BYTES;
+    const size_t slack = (over > sel && over - sel > 2048) ? over - sel : 2048;
+    return 5 * DLRM_MAX_FEATURES * sizeof(long long) + (size_t)W * (2 * (size_t)(2 * ni * IDMA_D * 4) + GSEL_WAVE_BYTES) + slack;
 }
 static int fwd_dma_waves(int ni) {
     static int forced = -1;      // env DLRM_INTERACT_WAVES (tuning aid)

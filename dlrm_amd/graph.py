@@ -126,13 +126,14 @@ class GraphedTrainStep:
         adagrad = any(type(optimizer).__name__ == n for n in ("RWSAdagrad", "FusedRWSAdagrad"))
         if not adagrad and getattr(model, "emb_update_mode", None) != ops.UPD_SORTED:
             return
-        safe, lookups = False, 0
+        safe, lookups, why = False, 0, None
         try:
             bags = ops.BagBatch(lS_o, lS_i, None)
             safe = ops.sort_is_graph_safe([e.weight for e in model.emb_l], bags)
             lookups = int(sum(bags.nnz))
-        except Exception:                                    # noqa: BLE001 - models without plain emb_l tables: be conservative
-            safe = False
+            # (decided once: every later batch has these segment sizes — _copy_struct refuses any other input shape)
+        except Exception as e:                               # noqa: BLE001 - models without plain emb_l tables: be conservative
+            safe, why = False, "%s: %s" % (type(e).__name__, e)
         # DLRM_GRAPH_SORTED: "1" keep the sorted update whenever it is replayable, "0" never, default "auto": keep it for batches of
         # >= 2^19 lookups (Criteo-Terabyte: 1.7 M) and take the atomic update for launch-bound batches, where the sort's nine small
         # launches cost more than its rows save (Criteo-Kaggle shapes, 53 k lookups: 0.83 ms sorted vs atomic, profiles/round3)
@@ -142,9 +143,10 @@ class GraphedTrainStep:
         if safe:
             return
         if adagrad:
-            raise RuntimeError("dlrm_amd.graph: this batch needs the general (rocPRIM) sorter for the fused row-wise Adagrad update "
-                               "(a table segment of more than 262144 lookups), which cannot be replayed from a HIP graph on this ROCm "
-                               "(tools/probes/graph_sorted_probe.py); use the eager step")
+            raise RuntimeError("dlrm_amd.graph: the fused row-wise Adagrad update of this batch cannot be replayed from a HIP graph: " +
+                               ("the sorter check itself failed (%s)" % why if why else
+                                "a table segment needs the general (rocPRIM) sorter, which cannot be replayed on this ROCm "
+                                "(tools/probes/graph_sorted_probe.py)") + "; use the eager step")
         model.emb_update_mode = ops.UPD_ATOMIC               # LDS pre-reduction for tiny tables + hardware fp32 atomics
 
     def _prove_one_lookup_per_bag(self, lS_o, lS_i) -> None:

@@ -57,7 +57,7 @@ int         dlrm_hip_device_info(int device, int* cu_count, int* lds_bytes,
  *   dlrm_calib_mfma:     kind 0 = v_mfma_f32_32x32x2_f32, kind 1 = v_mfma_f32_32x32x16_bf16, back to back on every SIMD, no memory traffic;
  *                        *flop_out = FLOPs the launch executes (so rate = flop / time; implied clock = rate / (CUs * 256 [* 16] FLOP/clk)).
  *                        scratch: device float[1].  iters = 15000 is ~50 ms of fp32, ~3 ms of bf16 work on MI355X.
- *   dlrm_calib_hbm_copy: float4 grid-stride copy of `bytes` (multiple of 16) from src to dst; HBM rate = 2 * bytes / time. */
+ *   dlrm_calib_hbm_copy: float4 copy (one float4 per thread) of `bytes` (multiple of 16) from src to dst; HBM rate = 2 * bytes / time. */
 int dlrm_calib_mfma(int kind, int iters, float* scratch, double* flop_out, void* stream);
 int dlrm_calib_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream);
 

@@ -444,6 +444,51 @@ def test_linear_bf16_arithmetic(M, N, K):
     assert 1e-4 < err < 0.1, err
 
 
+@pytest.mark.parametrize("M,N,K,act", [(512, 256, 512, 1), (1000, 320, 192, 1), (4100, 1024, 1024, 0), (65536, 512, 256, 1), (777, 3456, 512, 0),
+                                       (2048, 512, 3456, 1), (256, 192, 64, 2)])
+def test_gemm_bf16_phased_kernel(M, N, K, act, monkeypatch):
+    """dlrm_gemm_bf16 on the bf16-SHAPED kernel (csrc/gemm_bf16.hip: 256 x 256 x 64 tile, four phases per k-tile, two wave halves one
+    barrier apart) — forward form (bias, activation, fp32 + bf16 results, ReLU sign bits out) and data-gradient form (sign-bit mask in):
+      * against a float64 product of the SAME bf16 operands (the oracle's arithmetic: exact products, wide accumulation), and
+      * BIT-IDENTICAL to the fp32-shaped kernel (DLRM_BF16_PHASED=0 is read once per process, so the reference result comes from
+        dlrm_linear_fwd's in-loop rounding, ARITH bf16, which the storage kernels are tested to equal bit for bit): same MFMA, same k order.
+    Shapes: ragged M and N (clamped rows / columns), N = 3456 and K = 3456 (the DCN-v2 products of config 5), one tile, many k-tiles."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    A = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(dev()).to(torch.bfloat16)
+    B = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(dev()).to(torch.bfloat16)
+    bias = to_dev(rng.standard_normal(N).astype(np.float32))
+    Cf = torch.full((M, N), 7.0, device=dev())
+    Cb = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+    bits = ops.relu_bits_alloc(M, N, dev()) if act == 1 else None
+    ops.gemm_bf16(A, B, bias, act, Cf, Cb, relu_bits_out=bits)
+    torch.cuda.synchronize()
+    want = A.double().cpu().numpy() @ B.double().cpu().numpy().T + bias.double().cpu().numpy()
+    if act == 1:
+        want = np.maximum(want, 0.0)
+    elif act == 2:
+        want = 1.0 / (1.0 + np.exp(-want))
+    got = Cf.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=3e-5)
+    assert torch.equal(Cb, Cf.to(torch.bfloat16))                              # the bf16 copy is the rounding of the fp32 result
+    # the same product through dlrm_linear_fwd with in-loop rounding of fp32 operands that ARE bf16 values: bit-identical
+    Y2 = torch.empty((M, N), device=dev())
+    ops.linear_fwd(A.float(), B.float(), bias, act, Y2, "bf16")
+    assert torch.equal(Y2, Cf)
+    if act == 1:
+        # the sign bits drive the data gradient of the NEXT layer: dX = (dY . W) * (Y > 0), here with Y = Cf [M, N], dY [M, N2], W [N2, N]
+        N2 = 256
+        dY = torch.from_numpy(rng.standard_normal((M, N2)).astype(np.float32)).to(dev()).to(torch.bfloat16)
+        Wt = torch.from_numpy((rng.standard_normal((N, N2)) / 16).astype(np.float32)).to(dev()).to(torch.bfloat16)     # = W^T [N, N2]
+        dX = torch.empty((M, N), device=dev())
+        dXb = torch.empty((M, N), dtype=torch.bfloat16, device=dev())
+        ops.gemm_bf16(dY, Wt, None, 0, dX, dXb, relu_bits_in=bits, category="linear_bwd_data")
+        torch.cuda.synchronize()
+        wantd = (dY.double().cpu().numpy() @ Wt.double().cpu().numpy().T) * (got > 0)
+        np.testing.assert_allclose(dX.cpu().numpy(), wantd, rtol=2e-5, atol=3e-5)
+        assert torch.equal(dXb, dX.to(torch.bfloat16))
+
+
 def test_bf16_casts_are_round_to_nearest_even_and_padded():
     """dlrm_cast_bf16 / dlrm_cast_bf16_transposed against torch's fp32 -> bfloat16 conversion (round to nearest even), including the
     zero padding columns and odd shapes"""
