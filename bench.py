@@ -705,7 +705,7 @@ def main():
                          "avg_launch_ms": k["avg_ms"], "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                          "frac": ach / peak, "frac_of_measured_peak": ach / (hbm_measured if unit == "GB/s" else mfma_measured),
                          "algorithmic_work_per_step": work}
-    for name in ("act_bwd", "bce_loss", "sgd_dense"):
+    for name in ("act_bwd", "bce_loss", "sgd_dense", "cross_ew"):
         if name in ksum:
             kernels[name] = {"ms_per_step": ksum[name]["total_ms"] / max(timed_steps, 1),
                              "launches_per_step": ksum[name]["calls"] / max(timed_steps, 1)}

@@ -1106,8 +1106,8 @@ extern "C" int dlrm_cast_bf16_transposed(int R, int C, int Rpad, const float* sr
 // Preconditions (DLRM_E_ALIGN otherwise — the caller falls back to the fp32-storage kernels): K % 32 == 0, N % 4 == 0, 16-byte aligned
 // operand rows (lda, ldb % 8 == 0), 16-byte aligned fp32 rows (ldc % 4 == 0), 8-byte aligned bf16 rows (ldcb % 4 == 0).
 extern "C" int dlrm_gemm_bf16(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
-                              int act, uint64_t* relu_bits_out, const uint64_t* relu_bits_in, float* C, int64_t ldc, uint16_t* Cb,
-                              int64_t ldcb, void* stream) {
+                              int act, uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd, float* C,
+                              int64_t ldc, uint16_t* Cb, int64_t ldcb, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !Cb)) return DLRM_E_ARG;
     if (lda < K || ldb < K || (C && ldc < N) || (Cb && ldcb < N)) return DLRM_E_ARG;
     if (act < DLRM_ACT_NONE || act > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
@@ -1116,8 +1116,11 @@ extern "C" int dlrm_gemm_bf16(int64_t M, int N, int K, const uint16_t* A, int64_
         (Cb && ((((uintptr_t)Cb) & 7u) || ldcb % 4)))
         return DLRM_E_ALIGN;
     {   // the bf16-shaped kernel (gemm_bf16.hip: 256 x 256 x 64 tile, four phases per k-tile) wherever its preconditions hold
-        const int rc = dlrm_gemm_bf16_phased(M, N, K, A, lda, B, ldb, bias, act, relu_bits_out, relu_bits_in, C, ldc, Cb, ldcb, (hipStream_t)stream);
+        if (addend && (ldadd < N || ldadd % 4 || !dlrm_aligned16(addend))) return DLRM_E_ALIGN;
+        const int rc = dlrm_gemm_bf16_phased(M, N, K, A, lda, B, ldb, bias, act, relu_bits_out, relu_bits_in, addend, ldadd, C, ldc, Cb, ldcb,
+                                             (hipStream_t)stream);
         if (rc != DLRM_GEMV_NOT_HANDLED) return rc;
+        if (addend) return DLRM_E_MODE;                 // the fp32-shaped kernel has no addend operand
     }
     GemmArgs g = {};
     g.M = M; g.N = N; g.K = K / 2;                    // in units of one fp32 word = two bf16 values
@@ -1272,6 +1275,46 @@ extern "C" int dlrm_linear_bwd_weight_padded(int64_t M, int N, int K, int K_stor
                                              float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
                                              int arith, void* stream) {
     return linear_bwd_weight_impl(M, N, K, K_store, dY, lddy, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, arith, stream);
+}
+
+// Weight gradient of the bf16 tower from bf16 operands AS STORED: dW[N, K] (+)= dZ[M, N]^T . X[M, K], db[N] (+)= column sums of dZ — the
+// reference's AddmmBackward / sum over the batch (dlrm_s_pytorch.py:1613) in the arithmetic of dlrm_gemm_bf16 (bf16 products, fp32 accumulation).
+// Both operands are k-STRIDED (the batch is the reduction): csrc/gemm_bf16.hip reads them through ds_read_b64_tr_b16, split over the batch
+// into fp32 slabs that splitk_reduce_kernel sums in slice order (deterministic dW and db, no atomics, no zero fill).
+// DLRM_E_ALIGN when the shape is outside the kernel's preconditions (M % 64, N % 8, K % 8, widths >= 64, 16-byte aligned rows): the caller
+// keeps dlrm_linear_bwd_weight on fp32 operands.
+extern "C" int64_t dlrm_linear_bwd_weight_bf16_workspace_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    int splits; int64_t kchunk;
+    dlrm_gemm_bf16_wgrad_plan(M, N, K, &splits, &kchunk);
+    const int64_t ldp = ((int64_t)K + 3) & ~(int64_t)3;
+    return (int64_t)splits * N * (ldp + 1) * (int64_t)sizeof(float);
+}
+
+extern "C" int dlrm_linear_bwd_weight_bf16(int64_t M, int N, int K, int K_store, const uint16_t* dZ, int64_t lddz, const uint16_t* X, int64_t ldx,
+                                           float* dW, int64_t lddw, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
+                                           void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || K_store <= 0 || K_store > K || !dZ || !X || !dW || !workspace) return DLRM_E_ARG;
+    if (lddz < N || ldx < K || lddw < K_store) return DLRM_E_ARG;
+    if (!dlrm_gemm_bf16_wgrad_ok(M, N, K, lddz, ldx) || !dlrm_aligned16(dZ) || !dlrm_aligned16(X) || !dlrm_aligned16(workspace)) return DLRM_E_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    int splits; int64_t kchunk;
+    dlrm_gemm_bf16_wgrad_plan(M, N, K, &splits, &kchunk);
+    const int64_t ldp = ((int64_t)K + 3) & ~(int64_t)3, slab = (int64_t)N * ldp;
+    if (workspace_bytes < (int64_t)splits * (slab + N) * (int64_t)sizeof(float)) return DLRM_E_ARG;
+    float* rs_part = dbias ? (float*)workspace + (int64_t)splits * slab : nullptr;
+    const int rc = dlrm_gemm_bf16_wgrad_phased(M, N, K, dZ, lddz, X, ldx, (float*)workspace, ldp, slab, rs_part, splits, kchunk, st);
+    if (rc) return rc;
+    // dW may be NARROWER than the product (K_store < K: the trailing columns of X are zero padding whose gradient is dropped)
+    const bool v4 = dlrm_aligned16(dW) && lddw % 4 == 0 && K_store % 4 == 0;
+    const long long items = (long long)N * (v4 ? K_store / 4 : K_store);
+    int blocks = (int)((items + 255) / 256); if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, N, K_store, splits, (const float*)workspace,
+                               (long long)ldp, (long long)slab, dW, (long long)lddw, accumulate ? 1 : 0, (const float*)rs_part, dbias);
+    else    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, N, K_store, splits, (const float*)workspace,
+                               (long long)ldp, (long long)slab, dW, (long long)lddw, accumulate ? 1 : 0, (const float*)rs_part, dbias);
+    DLRM_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, const float* Y,

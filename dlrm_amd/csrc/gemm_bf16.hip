@@ -43,8 +43,14 @@ struct BfArgs {
     float* C; long long ldc;                 // nullable
     unsigned short* Cb; long long ldcb;      // nullable
     const float* bias; int act;
+    const float* addend; long long ldadd;    // nullable: fp32 [M, N] added to the result (after bias / activation / mask); may alias C
     unsigned* bits_out; const unsigned* bits_in; long long bits_nblk;
     int tiles_m, tiles_n;
+    // weight-gradient form (WG): the reduction runs over the ROWS of both operands (A = dZ [K, M], B = X [K, N], C = A^T B), split in
+    // gridDim.z slices of kchunk rows; slice z stores its fp32 partial at C + z * c_split_stride and the row sums of A^T (the bias
+    // gradient) at rowsum + z * M
+    long long kchunk, c_split_stride;
+    float* rowsum;
 };
 
 constexpr int PBM = 256, PBN = 256, PBK = 64;
@@ -71,7 +77,24 @@ __device__ __forceinline__ float p_act(float v, int act) {
 }
 #define P_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
 
-// MASKED: the result is multiplied by the previous layer's ReLU derivative, read from its sign bits (data gradient)
+typedef short shortx4 __attribute__((ext_vector_type(4)));
+// two ds_read_b64_tr_b16 = the 8 consecutive k-values of one column a lane feeds to v_mfma_f32_32x32x16_bf16 from a [k][column] image:
+// inside each 16-lane group lane p passes the address of [row p >> 2][columns 4 (p & 3) .. + 3] and lane i receives column i of rows 0..3
+// (measured: tools/probes/tr_read_probe.hip, profiles/round4/tr_read_probe.txt)
+__device__ __forceinline__ uintx4 p_tr_read8(unsigned lds_addr) {
+    typedef __attribute__((address_space(3))) shortx4* lp;
+    struct Pair { shortx4 lo, hi; } v;
+    v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)lds_addr);
+    v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds_addr + 256));      // k-rows + 4
+    return __builtin_bit_cast(uintx4, v);
+}
+
+// WG = false: C = A . B^T, both operands k-contiguous (forward, data gradient).
+// WG = true : C[M, N] = sum over rows r of A[r, m] * B[r, n] — the weight gradient dW = dZ^T X with A = dZ [batch, out], B = X [batch, in],
+//             both operands k-STRIDED.  LDS image of an operand and k-tile: 8 sub-runs of 32 columns, each [64 k-rows][64 B]; a 1 KiB DMA
+//             chunk = 16 k-rows x 64 B of one sub-run (the same lane -> (row, 16-byte slot) map as the k-contiguous chunks, no swizzle:
+//             a 32-lane ds_read_b64_tr_b16 touches 4 k-rows x 64 B = one whole 256-byte bank row); fragments by p_tr_read8.
+template <bool WG>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
@@ -83,22 +106,47 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
 
     // workgroups go to the 8 XCDs round-robin in dispatch order: every XCD gets a contiguous range of tiles (the tiles_n tiles of one A
     // row panel meet in one L2)
-    int id;
+    int id, zs = 0;
     {
-        const int nwg = g.tiles_m * g.tiles_n, lin = (int)blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7, local = lin >> 3;
-        id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        // (WG: the output tiles of one k-slice sit on ONE XCD and march through the same rows of dZ and X together, as in gemm3_kernel)
+        const int nwg = g.tiles_m * g.tiles_n, total = nwg * (int)gridDim.z, lin = (int)blockIdx.z * nwg + (int)blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = lin & 7, local = lin >> 3;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        zs = w / nwg; id = w - zs * nwg;
     }
+    zs = __builtin_amdgcn_readfirstlane(zs);
     const int tile_m = __builtin_amdgcn_readfirstlane(id / g.tiles_n), tile_n = __builtin_amdgcn_readfirstlane(id - tile_m * g.tiles_n);
     const long long m0 = (long long)tile_m * PBM, n0 = (long long)tile_n * PBN;
-    const int nk = (int)(g.K / PBK);
+    const long long k_begin = WG ? (long long)zs * g.kchunk : 0;
+    const long long k_end = WG ? ((k_begin + g.kchunk < g.K) ? k_begin + g.kchunk : g.K) : g.K;
+    const int nk = (int)((k_end - k_begin) / PBK);
 
     // ---- DMA plan.  A piece = 128 tile rows x 64 k = 16 chunks of 1 KiB (16 rows x 64 B of one k-half); wave w moves chunks w and w + 8
     // of every piece: k-half = w & 1, row group (16 rows) = (w >> 1) and (w >> 1) + 4.
     //   piece 0 (A0): A rows {0..63, 128..191}      piece 1 (B0): B rows {64 c + 0..31,  c = 0..3}
     //   piece 3 (A1): A rows {64..127, 192..255}    piece 2 (B1): B rows {64 c + 32..63, c = 0..3}
     unsigned voff[4][2], dst[4][2];
-    {
+    if constexpr (WG) {
+        // piece = 4 sub-runs x 4 chunks (16 k-rows each); wave w moves chunks w and w + 8: sub-run (c >> 2) of the piece, k-rows 16 (c & 3) ..
+        //   A sub-run = wr * 4 + tm (32 columns of dZ each): A0 = {0,1,4,5}, A1 = {2,3,6,7};  B sub-run = wc * 2 + tn: B0 = {0,2,4,6}, B1 = {1,3,5,7}
+        const int srow = lane >> 2, sslot = lane & 3;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = wave + 8 * i, sp = c >> 2, mc = c & 3;
+                int sub;
+                if (p == 0)      sub = (sp >> 1) * 4 + (sp & 1);
+                else if (p == 3) sub = (sp >> 1) * 4 + 2 + (sp & 1);
+                else if (p == 1) sub = 2 * sp;
+                else             sub = 2 * sp + 1;
+                const bool isA = (p == 0 || p == 3);
+                const long long c0 = isA ? m0 : n0, cmax = isA ? g.M : g.N, ld = isA ? g.lda : g.ldb;
+                long long col = c0 + sub * 32 + sslot * 8; if (col > cmax - 8) col = cmax - 8;      // (extents are multiples of 8: clamped columns are never stored)
+                voff[p][i] = (unsigned)((((long long)(mc * 16 + srow)) * ld + (col - c0)) * 2);
+                dst[p][i] = lds_base + (isA ? 0 : OP_BYTES) + sub * 4096 + mc * 1024;
+            }
+    } else {
         const int kh = wave & 1;
         const int srow = lane >> 2, sslot = (lane & 3) ^ ((lane >> 4) & 3);     // source k-slot of the lane's 16 bytes (XOR swizzle, see gemm.hip dma_offset)
 #pragma unroll
@@ -118,8 +166,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
                 dst[p][i] = lds_base + (isA ? 0 : OP_BYTES) + kh * KHALF_BYTES + row * 64;
             }
     }
-    const char* baseA = (const char*)(g.A + m0 * g.lda);
-    const char* baseB = (const char*)(g.B + n0 * g.ldb);
+    const char* baseA = (const char*)(WG ? g.A + k_begin * g.lda + m0 : g.A + m0 * g.lda);
+    const char* baseB = (const char*)(WG ? g.B + k_begin * g.ldb + n0 : g.B + n0 * g.ldb);
+    const long long stepA = WG ? (long long)PBK * 2 * g.lda : (long long)PBK * 2, stepB = WG ? (long long)PBK * 2 * g.ldb : (long long)PBK * 2;
 
 #define P_ISSUE(piece, stage_off)                                                                                   \
     do {                                                                                                            \
@@ -136,6 +185,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
         fa_off[jj] = (unsigned)((wr * 128 + l31) * 64) + sl;
         fb_off[jj] = (unsigned)OP_BYTES + (unsigned)((wc * 64 + l31) * 64) + sl;
     }
+    // WG: lane (group g4 = lane >> 4, i = lane & 15) reads k-row 8 (g4 >> 1) + (i >> 2) [+ 4 for the second read], columns 16 (g4 & 1) + 4 (i & 3) .. + 3
+    // of its 32-column sub-run; + 1024 per 16-k step j, + 4096 per sub-run
+    const unsigned tr_lane = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + 8 * (lane & 3));
+    const unsigned tra_off = tr_lane + (unsigned)(wr * 4 * 4096), trb_off = (unsigned)OP_BYTES + tr_lane + (unsigned)(wc * 2 * 4096);
+    // bias gradient (WG): row sums of A^T from the fragments the MFMAs consume; the four wave columns of a row half read the SAME A
+    // fragments, so wave column wc sums the 16-k step j == wc only (a quarter of the VALU work each), combined through LDS at the end
+    const bool do_rowsum = WG && g.rowsum != nullptr && tile_n == 0;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
 
     floatx16 acc[4][2];
 #pragma unroll
@@ -147,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
 
     // ---- prologue: the whole first k-tile, in the order of first use; its first two pieces have landed before anyone reads
     P_ISSUE(0, 0); P_ISSUE(1, 0); P_ISSUE(2, 0); P_ISSUE(3, 0);
-    baseA += PBK * 2; baseB += PBK * 2;
+    baseA += stepA; baseB += stepB;
     p_wait_vmcnt<4>();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();          // the second wave half runs one barrier behind the first
@@ -156,11 +213,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     unsigned cur = 0;                                   // byte offset of the stage being multiplied
 #define P_READ_A(half)                                                                                              \
         _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                               \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
-            fa[t][j] = *(const uintx4*)(ldsb + cur + fa_off[j & 1] + (j >> 1) * KHALF_BYTES + ((half) * 2 + t) * 2048);
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
+            if constexpr (WG) fa[t][j] = p_tr_read8(lds_base + cur + tra_off + ((half) * 2 + t) * 4096 + j * 1024); \
+            else fa[t][j] = *(const uintx4*)(ldsb + cur + fa_off[j & 1] + (j >> 1) * KHALF_BYTES + ((half) * 2 + t) * 2048); \
+        }
 #define P_READ_B(tn)                                                                                                \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
-            fb[j] = *(const uintx4*)(ldsb + cur + fb_off[j & 1] + (j >> 1) * KHALF_BYTES + (tn) * 2048);
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
+            if constexpr (WG) fb[j] = p_tr_read8(lds_base + cur + trb_off + (tn) * 4096 + j * 1024);                \
+            else fb[j] = *(const uintx4*)(ldsb + cur + fb_off[j & 1] + (j >> 1) * KHALF_BYTES + (tn) * 2048);        \
+        }
+    // (bf16 -> fp32 is a 16-bit shift: two VALU per packed pair)
+#define P_ROWSUM(half)                                                                                              \
+        if constexpr (WG) { if (do_rowsum) {                                                                        \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                         \
+                const uintx4 f_ = wc == 0 ? fa[t][0] : wc == 1 ? fa[t][1] : wc == 2 ? fa[t][2] : fa[t][3];          \
+                float a_ = 0.f;                                                                                     \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                       \
+                    a_ += __uint_as_float(f_[e] << 16) + __uint_as_float(f_[e] & 0xffff0000u);                      \
+                rs[(half) * 2 + t] += a_;                                                                           \
+            } } }
 #define P_MATH(half, tn)                                                                                            \
         __builtin_amdgcn_s_barrier();                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
@@ -180,14 +251,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     {                                                                                                               \
         const unsigned nxt = cur ^ (unsigned)STAGE_BYTES;                                                           \
         /* phase 1: quadrant (rows 0-63, cols 0-31) */                                                             \
-        P_READ_A(0) P_READ_B(0) P_STAGE(0, MORE) P_MATH(0, 0)                                                       \
+        P_READ_A(0) P_READ_B(0) P_STAGE(0, MORE) P_MATH(0, 0) P_ROWSUM(0)                                           \
         /* phase 2: (rows 0-63, cols 32-63) */                                                                     \
         P_READ_B(1) P_STAGE(1, MORE) P_MATH(0, 1)                                                                   \
         /* phase 3: (rows 64-127, cols 32-63) */                                                                   \
-        P_READ_A(1) P_STAGE(2, MORE) P_MATH(1, 1)                                                                   \
+        P_READ_A(1) P_STAGE(2, MORE) P_MATH(1, 1) P_ROWSUM(1)                                                       \
         /* phase 4: (rows 64-127, cols 0-31) */                                                                    \
         P_READ_B(0) P_STAGE(3, MORE) P_MATH(1, 0)                                                                   \
-        if (MORE) { baseA += PBK * 2; baseB += PBK * 2; }                                                           \
+        if (MORE) { baseA += stepA; baseB += stepB; }                                                               \
         cur = nxt;                                                                                                  \
     }
     for (int kt = 0; kt + 1 < nk; ++kt) P_KTILE(1)
@@ -195,12 +266,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
 #undef P_KTILE
 #undef P_READ_A
 #undef P_READ_B
+#undef P_ROWSUM
 #undef P_MATH
 #undef P_STAGE
 #undef P_ISSUE
     if (wr == 0) __builtin_amdgcn_s_barrier();          // the first half waits for the second: the tile buffers become epilogue staging
     __builtin_amdgcn_s_barrier();
 
+    if constexpr (WG) {
+        if (do_rowsum) {
+            // lanes l31 / l31 + 32 hold different k of the same row; the four wave columns hold different 16-k steps: summed in a fixed order
+            float* P = lds + 8 * (32 * P_EPI_LD);                   // behind the eight waves' staging areas: [wave][4 bands][32 rows]
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float v = rs[t] + __shfl_xor(rs[t], 32, 64);
+                if (lane < 32) P[wave * 128 + t * 32 + lane] = v;
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        if (do_rowsum && wc == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (lane < 32) {
+                    const float* P = lds + 8 * (32 * P_EPI_LD) + t * 32 + lane;
+                    const float v = ((P[(wr * 4 + 0) * 128] + P[(wr * 4 + 1) * 128]) + P[(wr * 4 + 2) * 128]) + P[(wr * 4 + 3) * 128];
+                    const long long m = m0 + wr * 128 + t * 32 + lane;
+                    if (m < g.M) g.rowsum[(long long)zs * g.M + m] = v;
+                }
+            }
+        }
+    }
+    float* const Cz = WG && g.C ? g.C + (long long)zs * g.c_split_stride : g.C;
     // ---- epilogue (gemm3_kernel's, for a 128 x 64 wave tile): one 32-row band at a time through wave-private LDS.
     // Transposed C/D layout of the 32x32 MFMA: lane owns m_local = lane & 31 and n_local = 8 q + 4 (lane >> 5) + {0..3}, q = reg >> 2.
     const int c4 = (lane & 15) * 4;
@@ -249,7 +345,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
                 if (!((wv >> (31 - (it * 4 + 2))) & 1u)) v.z = 0.f;
                 if (!((wv >> (31 - (it * 4 + 3))) & 1u)) v.w = 0.f;
             }
-            if (g.C) *(float4*)(g.C + m * g.ldc + nb) = v;
+            if (g.addend) {
+                const float4 a = *(const float4*)(g.addend + m * g.ldadd + nb);
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
+            if (Cz) *(float4*)(Cz + m * g.ldc + nb) = v;
             if (g.Cb) {
                 uint2 pk; pk.x = p_cvt_pk_bf16(v.x, v.y); pk.y = p_cvt_pk_bf16(v.z, v.w);
                 *(uint2*)(g.Cb + m * g.ldcb + nb) = pk;
@@ -264,27 +364,77 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
 
 }  // namespace
 
+static void phased_attr(const void* fn, bool& done) {
+    if (!done) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);      // 128 KiB: one workgroup per CU
+        done = true;
+    }
+}
+
+static int phased_enabled() {           // DLRM_BF16_PHASED=0: keep the fp32-shaped kernels everywhere (A/B runs)
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DLRM_BF16_PHASED"); enabled = e ? atoi(e) : 1; }
+    return enabled;
+}
+
 // returns 0 when the phased kernel took the call, DLRM_GEMV_NOT_HANDLED when the shape is outside its preconditions (the caller keeps gemm3_kernel)
 int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, int act,
-                          uint64_t* relu_bits_out, const uint64_t* relu_bits_in, float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, hipStream_t st) {
-    static int enabled = -1;           // DLRM_BF16_PHASED=0: keep the fp32-shaped kernel everywhere (A/B runs)
-    if (enabled < 0) { const char* e = getenv("DLRM_BF16_PHASED"); enabled = e ? atoi(e) : 1; }
-    if (!enabled || K % PBK || N % 4 || N < 192 || M < 256 || lda % 8 || ldb % 8) return DLRM_GEMV_NOT_HANDLED;
+                          uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd, float* C, int64_t ldc,
+                          uint16_t* Cb, int64_t ldcb, hipStream_t st) {
+    if (!phased_enabled() || K % PBK || N % 4 || N < 192 || M < 256 || lda % 8 || ldb % 8) return DLRM_GEMV_NOT_HANDLED;
     if (bias && !dlrm_aligned16(bias)) return DLRM_GEMV_NOT_HANDLED;
     BfArgs g = {};
     g.M = M; g.N = N; g.K = K;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.Cb = Cb; g.ldcb = ldcb;
-    g.bias = bias; g.act = act;
+    g.bias = bias; g.act = act; g.addend = addend; g.ldadd = ldadd;
     g.bits_out = (unsigned*)relu_bits_out; g.bits_in = (const unsigned*)relu_bits_in; g.bits_nblk = ((long long)N + 63) / 64;
     g.tiles_m = (int)((M + PBM - 1) / PBM); g.tiles_n = (int)((N + PBN - 1) / PBN);
-    const size_t lds = 2 * STAGE_BYTES;                 // 128 KiB: one workgroup per CU
     static bool attr_done[DLRM_MAX_DEVICES] = {};
+    phased_attr((const void*)gemm_bf16_phased_kernel<false>, attr_done[dlrm_current_device()]);
+    hipLaunchKernelGGL(gemm_bf16_phased_kernel<false>, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), 2 * STAGE_BYTES, st, g);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Weight-gradient form: slab z [N_out, ldc] (fp32) = sum over batch rows [z * kchunk, (z + 1) * kchunk) of dZ[r, n] * X[r, k]; rowsum z [N_out] =
+// column sums of dZ over the same rows (nullable).  dZ [Mb, N_out] and X [Mb, K_in] bf16 row-major.  The caller sums the slabs.
+bool dlrm_gemm_bf16_wgrad_ok(int64_t Mb, int N_out, int K_in, int64_t lddz, int64_t ldx) {
+    return phased_enabled() && Mb >= 256 && Mb % PBK == 0 && N_out % 8 == 0 && K_in % 8 == 0 && N_out >= 64 && K_in >= 64 && lddz % 8 == 0 && ldx % 8 == 0;
+}
+void dlrm_gemm_bf16_wgrad_plan(int64_t Mb, int N_out, int K_in, int* splits_out, int64_t* kchunk_out) {
+    const int tiles = ((N_out + PBM - 1) / PBM) * ((K_in + PBN - 1) / PBN);
+    static int cu_count[DLRM_MAX_DEVICES] = {};                   // per device, queried once
     const int dev = dlrm_current_device();
-    if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_phased_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done[dev] = true;
+    if (cu_count[dev] == 0) {
+        int n = 0;
+        cu_count[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
     }
-    hipLaunchKernelGGL(gemm_bf16_phased_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), lds, st, g);
+    const int cus = cu_count[dev];
+    // one workgroup per CU is resident: tiles x splits must not spill into a nearly empty second round (28 tiles x 10 slices = 280
+    // workgroups ran 1.7x longer than 28 x 9 = 252); more than a round's worth of tiles: whole rounds
+    int splits = tiles <= cus ? cus / tiles : 1;
+    const int64_t max_splits = Mb / 256;                           // at least four k-tiles per slice
+    if (splits > max_splits) splits = (int)max_splits;
+    if (splits < 1) splits = 1;
+    int64_t kchunk = (Mb + splits - 1) / splits;
+    kchunk = ((kchunk + PBK - 1) / PBK) * PBK;
+    *splits_out = (int)((Mb + kchunk - 1) / kchunk);
+    *kchunk_out = kchunk;
+}
+int dlrm_gemm_bf16_wgrad_phased(int64_t Mb, int N_out, int K_in, const uint16_t* dZ, int64_t lddz, const uint16_t* X, int64_t ldx,
+                                float* slabs, int64_t ldc, int64_t slab_stride, float* rowsum_parts, int splits, int64_t kchunk, hipStream_t st) {
+    if (!dlrm_gemm_bf16_wgrad_ok(Mb, N_out, K_in, lddz, ldx) || !dZ || !X || !slabs || ldc % 4 || !dlrm_aligned16(slabs) || !dlrm_aligned16(dZ) ||
+        !dlrm_aligned16(X) || kchunk % PBK || splits < 1)
+        return DLRM_E_ARG;
+    BfArgs g = {};
+    g.M = N_out; g.N = K_in; g.K = Mb;
+    g.A = dZ; g.lda = lddz; g.B = X; g.ldb = ldx; g.C = slabs; g.ldc = ldc;
+    g.act = DLRM_ACT_NONE;
+    g.kchunk = kchunk; g.c_split_stride = slab_stride; g.rowsum = rowsum_parts;
+    g.tiles_m = (N_out + PBM - 1) / PBM; g.tiles_n = (K_in + PBN - 1) / PBN;
+    static bool attr_done[DLRM_MAX_DEVICES] = {};
+    phased_attr((const void*)gemm_bf16_phased_kernel<true>, attr_done[dlrm_current_device()]);
+    hipLaunchKernelGGL(gemm_bf16_phased_kernel<true>, dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), dim3(512), 2 * STAGE_BYTES, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
 }

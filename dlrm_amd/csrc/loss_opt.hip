@@ -230,19 +230,27 @@ __global__ __launch_bounds__(256) void bce_elementwise_bwd_kernel(long long n, c
 }
 // DCN-v2 low-rank cross layer, elementwise part (torchrec LowRankCrossNet: x_{l+1} = x_0 * (W_l (V_l x_l) + b_l) + x_l; the two
 // products are dlrm_linear_fwd calls): forward out = x0 * u + xl; backward du = g * x0 and dx0 (+)= g * u.
+typedef __attribute__((ext_vector_type(2))) __bf16 lo_bf16x2;
+__device__ __forceinline__ unsigned lo_cvt_pk_bf16(float lo, float hi) { const lo_bf16x2 v = {(__bf16)lo, (__bf16)hi}; return __builtin_bit_cast(unsigned, v); }
+// out = x0 * u + xl;  out16 (nullable) = bf16(out): the operand copy the next cross layer's GEMM reads (bf16-storage towers)
 __global__ __launch_bounds__(256) void cross_fwd_kernel(long long n4, const float4* __restrict__ x0, const float4* __restrict__ u,
-                                                        const float4* __restrict__ xl, float4* __restrict__ out) {
+                                                        const float4* __restrict__ xl, float4* __restrict__ out, uint2* __restrict__ out16) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const float4 a = x0[i], b = u[i], c = xl[i];
-        out[i] = make_float4(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y), __builtin_fmaf(a.z, b.z, c.z), __builtin_fmaf(a.w, b.w, c.w));
+        const float4 r = make_float4(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y), __builtin_fmaf(a.z, b.z, c.z), __builtin_fmaf(a.w, b.w, c.w));
+        out[i] = r;
+        if (out16) out16[i] = make_uint2(lo_cvt_pk_bf16(r.x, r.y), lo_cvt_pk_bf16(r.z, r.w));
     }
 }
+// du = g * x0 (fp32, nullable) and / or du16 = bf16(g * x0) (nullable);  dx0 (+)= g * u
 __global__ __launch_bounds__(256) void cross_bwd_kernel(long long n4, const float4* __restrict__ g, const float4* __restrict__ x0,
-                                                        const float4* __restrict__ u, float4* __restrict__ du,
+                                                        const float4* __restrict__ u, float4* __restrict__ du, uint2* __restrict__ du16,
                                                         float4* __restrict__ dx0, int accumulate) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const float4 gg = g[i], a = x0[i], b = u[i];
-        du[i] = make_float4(gg.x * a.x, gg.y * a.y, gg.z * a.z, gg.w * a.w);
+        const float4 r = make_float4(gg.x * a.x, gg.y * a.y, gg.z * a.z, gg.w * a.w);
+        if (du) du[i] = r;
+        if (du16) du16[i] = make_uint2(lo_cvt_pk_bf16(r.x, r.y), lo_cvt_pk_bf16(r.z, r.w));
         float4 d = accumulate ? dx0[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         d.x = __builtin_fmaf(gg.x, b.x, d.x); d.y = __builtin_fmaf(gg.y, b.y, d.y); d.z = __builtin_fmaf(gg.z, b.z, d.z); d.w = __builtin_fmaf(gg.w, b.w, d.w);
         dx0[i] = d;
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(256) void clamp_bwd_kernel(long long n, const float
 
 }  // namespace
 
-extern "C" int dlrm_hip_abi_version(void) { return 8; }
+extern "C" int dlrm_hip_abi_version(void) { return 9; }
 
 extern "C" const char* dlrm_hip_build_info(void) {
     return "libdlrm_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " clang " __clang_version__;
@@ -440,21 +448,21 @@ static inline bool vec4_ok(int64_t n, const void* a, const void* b, const void* 
     return n % 4 == 0 && dlrm_aligned16(a) && dlrm_aligned16(b) && (!c || dlrm_aligned16(c)) && (!d || dlrm_aligned16(d)) && (!e || dlrm_aligned16(e));
 }
 
-extern "C" int dlrm_cross_fwd(int64_t n, const float* x0, const float* u, const float* xl, float* out, void* stream) {
+extern "C" int dlrm_cross_fwd(int64_t n, const float* x0, const float* u, const float* xl, float* out, uint16_t* out16, void* stream) {
     if (n <= 0 || !x0 || !u || !xl || !out) return DLRM_E_ARG;
-    if (!vec4_ok(n, x0, u, xl, out, nullptr)) return DLRM_E_ALIGN;
+    if (!vec4_ok(n, x0, u, xl, out, nullptr) || (out16 && (((uintptr_t)out16) & 7u))) return DLRM_E_ALIGN;
     hipLaunchKernelGGL(cross_fwd_kernel, dim3(ew_blocks(n / 4) * 2), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)x0,
-                       (const float4*)u, (const float4*)xl, (float4*)out);
+                       (const float4*)u, (const float4*)xl, (float4*)out, (uint2*)out16);
     DLRM_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const float* u, float* du, float* dx0, int accumulate,
+extern "C" int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const float* u, float* du, uint16_t* du16, float* dx0, int accumulate,
                               void* stream) {
-    if (n <= 0 || !g || !x0 || !u || !du || !dx0) return DLRM_E_ARG;
-    if (!vec4_ok(n, g, x0, u, du, dx0)) return DLRM_E_ALIGN;
+    if (n <= 0 || !g || !x0 || !u || (!du && !du16) || !dx0) return DLRM_E_ARG;
+    if (!vec4_ok(n, g, x0, u, du, dx0) || (du16 && (((uintptr_t)du16) & 7u))) return DLRM_E_ALIGN;
     hipLaunchKernelGGL(cross_bwd_kernel, dim3(ew_blocks(n / 4) * 2), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)g,
-                       (const float4*)x0, (const float4*)u, (float4*)du, (float4*)dx0, accumulate ? 1 : 0);
+                       (const float4*)x0, (const float4*)u, (float4*)du, (uint2*)du16, (float4*)dx0, accumulate ? 1 : 0);
     DLRM_LAUNCH_CHECK();
     return 0;
 }

@@ -23,7 +23,10 @@
 //                       (match-any), the lowest lane of each group advances the digit's cursor in LDS, every entry goes to
 //                       cursor + its rank in the group: stable by construction (rank order inside a 64-entry step, step order
 //                       inside a tile, tile order through the prefix)
-// Segments longer than SEG_MAX_TILES tiles (multi-hot batches with millions of lookups per table) stay with the general sorter.
+// Long segments (multi-hot batches: the 100-hot table of the MLPerf-v2 batch holds 6.5 M lookups = 3200 tiles): the per-tile histograms
+// [tiles][bins] are kept inside SEG_HIST_BUDGET words per table by NARROWER digits (3200 tiles -> 11 bits -> three rounds over 26 row bits;
+// rocPRIM's general sort took four 8-bit passes over all 31 key bits), and the prefix over the tiles is taken in GROUPS of SEG_GROUP_TILES
+// tiles (seg_colscan_kernel per group, then seg_groupscan_kernel over the groups' totals) so that no thread walks more than 128 tiles.
 #pragma once
 #include "common.h"
 
@@ -31,8 +34,10 @@ namespace {
 
 constexpr int SEG_TILE = 2048;           // entries per wave-tile (measured at Criteo-Terabyte shapes: 4096 -> 134 us per sort, 2048 -> 120 us)
 constexpr int SEG_MAX_DBITS = 13;        // 8192 bins: 32 KB of LDS per wave
-constexpr int SEG_MAX_TILES = 128;       // per table segment (262144 lookups)
-constexpr int SEG_MAX_ROUNDS = 3;        // rows < 2^39
+constexpr int SEG_GROUP_TILES = 128;     // tiles whose counts ONE thread of seg_colscan_kernel prefixes (262144 lookups); longer segments: several groups
+constexpr int SEG_MAX_GROUPS = 256;      // per table segment (67 M lookups)
+constexpr int SEG_MAX_ROUNDS = 4;
+constexpr long long SEG_HIST_BUDGET = 8ll << 20;   // words of per-tile histogram per table and round (32 MB): bounds the digit width of long segments
 
 struct SegRound {
     int ntab;                                                // participating tables of this round
@@ -45,6 +50,9 @@ struct SegRound {
     unsigned char dst_out[DLRM_MAX_TABLES_PER_LAUNCH];       // destination = OUT (else TMP); a later round's source is the other one
     unsigned hist_off[DLRM_MAX_TABLES_PER_LAUNCH];           // first counter of the table in the hist buffer  [tiles][bins]
     unsigned bin_off[DLRM_MAX_TABLES_PER_LAUNCH];            // first counter of the table in the bin-base buffer [bins]
+    unsigned short ngroups[DLRM_MAX_TABLES_PER_LAUNCH];      // tile groups of the table (1: the bins' totals go straight to the bin-base buffer)
+    unsigned gtot_off[DLRM_MAX_TABLES_PER_LAUNCH];           // first counter of the table in the group-total buffer [groups][bins]
+    unsigned gscan_start[DLRM_MAX_TABLES_PER_LAUNCH + 1];    // prefix of the 256-bin blocks of the tables WITH groups (grid of seg_groupscan_kernel)
     long long base[DLRM_MAX_TABLES_PER_LAUNCH];              // first global position of the table's segment
     long long nnz[DLRM_MAX_TABLES_PER_LAUNCH];
 };
@@ -52,31 +60,34 @@ struct SegRound {
 struct SegPlan {
     int rounds;
     SegRound round[SEG_MAX_ROUNDS];
-    size_t hist_words, bin_words;                            // buffer sizes (u32 words), the maximum over rounds
+    size_t hist_words, bin_words, gtot_words;                // buffer sizes (u32 words), the maximum over rounds
 };
 
 static int seg_bits_for(long long n) { int b = 0; while (((long long)1 << b) < n) ++b; return b < 1 ? 1 : b; }
 
-// false: a segment is too long for this sorter (or a table has >= 2^39 rows) -> the caller uses the general sorter
+// false: a segment is too long for this sorter (or a table has too many row bits for SEG_MAX_ROUNDS digits) -> the caller uses the general sorter
 static bool seg_plan(int n, const long long* nnz, const long long* rows, SegPlan* p) {
     int passes[DLRM_MAX_TABLES_PER_LAUNCH], rb[DLRM_MAX_TABLES_PER_LAUNCH];
     int R = 0;
     for (int k = 0; k < n; ++k) {
-        if (nnz[k] > (long long)SEG_TILE * SEG_MAX_TILES) return false;
+        const long long tiles = (nnz[k] + SEG_TILE - 1) / SEG_TILE;
+        if (tiles > (long long)SEG_GROUP_TILES * SEG_MAX_GROUPS) return false;
+        int dmax = SEG_MAX_DBITS;                             // widest digit whose [tiles][bins] histogram fits the budget
+        while (dmax > 6 && (tiles << dmax) > SEG_HIST_BUDGET) --dmax;
         rb[k] = seg_bits_for(rows[k]);
-        passes[k] = nnz[k] > 0 ? (rb[k] + SEG_MAX_DBITS - 1) / SEG_MAX_DBITS : 0;
+        passes[k] = nnz[k] > 0 ? (rb[k] + dmax - 1) / dmax : 0;
         if (passes[k] > SEG_MAX_ROUNDS) return false;
         if (passes[k] > R) R = passes[k];
     }
     p->rounds = R;
-    p->hist_words = 0; p->bin_words = 0;
+    p->hist_words = 0; p->bin_words = 0; p->gtot_words = 0;
     long long base[DLRM_MAX_TABLES_PER_LAUNCH];
     long long acc = 0;
     for (int k = 0; k < n; ++k) { base[k] = acc; acc += nnz[k]; }
     for (int r = 0; r < R; ++r) {
         SegRound& q = p->round[r];
-        q.ntab = 0; q.tile_start[0] = 0; q.scan_start[0] = 0;
-        size_t hw = 0, bw = 0;
+        q.ntab = 0; q.tile_start[0] = 0; q.scan_start[0] = 0; q.gscan_start[0] = 0;
+        size_t hw = 0, bw = 0, gw = 0;
         for (int k = 0; k < n; ++k) {
             const int pass = r - (R - passes[k]);             // this table's pass index in round r
             if (passes[k] == 0 || pass < 0) continue;
@@ -87,21 +98,29 @@ static bool seg_plan(int n, const long long* nnz, const long long* rows, SegPlan
             const int d = lo + (pass < rem ? 1 : 0);
             const int i = q.ntab++;
             const unsigned tiles = (unsigned)((nnz[k] + SEG_TILE - 1) / SEG_TILE);
+            const unsigned groups = (tiles + SEG_GROUP_TILES - 1) / SEG_GROUP_TILES;
+            const unsigned binblocks = (((unsigned)1 << d) + 255) / 256;
             q.tab[i] = k; q.tile_start[i + 1] = q.tile_start[i] + tiles;
-            q.scan_start[i + 1] = q.scan_start[i] + (((unsigned)1 << d) + 255) / 256;
+            q.scan_start[i + 1] = q.scan_start[i] + binblocks * groups;
+            q.gscan_start[i + 1] = q.gscan_start[i] + (groups > 1 ? binblocks : 0);
             q.dbits[i] = (unsigned char)d; q.shift[i] = (unsigned char)shift;
             q.first[i] = (unsigned char)(pass == 0);
             q.dst_out[i] = (unsigned char)(((R - 1 - r) & 1) == 0);
             q.hist_off[i] = (unsigned)hw; q.bin_off[i] = (unsigned)bw;
+            q.ngroups[i] = (unsigned short)groups; q.gtot_off[i] = (unsigned)gw;
             q.base[i] = base[k]; q.nnz[i] = nnz[k];
             hw += (size_t)tiles << d; bw += (size_t)1 << d;
+            if (groups > 1) gw += (size_t)groups << d;
         }
         for (int i = q.ntab; i < DLRM_MAX_TABLES_PER_LAUNCH; ++i) {
-            q.tab[i] = 0; q.tile_start[i + 1] = q.tile_start[q.ntab]; q.scan_start[i + 1] = q.scan_start[q.ntab]; q.dbits[i] = 1; q.shift[i] = 0; q.first[i] = 0; q.dst_out[i] = 1;
-            q.hist_off[i] = 0; q.bin_off[i] = 0; q.base[i] = 0; q.nnz[i] = 0;
+            q.tab[i] = 0; q.tile_start[i + 1] = q.tile_start[q.ntab]; q.scan_start[i + 1] = q.scan_start[q.ntab]; q.gscan_start[i + 1] = q.gscan_start[q.ntab];
+            q.dbits[i] = 1; q.shift[i] = 0; q.first[i] = 0; q.dst_out[i] = 1;
+            q.hist_off[i] = 0; q.bin_off[i] = 0; q.ngroups[i] = 1; q.gtot_off[i] = 0; q.base[i] = 0; q.nnz[i] = 0;
         }
         if (hw > p->hist_words) p->hist_words = hw;
         if (bw > p->bin_words) p->bin_words = bw;
+        if (gw > p->gtot_words) p->gtot_words = gw;
+        if (hw > 0xFFFFFFFFull || gw > 0xFFFFFFFFull) return false;      // (offsets are 32-bit words)
     }
     return true;
 }
@@ -145,17 +164,23 @@ __global__ __launch_bounds__(64) void seg_hist_kernel(SegRound q, const KT* __re
     for (unsigned b = lane; b < bins; b += 64) dst[b] = h[b];
 }
 
-// one thread per (table, bin): hist[tile][bin] -> exclusive prefix over the table's tiles (in place), tot[bin] = the bin's total.
+// one thread per (table, tile group, bin): hist[tile][bin] -> exclusive prefix over the GROUP's tiles (in place); the group's total goes to
+// tot[bin] (tables of one group) or to gtot[group][bin] (long segments: seg_groupscan_kernel prefixes those).
 // Neighbouring threads own neighbouring bins (coalesced), the tiles' counts are fetched 16 at a time (independent loads).
-__global__ __launch_bounds__(256) void seg_colscan_kernel(SegRound q, unsigned* __restrict__ hist, unsigned* __restrict__ tot) {
+__global__ __launch_bounds__(256) void seg_colscan_kernel(SegRound q, unsigned* __restrict__ hist, unsigned* __restrict__ tot,
+                                                          unsigned* __restrict__ gtot) {
     int i = 0;
     while (i + 1 < q.ntab && blockIdx.x >= q.scan_start[i + 1]) ++i;
     const int d = q.dbits[i];
-    const unsigned bins = 1u << d;
-    const unsigned b = (blockIdx.x - q.scan_start[i]) * 256 + threadIdx.x;
+    const unsigned bins = 1u << d, binblocks = (bins + 255) / 256;
+    const unsigned local = blockIdx.x - q.scan_start[i];
+    const unsigned grp = local / binblocks;
+    const unsigned b = (local - grp * binblocks) * 256 + threadIdx.x;
     if (b >= bins) return;
-    const unsigned tiles = q.tile_start[i + 1] - q.tile_start[i];
-    unsigned* __restrict__ h = hist + q.hist_off[i] + b;
+    const unsigned tiles_all = q.tile_start[i + 1] - q.tile_start[i];
+    const unsigned tbeg = grp * SEG_GROUP_TILES;
+    const unsigned tiles = tiles_all - tbeg < (unsigned)SEG_GROUP_TILES ? tiles_all - tbeg : (unsigned)SEG_GROUP_TILES;
+    unsigned* __restrict__ h = hist + q.hist_off[i] + ((size_t)tbeg << d) + b;
     unsigned run = 0;
     for (unsigned t0 = 0; t0 < tiles; t0 += 16) {
         unsigned c[16];
@@ -164,6 +189,29 @@ __global__ __launch_bounds__(256) void seg_colscan_kernel(SegRound q, unsigned* 
 #pragma unroll
         for (int u = 0; u < 16; ++u)
             if (t0 + u < tiles) { h[(size_t)(t0 + u) << d] = run; run += c[u]; }
+    }
+    if (q.ngroups[i] > 1) gtot[q.gtot_off[i] + ((size_t)grp << d) + b] = run;
+    else tot[q.bin_off[i] + b] = run;
+}
+
+// long segments only — one thread per (table, bin): gtot[group][bin] -> exclusive prefix over the table's groups (in place), tot[bin] = total
+__global__ __launch_bounds__(256) void seg_groupscan_kernel(SegRound q, unsigned* __restrict__ gtot, unsigned* __restrict__ tot) {
+    int i = 0;
+    while (i + 1 < q.ntab && blockIdx.x >= q.gscan_start[i + 1]) ++i;
+    const int d = q.dbits[i];
+    const unsigned bins = 1u << d;
+    const unsigned b = (blockIdx.x - q.gscan_start[i]) * 256 + threadIdx.x;
+    if (b >= bins) return;
+    const unsigned groups = q.ngroups[i];
+    unsigned* __restrict__ gp = gtot + q.gtot_off[i] + b;
+    unsigned run = 0;
+    for (unsigned g0 = 0; g0 < groups; g0 += 16) {
+        unsigned c[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) c[u] = (g0 + u < groups) ? gp[(size_t)(g0 + u) << d] : 0u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (g0 + u < groups) { gp[(size_t)(g0 + u) << d] = run; run += c[u]; }
     }
     tot[q.bin_off[i] + b] = run;
 }
@@ -203,8 +251,8 @@ __global__ __launch_bounds__(1024) void seg_binscan_kernel(SegRound q, unsigned*
 template <typename KT, bool FIRST>
 __device__ __forceinline__ void seg_scatter_tile(const SegRound& q, int i, unsigned tile, const KT* __restrict__ ksrc,
                                                  const unsigned* __restrict__ vsrc, KT* __restrict__ kdst, unsigned* __restrict__ vdst,
-                                                 const unsigned* __restrict__ hist, const unsigned* __restrict__ tot, int dbg,
-                                                 unsigned* cur, unsigned char* claim) {
+                                                 const unsigned* __restrict__ hist, const unsigned* __restrict__ tot,
+                                                 const unsigned* __restrict__ gtot, int dbg, unsigned* cur, unsigned char* claim) {
     const int lane = threadIdx.x;
     const int d = q.dbits[i], shift = q.shift[i];
     const unsigned bins = 1u << d, mask = bins - 1;
@@ -233,6 +281,11 @@ __device__ __forceinline__ void seg_scatter_tile(const SegRound& q, int i, unsig
     for (int j = 0; j < SEG_CHUNKS; ++j) { const unsigned dg = (unsigned)(k[j] >> shift) & mask; off[j] = tt[dg]; }
 #pragma unroll
     for (int j = 0; j < SEG_CHUNKS; ++j) { const unsigned dg = (unsigned)(k[j] >> shift) & mask; off[j] += h[dg]; }
+    if (q.ngroups[i] > 1) {                                   // long segment: + the entries of the digit in the earlier tile groups
+        const unsigned* __restrict__ gg = gtot + q.gtot_off[i] + ((size_t)(tile / SEG_GROUP_TILES) << d);
+#pragma unroll
+        for (int j = 0; j < SEG_CHUNKS; ++j) { const unsigned dg = (unsigned)(k[j] >> shift) & mask; off[j] += gg[dg]; }
+    }
 #pragma unroll 16
     for (unsigned b = lane; b < bins; b += 64) cur[b] = 0u;
     __builtin_amdgcn_wave_barrier();
@@ -283,7 +336,8 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
                                                          const KT* __restrict__ kout_r, KT* __restrict__ ktmp, KT* __restrict__ kout,
                                                          const unsigned* __restrict__ vtmp_r, const unsigned* __restrict__ vout_r,
                                                          unsigned* __restrict__ vtmp, unsigned* __restrict__ vout,
-                                                         const unsigned* __restrict__ hist, const unsigned* __restrict__ tot, int dbg) {
+                                                         const unsigned* __restrict__ hist, const unsigned* __restrict__ tot,
+                                                         const unsigned* __restrict__ gtot, int dbg) {
     // dbg (env DLRM_SEG_DEBUG, timing only — WRONG results): 1 no scattered stores, 2 no match-any, 4 no LDS cursor hand-over.
     // Lanes hand cursors to each other through `cur`.  One wave: its LDS instructions execute in program order; the
     // __builtin_amdgcn_wave_barrier() calls keep the COMPILER from moving LDS accesses across the hand-over points.
@@ -295,9 +349,9 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
     KT* __restrict__ kdst = to_out ? kout : ktmp;
     unsigned* __restrict__ vdst = to_out ? vout : vtmp;
     if (q.first[i])
-        seg_scatter_tile<KT, true>(q, i, tile, kin, nullptr, kdst, vdst, hist, tot, dbg, cur, claim);
+        seg_scatter_tile<KT, true>(q, i, tile, kin, nullptr, kdst, vdst, hist, tot, gtot, dbg, cur, claim);
     else
-        seg_scatter_tile<KT, false>(q, i, tile, to_out ? ktmp_r : kout_r, to_out ? vtmp_r : vout_r, kdst, vdst, hist, tot, dbg, cur, claim);
+        seg_scatter_tile<KT, false>(q, i, tile, to_out ? ktmp_r : kout_r, to_out ? vtmp_r : vout_r, kdst, vdst, hist, tot, gtot, dbg, cur, claim);
 }
 
 static int seg_debug() {
@@ -308,20 +362,24 @@ static int seg_debug() {
 
 template <typename KT>
 static int seg_sort_run(const SegPlan& p, const KT* keys_in, KT* keys_tmp, KT* keys_out, unsigned* vals_tmp, unsigned* vals_out,
-                        unsigned* hist, unsigned* binbase, hipStream_t st) {
+                        unsigned* hist, unsigned* binbase, unsigned* gtot, hipStream_t st) {
     for (int r = 0; r < p.rounds; ++r) {
         const SegRound& q = p.round[r];
         const unsigned tiles = q.tile_start[q.ntab];
         if (q.ntab == 0 || tiles == 0) continue;
         hipLaunchKernelGGL((seg_hist_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out, hist);
         DLRM_LAUNCH_CHECK();
-        hipLaunchKernelGGL(seg_colscan_kernel, dim3(q.scan_start[q.ntab]), dim3(256), 0, st, q, hist, binbase);
+        hipLaunchKernelGGL(seg_colscan_kernel, dim3(q.scan_start[q.ntab]), dim3(256), 0, st, q, hist, binbase, gtot);
         DLRM_LAUNCH_CHECK();
+        if (q.gscan_start[q.ntab] > 0) {
+            hipLaunchKernelGGL(seg_groupscan_kernel, dim3(q.gscan_start[q.ntab]), dim3(256), 0, st, q, gtot, binbase);
+            DLRM_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(seg_binscan_kernel, dim3((unsigned)q.ntab), dim3(1024), 0, st, q, binbase);
         DLRM_LAUNCH_CHECK();
         hipLaunchKernelGGL((seg_scatter_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out,
                            keys_tmp, keys_out, (const unsigned*)vals_tmp, (const unsigned*)vals_out, vals_tmp, vals_out,
-                           (const unsigned*)hist, (const unsigned*)binbase, seg_debug());
+                           (const unsigned*)hist, (const unsigned*)binbase, (const unsigned*)gtot, seg_debug());
         DLRM_LAUNCH_CHECK();
     }
     return 0;

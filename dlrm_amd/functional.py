@@ -31,6 +31,8 @@ RELU_BITS = os.environ.get("DLRM_RELU_BITS", "1") == "1"
 # arith "bf16": activations / weights are also kept as bf16 copies and the GEMMs read those (dlrm_gemm_bf16) instead of rounding fp32
 # operands inside the k-loop (DLRM_BF16_STORAGE=0: the in-loop rounding of rounds 1-2; results are bit-identical)
 BF16_STORAGE = os.environ.get("DLRM_BF16_STORAGE", "1") == "1"
+# bf16 storage, LEAN: hidden activations / gradients exist only as bf16 (+ ReLU sign bits) wherever every consumer reads bf16 (MLPFunction)
+BF16_LEAN = os.environ.get("DLRM_BF16_LEAN", "1") == "1"
 _side_streams = {}
 
 
@@ -142,45 +144,75 @@ class MLPFunction(Function):
         elif x.size(1) != K0:
             raise RuntimeError("dlrm_amd: MLP input width %d does not match the first layer (%d)" % (x.size(1), K0))
         cur = x
-        need_bits = RELU_BITS and any(ctx.needs_input_grad)          # a forward that will be differentiated (Function.forward itself runs grad-free)
+        need_grad = any(ctx.needs_input_grad)
+        need_bits = RELU_BITS and need_grad                          # a forward that will be differentiated (Function.forward itself runs grad-free)
         # arith "bf16" with bf16 STORAGE (default; DLRM_BF16_STORAGE=0 restores the in-loop rounding of rounds 1-2): every GEMM layer reads a
-        # bf16 copy of its input and of its weight (dlrm_gemm_bf16: no conversion in the k-loop) and writes its activation twice — fp32
-        # (what the weight gradient, the matrix-vector layer and the interaction read) and bf16 (what the next GEMM reads).  Same operand
-        # rounding and accumulation order as the in-loop path: results are bit-identical to it.
+        # bf16 copy of its input and of its weight (dlrm_gemm_bf16: no conversion in the k-loop).  LEAN (default, DLRM_BF16_LEAN=0 turns it
+        # off): a hidden activation is written ONLY as bf16 + ReLU sign bits when every consumer reads those — the next layer's forward
+        # GEMM, its weight gradient (dlrm_linear_bwd_weight_bf16 reads bf16 operands k-strided) and the data-gradient mask (sign bits); the
+        # fp32 copy (4 of the 6 bytes written per element) exists only where something reads it: the tower's output, the input of a
+        # matrix-vector layer, layers whose shapes the bf16 weight gradient does not take.  Same operand rounding and accumulation
+        # order as the in-loop path for every product.
         store16 = BF16_STORAGE and arith == ops.arith_code("bf16")
-        cur16 = None                                                  # bf16 copy of `cur`, [M, round32(width)], when a layer produced one
-        outs, bits = [], []
+        lean = store16 and BF16_LEAN
+        widths = [params[2 * i].size(0) for i in range(L)]                                   # N_i
+        kin = [W0p.size(1) if (i == 0 and W0p is not None) else params[2 * i].size(1) for i in range(L)]
+        out_last = out_slot.get() if out_slot is not None else None
+        use16 = [store16 and widths[i] % 4 == 0 and widths[i] != 1 for i in range(L)]
+        if out_last is not None and use16[L - 1] and not (_ld(out_last) % 4 == 0 and out_last.data_ptr() % 16 == 0):
+            use16[L - 1] = False
+        kb = [ops.round_bf16_k(kin[i]) for i in range(L)]
+        # weight gradient of layer i from bf16 operands as stored (X16_i = the bf16 input of its forward GEMM, dZ16_i)
+        wg16 = [lean and need_grad and use16[i] and M >= 256 and M % 64 == 0 and widths[i] % 8 == 0 and widths[i] >= 64 and kin[i] >= 64
+                and os.environ.get("DLRM_BF16_PHASED", "1") != "0" for i in range(L)]
+        # data gradient of layer i (dX = dZ . W) on bf16 operands: reduction over widths[i]
+        # (its epilogue applies the derivative of the activation BELOW it: none, or ReLU through that layer's sign bits)
+        dg16 = [store16 and use16[i] and widths[i] % 32 == 0 and kin[i] % 4 == 0 and
+                (i == 0 or acts[i - 1] == ACT_NONE or (acts[i - 1] == ACT_RELU and need_bits)) for i in range(L)]
+        need32 = []
+        for i in range(L):
+            n32 = (not lean) or i == L - 1 or not use16[i + 1] or kb[i + 1] != widths[i]
+            if not n32 and need_grad:
+                # backward consumers of the fp32 activation: the next layer's weight gradient when it is not the bf16 one; the ReLU
+                # derivative when there are no sign bits; any other activation's derivative
+                n32 = (not wg16[i + 1]) or (acts[i] == ACT_RELU and not need_bits) or acts[i] not in (ACT_RELU, ACT_NONE)
+            need32.append(n32)
+        cur16 = None                                                  # bf16 copy of the current activation, [M, kb of the next layer]
+        outs, outs16, bits, x16_0 = [], [], [], None
         for i in range(L):
             W, b = params[2 * i], params[2 * i + 1]
             if i == 0 and W0p is not None:
                 W = W0p
-            N = W.size(0)
-            if i == L - 1 and out_slot is not None:
-                y = out_slot.get()
-            else:
-                y = alloc2d(M, N, x)
+            N = widths[i]
+            y = (out_last if (i == L - 1 and out_last is not None) else alloc2d(M, N, x)) if need32[i] else None
             # hidden ReLU layers also store their sign bits (1 bit per element): the data-gradient GEMM of the NEXT layer reads
             # those instead of this fp32 activation for its fused ReLU derivative
             rb = ops.relu_bits_alloc(M, N, x.device) if (i < L - 1 and acts[i] == ACT_RELU and need_bits) else None
-            if store16 and N % 4 == 0 and _ld(y) % 4 == 0 and y.data_ptr() % 16 == 0:
-                Kb = ops.round32(W.size(1))
-                a16 = cur16 if (cur16 is not None and cur16.size(1) == Kb) else ops.cast_bf16(cur, Kb, category="linear_fwd")
-                w16 = ops.cast_bf16(W, Kb, category="linear_fwd")
-                # the bf16 copy of this activation, if the NEXT layer is a GEMM that can take it as it is (width a multiple of 32)
-                nxt = i + 1 < L and params[2 * (i + 1)].size(0) % 4 == 0 and N % 32 == 0
-                y16 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if nxt else None
+            y16 = None
+            if use16[i]:
+                a16 = cur16 if (cur16 is not None and cur16.size(1) == kb[i]) else ops.cast_bf16(cur, kb[i], category="linear_fwd")
+                if i == 0:
+                    x16_0 = a16
+                w16 = ops.cast_bf16(W, kb[i], category="linear_fwd")
+                # the bf16 copy of this activation, if the NEXT layer is a GEMM that can take it as it is
+                nxt = i + 1 < L and use16[i + 1] and kb[i + 1] == N
+                y16 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if (nxt or not need32[i]) else None
                 ops.gemm_bf16(a16, w16, b, acts[i], y, y16, relu_bits_out=rb, category="linear_fwd")
-                cur16 = y16
             else:
                 ops.linear_fwd(cur, W, b, acts[i], y, arith, relu_bits=rb)
-                cur16 = None
+            cur16 = y16
             outs.append(y)
+            outs16.append(y16 if lean else None)
             bits.append(rb)
             cur = y
         ctx.bits = bits
         ctx.acts = acts
         ctx.padded = W0p is not None
-        ctx.save_for_backward(x, *params, *outs, *([W0p] if W0p is not None else []))
+        ctx.plan = (use16, wg16, dg16, need32, kb) if store16 else None
+        ctx.x16_0 = x16_0 if (lean and need_grad and wg16[0]) else None
+        ctx.outs16 = outs16 if (lean and need_grad) else [None] * L
+        ctx.have32 = [o is not None for o in outs]
+        ctx.save_for_backward(x, *params, *[o for o in outs if o is not None], *([W0p] if W0p is not None else []))
         return outs[-1]
 
     @staticmethod
@@ -190,11 +222,16 @@ class MLPFunction(Function):
         saved = ctx.saved_tensors
         x = saved[0]
         params = saved[1:1 + 2 * L]
-        outs = saved[1 + 2 * L:1 + 3 * L]
-        W0p = saved[1 + 3 * L] if ctx.padded else None
+        n32 = sum(ctx.have32)
+        it32 = iter(saved[1 + 2 * L:1 + 2 * L + n32])
+        outs = [next(it32) if h else None for h in ctx.have32]          # fp32 activations (None: the layer kept bf16 + sign bits only)
+        W0p = saved[1 + 2 * L + n32] if ctx.padded else None
+        outs16 = ctx.outs16
         M = x.size(0)
         dY = _rowmajor(dY)
         grads: List[Optional[torch.Tensor]] = [None] * (2 * L)
+        store16 = ctx.plan is not None
+        use16, wg16, dg16, need32, kb = ctx.plan if store16 else ([False] * L,) * 4 + ([0] * L,)
 
         # last layer: activation backward (its dY comes from outside, e.g. the loss or the interaction)
         N_last = params[2 * (L - 1)].size(0)
@@ -207,43 +244,57 @@ class MLPFunction(Function):
         main = torch.cuda.current_stream()
         side = _side_stream(x.device) if OVERLAP_WGRAD else None
         keep = []                                          # tensors the side stream reads stay alive until the join
-        store16 = BF16_STORAGE and arith == ops.arith_code("bf16")
         dZ16 = None                                        # bf16 copy of dZ when the previous data-gradient GEMM produced one
         for i in range(L - 1, -1, -1):
             W = params[2 * i] if not (i == 0 and W0p is not None) else W0p
             X_i = x if i == 0 else outs[i - 1]
+            X16_i = (ctx.x16_0 if i == 0 else outs16[i - 1]) if wg16[i] else None
             # first layer on a zero-padded input: the gradient is written at the parameter's true width (the padding
             # columns of X are dropped inside the kernel) — contiguous, no slicing / re-packing afterwards
             dW = _grad_out(params[2 * i])
             db = _grad_out(params[2 * i + 1])
+            N_i, K_i = W.size(0), W.size(1)
+            do16 = wg16[i] and X16_i is not None and ops.linear_bwd_weight_bf16_ok(M, N_i, dW.size(1), dZ16 if dZ16 is not None else X16_i, X16_i)
+            if do16 and dZ16 is None:
+                dZ16 = ops.cast_bf16(dZ, N_i, category="linear_bwd_weight")          # (the tower's last layer: its dZ comes from act_bwd in fp32)
+
+            def wgrad():
+                if do16:
+                    ops.linear_bwd_weight_bf16(dZ16, X16_i, dW, db)               # bf16 operands as stored, k-strided reads
+                else:
+                    ops.linear_bwd_weight(dZ, X_i, dW, db, arith=arith)           # dW and db (row sums of dZ^T) in one GEMM
             if side is not None:
                 side.wait_event(main.record_event())
                 with torch.cuda.stream(side):
-                    ops.linear_bwd_weight(dZ, X_i, dW, db, arith=arith)  # dW and db (row sums of dZ^T) in one GEMM
-                keep.append(dZ)
+                    wgrad()
+                keep += [dZ, dZ16]
             else:
-                ops.linear_bwd_weight(dZ, X_i, dW, db, arith=arith)
+                wgrad()
             grads[2 * i], grads[2 * i + 1] = dW, db
             need_dx = i > 0 or ctx.needs_input_grad[0]
             if not need_dx:
                 continue
-            N_i, K_i = W.size(0), W.size(1)
             mask_act = acts[i - 1] if i > 0 else ACT_NONE
             rbits = ctx.bits[i - 1] if i > 0 else None
-            dprev = alloc2d(M, K_i, x)
-            ok16 = (store16 and N_i % 32 == 0 and K_i % 4 == 0 and _ld(dprev) % 4 == 0
-                    and (mask_act == ACT_NONE or (mask_act == ACT_RELU and rbits is not None)))
+            # what the layer below reads of this gradient: its bf16 weight / data gradient take the bf16 copy; fp32 is written only when
+            # something reads it (the tower's input gradient, an fp32-storage weight / data gradient below)
+            want16 = i > 0 and store16 and (wg16[i - 1] or (dg16[i - 1] and (i - 1 > 0 or ctx.needs_input_grad[0]))) and K_i % 32 == 0
+            want32 = i == 0 or not store16 or not (wg16[i - 1] and (dg16[i - 1] or not (i - 1 > 0 or ctx.needs_input_grad[0]))) or not want16
+            ok16 = (store16 and dg16[i] and (mask_act == ACT_NONE or (mask_act == ACT_RELU and rbits is not None)))
+            dprev = alloc2d(M, K_i, x) if (want32 or not ok16) else None
+            if ok16 and dprev is not None and _ld(dprev) % 4 != 0:
+                ok16 = False
             if ok16:
-                # bf16 storage: dX = dZ . W as a <k-contiguous, k-contiguous> GEMM over a transposed bf16 copy of W; the gradient is
-                # written in fp32 (the next weight gradient reads it) and in bf16 (the next data gradient reads it)
+                # bf16 storage: dX = dZ . W as a <k-contiguous, k-contiguous> GEMM over a transposed bf16 copy of W
                 a16 = dZ16 if dZ16 is not None else ops.cast_bf16(dZ, N_i, category="linear_bwd_data")
                 wT16 = ops.cast_bf16_transposed(W, N_i, category="linear_bwd_data")
-                want16 = i > 0 and K_i % 32 == 0 and (i - 1 > 0 or ctx.needs_input_grad[0])
                 d16 = torch.empty((M, K_i), dtype=torch.bfloat16, device=x.device) if want16 else None
                 ops.gemm_bf16(a16, wT16, None, ACT_NONE, dprev, d16, relu_bits_in=rbits, category="linear_bwd_data")
                 dZ16 = d16
             else:
                 # dgrad GEMM with the previous layer's activation derivative fused into the epilogue
+                if dZ is None:
+                    raise RuntimeError("dlrm_amd: internal: fp32 gradient missing for an fp32-storage data gradient")
                 ops.linear_bwd_data(dZ, W, X_i if i > 0 else None, mask_act, dprev, arith, relu_bits=rbits)
                 dZ16 = None
             if i > 0:
@@ -377,10 +428,37 @@ class LowRankCrossNetFunction(Function):
     of autograd's ATen adds."""
 
     @staticmethod
+    def _bf16_ok(arith, M, n_in, r) -> bool:
+        """bf16 STORAGE form (arith "bf16"): every product reads bf16 operands as stored — x_l and du as the bf16 copies the elementwise
+        kernels write beside (or instead of) their fp32 results, v and dv as bf16-only GEMM outputs; weight gradients from the stored
+        operands (dlrm_linear_bwd_weight_bf16); the gradient sum g + dv.V inside the GEMM epilogue (addend).  Needs the shapes of the
+        bf16-shaped kernels."""
+        return (BF16_STORAGE and BF16_LEAN and arith == ops.arith_code("bf16") and M >= 256 and M % 64 == 0 and n_in % 64 == 0 and r % 64 == 0
+                and n_in >= 192 and r >= 192 and os.environ.get("DLRM_BF16_PHASED", "1") != "0")
+
+    @staticmethod
     def forward(ctx, arith, x0, *params):
         x0 = x0.contiguous()
         L = len(params) // 3
         M, n_in = x0.shape
+        ctx.bf16 = LowRankCrossNetFunction._bf16_ok(arith, M, n_in, params[0].size(0))
+        if ctx.bf16:
+            xl, xl16 = x0, ops.cast_bf16(x0, n_in, category="linear_fwd")
+            xs16, vs16, us = [], [], []
+            for l in range(L):
+                V, W, b = params[3 * l], params[3 * l + 1], params[3 * l + 2]
+                v16 = torch.empty((M, V.size(0)), dtype=torch.bfloat16, device=x0.device)
+                ops.gemm_bf16(xl16, ops.cast_bf16(V, n_in, category="linear_fwd"), None, ACT_NONE, None, v16, category="linear_fwd")
+                u = torch.empty((M, n_in), dtype=torch.float32, device=x0.device)
+                ops.gemm_bf16(v16, ops.cast_bf16(W, V.size(0), category="linear_fwd"), b, ACT_NONE, u, None, category="linear_fwd")
+                xs16.append(xl16); vs16.append(v16); us.append(u)
+                if l + 1 < L:
+                    xl, xl16 = ops.cross_fwd(x0, u, xl, want16=True)
+                else:
+                    xl = ops.cross_fwd(x0, u, xl)
+            ctx.arith, ctx.L = arith, L
+            ctx.save_for_backward(*params, x0, *xs16, *vs16, *us)
+            return xl
         xs, vs, us = [x0], [], []
         for l in range(L):
             V, W, b = params[3 * l], params[3 * l + 1], params[3 * l + 2]
@@ -398,6 +476,35 @@ class LowRankCrossNetFunction(Function):
     def backward(ctx, g):
         L, arith = ctx.L, ctx.arith
         sv = ctx.saved_tensors
+        if ctx.bf16:
+            params, x0 = sv[:3 * L], sv[3 * L]
+            xs16, vs16, us = sv[3 * L + 1:4 * L + 1], sv[4 * L + 1:5 * L + 1], sv[5 * L + 1:6 * L + 1]
+            M, n_in = x0.shape
+            g = g.contiguous()
+            dx0 = torch.empty_like(x0)
+            grads = [None] * (3 * L)
+            gsum = None                                                               # g + sum of the V-path gradients so far (own buffer)
+            for l in range(L - 1, -1, -1):
+                V, W = params[3 * l], params[3 * l + 1]
+                r = V.size(0)
+                gl = g if gsum is None else gsum
+                du16 = ops.cross_bwd(gl, x0, us[l], dx0, accumulate=(l != L - 1), out="bf16")   # du = g * x0 (bf16 only);  dx0 (+)= g * u_l
+                dW, db = torch.empty_like(W), torch.empty(W.size(0), dtype=torch.float32, device=g.device)
+                ops.linear_bwd_weight_bf16(du16, vs16[l], dW, db)
+                dv16 = torch.empty((M, r), dtype=torch.bfloat16, device=g.device)
+                ops.gemm_bf16(du16, ops.cast_bf16_transposed(W, n_in, category="linear_bwd_data"), None, ACT_NONE, None, dv16,
+                              category="linear_bwd_data")
+                dV = torch.empty_like(V)
+                ops.linear_bwd_weight_bf16(dv16, xs16[l], dV, None)
+                # gradient reaching x_l = identity path + V path: g + dv . V, summed in the GEMM epilogue (the incoming g itself is never
+                # written: the first layer processed gets a fresh buffer, later ones accumulate in place)
+                out = torch.empty_like(x0) if gsum is None else gsum
+                ops.gemm_bf16(dv16, ops.cast_bf16_transposed(V, r, category="linear_bwd_data"), None, ACT_NONE, out, None,
+                              category="linear_bwd_data", addend=gl)
+                gsum = out
+                grads[3 * l], grads[3 * l + 1], grads[3 * l + 2] = dV, dW, db
+            dx0 = ops.add(dx0, gsum)                                                  # x_l of layer 0 IS x_0
+            return (None, dx0, *grads)
         params, xs, vs, us = sv[:3 * L], sv[3 * L:4 * L], sv[4 * L:5 * L], sv[5 * L:6 * L]
         x0 = xs[0]
         M, n_in = x0.shape

@@ -7,6 +7,8 @@ buffer) are used in place.  Anything else raises — there is no CPU/eager fallb
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import List, Optional, Sequence
 
@@ -634,6 +636,11 @@ def arith_code(arith) -> int:
     return ARITH_NAMES[arith]
 
 
+def round_bf16_k(K: int) -> int:
+    """reduction length a bf16 operand copy is padded to: a multiple of 64 from 64 up (the bf16-shaped kernel's k-tile), of 32 below"""
+    return (K + 63) & ~63 if K >= 64 else (K + 31) & ~31
+
+
 def relu_bits_alloc(M: int, N: int, device) -> torch.Tensor:
     """buffer for the ReLU sign bits of an [M, N] activation (one bit per element, include/dlrm_hip.h)"""
     return torch.empty(_lib.load().dlrm_relu_bits_bytes(M, N) // 8, dtype=torch.int64, device=device)
@@ -712,7 +719,7 @@ def cast_bf16_transposed(src: torch.Tensor, Rpad: Optional[int] = None, category
 
 def gemm_bf16(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], act: int, Cf: Optional[torch.Tensor],
               Cb: Optional[torch.Tensor], relu_bits_out: Optional[torch.Tensor] = None, relu_bits_in: Optional[torch.Tensor] = None,
-              category: str = "linear_fwd") -> None:
+              category: str = "linear_fwd", addend: Optional[torch.Tensor] = None) -> None:
     """Cf (fp32) and/or Cb (bf16) [M, N] = epilogue(A[M, K] @ B[N, K]^T) with bf16 operands in memory (dlrm_gemm_bf16)."""
     lib = _lib.load()
     for t, name in ((A, "A"), (B, "B")):
@@ -732,6 +739,7 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], ac
                                 C.c_void_p(bias.data_ptr()) if bias is not None else None, int(act),
                                 C.c_void_p(relu_bits_out.data_ptr()) if relu_bits_out is not None else None,
                                 C.c_void_p(relu_bits_in.data_ptr()) if relu_bits_in is not None else None,
+                                C.c_void_p(addend.data_ptr()) if addend is not None else None, _ld(addend) if addend is not None else 0,
                                 C.c_void_p(Cf.data_ptr()) if Cf is not None else None, _ld(Cf) if Cf is not None else 0,
                                 C.c_void_p(Cb.data_ptr()) if Cb is not None else None, Cb.stride(0) if Cb is not None else 0, _stream(out))
     _lib.check(rc, "dlrm_gemm_bf16")
@@ -780,6 +788,38 @@ def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias
         else:
             rc = lib.dlrm_linear_bwd_weight_padded(M, N, K, K_store, *common)
     _lib.check(rc, "dlrm_linear_bwd_weight")
+    return dW
+
+
+def linear_bwd_weight_bf16_ok(M: int, N: int, K: int, dZ16: torch.Tensor, X16: torch.Tensor) -> bool:
+    """preconditions of dlrm_linear_bwd_weight_bf16 (csrc/gemm_bf16.hip, weight-gradient form)"""
+    K = (K + 7) & ~7
+    return (M >= 256 and M % 64 == 0 and N % 8 == 0 and N >= 64 and K >= 64 and X16.size(1) >= K and dZ16.stride(0) % 8 == 0 and X16.stride(0) % 8 == 0
+            and dZ16.data_ptr() % 16 == 0 and X16.data_ptr() % 16 == 0 and os.environ.get("DLRM_BF16_PHASED", "1") != "0")
+
+
+def linear_bwd_weight_bf16(dZ16: torch.Tensor, X16: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor] = None,
+                           accumulate: bool = False) -> torch.Tensor:
+    """dW [N, K] fp32 = dZ16[M, N]^T @ X16[M, :K] and dbias = column sums of dZ16, both operands bf16 AS STORED (read k-strided through
+    ds_read_b64_tr_b16).  dW may be narrower than the product: X16's columns dW.size(1) .. round8(dW.size(1)) must then be ZERO padding."""
+    lib = _lib.load()
+    for t, name in ((dZ16, "dZ16"), (X16, "X16")):
+        if t.dtype != torch.bfloat16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError(f"dlrm_amd: linear_bwd_weight_bf16 operand {name} must be a 2-D bf16 GPU tensor with contiguous rows")
+    _req(dW, "dW", ndim=2)
+    M, N = dZ16.shape
+    K_store = dW.size(1)
+    K = (K_store + 7) & ~7                       # the product's width; columns K_store.. of X16 are zero padding
+    if X16.size(0) != M or dW.size(0) != N or X16.size(1) < K:
+        raise RuntimeError("dlrm_amd: linear_bwd_weight_bf16 shape mismatch")
+    if dbias is not None:
+        _req(dbias, "dbias", ndim=1)
+    ws = _wgrad_workspace(lib.dlrm_linear_bwd_weight_bf16_workspace_bytes(M, N, K), dW.device)
+    with _timed("linear_bwd_weight"):
+        rc = lib.dlrm_linear_bwd_weight_bf16(M, N, K, K_store, C.c_void_p(dZ16.data_ptr()), dZ16.stride(0), C.c_void_p(X16.data_ptr()), X16.stride(0),
+                                             C.c_void_p(dW.data_ptr()), _ld(dW), C.c_void_p(dbias.data_ptr()) if dbias is not None else None,
+                                             int(bool(accumulate)), C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dW))
+    _lib.check(rc, "dlrm_linear_bwd_weight_bf16")
     return dW
 
 
@@ -1028,30 +1068,38 @@ def _flat3(*ts):
     return n
 
 
-def cross_fwd(x0: torch.Tensor, u: torch.Tensor, xl: torch.Tensor) -> torch.Tensor:
-    """x0 * u + xl (DCN-v2 cross layer, elementwise half)"""
+def cross_fwd(x0: torch.Tensor, u: torch.Tensor, xl: torch.Tensor, want16: bool = False):
+    """x0 * u + xl (DCN-v2 cross layer, elementwise half); want16: also its bf16 rounding (returns (out, out16))"""
     n = _flat3(x0, u, xl)
     out = torch.empty_like(x0)
-    _lib.check(_lib.load().dlrm_cross_fwd(n, C.c_void_p(x0.data_ptr()), C.c_void_p(u.data_ptr()), C.c_void_p(xl.data_ptr()),
-                                          C.c_void_p(out.data_ptr()), _stream(out)), "dlrm_cross_fwd")
-    return out
+    out16 = torch.empty(x0.shape, dtype=torch.bfloat16, device=x0.device) if want16 else None
+    with _timed("cross_ew"):
+        rc = _lib.load().dlrm_cross_fwd(n, C.c_void_p(x0.data_ptr()), C.c_void_p(u.data_ptr()), C.c_void_p(xl.data_ptr()),
+                                        C.c_void_p(out.data_ptr()), C.c_void_p(out16.data_ptr()) if want16 else None, _stream(out))
+    _lib.check(rc, "dlrm_cross_fwd")
+    return (out, out16) if want16 else out
 
 
-def cross_bwd(g: torch.Tensor, x0: torch.Tensor, u: torch.Tensor, dx0: torch.Tensor, accumulate: bool) -> torch.Tensor:
-    """returns du = g * x0; dx0 (+)= g * u"""
+def cross_bwd(g: torch.Tensor, x0: torch.Tensor, u: torch.Tensor, dx0: torch.Tensor, accumulate: bool, out: str = "f32"):
+    """du = g * x0 (out "f32": fp32 tensor; "bf16": only its bf16 rounding — what a bf16-storage weight / data gradient reads); dx0 (+)= g * u"""
     n = _flat3(g, x0, u, dx0)
-    du = torch.empty_like(g)
-    _lib.check(_lib.load().dlrm_cross_bwd(n, C.c_void_p(g.data_ptr()), C.c_void_p(x0.data_ptr()), C.c_void_p(u.data_ptr()),
-                                          C.c_void_p(du.data_ptr()), C.c_void_p(dx0.data_ptr()), int(bool(accumulate)), _stream(g)),
-               "dlrm_cross_bwd")
-    return du
+    du = torch.empty_like(g) if out == "f32" else None
+    du16 = torch.empty(g.shape, dtype=torch.bfloat16, device=g.device) if out == "bf16" else None
+    with _timed("cross_ew"):
+        rc = _lib.load().dlrm_cross_bwd(n, C.c_void_p(g.data_ptr()), C.c_void_p(x0.data_ptr()), C.c_void_p(u.data_ptr()),
+                                        C.c_void_p(du.data_ptr()) if du is not None else None,
+                                        C.c_void_p(du16.data_ptr()) if du16 is not None else None,
+                                        C.c_void_p(dx0.data_ptr()), int(bool(accumulate)), _stream(g))
+    _lib.check(rc, "dlrm_cross_bwd")
+    return du if out == "f32" else du16
 
 
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     n = _flat3(a, b)
     out = torch.empty_like(a)
-    _lib.check(_lib.load().dlrm_add(n, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), _stream(a)),
-               "dlrm_add")
+    with _timed("cross_ew"):
+        rc = _lib.load().dlrm_add(n, C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(out.data_ptr()), _stream(a))
+    _lib.check(rc, "dlrm_add")
     return out
 
 

@@ -236,7 +236,21 @@ int dlrm_interact_bwd_gather(int64_t B, int F, int D, const void* const* feat_ho
 int dlrm_cast_bf16(int64_t M, int N, int Npad, const float* src, int64_t lds, uint16_t* dst, int64_t ldd, void* stream);
 int dlrm_cast_bf16_transposed(int R, int C, int Rpad, const float* src, int64_t lds, uint16_t* dstT, int64_t ldd, void* stream);
 int dlrm_gemm_bf16(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, int act,
-                   uint64_t* relu_bits_out, const uint64_t* relu_bits_in, float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, void* stream);
+                   uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd, float* C, int64_t ldc, uint16_t* Cb,
+                   int64_t ldcb, void* stream);
+/* (addend: nullable fp32 [M, N] added to the product AFTER bias / activation / mask — C = A.B^T + addend, the DCN-v2 cross layer's
+ *  gradient sum g + dv.V without a separate add kernel; may alias C for an in-place accumulation; only where the bf16-shaped kernel runs,
+ *  DLRM_E_MODE otherwise) */
+/* Weight gradient of a bf16 layer from bf16 operands as stored (no fp32 activation / gradient copy is read): dW[N, K] (+)= dZ[M, N]^T . X[M, K],
+ * dbias[N] (+)= column sums of dZ (nullable).  Replaces AddmmBackward's weight / bias branch (dlrm_s_pytorch.py:1613) in the arithmetic of
+ * dlrm_gemm_bf16.  Both operands are read k-strided through ds_read_b64_tr_b16 (csrc/gemm_bf16.hip), the batch is split into fp32 slabs in
+ * `workspace` (dlrm_linear_bwd_weight_bf16_workspace_bytes) summed in a fixed order: deterministic.  DLRM_E_ALIGN when M % 64, N % 8, K % 8,
+ * N < 64, K < 64 or unaligned rows: use dlrm_linear_bwd_weight on fp32 operands.  dW is [N, K_store], K_store <= K: the trailing K - K_store
+ * columns of X are alignment padding (zeros) whose gradient is dropped (the 479 -> 480 interaction width). */
+int64_t dlrm_linear_bwd_weight_bf16_workspace_bytes(int64_t M, int N, int K);
+int dlrm_linear_bwd_weight_bf16(int64_t M, int N, int K, int K_store, const uint16_t* dZ, int64_t lddz, const uint16_t* X, int64_t ldx,
+                                float* dW, int64_t lddw, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
+                                void* stream);
 
 int64_t dlrm_relu_bits_bytes(int64_t M, int N);
 int dlrm_linear_fwd(int64_t M, int N, int K,
@@ -397,8 +411,9 @@ int dlrm_bce_elementwise_bwd(int64_t n, const float* p, const float* target, con
  *   dlrm_linear_fwd calls (act none; V without bias); these are the elementwise halves, contiguous fp32 arrays of n elements
  *   (n % 4 == 0, 16-byte aligned):  dlrm_cross_fwd  out = x0 * u + xl;   dlrm_cross_bwd  du = g * x0,  dx0 (+)= g * u
  *   (accumulate != 0 adds into dx0);  dlrm_add  out = a + b  (the gradient reaching x_l through the V product joins g). */
-int dlrm_cross_fwd(int64_t n, const float* x0, const float* u, const float* xl, float* out, void* stream);
-int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const float* u, float* du, float* dx0, int accumulate, void* stream);
+int dlrm_cross_fwd(int64_t n, const float* x0, const float* u, const float* xl, float* out, uint16_t* out16 /* nullable: bf16(out) */, void* stream);
+int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const float* u, float* du /* nullable */, uint16_t* du16 /* nullable: bf16(g * x0) */,
+                   float* dx0, int accumulate, void* stream);
 int dlrm_add(int64_t n, const float* a, const float* b, float* out, void* stream);
 
 /* torch.clamp(p, lo, hi) of the predictions and its backward (--loss-threshold, dlrm_s_pytorch.py:580-583, 607-610):

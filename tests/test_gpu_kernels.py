@@ -158,12 +158,13 @@ CRITEO_TB_ROWS = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 385329
 
 
 @pytest.mark.parametrize("case", ["criteo_onehot", "ragged_hot_rows_int32", "wide_keys_three_rounds", "tiny_tables_many_tiles",
-                                  "long_segment_general_sorter", "single_lookup"])
+                                  "long_segment_general_sorter", "single_lookup", "mlperf_v2_100hot_segment"])
 def test_lookup_sort_is_stable_and_exact(case):
     """The (table, row) sort in front of the sort-based updates (csrc/seg_sort.h; dlrm_emb_sort_lookups) against numpy's stable
     argsort of the same keys — positions, keys and the bag of every position, exactly: one-hot Criteo tables (1- and 2-round tables
     mixed), ragged multi-hot bags with hot rows and an empty table (int32), 64-bit keys over three rounds, segments of many tiles
-    over 1- and 2-row tables (every cursor hit by every lane), and a segment too long for the segmented sorter (general sorter)."""
+    over 1- and 2-row tables (every cursor hit by every lane), a 300 k-lookup segment (three tile groups) and the 6.55 M-lookup segment of
+    the MLPerf-v2 batch's 100-hot table (narrower digits, 25 tile groups, hot row)."""
     from dlrm_amd import ops
     rng = np.random.default_rng(len(case))
     idx_dtype = torch.int64
@@ -184,6 +185,13 @@ def test_lookup_sort_is_stable_and_exact(case):
     elif case == "long_segment_general_sorter":
         rows, B = [1000, 50], 300000
         bags = [(np.arange(B, dtype=np.int64), rng.integers(0, n, size=B).astype(np.int64)) for n in rows]
+    elif case == "mlperf_v2_100hot_segment":
+        # config 5's longest segments: the 100-hot 40 M-row table of a 65536-sample batch = 6.55 M lookups (3200 tiles, 25 tile groups,
+        # 26 row bits in three 9/9/8-bit rounds) next to a 27-hot one and a one-hot tiny table; int32 ids as the KJT carries them
+        rows, B, idx_dtype = [40000000, 3, 40000000], 65536, torch.int32
+        hots = [100, 1, 27]
+        bags = [(np.arange(B, dtype=np.int64) * h, rng.integers(0, n, size=B * h).astype(np.int64)) for n, h in zip(rows, hots)]
+        bags[0][1][::7] = 12345                                         # a hot row: 936 k equal keys in input order
     else:
         rows, B = [7], 1
         bags = [(np.zeros(1, dtype=np.int64), np.asarray([5], dtype=np.int64))]
@@ -489,6 +497,42 @@ def test_gemm_bf16_phased_kernel(M, N, K, act, monkeypatch):
         assert torch.equal(dXb, dX.to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 1024), (65536, 512, 256), (1024, 320, 192), (8192, 128, 256), (2048, 3456, 512), (256, 64, 64),
+                                   (16384, 1024, 480), (4096, 1024, 479)])
+def test_linear_bwd_weight_bf16_from_stored_operands(M, N, K):
+    """dlrm_linear_bwd_weight_bf16 (csrc/gemm_bf16.hip, weight-gradient form: both operands k-strided, fragments by ds_read_b64_tr_b16, batch
+    split into fp32 slabs summed in slice order) against a float64 product of the SAME bf16 operands (AddmmBackward's weight / bias
+    branch, dlrm_s_pytorch.py:1613): dW = dZ^T X, db = column sums of dZ; overwrite and accumulate forms; run-to-run bit-identical.
+    Shapes: ragged output tiles (N, K not multiples of 256), one tile, the 3456-wide DCN-v2 product, K = 480 (the padded interaction width)."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    dZ = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(dev()).to(torch.bfloat16)
+    Kp = (K + 31) & ~31                                        # activations are stored at widths that are multiples of 32; columns K.. are zero
+    X = torch.zeros((M, Kp), dtype=torch.bfloat16, device=dev())
+    X[:, :K] = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(dev()).to(torch.bfloat16)
+    assert ops.linear_bwd_weight_bf16_ok(M, N, K, dZ, X)
+    dW = torch.full((N, K), 7.0, device=dev())
+    db = torch.full((N,), 7.0, device=dev())
+    ops.linear_bwd_weight_bf16(dZ, X, dW, db)
+    torch.cuda.synchronize()
+    want = dZ.double().cpu().numpy().T @ X[:, :K].double().cpu().numpy()
+    wdb = dZ.double().cpu().numpy().sum(0)
+    np.testing.assert_allclose(dW.cpu().numpy(), want, rtol=1e-4, atol=2e-4 * np.sqrt(M))
+    np.testing.assert_allclose(db.cpu().numpy(), wdb, rtol=1e-4, atol=2e-4 * np.sqrt(M))
+    dW2, db2 = dW.clone(), db.clone()
+    ops.linear_bwd_weight_bf16(dZ, X, dW2, db2, accumulate=True)
+    dW3, db3 = torch.empty_like(dW), torch.empty_like(db)
+    ops.linear_bwd_weight_bf16(dZ, X, dW3, db3)
+    torch.cuda.synchronize()
+    assert torch.equal(dW3, dW) and torch.equal(db3, db)                       # deterministic
+    np.testing.assert_allclose(dW2.cpu().numpy(), 2 * want, rtol=1e-4, atol=4e-4 * np.sqrt(M))
+    np.testing.assert_allclose(db2.cpu().numpy(), 2 * wdb, rtol=1e-4, atol=4e-4 * np.sqrt(M))
+    # same product as the fp32-storage weight gradient with in-loop rounding (ARITH bf16) of operands that already are bf16 values
+    dW4 = torch.empty((N, K), device=dev())
+    ops.linear_bwd_weight(dZ.float(), X[:, :K].float().contiguous() if K % 4 else X.float()[:, :K], dW4, None, arith="bf16")
+    np.testing.assert_allclose(dW.cpu().numpy(), dW4.cpu().numpy(), rtol=1e-4, atol=2e-4 * np.sqrt(M))
+
+
 def test_bf16_casts_are_round_to_nearest_even_and_padded():
     """dlrm_cast_bf16 / dlrm_cast_bf16_transposed against torch's fp32 -> bfloat16 conversion (round to nearest even), including the
     zero padding columns and odd shapes"""
@@ -509,7 +553,8 @@ def test_bf16_casts_are_round_to_nearest_even_and_padded():
         assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (R, C_, Rp)
 
 
-@pytest.mark.parametrize("ln,B", [([13, 512, 256, 128], 4096), ([479, 1024, 1024, 512, 256, 1], 2048), ([13, 64, 48, 16], 300), ([96, 64, 32], 129)])
+@pytest.mark.parametrize("ln,B", [([13, 512, 256, 128], 4096), ([479, 1024, 1024, 512, 256, 1], 2048), ([13, 64, 48, 16], 300), ([96, 64, 32], 129),
+                                  ([64, 256, 128, 64], 65536)])
 def test_bf16_storage_tower_is_bit_identical_to_in_loop_rounding(ln, B):
     """arith "bf16" with bf16 STORAGE (dlrm_gemm_bf16: activations / weights read as bf16 copies, nothing converted in the k-loop, the
     data gradient over a transposed bf16 weight copy) against the in-loop rounding path of rounds 1-2 (dlrm_linear_fwd / _bwd_data with
@@ -529,10 +574,10 @@ def test_bf16_storage_tower_is_bit_identical_to_in_loop_rounding(ln, B):
     x0 = to_dev(rng.random((B, ln[0])).astype(np.float32))
     dy = to_dev(rng.standard_normal((B, ln[-1])).astype(np.float32))
     results = []
-    saved = functional.BF16_STORAGE
+    saved = functional.BF16_STORAGE, functional.BF16_LEAN
     try:
-        for storage in (False, True):
-            functional.BF16_STORAGE = storage
+        for storage, lean in ((False, False), (True, False), (True, True)):
+            functional.BF16_STORAGE, functional.BF16_LEAN = storage, lean
             x = x0.clone().requires_grad_(True)
             for p in params:
                 p.grad = None
@@ -541,12 +586,21 @@ def test_bf16_storage_tower_is_bit_identical_to_in_loop_rounding(ln, B):
             torch.cuda.synchronize()
             results.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in params]))
     finally:
-        functional.BF16_STORAGE = saved
-    (y0, dx0, g0), (y1, dx1, g1) = results
+        functional.BF16_STORAGE, functional.BF16_LEAN = saved
+    (y0, dx0, g0), (y1, dx1, g1), (y2, dx2, g2) = results
     assert torch.equal(y0, y1), float((y0 - y1).abs().max())
     assert torch.equal(dx0, dx1), float((dx0 - dx1).abs().max())
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)
+    # LEAN storage (hidden activations / gradients only as bf16 + sign bits; weight gradient from the bf16 operands as stored, k-strided
+    # reads): every forward and data-gradient product has the same operands and the same k order -> y and dx still bit-identical; the
+    # weight gradient sums the same bf16 products in another slice order and the bias gradient sums bf16-rounded dZ -> fp32 round-off /
+    # one bf16 rounding per term apart
+    assert torch.equal(y0, y2), float((y0 - y2).abs().max())
+    assert torch.equal(dx0, dx2), float((dx0 - dx2).abs().max())
+    for k, (a, b) in enumerate(zip(g0, g2)):
+        scale = float(a.abs().max())
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-3, atol=(2e-3 if k % 2 else 2e-5) * scale, err_msg="param %d" % k)
     # and the arithmetic is what it claims to be: bf16 operands, fp32 accumulation
     h = x0.double().cpu().numpy()
     for i in range(L):

@@ -641,6 +641,48 @@ def test_dcn_v2_cross_network_matches_oracle(B, n, r, L, arith):
         np.testing.assert_allclose(ps[3 * l + 2].grad.cpu().numpy(), dbs[l], rtol=1e-4, atol=3e-5 * scale(dbs[l]))
 
 
+def test_dcn_v2_cross_network_bf16_storage_equals_in_loop_rounding():
+    """arith "bf16" at the benchmark's shape (27 x 128 features -> rank 512, 3 layers): the bf16-STORAGE form of the cross network — x_l and
+    du kept as bf16 copies written by the elementwise kernels, v and dv as bf16-only GEMM outputs, weight gradients from the stored
+    operands (ds_read_b64_tr_b16), g + dv.V summed in the GEMM epilogue — against the in-loop rounding form (fp32 storage, every GEMM rounds
+    its operands to bf16 in the k-loop).  Same products: the output and dx_0 agree to fp32 round-off of the same bf16 products except where
+    the storage form rounds v / dv to bf16 a second time as OPERANDS of the next product (the in-loop form does the same rounding when it
+    reads them) — i.e. everywhere; parameter gradients differ by the summation order only."""
+    from dlrm_amd import functional, ops
+    from dlrm_amd.functional import LowRankCrossNetFunction
+    device = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    B, n, r, L = 8192, 3456, 512, 3
+    x0 = torch.from_numpy(rng.standard_normal((B, n)).astype(np.float32)).to(device)
+    g = torch.from_numpy(rng.standard_normal((B, n)).astype(np.float32)).to(device)
+    base = []
+    for l in range(L):
+        base += [torch.from_numpy((rng.standard_normal((r, n)) / np.sqrt(n)).astype(np.float32)).to(device),
+                 torch.from_numpy((rng.standard_normal((n, r)) / np.sqrt(r)).astype(np.float32)).to(device),
+                 torch.from_numpy((rng.standard_normal(n) * 0.1).astype(np.float32)).to(device)]
+    res = []
+    saved = functional.BF16_STORAGE
+    try:
+        for storage in (False, True):
+            functional.BF16_STORAGE = storage
+            tx0 = x0.clone().requires_grad_(True)
+            ps = [p.clone().requires_grad_(True) for p in base]
+            out = LowRankCrossNetFunction.apply(ops.arith_code("bf16"), tx0, *ps)
+            out.backward(g)
+            torch.cuda.synchronize()
+            res.append((out.detach(), tx0.grad, [p.grad for p in ps]))
+    finally:
+        functional.BF16_STORAGE = saved
+    (o0, d0, g0), (o1, d1, g1) = res
+    sc = lambda a: float(a.abs().max())      # noqa: E731
+    assert float((o0 - o1).abs().max()) <= 1e-5 * sc(o0)
+    assert float((d0 - d1).abs().max()) <= 2e-5 * sc(d0)
+    for k, (a, b) in enumerate(zip(g0, g1)):
+        # (bias gradients: column sums of bf16-ROUNDED du — 8192 terms with an independent relative rounding of up to 2^-9 each — against
+        # sums of the fp32 du: a random walk of ~1e-3 of the sum's own scale, a few times that at the worst of 3456 columns)
+        assert float((a - b).abs().max()) <= (6e-3 if k % 3 == 2 else 1e-4) * sc(a), k
+
+
 def test_dlrm_dcn_model_trains_like_a_torch_composition():
     """torchrec_variant.DLRM_DCN (dense arch + pooled embeddings -> DCN-v2 cross network -> over arch -> logits, BCEWithLogits)
     for 2 SGD steps against the same model composed of torch CPU operators with autograd (torchrec itself is absent: UNPINNED)."""

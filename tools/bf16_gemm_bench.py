@@ -31,6 +31,11 @@ def main():
         for tag, cf, cb in (("f32+bf16", Cf, Cb), ("bf16", None, Cb), ("f32", Cf, None)):
             t = timeit(lambda: ops.gemm_bf16(A, B, bias, 1, cf, cb, relu_bits_out=bits), iters=20)
             row[tag] = [round(t * 1e3, 1), round(fl / t / 1e9, 1)]       # us, TFLOP/s
+        dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+        dZ = torch.randn(M, N, device=dev).to(torch.bfloat16)
+        if ops.linear_bwd_weight_bf16_ok(M, N, K, dZ, A):
+            t = timeit(lambda: ops.linear_bwd_weight_bf16(dZ, A, dW, db), iters=20)
+            row["wgrad_bf16"] = [round(t * 1e3, 1), round(fl / t / 1e9, 1)]
         out["%dx%dx%d" % (M, N, K)] = row
         print("%-22s" % ("%dx%dx%d" % (M, N, K)), "  ".join("%s %7.1f us %7.1f TF" % (k, v[0], v[1]) for k, v in row.items()), flush=True)
         del A, B, Cf, Cb
