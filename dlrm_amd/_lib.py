@@ -39,7 +39,7 @@ SIGNATURES = {
     "dlrm_emb_sort_kind": (_i32, [_i32, _pi64, _pi64]),
     "dlrm_cast_bf16": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_cast_bf16_transposed": (_i32, [_i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
-    "dlrm_gemm_bf16": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "dlrm_gemm_bf16": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_linear_bwd_weight_bf16_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "dlrm_linear_bwd_weight_bf16": (_i32, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
     "dlrm_emb_sort_lookups": (_i32, [_i32, _i64, _pi64, _pp, _pp, _pi64, _i32, _vp, _i64, _vp, _vp, _vp, C.POINTER(_i32), _vp, _vp]),

@@ -213,7 +213,7 @@ extern "C" int dlrm_emb_sort_kind(int T, const int64_t* nnz_host, const int64_t*
         long long nz[DLRM_MAX_TABLES_PER_LAUNCH], rw[DLRM_MAX_TABLES_PER_LAUNCH];
         for (int k = 0; k < n; ++k) { nz[k] = (long long)nnz_host[t0 + k]; rw[k] = (long long)rows_host[t0 + k]; }
         SegPlan plan;
-        if (!seg_plan(n, nz, rw, &plan)) return 0;
+        if (!seg_plan(n, nz, rw, &plan, seg_sort_mode() == 2)) return 0;
     }
     return 1;
 }

@@ -1106,8 +1106,8 @@ extern "C" int dlrm_cast_bf16_transposed(int R, int C, int Rpad, const float* sr
 // Preconditions (DLRM_E_ALIGN otherwise — the caller falls back to the fp32-storage kernels): K % 32 == 0, N % 4 == 0, 16-byte aligned
 // operand rows (lda, ldb % 8 == 0), 16-byte aligned fp32 rows (ldc % 4 == 0), 8-byte aligned bf16 rows (ldcb % 4 == 0).
 extern "C" int dlrm_gemm_bf16(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
-                              int act, uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd, float* C,
-                              int64_t ldc, uint16_t* Cb, int64_t ldcb, void* stream) {
+                              int act, uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd,
+                              const float* addend2, int64_t ldadd2, float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !Cb)) return DLRM_E_ARG;
     if (lda < K || ldb < K || (C && ldc < N) || (Cb && ldcb < N)) return DLRM_E_ARG;
     if (act < DLRM_ACT_NONE || act > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
@@ -1117,8 +1117,9 @@ extern "C" int dlrm_gemm_bf16(int64_t M, int N, int K, const uint16_t* A, int64_
         return DLRM_E_ALIGN;
     {   // the bf16-shaped kernel (gemm_bf16.hip: 256 x 256 x 64 tile, four phases per k-tile) wherever its preconditions hold
         if (addend && (ldadd < N || ldadd % 4 || !dlrm_aligned16(addend))) return DLRM_E_ALIGN;
-        const int rc = dlrm_gemm_bf16_phased(M, N, K, A, lda, B, ldb, bias, act, relu_bits_out, relu_bits_in, addend, ldadd, C, ldc, Cb, ldcb,
-                                             (hipStream_t)stream);
+        if (addend2 && (!addend || ldadd2 < N || ldadd2 % 4 || !dlrm_aligned16(addend2))) return DLRM_E_ALIGN;
+        const int rc = dlrm_gemm_bf16_phased(M, N, K, A, lda, B, ldb, bias, act, relu_bits_out, relu_bits_in, addend, ldadd, addend2, ldadd2, C, ldc,
+                                             Cb, ldcb, (hipStream_t)stream);
         if (rc != DLRM_GEMV_NOT_HANDLED) return rc;
         if (addend) return DLRM_E_MODE;                 // the fp32-shaped kernel has no addend operand
     }

@@ -44,6 +44,7 @@ struct BfArgs {
     unsigned short* Cb; long long ldcb;      // nullable
     const float* bias; int act;
     const float* addend; long long ldadd;    // nullable: fp32 [M, N] added to the result (after bias / activation / mask); may alias C
+    const float* addend2; long long ldadd2;  // nullable: a second one (the DCN-v2 backward's last sum: dx0 + g + dv.V in one epilogue)
     unsigned* bits_out; const unsigned* bits_in; long long bits_nblk;
     int tiles_m, tiles_n;
     // weight-gradient form (WG): the reduction runs over the ROWS of both operands (A = dZ [K, M], B = X [K, N], C = A^T B), split in
@@ -349,6 +350,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
                 const float4 a = *(const float4*)(g.addend + m * g.ldadd + nb);
                 v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
             }
+            if (g.addend2) {
+                const float4 a = *(const float4*)(g.addend2 + m * g.ldadd2 + nb);
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
             if (Cz) *(float4*)(Cz + m * g.ldc + nb) = v;
             if (g.Cb) {
                 uint2 pk; pk.x = p_cvt_pk_bf16(v.x, v.y); pk.y = p_cvt_pk_bf16(v.z, v.w);
@@ -379,14 +384,14 @@ static int phased_enabled() {           // DLRM_BF16_PHASED=0: keep the fp32-sha
 
 // returns 0 when the phased kernel took the call, DLRM_GEMV_NOT_HANDLED when the shape is outside its preconditions (the caller keeps gemm3_kernel)
 int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, int act,
-                          uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd, float* C, int64_t ldc,
-                          uint16_t* Cb, int64_t ldcb, hipStream_t st) {
+                          uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd, const float* addend2,
+                          int64_t ldadd2, float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, hipStream_t st) {
     if (!phased_enabled() || K % PBK || N % 4 || N < 192 || M < 256 || lda % 8 || ldb % 8) return DLRM_GEMV_NOT_HANDLED;
     if (bias && !dlrm_aligned16(bias)) return DLRM_GEMV_NOT_HANDLED;
     BfArgs g = {};
     g.M = M; g.N = N; g.K = K;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.Cb = Cb; g.ldcb = ldcb;
-    g.bias = bias; g.act = act; g.addend = addend; g.ldadd = ldadd;
+    g.bias = bias; g.act = act; g.addend = addend; g.ldadd = ldadd; g.addend2 = addend2; g.ldadd2 = ldadd2;
     g.bits_out = (unsigned*)relu_bits_out; g.bits_in = (const unsigned*)relu_bits_in; g.bits_nblk = ((long long)N + 63) / 64;
     g.tiles_m = (int)((M + PBM - 1) / PBM); g.tiles_n = (int)((N + PBN - 1) / PBN);
     static bool attr_done[DLRM_MAX_DEVICES] = {};

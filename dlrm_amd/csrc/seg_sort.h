@@ -66,12 +66,16 @@ struct SegPlan {
 static int seg_bits_for(long long n) { int b = 0; while (((long long)1 << b) < n) ++b; return b < 1 ? 1 : b; }
 
 // false: a segment is too long for this sorter (or a table has too many row bits for SEG_MAX_ROUNDS digits) -> the caller uses the general sorter
-static bool seg_plan(int n, const long long* nnz, const long long* rows, SegPlan* p) {
+// allow_long: take segments of more than SEG_GROUP_TILES tiles too.  Correct and tested (a 6.55 M-lookup segment), but MEASURED SLOWER than the
+// general sorter there (profiles/round4/sort_long_segments.md: 14 M lookups of the MLPerf-v2 batch 1146 vs 773 us — three rounds of scattered
+// 4-byte stores at 1-4 entries per bin and tile against onesweep's block-local reordering into coalesced runs), so the default keeps long
+// segments on the general sorter and DLRM_SORT=own opts in.
+static bool seg_plan(int n, const long long* nnz, const long long* rows, SegPlan* p, bool allow_long) {
     int passes[DLRM_MAX_TABLES_PER_LAUNCH], rb[DLRM_MAX_TABLES_PER_LAUNCH];
     int R = 0;
     for (int k = 0; k < n; ++k) {
         const long long tiles = (nnz[k] + SEG_TILE - 1) / SEG_TILE;
-        if (tiles > (long long)SEG_GROUP_TILES * SEG_MAX_GROUPS) return false;
+        if (tiles > (long long)SEG_GROUP_TILES * (allow_long ? SEG_MAX_GROUPS : 1)) return false;
         int dmax = SEG_MAX_DBITS;                             // widest digit whose [tiles][bins] histogram fits the budget
         while (dmax > 6 && (tiles << dmax) > SEG_HIST_BUDGET) --dmax;
         rb[k] = seg_bits_for(rows[k]);

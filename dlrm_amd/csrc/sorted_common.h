@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void expand_kernel(EmbArgs a, SortedArgs sa, l
             r = 0; bag = DLRM_DEAD_BAG;
         }
         keys[pos] = ((KT)t << row_bits) | (KT)r;
-        vals[pos] = (unsigned)pos;
+        if (vals) vals[pos] = (unsigned)pos;      // (the segmented sorter's first round takes the position itself: vals == nullptr)
         bag_of[pos] = bag;
     }
 }
@@ -78,11 +78,17 @@ __global__ __launch_bounds__(256) void expand_positions_kernel(EmbArgs a, Sorted
     const long long base = sa.base[t];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nnz; i += (long long)gridDim.x * 256) {
         // owner of position i = the LAST bag whose start is <= i (empty bags share their start with the bag that follows them and own
-        // nothing; off[0] == 0 as EmbeddingBag requires)
-        long long lo = 0, hi = B - 1;
-        while (lo < hi) {
-            const long long mid = (lo + hi + 1) >> 1;
-            if ((long long)off[mid] <= i) lo = mid; else hi = mid - 1;
+        // nothing; off[0] == 0 as EmbeddingBag requires).  Multi-hot batches of the reference have a FIXED number of lookups per bag
+        // (torchrec_dlrm/multi_hot.py:80-159), so the proportional guess i * B / nnz is the owner: two loads confirm it instead of the
+        // 17 dependent loads of the binary search (228 -> ~90 us for the 14 M lookups of the MLPerf-v2 batch); ragged bags fall through
+        long long lo = (long long)(((unsigned long long)i * (unsigned long long)B) / (unsigned long long)(nnz > 0 ? nnz : 1)), hi = B - 1;   // (i < 2^32, B < 2^32)
+        if (lo > hi) lo = hi;
+        if (!((long long)off[lo] <= i && (lo + 1 >= B || (long long)off[lo + 1] > i))) {
+            lo = 0;
+            while (lo < hi) {
+                const long long mid = (lo + hi + 1) >> 1;
+                if ((long long)off[mid] <= i) lo = mid; else hi = mid - 1;
+            }
         }
         long long r = (long long)idx[i];
         unsigned bag = (unsigned)lo;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void expand_positions_kernel(EmbArgs a, Sorted
         }
         const long long pos = base + i;
         keys[pos] = ((KT)t << row_bits) | (KT)r;
-        vals[pos] = (unsigned)pos;
+        if (vals) vals[pos] = (unsigned)pos;      // (the segmented sorter's first round takes the position itself: vals == nullptr)
         bag_of[pos] = bag;
     }
 }
@@ -110,12 +116,14 @@ struct Layout {
     SegPlan plan;
 };
 
-// env DLRM_SORT=rocprim forces the general (vendor) sorter: A/B and fallback
-static bool seg_sort_enabled() {
+// env DLRM_SORT: "rocprim" forces the general (vendor) sorter everywhere (A/B), "own" lets the segmented sorter take long segments too
+// (> 262144 lookups per table: measured slower than the general sorter there, see seg_plan); default: segmented sorter for short segments
+static int seg_sort_mode() {            // 0 rocprim, 1 default, 2 own everywhere
     static int v = -1;
-    if (v < 0) { const char* e = getenv("DLRM_SORT"); v = (e && strcmp(e, "rocprim") == 0) ? 0 : 1; }
-    return v == 1;
+    if (v < 0) { const char* e = getenv("DLRM_SORT"); v = (e && strcmp(e, "rocprim") == 0) ? 0 : (e && strcmp(e, "own") == 0) ? 2 : 1; }
+    return v;
 }
+static bool seg_sort_enabled() { return seg_sort_mode() != 0; }
 
 template <typename KT>
 static hipError_t sort_temp_bytes(size_t L, int bits, size_t* bytes) {
@@ -132,7 +140,7 @@ static int make_layout(size_t L, bool wide, int bits, Layout* lo, int n = 0, con
     if (n > 0 && n <= DLRM_MAX_TABLES_PER_LAUNCH && nnz && rows && seg_sort_enabled()) {
         long long nz[DLRM_MAX_TABLES_PER_LAUNCH], rw[DLRM_MAX_TABLES_PER_LAUNCH];
         for (int k = 0; k < n; ++k) { nz[k] = (long long)nnz[k]; rw[k] = (long long)rows[k]; }
-        lo->own = seg_plan(n, nz, rw, &lo->plan);
+        lo->own = seg_plan(n, nz, rw, &lo->plan, seg_sort_mode() == 2);
     }
     lo->keys_in = o;  o += align256(L * ksz);
     lo->keys_out = o; o += align256(L * ksz);
@@ -193,15 +201,15 @@ static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight
         long long gx = (mx + 255) / 256; if (gx > 8192) gx = 8192; if (gx < 1) gx = 1;
         dim3 grid((unsigned)gx, (unsigned)n, 1);
         if (idx_bits == 64)
-            hipLaunchKernelGGL((expand_positions_kernel<long long, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
+            hipLaunchKernelGGL((expand_positions_kernel<long long, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, lo.own ? nullptr : vals_in, bag_of);
         else
-            hipLaunchKernelGGL((expand_positions_kernel<int, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
+            hipLaunchKernelGGL((expand_positions_kernel<int, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, lo.own ? nullptr : vals_in, bag_of);
     } else {
         dim3 grid((unsigned)((B + 255) / 256), (unsigned)n, 1);
         if (idx_bits == 64)
-            hipLaunchKernelGGL((expand_kernel<long long, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
+            hipLaunchKernelGGL((expand_kernel<long long, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, lo.own ? nullptr : vals_in, bag_of);
         else
-            hipLaunchKernelGGL((expand_kernel<int, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, vals_in, bag_of);
+            hipLaunchKernelGGL((expand_kernel<int, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, lo.own ? nullptr : vals_in, bag_of);
     }
     DLRM_LAUNCH_CHECK();
     if (lo.own)         // table-major segments, per-table digit counts: seg_sort.h (graph-replayable: plain kernels, no memsets)

@@ -498,13 +498,13 @@ class LowRankCrossNetFunction(Function):
                 ops.linear_bwd_weight_bf16(dv16, xs16[l], dV, None)
                 # gradient reaching x_l = identity path + V path: g + dv . V, summed in the GEMM epilogue (the incoming g itself is never
                 # written: the first layer processed gets a fresh buffer, later ones accumulate in place)
-                out = torch.empty_like(x0) if gsum is None else gsum
+                # (layer 0: x_l IS x_0, so the accumulated Hadamard-path gradient dx0 joins the same epilogue: dx0 + g + dv . V, in place)
+                out = dx0 if l == 0 else (torch.empty_like(x0) if gsum is None else gsum)
                 ops.gemm_bf16(dv16, ops.cast_bf16_transposed(V, r, category="linear_bwd_data"), None, ACT_NONE, out, None,
-                              category="linear_bwd_data", addend=gl)
+                              category="linear_bwd_data", addend=gl, addend2=dx0 if l == 0 else None)
                 gsum = out
                 grads[3 * l], grads[3 * l + 1], grads[3 * l + 2] = dV, dW, db
-            dx0 = ops.add(dx0, gsum)                                                  # x_l of layer 0 IS x_0
-            return (None, dx0, *grads)
+            return (None, gsum, *grads)
         params, xs, vs, us = sv[:3 * L], sv[3 * L:4 * L], sv[4 * L:5 * L], sv[5 * L:6 * L]
         x0 = xs[0]
         M, n_in = x0.shape

@@ -719,7 +719,7 @@ def cast_bf16_transposed(src: torch.Tensor, Rpad: Optional[int] = None, category
 
 def gemm_bf16(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], act: int, Cf: Optional[torch.Tensor],
               Cb: Optional[torch.Tensor], relu_bits_out: Optional[torch.Tensor] = None, relu_bits_in: Optional[torch.Tensor] = None,
-              category: str = "linear_fwd", addend: Optional[torch.Tensor] = None) -> None:
+              category: str = "linear_fwd", addend: Optional[torch.Tensor] = None, addend2: Optional[torch.Tensor] = None) -> None:
     """Cf (fp32) and/or Cb (bf16) [M, N] = epilogue(A[M, K] @ B[N, K]^T) with bf16 operands in memory (dlrm_gemm_bf16)."""
     lib = _lib.load()
     for t, name in ((A, "A"), (B, "B")):
@@ -740,6 +740,7 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], ac
                                 C.c_void_p(relu_bits_out.data_ptr()) if relu_bits_out is not None else None,
                                 C.c_void_p(relu_bits_in.data_ptr()) if relu_bits_in is not None else None,
                                 C.c_void_p(addend.data_ptr()) if addend is not None else None, _ld(addend) if addend is not None else 0,
+                                C.c_void_p(addend2.data_ptr()) if addend2 is not None else None, _ld(addend2) if addend2 is not None else 0,
                                 C.c_void_p(Cf.data_ptr()) if Cf is not None else None, _ld(Cf) if Cf is not None else 0,
                                 C.c_void_p(Cb.data_ptr()) if Cb is not None else None, Cb.stride(0) if Cb is not None else 0, _stream(out))
     _lib.check(rc, "dlrm_gemm_bf16")

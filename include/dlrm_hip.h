@@ -236,11 +236,11 @@ int dlrm_interact_bwd_gather(int64_t B, int F, int D, const void* const* feat_ho
 int dlrm_cast_bf16(int64_t M, int N, int Npad, const float* src, int64_t lds, uint16_t* dst, int64_t ldd, void* stream);
 int dlrm_cast_bf16_transposed(int R, int C, int Rpad, const float* src, int64_t lds, uint16_t* dstT, int64_t ldd, void* stream);
 int dlrm_gemm_bf16(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, int act,
-                   uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd, float* C, int64_t ldc, uint16_t* Cb,
-                   int64_t ldcb, void* stream);
+                   uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd, const float* addend2, int64_t ldadd2,
+                   float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, void* stream);
 /* (addend: nullable fp32 [M, N] added to the product AFTER bias / activation / mask — C = A.B^T + addend, the DCN-v2 cross layer's
- *  gradient sum g + dv.V without a separate add kernel; may alias C for an in-place accumulation; only where the bf16-shaped kernel runs,
- *  DLRM_E_MODE otherwise) */
+ *  gradient sum g + dv.V without a separate add kernel; may alias C for an in-place accumulation; addend2: a second one (needs addend);
+ *  only where the bf16-shaped kernel runs, DLRM_E_MODE otherwise) */
 /* Weight gradient of a bf16 layer from bf16 operands as stored (no fp32 activation / gradient copy is read): dW[N, K] (+)= dZ[M, N]^T . X[M, K],
  * dbias[N] (+)= column sums of dZ (nullable).  Replaces AddmmBackward's weight / bias branch (dlrm_s_pytorch.py:1613) in the arithmetic of
  * dlrm_gemm_bf16.  Both operands are read k-strided through ds_read_b64_tr_b16 (csrc/gemm_bf16.hip), the batch is split into fp32 slabs in
