@@ -69,3 +69,27 @@ extern "C" int dlrm_calib_hbm_copy(const void* src, void* dst, int64_t bytes, vo
     DLRM_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- CU-partitioned streams (does an HBM-bound kernel on a few CUs compose with an MFMA-bound one on the rest?) ------------
+// dlrm_stream_create_cu_range: a HIP stream whose kernels may only run on CUs [first, first + count) (hipExtStreamCreateWithCUMask; CU i = bit i
+// of the mask, 32 bits per word).  The caller owns the stream (dlrm_stream_destroy).  Used by tools/probes/cu_mask_probe.py only.
+extern "C" int dlrm_stream_create_cu_range(int first, int count, void** stream_out) {
+    if (!stream_out || first < 0 || count <= 0) return DLRM_E_ARG;
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, dlrm_current_device());
+    if (e != hipSuccess) return (int)e;
+    const int cus = p.multiProcessorCount;
+    if (first + count > cus) return DLRM_E_RANGE;
+    uint32_t mask[16] = {};
+    for (int i = first; i < first + count; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t st = nullptr;
+    e = hipExtStreamCreateWithCUMask(&st, (uint32_t)((cus + 31) / 32), mask);
+    if (e != hipSuccess) return (int)e;
+    *stream_out = (void*)st;
+    return 0;
+}
+extern "C" int dlrm_stream_destroy(void* stream) {
+    if (!stream) return DLRM_E_ARG;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}

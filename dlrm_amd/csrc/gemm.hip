@@ -410,6 +410,8 @@ __device__ __forceinline__ unsigned dma_offset(int c, int lane, long long ld, lo
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 template <int N> struct FVec;
+struct FloatX1 { float v; __device__ __forceinline__ float operator[](int) const { return v; } };
+template <> struct FVec<1> { using T = FloatX1; };
 template <> struct FVec<2> { using T = floatx2; };
 template <> struct FVec<4> { using T = floatx4; };
 
@@ -1009,10 +1011,20 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
         if (wgrad_tm < 0) { const char* e = getenv("DLRM_WGRAD_TM"); wgrad_tm = e ? atoi(e) : 0; }
         if (splits > 1 && wgrad_tm == 2) big = false;
         if (fast) *fast = true;
+        // SMALL launches (Criteo-Kaggle: batch 2048): a 128 x 128 tiling leaves most CUs idle and every wave walks its k-loop alone at one
+        // SIMD's MFMA rate (29 / 25 / 44 us per forward / data- / weight-gradient GEMM of ~0.5 GFLOP, profiles/round4/kaggle_kernels.md).
+        // 64-row tiles (TM = 1) double the workgroups and halve each wave's MFMA chain.  fp32 MFMA only.
+        static int small_tm = -1;       // tuning aid: DLRM_GEMM_SMALL=0 keeps the 128-row tiles
+        if (small_tm < 0) { const char* e = getenv("DLRM_GEMM_SMALL"); small_tm = e ? atoi(e) : 1; }
+        const long long wg128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) * splits;
+        const bool small = small_tm && !big && arith == DLRM_ARITH_F32 && wg128 < 128 && force_tm == 0;
         if constexpr (!A_KC || !B_KC) {
-            if (arith == DLRM_ARITH_F32 && frag)
+            if (arith == DLRM_ARITH_F32 && frag) {
+                if (small) return launch_gemm3<A_KC, B_KC, 1, 0, 1>(g, splits, st);
                 return big ? launch_gemm3<A_KC, B_KC, 4, 0, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0, 1>(g, splits, st);
+            }
         }
+        if (small) return launch_gemm3<A_KC, B_KC, 1, 0>(g, splits, st);
         if (arith == DLRM_ARITH_BF16X6)
             return big ? launch_gemm3<A_KC, B_KC, 4, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 1>(g, splits, st);
         if (arith == DLRM_ARITH_BF16)
@@ -1177,7 +1189,13 @@ static void wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* kchunk
     const int tiles = (int)(((N + BM - 1) / BM) * ((K + BN - 1) / BN));
     int splits = (1024 + tiles - 1) / tiles;
     const int64_t max_splits = (M + 511) / 512;
-    if (splits > max_splits) splits = (int)max_splits;
+    if (splits > max_splits) {
+        // small batches (Criteo-Kaggle: 2048 rows): slices down to 128 rows while the launch still has fewer workgroups than the chip has CUs
+        const int64_t max128 = (M + 127) / 128;
+        int64_t want = (256 + tiles - 1) / tiles;
+        if (want > max128) want = max128;
+        splits = (int)(want > max_splits ? want : max_splits);
+    }
     if (splits < 1) splits = 1;
     int64_t kchunk = (M + splits - 1) / splits;
     kchunk = ((kchunk + BK - 1) / BK) * BK;

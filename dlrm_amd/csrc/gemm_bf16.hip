@@ -22,7 +22,8 @@
 //     first sub-tile column, B second column, A last two rows), one piece per phase: every piece is issued >= 3 phases before its first
 //     read and its slot is rewritten >= 2 phases after its last read; `s_waitcnt vmcnt(4)` leaves two pieces in flight across every barrier;
 //   * LDS image per operand and k-half: [256 rows][64 B] with the 16-byte slots XOR-swizzled through the SOURCE address (the DMA
-//     destination is lane-linear) — the image gemm3_kernel uses, conflict-free for the 32-row x 16-byte fragment reads;
+//     destination is lane-linear) — the image gemm3_kernel uses, conflict-free for the 32-row x 16-byte fragment reads.  (A [256 rows][128 B]
+//     image fed by full-line DMA chunks of 8 rows x 128 B measured 4-10 % SLOWER, profiles/round4/bf16_gemm_notes.md);
 //   * epilogue as in gemm3_kernel: accumulators hold the TRANSPOSED sub-tiles, bands pass through wave-private LDS and leave as 16-byte
 //     (fp32) / 8-byte (bf16) row segments; bias, activation, sign bits out (one 4-byte word per lane and 32 x 64 block), sign-bit mask in.
 // Preconditions (checked by the host; otherwise the caller keeps gemm3_kernel): K % 64 == 0, N % 4 == 0, N >= 192, M >= 256, 16-byte aligned
@@ -122,8 +123,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     const long long k_end = WG ? ((k_begin + g.kchunk < g.K) ? k_begin + g.kchunk : g.K) : g.K;
     const int nk = (int)((k_end - k_begin) / PBK);
 
-    // ---- DMA plan.  A piece = 128 tile rows x 64 k = 16 chunks of 1 KiB (16 rows x 64 B of one k-half); wave w moves chunks w and w + 8
-    // of every piece: k-half = w & 1, row group (16 rows) = (w >> 1) and (w >> 1) + 4.
+    // ---- DMA plan.  A piece = 128 tile rows (or columns) x 64 k = 16 chunks of 1 KiB; wave w moves chunks w and w + 8 of every piece.
     //   piece 0 (A0): A rows {0..63, 128..191}      piece 1 (B0): B rows {64 c + 0..31,  c = 0..3}
     //   piece 3 (A1): A rows {64..127, 192..255}    piece 2 (B1): B rows {64 c + 32..63, c = 0..3}
     unsigned voff[4][2], dst[4][2];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();          // the second wave half runs one barrier behind the first
 
-    uintx4 fa[2][4], fb[4];                             // fragments of the current quadrant: A [2 sub-tile rows][4 k-steps], B [4 k-steps]
+    uintx4 fa[2][4], fb0[4], fb1[4];                    // fragments: A [2 sub-tile rows][4 k-steps] of the current row half, B column 0 / 1 [4 k-steps]
     unsigned cur = 0;                                   // byte offset of the stage being multiplied
 #define P_READ_A(half)                                                                                              \
         _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                               \
@@ -218,10 +218,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
             if constexpr (WG) fa[t][j] = p_tr_read8(lds_base + cur + tra_off + ((half) * 2 + t) * 4096 + j * 1024); \
             else fa[t][j] = *(const uintx4*)(ldsb + cur + fa_off[j & 1] + (j >> 1) * KHALF_BYTES + ((half) * 2 + t) * 2048); \
         }
-#define P_READ_B(tn)                                                                                                \
+#define P_READ_B(FB, tn)                                                                                            \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
-            if constexpr (WG) fb[j] = p_tr_read8(lds_base + cur + trb_off + (tn) * 4096 + j * 1024);                \
-            else fb[j] = *(const uintx4*)(ldsb + cur + fb_off[j & 1] + (j >> 1) * KHALF_BYTES + (tn) * 2048);        \
+            if constexpr (WG) FB[j] = p_tr_read8(lds_base + cur + trb_off + (tn) * 4096 + j * 1024);                \
+            else FB[j] = *(const uintx4*)(ldsb + cur + fb_off[j & 1] + (j >> 1) * KHALF_BYTES + (tn) * 2048);        \
         }
     // (bf16 -> fp32 is a 16-bit shift: two VALU per packed pair)
 #define P_ROWSUM(half)                                                                                              \
@@ -233,32 +233,47 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
                     a_ += __uint_as_float(f_[e] << 16) + __uint_as_float(f_[e] & 0xffff0000u);                      \
                 rs[(half) * 2 + t] += a_;                                                                           \
             } } }
-#define P_MATH(half, tn)                                                                                            \
+    // MATH: the quadrant's 8 MFMAs at raised priority, with the two LDS-DMA issues of ONE piece of the next k-tile between them (an
+    // LDS-DMA issue costs ~60 cycles among bare MFMAs but 100-185 in a segment that also carries the fragment reads — MI355X_MICROARCH.md;
+    // round 4's first version issued them in the LOAD segment and ran 534 instead of ~300 cycles per half-phase).  sched_barrier pins the order.
+#define P_MM(half, tn, FB, j, t) acc[(half) * 2 + (t)][tn] = P_MFMA(FB[j], fa[t][j], acc[(half) * 2 + (t)][tn]);
+#define P_MATH(half, tn, FB, piece, MORE)                                                                           \
         __builtin_amdgcn_s_barrier();                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
-        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                               \
-            acc[(half) * 2 + t][tn] = P_MFMA(fb[j], fa[t][j], acc[(half) * 2 + t][tn]);                             \
+        P_MM(half, tn, FB, 0, 0) P_MM(half, tn, FB, 0, 1)                                                           \
+        asm volatile("" : "+v"(acc[(half) * 2][tn]), "+v"(acc[(half) * 2 + 1][tn]));                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if (MORE) p_glds16(voff[piece][0], ((piece) == 0 || (piece) == 3) ? baseA : baseB, dst[piece][0] + nxt);    \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        P_MM(half, tn, FB, 1, 0) P_MM(half, tn, FB, 1, 1) P_MM(half, tn, FB, 2, 0)                                  \
+        asm volatile("" : "+v"(acc[(half) * 2][tn]), "+v"(acc[(half) * 2 + 1][tn]));                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if (MORE) p_glds16(voff[piece][1], ((piece) == 0 || (piece) == 3) ? baseA : baseB, dst[piece][1] + nxt);    \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        P_MM(half, tn, FB, 2, 1) P_MM(half, tn, FB, 3, 0) P_MM(half, tn, FB, 3, 1)                                  \
+        /* (MFMAs are pure register operations: the IR optimizer SINKS them towards their next use, across setprio and the barrier, \
+           into the next segment — an empty volatile asm that claims to rewrite the two accumulators pins them here) */             \
+        asm volatile("" : "+v"(acc[(half) * 2][tn]), "+v"(acc[(half) * 2 + 1][tn]));                                \
         __builtin_amdgcn_s_setprio(0);                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         __builtin_amdgcn_s_barrier();                                                                               \
         asm volatile("" ::: "memory");
-    // MORE = 1: one piece of the next k-tile is issued per phase and two pieces stay in flight across the barrier; the last k-tile
-    // (MORE = 0, peeled) only drains
-#define P_STAGE(piece, MORE)                                                                                        \
-        if (MORE) { P_ISSUE(piece, nxt); p_wait_vmcnt<4>(); } else p_wait_vmcnt<0>();
+    // LOAD ends with the counted wait: MORE = 1 leaves ONE piece (two DMA) in flight across the barrier — the piece issued in the MATH
+    // segment before this LOAD; everything older has landed, so what the NEXT phase reads is complete for every wave after the barrier.
+    // The last k-tile (MORE = 0, peeled) only drains.
+#define P_WAIT(MORE) if (MORE) p_wait_vmcnt<2>(); else p_wait_vmcnt<0>();
 #define P_KTILE(MORE)                                                                                               \
     {                                                                                                               \
         const unsigned nxt = cur ^ (unsigned)STAGE_BYTES;                                                           \
-        /* phase 1: quadrant (rows 0-63, cols 0-31) */                                                             \
-        P_READ_A(0) P_READ_B(0) P_STAGE(0, MORE) P_MATH(0, 0) P_ROWSUM(0)                                           \
-        /* phase 2: (rows 0-63, cols 32-63) */                                                                     \
-        P_READ_B(1) P_STAGE(1, MORE) P_MATH(0, 1)                                                                   \
-        /* phase 3: (rows 64-127, cols 32-63) */                                                                   \
-        P_READ_A(1) P_STAGE(2, MORE) P_MATH(1, 1) P_ROWSUM(1)                                                       \
-        /* phase 4: (rows 64-127, cols 0-31) */                                                                    \
-        P_READ_B(0) P_STAGE(3, MORE) P_MATH(1, 0)                                                                   \
+        /* phase 1: quadrant (rows 0-63, cols 0-31); piece A0 of the next k-tile */                                \
+        P_READ_A(0) P_READ_B(fb0, 0) P_WAIT(MORE) P_MATH(0, 0, fb0, 0, MORE) P_ROWSUM(0)                            \
+        /* phase 2: (rows 0-63, cols 32-63); piece B0 */                                                           \
+        P_READ_B(fb1, 1) P_WAIT(MORE) P_MATH(0, 1, fb1, 1, MORE)                                                    \
+        /* phase 3: (rows 64-127, cols 32-63); piece B1 */                                                         \
+        P_READ_A(1) P_WAIT(MORE) P_MATH(1, 1, fb1, 2, MORE) P_ROWSUM(1)                                             \
+        /* phase 4: (rows 64-127, cols 0-31): both operands are still in registers; piece A1 */                    \
+        P_WAIT(MORE) P_MATH(1, 0, fb0, 3, MORE)                                                                     \
         if (MORE) { baseA += stepA; baseB += stepB; }                                                               \
         cur = nxt;                                                                                                  \
     }
@@ -269,7 +284,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
 #undef P_READ_B
 #undef P_ROWSUM
 #undef P_MATH
-#undef P_STAGE
+#undef P_MM
+#undef P_WAIT
 #undef P_ISSUE
     if (wr == 0) __builtin_amdgcn_s_barrier();          // the first half waits for the second: the tile buffers become epilogue staging
     __builtin_amdgcn_s_barrier();

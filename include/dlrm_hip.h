@@ -60,6 +60,10 @@ int         dlrm_hip_device_info(int device, int* cu_count, int* lds_bytes,
  *   dlrm_calib_hbm_copy: float4 copy (one float4 per thread) of `bytes` (multiple of 16) from src to dst; HBM rate = 2 * bytes / time. */
 int dlrm_calib_mfma(int kind, int iters, float* scratch, double* flop_out, void* stream);
 int dlrm_calib_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream);
+/* CU-partitioned streams for composition experiments (tools/probes/cu_mask_probe.py; not used by the training path): a stream restricted to
+ * CUs [first, first + count) of the current device (hipExtStreamCreateWithCUMask).  The caller destroys it. */
+int dlrm_stream_create_cu_range(int first, int count, void** stream_out);
+int dlrm_stream_destroy(void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K1  EmbeddingBag(mode="sum") forward for ALL tables in one launch.
