@@ -48,6 +48,7 @@ struct BfArgs {
     const float* addend2; long long ldadd2;  // nullable: a second one (the DCN-v2 backward's last sum: dx0 + g + dv.V in one epilogue)
     unsigned* bits_out; const unsigned* bits_in; long long bits_nblk;
     int tiles_m, tiles_n;
+    int wide16;                              // bf16-only output through 16-byte stores (set by the host when its preconditions hold)
     // weight-gradient form (WG): the reduction runs over the ROWS of both operands (A = dZ [K, M], B = X [K, N], C = A^T B), split in
     // gridDim.z slices of kchunk rows; slice z stores its fp32 partial at C + z * c_split_stride and the row sums of A^T (the bias
     // gradient) at rowsum + z * M
@@ -79,6 +80,7 @@ __device__ __forceinline__ float p_act(float v, int act) {
 }
 #define P_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)
 
+template <int V> struct IC { static constexpr int value = V; };
 typedef short shortx4 __attribute__((ext_vector_type(4)));
 // two ds_read_b64_tr_b16 = the 8 consecutive k-values of one column a lane feeds to v_mfma_f32_32x32x16_bf16 from a [k][column] image:
 // inside each 16-lane group lane p passes the address of [row p >> 2][columns 4 (p & 3) .. + 3] and lane i receives column i of rows 0..3
@@ -329,8 +331,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     float* S = lds + wave * (32 * P_EPI_LD);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias && nb < g.N) bv = *(const float4*)(g.bias + nb);      // N % 4 == 0 and nb % 4 == 0: the quad is inside the bias vector
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
+    // (one instantiation per band through a generic lambda: with the second output form the unroller refused the pragma on a plain loop —
+    // "unrolled size is too large" — and a rolled loop indexes acc[tm] dynamically, i.e. puts the accumulators into scratch memory)
+    auto band = [&](auto TMC) {
+        constexpr int tm = decltype(TMC)::value;
         unsigned myword = 0u;
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
@@ -339,6 +343,57 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
                 const float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
                 *(float4*)__builtin_assume_aligned(S + l31 * P_EPI_LD + tn * 32 + 8 * q + 4 * h, 16) = v;
             }
+        if (!WG && g.wide16) {
+            // bf16-ONLY output (lean storage): the band leaves as 16-byte stores — a lane owns 8 consecutive columns of one row, four store
+            // instructions per band instead of eight 8-byte ones (the epilogue is store-ISSUE-bound, ~7 B/clk/CU: MI355X_MICROARCH.md).
+            // The ReLU sign bits keep their documented ownership (dlrm_relu_bits_bytes: lane l = rows it*4 + (l >> 4), columns 4 (l & 15) + c):
+            // written from a separate pass over the staged band in that ownership, read through two cross-lane fetches per row.
+            if (g.bits_out) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const float4 v = *(const float4*)__builtin_assume_aligned(S + (it * 4 + (lane >> 4)) * P_EPI_LD + c4, 16);
+                    const float x0 = v.x + bv.x, x1 = v.y + bv.y, x2 = v.z + bv.z, x3 = v.w + bv.w;          // (ReLU(x) > 0 <=> x > 0)
+                    asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                 "v_cmp_lt_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                 "v_cmp_lt_f32 vcc, 0, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                 "v_cmp_lt_f32 vcc, 0, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                 : "+v"(myword) : "v"(x0), "v"(x1), "v"(x2), "v"(x3) : "vcc");
+                }
+            }
+            const int c8 = (lane & 7) * 8;
+            const long long nb8 = n0 + wc * 64 + c8;
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (g.bias && nb8 < g.N) { b0 = *(const float4*)(g.bias + nb8); b1 = *(const float4*)(g.bias + nb8 + 4); }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                const long long m = m0 + wr * 128 + tm * 32 + row;
+                float4 v0 = *(const float4*)__builtin_assume_aligned(S + row * P_EPI_LD + c8, 16);
+                float4 v1 = *(const float4*)__builtin_assume_aligned(S + row * P_EPI_LD + c8 + 4, 16);
+                v0.x = p_act(v0.x + b0.x, g.act); v0.y = p_act(v0.y + b0.y, g.act); v0.z = p_act(v0.z + b0.z, g.act); v0.w = p_act(v0.w + b0.w, g.act);
+                v1.x = p_act(v1.x + b1.x, g.act); v1.y = p_act(v1.y + b1.y, g.act); v1.z = p_act(v1.z + b1.z, g.act); v1.w = p_act(v1.w + b1.w, g.act);
+                if (g.bits_in) {
+                    // the word of the lane that owns (row, column quad) in the documented layout: lane (row & 3) * 16 + quad, bit 31 - (4 (row >> 2) + c)
+                    const int src = (row & 3) * 16 + (lane & 7) * 2;
+                    const unsigned w0 = (unsigned)__shfl((int)mkb[tm], src, 64), w1 = (unsigned)__shfl((int)mkb[tm], src + 1, 64);
+                    const int sh = 31 - 4 * (row >> 2);
+                    if (!((w0 >> (sh - 0)) & 1u)) v0.x = 0.f;
+                    if (!((w0 >> (sh - 1)) & 1u)) v0.y = 0.f;
+                    if (!((w0 >> (sh - 2)) & 1u)) v0.z = 0.f;
+                    if (!((w0 >> (sh - 3)) & 1u)) v0.w = 0.f;
+                    if (!((w1 >> (sh - 0)) & 1u)) v1.x = 0.f;
+                    if (!((w1 >> (sh - 1)) & 1u)) v1.y = 0.f;
+                    if (!((w1 >> (sh - 2)) & 1u)) v1.z = 0.f;
+                    if (!((w1 >> (sh - 3)) & 1u)) v1.w = 0.f;
+                }
+                if (m < g.M && nb8 < g.N) {
+                    uintx4 pk;
+                    pk[0] = p_cvt_pk_bf16(v0.x, v0.y); pk[1] = p_cvt_pk_bf16(v0.z, v0.w);
+                    pk[2] = p_cvt_pk_bf16(v1.x, v1.y); pk[3] = p_cvt_pk_bf16(v1.z, v1.w);
+                    *(uintx4*)(g.Cb + m * g.ldcb + nb8) = pk;
+                }
+            }
+        } else
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 4 + (lane >> 4);
@@ -380,7 +435,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
             const long long mb = (m0 + wr * 128 + tm * 32) >> 5, nbk = (n0 + wc * 64) >> 6;
             if (mb <= ((g.M - 1) >> 5) && nbk < g.bits_nblk) g.bits_out[(mb * g.bits_nblk + nbk) * 64 + lane] = myword;
         }
-    }
+    };
+    band(IC<0>{}); band(IC<1>{}); band(IC<2>{}); band(IC<3>{});
 }
 
 }  // namespace
@@ -410,6 +466,9 @@ int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t ld
     g.bias = bias; g.act = act; g.addend = addend; g.ldadd = ldadd; g.addend2 = addend2; g.ldadd2 = ldadd2;
     g.bits_out = (unsigned*)relu_bits_out; g.bits_in = (const unsigned*)relu_bits_in; g.bits_nblk = ((long long)N + 63) / 64;
     g.tiles_m = (int)((M + PBM - 1) / PBM); g.tiles_n = (int)((N + PBN - 1) / PBN);
+    static int wide = -1;               // tuning aid: DLRM_BF16_WIDE_STORE=0 keeps the 8-byte bf16 stores
+    if (wide < 0) { const char* e = getenv("DLRM_BF16_WIDE_STORE"); wide = e ? atoi(e) : 1; }
+    g.wide16 = (wide && Cb && !C && !addend && N % 8 == 0 && ldcb % 8 == 0 && dlrm_aligned16(Cb) && (!bias || dlrm_aligned16(bias))) ? 1 : 0;
     static bool attr_done[DLRM_MAX_DEVICES] = {};
     phased_attr((const void*)gemm_bf16_phased_kernel<false>, attr_done[dlrm_current_device()]);
     hipLaunchKernelGGL(gemm_bf16_phased_kernel<false>, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), 2 * STAGE_BYTES, st, g);

@@ -101,6 +101,7 @@ class GraphedTrainStep:
         # own kernels (csrc/seg_sort.h: no memsets, no vendor code, replayable); whether THIS step's shapes are covered is only known
         # when the first batch arrives — decided in _settle_sort_mode().
         self._sort_checked = False
+        self._one = None
         # the captured step is single-stream: a replayed graph has no launch gaps to hide, and the side-stream overlap
         # of the eager path (DLRM_Net.overlap_streams) would put cross-stream joins into the capture
         model.overlap_streams = False
@@ -180,7 +181,9 @@ class GraphedTrainStep:
         # AccumulateGrad; the embedding tables are listed so that their Function's backward (the fused-update stash)
         # runs, and come back as None exactly like after backward().
         params = [p for g in self.optimizer.param_groups for p in g["params"] if p.requires_grad]
-        grads = torch.autograd.grad(E, params, allow_unused=True)
+        if self._one is None or self._one.device != E.device:
+            self._one = torch.ones((), dtype=E.dtype, device=E.device)      # the seed of backward: without it autograd launches an ATen fill per step
+        grads = torch.autograd.grad(E, params, grad_outputs=self._one, allow_unused=True)
         for p, g in zip(params, grads):
             p.grad = g
         self.optimizer.step()
