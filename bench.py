@@ -616,8 +616,12 @@ def main():
         if len(set(uuids)) != N and not selftest:
             sys.exit("ERROR: %d ranks share %d GPUs; one process per GPU is required" % (N, len(set(uuids))))
         watchdog(args.hang_timeout, "first training step (RCCL all-to-all + DDP all-reduce for the first time)")
+    calls_per_step = None
     for i in range(args.warmup):
+        c0_ = ops.CALL_COUNT[0]
         step(i)
+        if i <= 1:                  # C-ABI calls of one EAGER step (the graphed step's first two calls are eager too); a call is 1-4 kernels
+            calls_per_step = ops.CALL_COUNT[0] - c0_
         if i == 0 and N > 1:
             torch.cuda.synchronize()
             watchdog(args.hang_timeout + 20 * (args.warmup + args.steps), "warm-up + timed region")
@@ -806,6 +810,9 @@ def main():
                                          "v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate, fp32 master weights (reduced precision: NOT the headline "
                                          "configuration)"}[args.mlp_arith]},
         "final_loss": final_loss,
+        "launches": {"c_abi_calls_per_step": calls_per_step, "us_per_step": ms * 1e3,
+                     "note": "categorised C-ABI calls of one eager step (one call = 1-4 kernel launches; rocprofv3 kernel counts per step: "
+                             "profiles/round4/kaggle_kernels.md); the whole-step HIP graph (--graph) replays them with one launch"},
         "box": box,
         "parity_check": parity,
         "kernel_timing": "HIP events on the launch stream, one per change of launch category (a run of consecutive launches of one category "

@@ -25,6 +25,8 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
 # Measured on MI355X (profiles/r01, g02): 11.83 ms/step with the overlap vs 11.30 ms without — two chip-filling GEMMs
 # sharing the CUs thrash each other's L2 panels — so it is OFF by default.
 OVERLAP_WGRAD = os.environ.get("DLRM_OVERLAP_WGRAD", "0") == "1"
+# ... except for SMALL batches inside a HIP-graph capture: rows at or below this run weight and data gradient concurrently (0 = never)
+SMALL_BATCH_OVERLAP = int(os.environ.get("DLRM_SMALL_BATCH_OVERLAP", "8192"))
 # hidden ReLU layers store 1 sign bit per activation for the next layer's data-gradient epilogue (DLRM_RELU_BITS=0: the
 # epilogue re-reads the fp32 activation instead)
 RELU_BITS = os.environ.get("DLRM_RELU_BITS", "1") == "1"
@@ -242,7 +244,12 @@ class MLPFunction(Function):
         # are independent: wgrad goes to a side HIP stream so the two kernels share the chip (their epilogue
         # store bursts and tail rounds interleave with the other's MFMA phases instead of idling the matrix cores).
         main = torch.cuda.current_stream()
-        side = _side_stream(x.device) if OVERLAP_WGRAD else None
+        # (small batches — Criteo-Kaggle's 2048 rows — are the opposite regime: every GEMM of the step occupies a fraction of the chip, so the
+        # independent weight-gradient launch runs BESIDE the data-gradient launch for free; the fork / join are events a graph capture records)
+        # — measured at Criteo-Kaggle shapes: graphed step 0.515 -> 0.497 ms; in the EAGER step the two extra event records per layer cost the
+        # host more than the overlap saves (1.51 -> 1.74 ms), so only a capturing stream forks
+        side = _side_stream(x.device) if (OVERLAP_WGRAD or (0 < SMALL_BATCH_OVERLAP and M <= SMALL_BATCH_OVERLAP
+                                                          and torch.cuda.is_current_stream_capturing())) else None
         keep = []                                          # tensors the side stream reads stay alive until the join
         dZ16 = None                                        # bf16 copy of dZ when the previous data-gradient GEMM produced one
         for i in range(L - 1, -1, -1):

@@ -106,6 +106,9 @@ def timer_mark() -> None:
         timers.mark()
 
 
+CALL_COUNT = [0]      # categorised C-ABI calls since import (bench.py reports calls per step for the launch-bound workload)
+
+
 class _timed:
     __slots__ = ("name",)
 
@@ -113,6 +116,7 @@ class _timed:
         self.name = name
 
     def __enter__(self):
+        CALL_COUNT[0] += 1
         if timers is not None:
             timers.enter(self.name)
         return self
