@@ -13,7 +13,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdlrm_hip.so")
+# DLRM_HIP_LIB: load another build of the same library (tools/probes: the TUNING build with its timing-only switches); never rebuilt
+LIB_PATH = os.environ.get("DLRM_HIP_LIB") or os.path.join(_HERE, "libdlrm_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
@@ -135,7 +136,7 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
-        if _sources_newer_than_lib():
+        if not os.environ.get("DLRM_HIP_LIB") and _sources_newer_than_lib():
             if os.path.exists("/opt/rocm/bin/hipcc"):
                 build()          # cross-process safe; a rank that lost the race finds everything up to date
             elif not os.path.exists(LIB_PATH):

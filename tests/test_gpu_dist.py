@@ -400,6 +400,26 @@ def test_bench_two_rank_control_flow(dense_sync):
     assert "linear_fwd" in d["kernels"] and d["roofline"] is not None
 
 
+def test_bench_two_rank_self_launch_with_bf16_lean_towers_and_flat_allreduce():
+    """`python bench.py --gpus 2` WITHOUT a launcher (VERDICT r3 missing-3): bench.py re-executes itself under torch.distributed.run and the
+    line says n_gpus 2.  Run with `--mlp-arith bf16 --dense-sync flat`: the lean bf16 towers (bf16-only hidden activations, weight gradient from
+    the stored bf16 operands) write their gradients into FlatDDP's flat all-reduce buffers — the combination no other test exercises."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(DLRM_BENCH_SELFTEST_GLOO="1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4096", "--row-cap", "50000",
+                        "--hang-timeout", "120", "--mlp-arith", "bf16", "--dense-sync", "flat"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and lines, (r.returncode, r.stderr[-3000:])
+    d = json.loads(lines[-1])
+    assert "re-executing" in r.stderr and "--nproc-per-node=2" in r.stderr
+    assert d["n_gpus"] == 2 and d["dtype"] == "bf16" and "flat" in d["config"]["parallelism"] and np.isfinite(d["final_loss"]) and d["final_loss"] < 1.0
+    assert abs(d["alt_dense_sync"]["final_loss"] - d["final_loss"]) < 2e-2          # torch DDP on the same towers trains to the same loss
+
+
 def test_bench_two_rank_sharded_multihot_control_flow():
     """VERDICT r2 #8 / SURVEY 8 f-3: `bench.py --gpus 2 --workload mlperf_v2_multihot` — planned sharding (ShardedDLRM), per-rank input
     slices through kjt_input_dist (id re-layouts as block-copy kernels), fused row-wise Adagrad, DDP towers — end to end through

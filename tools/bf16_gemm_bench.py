@@ -15,6 +15,9 @@ SHAPES = [(65536, 1024, 1024), (65536, 1024, 512), (65536, 512, 1024), (65536, 5
 
 
 def main():
+    global SHAPES
+    if os.environ.get("BF16_BENCH_SHAPES"):         # ablation runs: the two layer shapes that matter
+        SHAPES = [(65536, 1024, 1024), (65536, 512, 3456)]
     from dlrm_amd import ops
     from tools.microbench import timeit
     dev = torch.device("cuda:0")
