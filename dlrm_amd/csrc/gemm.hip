@@ -415,9 +415,11 @@ template <> struct FVec<1> { using T = FloatX1; };
 template <> struct FVec<2> { using T = floatx2; };
 template <> struct FVec<4> { using T = floatx4; };
 
-template <bool A_KC, bool B_KC, int TM, int ARITH, bool ROWSUM, int FRAG = 0>
+// TN = 1 (with TM = 1: a 64 x 64 tile, four waves of 32 x 32): SMALL launches only (Criteo-Kaggle's batch of 2048, see launch_gemm) — no sign
+// bits in or out (the host takes the fp32 mask / the stand-alone bit kernel), the mask of the data gradient is read in the epilogue.
+template <bool A_KC, bool B_KC, int TM, int ARITH, bool ROWSUM, int FRAG = 0, int TN = 2>
 __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
-    constexpr int TN = 2;
+    static_assert(TN == 2 || (TN == 1 && TM == 1 && ARITH == 0), "the 32-column wave tile exists for the small fp32 launches only");
     constexpr bool A_IL = FRAG && !A_KC, B_IL = FRAG && !B_KC;      // operand's sub-tiles interleaved (see above)
     static_assert(!FRAG || ARITH == 0, "vector fragments are implemented for the native fp32 main loop");
     static_assert(ARITH != 3 || (A_KC && B_KC), "bf16-storage operands are k-contiguous (the data gradient reads a transposed weight copy)");
@@ -515,11 +517,11 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     // 1024x1024 layer).  The 8 row segments of the first 32-row band are requested while the last two k-tiles are
     // still being multiplied, band b+1 is requested before band b is transposed and stored.
     constexpr bool MASKED = (A_KC && !B_KC) || ARITH == 3;      // (bf16 storage: forward and data gradient share the <KC, KC> instance)
-    const int c4 = (lane & 15) * 4;
-    const long long nb = n0 + wn * 64 + c4;
+    const int c4 = TN == 2 ? (lane & 15) * 4 : (lane & 7) * 4;
+    const long long nb = n0 + wn * (32 * TN) + c4;
     const bool full_n = nb + 3 < g.N;
-    const bool use_bits = MASKED && g.bits_in != nullptr;
-    const bool mask_pf = MASKED && !use_bits && g.mask != nullptr && g.vecC && full_n;
+    const bool use_bits = TN == 2 && MASKED && g.bits_in != nullptr;
+    const bool mask_pf = TN == 2 && MASKED && !use_bits && g.mask != nullptr && g.vecC && full_n;
     float4 mk[2][8];
     // bit form of the same mask: every lane holds ITS 32 sign bits of the band (one dword: 256 B per 32 x 64 band instead of 8 KB)
     unsigned mkb[TM];       // ALL bands' words are loaded before the first store of the epilogue: a load issued between the store bursts makes
@@ -718,14 +720,15 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     // ---- epilogue, one 32-row band of the wave tile at a time: registers -> wave-private LDS
     // (transposes back to [m][n]) -> 16-byte row segments.  Transposed C/D layout of the 32x32 MFMA:
     // lane owns m_local = lane & 31 and n_local = 8*q + 4*(lane>>5) + {0..3} for q = reg>>2.
-    static_assert(4 * 32 * EPI_LD * 4 <= NSTAGE3 * STAGE, "epilogue staging does not fit the ring");
+    constexpr int ELD = TN == 2 ? EPI_LD : 32 + 4;                  // staged row pitch (floats)
+    static_assert(4 * 32 * ELD * 4 <= NSTAGE3 * STAGE, "epilogue staging does not fit the ring");
     if constexpr (MASKED) {
         // the words were requested two k-tiles ago and the loop's final vmcnt(0) has retired them; the compiler cannot see that
         // through the hand-placed waits, and would drain vmcnt (= wait for the previous band's STORES) in front of every later use
 #pragma unroll
         for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(mkb[i]));
     }
-    float* S = lds + wave * (32 * EPI_LD);
+    float* S = lds + wave * (32 * ELD);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias) {
         if (nb + 0 < g.N) bv.x = g.bias[nb + 0];
@@ -737,14 +740,56 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) bits_fetch(i, mkb[i]);
         } }
-    const bool write_bits = A_KC && B_KC && g.bits_out != nullptr;
+    const bool write_bits = TN == 2 && A_KC && B_KC && g.bits_out != nullptr;
+    if constexpr (TN == 1) {
+        // 32-column wave tile: a lane owns 4 columns of rows it*8 + (lane >> 3); the mask (data gradient) is read here — a small launch has no
+        // synchronised epilogue burst to hide it from
+        const bool mvec = g.mask != nullptr && g.vecC && full_n && (((size_t)g.mask) & 15) == 0 && (g.ldmask & 3) == 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = make_float4(acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]);
+            *(float4*)__builtin_assume_aligned(S + l31 * ELD + 8 * q + 4 * h, 16) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const long long m = m0 + wm * 32 + row;                 // (TM == 1: interleaved and stacked row orders coincide)
+            if (!(m < g.M && nb < g.N)) continue;
+            float4 v = *(const float4*)__builtin_assume_aligned(S + row * ELD + c4, 16);
+            v.x = act_apply(v.x + bv.x, g.act); v.y = act_apply(v.y + bv.y, g.act);
+            v.z = act_apply(v.z + bv.z, g.act); v.w = act_apply(v.w + bv.w, g.act);
+            float* c = g.C + (long long)zs * g.c_split_stride + m * g.ldc + nb;
+            if (g.vecC && full_n) {
+                if (MASKED && g.mask) {
+                    float4 y;
+                    if (mvec) y = *(const float4*)(g.mask + m * g.ldmask + nb);
+                    else { const float* yp = g.mask + m * g.ldmask + nb; y = make_float4(yp[0], yp[1], yp[2], yp[3]); }
+                    v.x = act_grad(v.x, y.x, g.mask_act); v.y = act_grad(v.y, y.y, g.mask_act);
+                    v.z = act_grad(v.z, y.z, g.mask_act); v.w = act_grad(v.w, y.w, g.mask_act);
+                }
+                if (g.atomic_out) { atomicAdd(c, v.x); atomicAdd(c + 1, v.y); atomicAdd(c + 2, v.z); atomicAdd(c + 3, v.w); }
+                else *(float4*)c = v;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    if (nb + x < g.N) {
+                        float o = e[x];
+                        if (MASKED && g.mask) o = act_grad(o, g.mask[m * g.ldmask + nb + x], g.mask_act);
+                        if (g.atomic_out) atomicAdd(c + x, o); else c[x] = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         if constexpr (MASKED) {
             if (mask_pf && tm + 1 < TM) mask_fetch(tm + 1, mk[(tm + 1) & 1]);
         }
         unsigned myword = 0u;                      // forward: this lane's 32 sign bits of the band, shifted in one element at a time
-        if constexpr (B_IL) {
+        if constexpr (B_IL && TN == 2) {
             // column sub-tiles interleaved (output column 2*n_local + tn): element e of quad q lands at staged column 16q + 8h + 2e + tn
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -948,10 +993,11 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(int R, int C, int Rpad
 
 static int pow2ceil_i(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <bool A_KC, bool B_KC, int TM, int ARITH, int FRAG = 0>
+template <bool A_KC, bool B_KC, int TM, int ARITH, int FRAG = 0, int TN = 2>
 static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     constexpr bool ROWSUM = !A_KC && !B_KC;          // only the weight-gradient GEMM carries the bias-gradient row sums
-    constexpr int BMt = 64 * TM, BNt = 128;
+    constexpr int BMt = 64 * TM, BNt = 64 * TN;
+    if (TN == 1) { g.bits_in = nullptr; g.bits_out = nullptr; }       // (the caller falls back to the fp32 mask / the stand-alone bit kernel)
     g.tiles_m = (int)((g.M + BMt - 1) / BMt);
     g.tiles_n = (int)((g.N + BNt - 1) / BNt);
     {   // tuning aid (env DLRM_GEMM_DEBUG): 1 no DMA refill in the k-loop, 2 no wait + barrier, 4 no epilogue — WRONG results, timing only
@@ -968,11 +1014,11 @@ static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     static bool attr_done[DLRM_MAX_DEVICES] = {};      // the attribute is per (function, device)
     const int dev = dlrm_current_device();
     if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[dev] = true;
     }
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), block(256);
-    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG>), grid, block, lds, st, g);
+    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN>), grid, block, lds, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
 }
@@ -1015,15 +1061,22 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
         // SIMD's MFMA rate (29 / 25 / 44 us per forward / data- / weight-gradient GEMM of ~0.5 GFLOP, profiles/round4/kaggle_kernels.md).
         // 64-row tiles (TM = 1) double the workgroups and halve each wave's MFMA chain.  fp32 MFMA only.
         static int small_tm = -1;       // tuning aid: DLRM_GEMM_SMALL=0 keeps the 128-row tiles
-        if (small_tm < 0) { const char* e = getenv("DLRM_GEMM_SMALL"); small_tm = e ? atoi(e) : 1; }
+        if (small_tm < 0) { const char* e = getenv("DLRM_GEMM_SMALL"); small_tm = e ? atoi(e) : 2; }      // 0 off, 1 64-row tiles only, 2 (default) also 64 x 64
         const long long wg128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) * splits;
         const bool small = small_tm && !big && arith == DLRM_ARITH_F32 && wg128 < 128 && force_tm == 0;
+        // ... and 64 x 64 tiles (TN = 1 too) while even the 64 x 128 tiling has fewer workgroups than 3/4 of the CUs; that kernel neither writes
+        // nor reads sign bits: `fast` stays false so that dlrm_linear_fwd runs the stand-alone bit kernel, the data gradient takes its fp32 mask
+        const long long wg64 = ((g.M + 63) / 64) * ((g.N + 127) / 128) * splits;
+        const bool tiny = small && small_tm >= 2 && wg64 < 192 && (g.bits_in == nullptr || g.mask != nullptr);
+        if (tiny && fast) *fast = false;
         if constexpr (!A_KC || !B_KC) {
             if (arith == DLRM_ARITH_F32 && frag) {
+                if (tiny) return launch_gemm3<A_KC, B_KC, 1, 0, 1, 1>(g, splits, st);
                 if (small) return launch_gemm3<A_KC, B_KC, 1, 0, 1>(g, splits, st);
                 return big ? launch_gemm3<A_KC, B_KC, 4, 0, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0, 1>(g, splits, st);
             }
         }
+        if (tiny) return launch_gemm3<A_KC, B_KC, 1, 0, 0, 1>(g, splits, st);
         if (small) return launch_gemm3<A_KC, B_KC, 1, 0>(g, splits, st);
         if (arith == DLRM_ARITH_BF16X6)
             return big ? launch_gemm3<A_KC, B_KC, 4, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 1>(g, splits, st);

@@ -27,6 +27,7 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
 OVERLAP_WGRAD = os.environ.get("DLRM_OVERLAP_WGRAD", "0") == "1"
 # ... except for SMALL batches inside a HIP-graph capture: rows at or below this run weight and data gradient concurrently (0 = never)
 SMALL_BATCH_OVERLAP = int(os.environ.get("DLRM_SMALL_BATCH_OVERLAP", "8192"))
+SMALL_BATCH_BITS = int(os.environ.get("DLRM_SMALL_BATCH_BITS", "8192"))      # no ReLU sign bits at or below this many rows (fp32 towers)
 # hidden ReLU layers store 1 sign bit per activation for the next layer's data-gradient epilogue (DLRM_RELU_BITS=0: the
 # epilogue re-reads the fp32 activation instead)
 RELU_BITS = os.environ.get("DLRM_RELU_BITS", "1") == "1"
@@ -147,7 +148,10 @@ class MLPFunction(Function):
             raise RuntimeError("dlrm_amd: MLP input width %d does not match the first layer (%d)" % (x.size(1), K0))
         cur = x
         need_grad = any(ctx.needs_input_grad)
-        need_bits = RELU_BITS and need_grad                          # a forward that will be differentiated (Function.forward itself runs grad-free)
+        # sign bits: a forward that will be differentiated (Function.forward itself runs grad-free), and not a SMALL batch — there the GEMMs run
+        # on 64 x 64 tiles that neither write nor read the bits (the bits would come from a stand-alone kernel: one more launch per layer of a
+        # launch-bound step) and the data gradient reads the fp32 activation, which small batches keep in cache anyway
+        need_bits = RELU_BITS and need_grad and (M > SMALL_BATCH_BITS or (BF16_STORAGE and arith == ops.arith_code("bf16")))
         # arith "bf16" with bf16 STORAGE (default; DLRM_BF16_STORAGE=0 restores the in-loop rounding of rounds 1-2): every GEMM layer reads a
         # bf16 copy of its input and of its weight (dlrm_gemm_bf16: no conversion in the k-loop).  LEAN (default, DLRM_BF16_LEAN=0 turns it
         # off): a hidden activation is written ONLY as bf16 + ReLU sign bits when every consumer reads those — the next layer's forward
