@@ -305,8 +305,20 @@ def parity_check(args, device):
     import golden_tb
     mode = {"sorted": 2, "atomic": 0, "deterministic": 1}[args.emb_update]
     try:
-        rel = golden_tb.run_on_gpu(device, arith=args.mlp_arith, mode=mode, check=True, overlap=bool(args.overlap) and not args.no_overlap,
-                                   fuse=bool(args.fuse), name=args.parity_fixture)
+        reduced = None
+        if args.mlp_arith == "bf16":
+            # bf16 operand rounding is an opt-in arithmetic, not the north_star fp32 path: the fp32 run below stays the parity claim for this
+            # configuration; the bf16 run itself is held to its own stated bar on the loss (measured: <= 2e-4; predictions differ by ~5e-4)
+            rel16 = golden_tb.run_on_gpu(device, arith="bf16", mode=mode, check=False, overlap=bool(args.overlap) and not args.no_overlap,
+                                         fuse=bool(args.fuse), name=args.parity_fixture)
+            reduced = {"mlp_arith": "bf16", "rel_err_per_step": rel16, "bar": 1e-3, "pass": bool(max(rel16) <= 1e-3),
+                       "note": "loss only: bf16 operands (2^-9 relative rounding) cannot meet the fp32 bars; the fp32 entry beside this is the parity claim"}
+            torch.cuda.empty_cache()
+        rel = golden_tb.run_on_gpu(device, arith="f32" if reduced else args.mlp_arith, mode=mode, check=True,
+                                   overlap=bool(args.overlap) and not args.no_overlap, fuse=bool(args.fuse), name=args.parity_fixture)
+        if reduced:
+            return {"fixture": "tests/golden/%s.npz" % args.parity_fixture, "f32": {"rel_err_per_step": rel, "bar": 1e-5, "pass": bool(max(rel) <= 1e-5)},
+                    "bf16": reduced, "pass": bool(max(rel) <= 1e-5 and reduced["pass"]), "mlp_arith": args.mlp_arith, "embedding_update": args.emb_update}
         return {"fixture": "tests/golden/%s.npz (3 training steps of the live reference at B=65536, T=26, D=128, "
                            "towers 13-512-256-128 / 479-1024-1024-512-256-1, lr 1.0, rows capped at %s)"
                            % (args.parity_fixture, "4000000" if args.parity_fixture.endswith("cap4m") else "2000"),
@@ -804,7 +816,7 @@ def main():
                                "(per-kernel event times then overlap: their sum exceeds the step time)"),
                    "launch": "HIP graph replay of the captured step (dlrm_amd.graph)" if graphed is not None else "eager (one C-ABI call per kernel)",
                    "mlp_arith": {"f32": "f32: native fp32 MFMA (v_mfma_f32_32x32x2_f32)",
-                                 "bf16x6": "bf16x6: fp32 operands split exactly into 3 bf16 terms in-kernel, 6 bf16 MFMA products, fp32 accumulate",
+                                 "bf16x6": "bf16x6: fp32 operands as an exact 3-term bf16 split (pre-split planes through dlrm_gemm_bf16x6 where its shapes hold, else split in the k-loop), 6 bf16 MFMA products, fp32 accumulate",
                                  "bf16": "bf16: forward / data-gradient GEMMs read bf16 copies of activations and weights (dlrm_gemm_bf16, nothing converted "
                                          "in the k-loop; activations written in fp32 + bf16), weight gradient rounds its fp32 operands in the loop; one "
                                          "v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate, fp32 master weights (reduced precision: NOT the headline "
@@ -865,7 +877,8 @@ def main():
         model.set_mlp_arith("f32")
         result["alt_mlp_arith"] = {"mlp_arith": "bf16x6", "value": B / dta, "unit": "samples/s", "ms_per_step": dta * 1e3,
                                    "final_loss": float(loss_alt.detach()),
-                                   "note": "opt-in (--mlp-arith bf16x6); parity-tested at the fp32 tolerances"}
+                                   "note": "opt-in (--mlp-arith bf16x6); parity-tested at the fp32 tolerances; GEMM layers on pre-split bf16 planes (csrc/gemm_bf16.hip PL = 3; "
+                                           "DLRM_BF16X6_PLANES=0: split inside every k-loop, bit-identical products)"}
         del loss_alt
     if N == 1 and graphed is None and not hot and args.fuse and getattr(model, "fuse_emb_interact", False) and not args.no_alt_fuse:
         # the same step with the lookups and the interaction as two kernels (rounds 1-2's forward; what multi-hot and distributed runs launch)

@@ -43,6 +43,11 @@ SIGNATURES = {
     "dlrm_cast_bf16": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_cast_bf16_transposed": (_i32, [_i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_gemm_bf16": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "dlrm_split_bf16x3": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "dlrm_split_bf16x3_transposed": (_i32, [_i32, _i32, _i32, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "dlrm_gemm_bf16x6_supported": (_i32, [_i64, _i32, _i32, _i64, _i64]),
+    "dlrm_gemm_bf16x6": (_i32, [_i64, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _vp]),
+    "dlrm_linear_bwd_weight_bf16x6": (_i32, [_i64, _i32, _i32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
     "dlrm_linear_bwd_weight_bf16_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "dlrm_linear_bwd_weight_bf16": (_i32, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
     "dlrm_emb_sort_lookups": (_i32, [_i32, _i64, _pi64, _pp, _pp, _pi64, _i32, _vp, _i64, _vp, _vp, _vp, C.POINTER(_i32), _vp, _vp]),

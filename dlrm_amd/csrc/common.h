@@ -125,4 +125,9 @@ int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t ld
 bool dlrm_gemm_bf16_wgrad_ok(int64_t Mb, int N_out, int K_in, int64_t lddz, int64_t ldx);
 void dlrm_gemm_bf16_wgrad_plan(int64_t Mb, int N_out, int K_in, int* splits_out, int64_t* kchunk_out);
 int dlrm_gemm_bf16_wgrad_phased(int64_t Mb, int N_out, int K_in, const uint16_t* dZ, int64_t lddz, const uint16_t* X, int64_t ldx,
-                                float* slabs, int64_t ldc, int64_t slab_stride, float* rowsum_parts, int splits, int64_t kchunk, hipStream_t st);
+                                float* slabs, int64_t ldc, int64_t slab_stride, float* rowsum_parts, int splits, int64_t kchunk, hipStream_t st,
+                                int planes, int64_t planeZ, int64_t planeX);
+bool dlrm_gemm_bf16x6_ok(int64_t M, int N, int K, int64_t lda, int64_t ldb);
+int dlrm_gemm_bf16x6_phased(int64_t M, int N, int K, const uint16_t* A, int64_t lda, int64_t planeA, const uint16_t* B, int64_t ldb, int64_t planeB,
+                            const float* bias, int act, uint64_t* relu_bits_out, const uint64_t* relu_bits_in, float* C, int64_t ldc, uint16_t* Cp,
+                            int64_t ldcp, int64_t planeC, hipStream_t st);

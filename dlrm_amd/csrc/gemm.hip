@@ -974,6 +974,23 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(long long M, int N, int 
         *(unsigned*)(dst + m * ldd + n) = cvt_pk_bf16(a, b);
     }
 }
+// the same for 16-byte aligned rows and N % 8 == 0: a thread converts 8 consecutive values (two 16-byte loads, one 16-byte store), one group per thread
+// over a full grid — the [65536, 3456] feature buffer of the DCN-v2 cross network and the [65536, 480] interaction output are cast every step
+__global__ __launch_bounds__(256) void cast_bf16_vec8_kernel(long long M, int N, int Npad, const float* __restrict__ src, long long lds_,
+                                                             unsigned short* __restrict__ dst, long long ldd) {
+    const int np8 = Npad / 8;
+    const long long total = M * np8;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long m = e / np8;
+        const int n = (int)(e - m * np8) * 8;
+        uintx4 pk = {0u, 0u, 0u, 0u};
+        if (n < N) {                                                   // (N % 8 == 0: a group lies entirely inside the row or entirely in the padding)
+            const float4 a = *(const float4*)(src + m * lds_ + n), b = *(const float4*)(src + m * lds_ + n + 4);
+            pk[0] = cvt_pk_bf16(a.x, a.y); pk[1] = cvt_pk_bf16(a.z, a.w); pk[2] = cvt_pk_bf16(b.x, b.y); pk[3] = cvt_pk_bf16(b.z, b.w);
+        }
+        *(uintx4*)(dst + m * ldd + n) = pk;
+    }
+}
 // transposed copy (weights: dstT[c, r] = bf16(src[r, c]), zero for R <= r < Rpad): 32 x 32 tiles through LDS
 __global__ __launch_bounds__(256) void cast_bf16_t_kernel(int R, int C, int Rpad, const float* __restrict__ src, long long lds_,
                                                           unsigned short* __restrict__ dstT, long long ldd) {
@@ -988,6 +1005,68 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(int R, int C, int Rpad
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;
         if (c < C && r < Rpad) dstT[(long long)c * ldd + r] = (unsigned short)(cvt_pk_bf16(tile[tx][i], 0.f) & 0xffffu);
+    }
+}
+
+// ---- fp32 -> three bf16 planes (arith "bf16x6" with PRE-SPLIT operands: gemm_bf16.hip PL = 3).  The truncation split of split3 above, done ONCE
+// per tensor instead of in every k-loop that reads it: x == h + m + l exactly.  dst = planes h, m, l of [M, ldd], `plane` elements apart.
+__device__ __forceinline__ void split2_planes(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ph = __builtin_amdgcn_perm(ub, ua, 0x07060302);
+    const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
+    const unsigned ura = __float_as_uint(ra), urb = __float_as_uint(rb);
+    pm = __builtin_amdgcn_perm(urb, ura, 0x07060302);
+    const float sa = ra - __uint_as_float(ura & 0xffff0000u), sb = rb - __uint_as_float(urb & 0xffff0000u);
+    pl = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302);
+}
+// one thread = 8 consecutive values of a row (Npad % 8 == 0; columns N..Npad-1 are zero); VEC: two 16-byte loads (N % 8 == 0, aligned rows)
+template <bool VEC>
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(long long M, int N, int Npad, const float* __restrict__ src, long long lds_,
+                                                           unsigned short* __restrict__ dst, long long ldd, long long plane) {
+    const int np8 = Npad / 8;
+    const long long total = M * np8;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long m = e / np8;
+        const int n = (int)(e - m * np8) * 8;
+        float x[8];
+        if (VEC) {
+            if (n < N) {
+                const float4 a = *(const float4*)(src + m * lds_ + n), b = *(const float4*)(src + m * lds_ + n + 4);
+                x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = (n + i < N) ? src[m * lds_ + n + i] : 0.f;
+        }
+        uintx4 ph, pm, pl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { unsigned h_, m_, l_; split2_planes(x[2 * i], x[2 * i + 1], h_, m_, l_); ph[i] = h_; pm[i] = m_; pl[i] = l_; }
+        unsigned short* d = dst + m * ldd + n;
+        *(uintx4*)d = ph; *(uintx4*)(d + plane) = pm; *(uintx4*)(d + 2 * plane) = pl;
+    }
+}
+// transposed (weights: planes of dstT[c, r] = src[r, c], zero for R <= r < Rpad): 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void split_bf16x3_t_kernel(int R, int C, int Rpad, const float* __restrict__ src, long long lds_,
+                                                             unsigned short* __restrict__ dstT, long long ldd, long long plane) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(long long)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < Rpad) {
+            unsigned ph, pm, pl;
+            { unsigned h_, m_, l_; split2_planes(tile[tx][i], 0.f, h_, m_, l_); ph = h_; pm = m_; pl = l_; }
+            unsigned short* d = dstT + (long long)c * ldd + r;
+            d[0] = (unsigned short)(ph & 0xffffu); d[plane] = (unsigned short)(pm & 0xffffu); d[2 * plane] = (unsigned short)(pl & 0xffffu);
+        }
     }
 }
 
@@ -1149,6 +1228,13 @@ extern "C" int dlrm_linear_fwd(int64_t M, int N, int K, const float* X, int64_t 
 
 extern "C" int dlrm_cast_bf16(int64_t M, int N, int Npad, const float* src, int64_t lds_, uint16_t* dst, int64_t ldd, void* stream) {
     if (M <= 0 || N <= 0 || Npad < N || (Npad & 1) || !src || !dst || lds_ < N || ldd < Npad || (ldd & 1) || (((uintptr_t)dst) & 3u)) return DLRM_E_ARG;
+    if (N % 8 == 0 && Npad % 8 == 0 && lds_ % 4 == 0 && ldd % 8 == 0 && dlrm_aligned16(src) && dlrm_aligned16(dst)) {
+        long long nb = (M * (Npad / 8) + 255) / 256; if (nb > 0x7fffffffll) nb = 0x7fffffffll;
+        hipLaunchKernelGGL(cast_bf16_vec8_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (long long)M, N, Npad, src, (long long)lds_,
+                           (unsigned short*)dst, (long long)ldd);
+        DLRM_LAUNCH_CHECK();
+        return 0;
+    }
     long long nb = (M * (Npad / 2) + 255) / 256; if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (long long)M, N, Npad, src, (long long)lds_,
                        (unsigned short*)dst, (long long)ldd);
@@ -1163,6 +1249,50 @@ extern "C" int dlrm_cast_bf16_transposed(int R, int C, int Rpad, const float* sr
                        (long long)ldd);
     DLRM_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int dlrm_split_bf16x3(int64_t M, int N, int Npad, const float* src, int64_t lds_, uint16_t* dst, int64_t ldd, int64_t plane_stride,
+                                 void* stream) {
+    if (M <= 0 || N <= 0 || Npad < N || !src || !dst || lds_ < N || ldd < Npad || plane_stride < (M - 1) * ldd + Npad) return DLRM_E_ARG;
+    if (Npad % 8 || ldd % 8 || plane_stride % 8 || !dlrm_aligned16(dst)) return DLRM_E_ALIGN;
+    long long nb = (M * (Npad / 8) + 255) / 256; if (nb > 0x7fffffffll) nb = 0x7fffffffll;
+    if (N % 8 == 0 && lds_ % 4 == 0 && dlrm_aligned16(src))
+        hipLaunchKernelGGL(split_bf16x3_kernel<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (long long)M, N, Npad, src, (long long)lds_,
+                           (unsigned short*)dst, (long long)ldd, (long long)plane_stride);
+    else
+        hipLaunchKernelGGL(split_bf16x3_kernel<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (long long)M, N, Npad, src, (long long)lds_,
+                           (unsigned short*)dst, (long long)ldd, (long long)plane_stride);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_split_bf16x3_transposed(int R, int C, int Rpad, const float* src, int64_t lds_, uint16_t* dstT, int64_t ldd, int64_t plane_stride,
+                                            void* stream) {
+    if (R <= 0 || C <= 0 || Rpad < R || !src || !dstT || lds_ < C || ldd < Rpad || plane_stride < (int64_t)(C - 1) * ldd + Rpad) return DLRM_E_ARG;
+    dim3 grid((unsigned)((C + 31) / 32), (unsigned)((Rpad + 31) / 32));
+    hipLaunchKernelGGL(split_bf16x3_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, R, C, Rpad, src, (long long)lds_, (unsigned short*)dstT,
+                       (long long)ldd, (long long)plane_stride);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// fp32-class product from PRE-SPLIT operands (arith "bf16x6"): C[M, N] (fp32, nullable) and / or Cp (three bf16 planes of the result, nullable)
+// = epilogue(A . B^T), A [M, K] and B [N, K] given as three bf16 planes each (dlrm_split_bf16x3 / the Cp output of an earlier call), six
+// v_mfma_f32_32x32x16_bf16 per 16 k in the order of the in-loop kernel: bit-identical to dlrm_linear_fwd / _bwd_data with DLRM_ARITH_BF16X6.
+// dlrm_gemm_bf16x6_supported() == 0 (or DLRM_E_ALIGN here): the shape is outside the kernel's preconditions and the caller keeps fp32 storage.
+extern "C" int dlrm_gemm_bf16x6_supported(int64_t M, int N, int K, int64_t lda, int64_t ldb) { return dlrm_gemm_bf16x6_ok(M, N, K, lda, ldb) ? 1 : 0; }
+
+extern "C" int dlrm_gemm_bf16x6(int64_t M, int N, int K, const uint16_t* A, int64_t lda, int64_t planeA, const uint16_t* B, int64_t ldb, int64_t planeB,
+                                const float* bias, int act, uint64_t* relu_bits_out, const uint64_t* relu_bits_in, float* C, int64_t ldc, uint16_t* Cp,
+                                int64_t ldcp, int64_t planeC, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || (!C && !Cp)) return DLRM_E_ARG;
+    if (lda < K || ldb < K || (C && ldc < N) || (Cp && (ldcp < N || planeC < (M - 1) * ldcp + N))) return DLRM_E_ARG;
+    if (planeA < (M - 1) * lda + K || planeB < (int64_t)(N - 1) * ldb + K) return DLRM_E_ARG;
+    if (act < DLRM_ACT_NONE || act > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
+    if (relu_bits_out && act != DLRM_ACT_RELU) return DLRM_E_MODE;
+    if (!dlrm_aligned16(A) || !dlrm_aligned16(B) || (C && (!dlrm_aligned16(C) || ldc % 4)) || (Cp && (((uintptr_t)Cp) & 7u))) return DLRM_E_ALIGN;
+    return dlrm_gemm_bf16x6_phased(M, N, K, A, lda, planeA, B, ldb, planeB, bias, act, relu_bits_out, relu_bits_in, C, ldc, Cp, ldcp, planeC,
+                                   (hipStream_t)stream);
 }
 
 // C[M, N] (fp32, nullable) and / or Cb[M, N] (bf16, nullable) = epilogue(A[M, K] . B[N, K]^T), A and B bf16 in memory, fp32 accumulation:
@@ -1363,9 +1493,9 @@ extern "C" int64_t dlrm_linear_bwd_weight_bf16_workspace_bytes(int64_t M, int N,
     return (int64_t)splits * N * (ldp + 1) * (int64_t)sizeof(float);
 }
 
-extern "C" int dlrm_linear_bwd_weight_bf16(int64_t M, int N, int K, int K_store, const uint16_t* dZ, int64_t lddz, const uint16_t* X, int64_t ldx,
-                                           float* dW, int64_t lddw, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
-                                           void* stream) {
+static int linear_bwd_weight_planes(int64_t M, int N, int K, int K_store, const uint16_t* dZ, int64_t lddz, const uint16_t* X, int64_t ldx,
+                                    float* dW, int64_t lddw, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
+                                    void* stream, int planes, int64_t planeZ, int64_t planeX) {
     if (M <= 0 || N <= 0 || K <= 0 || K_store <= 0 || K_store > K || !dZ || !X || !dW || !workspace) return DLRM_E_ARG;
     if (lddz < N || ldx < K || lddw < K_store) return DLRM_E_ARG;
     if (!dlrm_gemm_bf16_wgrad_ok(M, N, K, lddz, ldx) || !dlrm_aligned16(dZ) || !dlrm_aligned16(X) || !dlrm_aligned16(workspace)) return DLRM_E_ALIGN;
@@ -1375,7 +1505,7 @@ extern "C" int dlrm_linear_bwd_weight_bf16(int64_t M, int N, int K, int K_store,
     const int64_t ldp = ((int64_t)K + 3) & ~(int64_t)3, slab = (int64_t)N * ldp;
     if (workspace_bytes < (int64_t)splits * (slab + N) * (int64_t)sizeof(float)) return DLRM_E_ARG;
     float* rs_part = dbias ? (float*)workspace + (int64_t)splits * slab : nullptr;
-    const int rc = dlrm_gemm_bf16_wgrad_phased(M, N, K, dZ, lddz, X, ldx, (float*)workspace, ldp, slab, rs_part, splits, kchunk, st);
+    const int rc = dlrm_gemm_bf16_wgrad_phased(M, N, K, dZ, lddz, X, ldx, (float*)workspace, ldp, slab, rs_part, splits, kchunk, st, planes, planeZ, planeX);
     if (rc) return rc;
     // dW may be NARROWER than the product (K_store < K: the trailing columns of X are zero padding whose gradient is dropped)
     const bool v4 = dlrm_aligned16(dW) && lddw % 4 == 0 && K_store % 4 == 0;
@@ -1387,6 +1517,20 @@ extern "C" int dlrm_linear_bwd_weight_bf16(int64_t M, int N, int K, int K_store,
                                (long long)ldp, (long long)slab, dW, (long long)lddw, accumulate ? 1 : 0, (const float*)rs_part, dbias);
     DLRM_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int dlrm_linear_bwd_weight_bf16(int64_t M, int N, int K, int K_store, const uint16_t* dZ, int64_t lddz, const uint16_t* X, int64_t ldx,
+                                           float* dW, int64_t lddw, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
+                                           void* stream) {
+    return linear_bwd_weight_planes(M, N, K, K_store, dZ, lddz, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, stream, 0, 0, 0);
+}
+
+// the same from three bf16 planes per operand (arith "bf16x6"; workspace: dlrm_linear_bwd_weight_bf16_workspace_bytes)
+extern "C" int dlrm_linear_bwd_weight_bf16x6(int64_t M, int N, int K, int K_store, const uint16_t* dZ, int64_t lddz, int64_t planeZ, const uint16_t* X,
+                                             int64_t ldx, int64_t planeX, float* dW, int64_t lddw, float* dbias, int accumulate, void* workspace,
+                                             int64_t workspace_bytes, void* stream) {
+    if (planeZ < (M - 1) * lddz + N || planeX < (M - 1) * ldx + K) return DLRM_E_ARG;
+    return linear_bwd_weight_planes(M, N, K, K_store, dZ, lddz, X, ldx, dW, lddw, dbias, accumulate, workspace, workspace_bytes, stream, 1, planeZ, planeX);
 }
 
 extern "C" int dlrm_act_bwd(int64_t M, int N, const float* dY, int64_t lddy, const float* Y,

@@ -55,6 +55,10 @@ struct BfArgs {
     // gradient) at rowsum + z * M
     long long kchunk, c_split_stride;
     float* rowsum;
+    // PL = 3 ("bf16x6": fp32 operands stored as three bf16 planes h, m, l with x == h + m + l exactly — split3 of gemm.hip): the planes of an
+    // operand are [rows, ld] matrices planeA / planeB BYTES apart (one allocation: the DMA adds the plane to its 32-bit lane offset); the bf16
+    // output Cb becomes three planes planeC ELEMENTS apart
+    long long planeA, planeB, planeC;
 };
 
 constexpr int PBM = 256, PBN = 256, PBK = 64;
@@ -73,6 +77,16 @@ __device__ __forceinline__ void p_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt
 __device__ __forceinline__ unsigned p_cvt_pk_bf16(float lo, float hi) {
     const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(unsigned, v);
+}
+// two fp32 values -> packed pairs of their three bf16 planes (truncation split, x == h + m + l exactly: split3 of gemm.hip)
+__device__ __forceinline__ void p_split2(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ph = __builtin_amdgcn_perm(ub, ua, 0x07060302);
+    const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);
+    const unsigned ura = __float_as_uint(ra), urb = __float_as_uint(rb);
+    pm = __builtin_amdgcn_perm(urb, ura, 0x07060302);
+    const float sa = ra - __uint_as_float(ura & 0xffff0000u), sb = rb - __uint_as_float(urb & 0xffff0000u);
+    pl = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302);
 }
 __device__ __forceinline__ float p_act(float v, int act) {
     if (act == DLRM_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -99,8 +113,23 @@ __device__ __forceinline__ uintx4 p_tr_read8(unsigned lds_addr) {
 //             both operands k-STRIDED.  LDS image of an operand and k-tile: 8 sub-runs of 32 columns, each [64 k-rows][64 B]; a 1 KiB DMA
 //             chunk = 16 k-rows x 64 B of one sub-run (the same lane -> (row, 16-byte slot) map as the k-contiguous chunks, no swizzle:
 //             a 32-lane ds_read_b64_tr_b16 touches 4 k-rows x 64 B = one whole 256-byte bank row); fragments by p_tr_read8.
-template <bool WG>
+//
+// PL = 3: the SAME pipeline for fp32 operands held as three bf16 planes (arith "bf16x6", split once by the producer instead of in every
+// k-loop that reads them: VERDICT r3 item 7).  A k-tile is 16 k of all three planes (A 24 KiB + B 24 KiB per stage): per quadrant the
+// LOAD segment reads 2 x 3 A and 3 B fragments and the MATH segment issues the SIX products of gemm3_kernel<ARITH = 1> for each of its two
+// accumulators, in that kernel's order (l.h, h.l, m.m, m.h, h.m, h.h) — every accumulator sees the same sequence of MFMAs as in the in-loop
+// kernel, so the k-contiguous forms are BIT-IDENTICAL to it.  12 MFMAs per 9 fragment reads (PL = 1: 8 per 12): the LDS pipe, which
+// co-limits the bf16 form, has 2.7x the slack here.  LDS image, k-contiguous: [plane][256 rows][32 B], the two 16-byte slots of a row
+// swapped for rows 16-31 of every 32 (ds_read_b128 serves lanes {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} together: each group then
+// covers the 256-byte bank row once); k-strided (WG): [sub-run][plane][16 k-rows][64 B].  A piece = 12 chunks of 1 KiB (4 row groups x 3
+// planes): every wave issues one, waves 0-3 a second one — the counted waits differ by wave accordingly.
+template <bool WG, int PL>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
+    constexpr int BK_ = PL == 1 ? PBK : 16;                       // k per tile
+    constexpr int OPB = PL == 1 ? OP_BYTES : 3 * 256 * 32;        // one operand of one k-tile (PL 3: 24 KiB)
+    constexpr int STG = 2 * OPB;
+    constexpr int NJ = PL == 1 ? 4 : 3;                           // fragments per sub-tile and k-tile: four 16-k steps / three planes
+    constexpr int SUBB = PL == 1 ? 4096 : 3072;                   // WG: bytes of one 32-column sub-run
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
     const char* ldsb = (const char*)lds;
@@ -124,7 +153,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     const long long m0 = (long long)tile_m * PBM, n0 = (long long)tile_n * PBN;
     const long long k_begin = WG ? (long long)zs * g.kchunk : 0;
     const long long k_end = WG ? ((k_begin + g.kchunk < g.K) ? k_begin + g.kchunk : g.K) : g.K;
-    const int nk = (int)((k_end - k_begin) / PBK);
+    const int nk = (int)((k_end - k_begin) / BK_);
+    const bool second = PL == 1 || wave < 4;                      // this wave issues a second chunk of every piece
 
     // ---- DMA plan.  A piece = 128 tile rows (or columns) x 64 k = 16 chunks of 1 KiB; wave w moves chunks w and w + 8 of every piece.
     //   piece 0 (A0): A rows {0..63, 128..191}      piece 1 (B0): B rows {64 c + 0..31,  c = 0..3}
@@ -138,7 +168,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
         for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int c = wave + 8 * i, sp = c >> 2, mc = c & 3;
+                const int c = wave + 8 * i;
+                const int sp = PL == 1 ? c >> 2 : c & 3, mc = PL == 1 ? c & 3 : 0, plane = PL == 1 ? 0 : c >> 2;      // (PL 3: chunk = (sub-run, plane), all 16 k-rows)
                 int sub;
                 if (p == 0)      sub = (sp >> 1) * 4 + (sp & 1);
                 else if (p == 3) sub = (sp >> 1) * 4 + 2 + (sp & 1);
@@ -147,8 +178,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
                 const bool isA = (p == 0 || p == 3);
                 const long long c0 = isA ? m0 : n0, cmax = isA ? g.M : g.N, ld = isA ? g.lda : g.ldb;
                 long long col = c0 + sub * 32 + sslot * 8; if (col > cmax - 8) col = cmax - 8;      // (extents are multiples of 8: clamped columns are never stored)
-                voff[p][i] = (unsigned)((((long long)(mc * 16 + srow)) * ld + (col - c0)) * 2);
-                dst[p][i] = lds_base + (isA ? 0 : OP_BYTES) + sub * 4096 + mc * 1024;
+                voff[p][i] = (unsigned)((((long long)(mc * 16 + srow)) * ld + (col - c0)) * 2 + plane * (isA ? g.planeA : g.planeB));
+                dst[p][i] = lds_base + (isA ? 0 : OPB) + (PL == 1 ? sub * 4096 + mc * 1024 : sub * 3072 + plane * 1024);
+            }
+    } else if constexpr (PL == 3) {
+        // chunk = 32 rows x 32 B (the whole 16-k tile) of one plane; chunk c of a piece = row group c & 3, plane c >> 2
+        const int srow = lane >> 1, sslot = (lane & 1) ^ ((lane >> 5) & 1);     // source k-slot: swapped for rows 16-31 (lane >> 5 = srow >> 4)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = wave + 8 * i, rg = c & 3, plane = c >> 2;
+                int row;
+                if (p == 0)      row = (rg >> 1) * 128 + (rg & 1) * 32;
+                else if (p == 3) row = (rg >> 1) * 128 + 64 + (rg & 1) * 32;
+                else if (p == 1) row = rg * 64;
+                else             row = rg * 64 + 32;
+                const bool isA = (p == 0 || p == 3);
+                const long long r0 = isA ? m0 : n0, rmax = isA ? g.M : g.N, ld = isA ? g.lda : g.ldb;
+                long long rgl = r0 + row + srow; if (rgl > rmax - 1) rgl = rmax - 1;
+                voff[p][i] = (unsigned)(((rgl - r0) * ld + sslot * 8) * 2 + plane * (isA ? g.planeA : g.planeB));
+                dst[p][i] = lds_base + (isA ? 0 : OPB) + plane * 8192 + row * 32;
             }
     } else {
         const int kh = wave & 1;
@@ -172,13 +222,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     }
     const char* baseA = (const char*)(WG ? g.A + k_begin * g.lda + m0 : g.A + m0 * g.lda);
     const char* baseB = (const char*)(WG ? g.B + k_begin * g.ldb + n0 : g.B + n0 * g.ldb);
-    const long long stepA = WG ? (long long)PBK * 2 * g.lda : (long long)PBK * 2, stepB = WG ? (long long)PBK * 2 * g.ldb : (long long)PBK * 2;
+    const long long stepA = WG ? (long long)BK_ * 2 * g.lda : (long long)BK_ * 2, stepB = WG ? (long long)BK_ * 2 * g.ldb : (long long)BK_ * 2;
 
 #define P_ISSUE(piece, stage_off)                                                                                   \
     do {                                                                                                            \
         const char* sb_ = ((piece) == 0 || (piece) == 3) ? baseA : baseB;                                           \
         p_glds16(voff[piece][0], sb_, dst[piece][0] + (stage_off));                                                 \
-        p_glds16(voff[piece][1], sb_, dst[piece][1] + (stage_off));                                                 \
+        if (second) p_glds16(voff[piece][1], sb_, dst[piece][1] + (stage_off));                                     \
     } while (0)
 
     // ---- fragment read offsets inside an operand image: lane (l31, h) reads row l31 of a 32-row sub-tile, 16-byte slot (2 jj + h) of k-half kh
@@ -187,12 +237,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     for (int jj = 0; jj < 2; ++jj) {
         const unsigned sl = (unsigned)(((2 * jj + h) ^ ((l31 >> 2) & 3)) * 16);
         fa_off[jj] = (unsigned)((wr * 128 + l31) * 64) + sl;
-        fb_off[jj] = (unsigned)OP_BYTES + (unsigned)((wc * 64 + l31) * 64) + sl;
+        fb_off[jj] = (unsigned)OPB + (unsigned)((wc * 64 + l31) * 64) + sl;
     }
+    // PL 3: row l31 of a 32-row group, k-slot h (swapped for rows 16-31); + 1024 per row group, + 8192 per plane
+    const unsigned fa3_off = (unsigned)((wr * 128 + l31) * 32 + ((h ^ ((l31 >> 4) & 1)) * 16));
+    const unsigned fb3_off = (unsigned)OPB + (unsigned)((wc * 64 + l31) * 32 + ((h ^ ((l31 >> 4) & 1)) * 16));
     // WG: lane (group g4 = lane >> 4, i = lane & 15) reads k-row 8 (g4 >> 1) + (i >> 2) [+ 4 for the second read], columns 16 (g4 & 1) + 4 (i & 3) .. + 3
     // of its 32-column sub-run; + 1024 per 16-k step j, + 4096 per sub-run
     const unsigned tr_lane = (unsigned)((8 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + ((lane >> 4) & 1) * 32 + 8 * (lane & 3));
-    const unsigned tra_off = tr_lane + (unsigned)(wr * 4 * 4096), trb_off = (unsigned)OP_BYTES + tr_lane + (unsigned)(wc * 2 * 4096);
+    const unsigned tra_off = tr_lane + (unsigned)(wr * 4 * SUBB), trb_off = (unsigned)OPB + tr_lane + (unsigned)(wc * 2 * SUBB);
     // bias gradient (WG): row sums of A^T from the fragments the MFMAs consume; the four wave columns of a row half read the SAME A
     // fragments, so wave column wc sums the 16-k step j == wc only (a quarter of the VALU work each), combined through LDS at the end
     const bool do_rowsum = WG && g.rowsum != nullptr && tile_n == 0;
@@ -209,7 +262,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     // ---- prologue: the whole first k-tile, in the order of first use; its first two pieces have landed before anyone reads
     P_ISSUE(0, 0); P_ISSUE(1, 0); P_ISSUE(2, 0); P_ISSUE(3, 0);
     baseA += stepA; baseB += stepB;
-    p_wait_vmcnt<4>();
+    if (second) p_wait_vmcnt<4>(); else p_wait_vmcnt<2>();
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();          // the second wave half runs one barrier behind the first
 
@@ -224,21 +277,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
 #define P_READ_A(half)                                                                                              \
         if (!(P_DBG & 2) || first_tile)                                                                             \
         _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                               \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
-            if constexpr (WG) fa[t][j] = p_tr_read8(lds_base + cur + tra_off + ((half) * 2 + t) * 4096 + j * 1024); \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                            \
+            if constexpr (WG) fa[t][j] = p_tr_read8(lds_base + cur + tra_off + ((half) * 2 + t) * SUBB + j * 1024); \
+            else if constexpr (PL == 3) fa[t][j] = *(const uintx4*)(ldsb + cur + fa3_off + j * 8192 + ((half) * 2 + t) * 1024); \
             else fa[t][j] = *(const uintx4*)(ldsb + cur + fa_off[j & 1] + (j >> 1) * KHALF_BYTES + ((half) * 2 + t) * 2048); \
         }
 #define P_READ_B(FB, tn)                                                                                            \
         if (!(P_DBG & 2) || first_tile)                                                                             \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
-            if constexpr (WG) FB[j] = p_tr_read8(lds_base + cur + trb_off + (tn) * 4096 + j * 1024);                \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                            \
+            if constexpr (WG) FB[j] = p_tr_read8(lds_base + cur + trb_off + (tn) * SUBB + j * 1024);                \
+            else if constexpr (PL == 3) FB[j] = *(const uintx4*)(ldsb + cur + fb3_off + j * 8192 + (tn) * 1024);    \
             else FB[j] = *(const uintx4*)(ldsb + cur + fb_off[j & 1] + (j >> 1) * KHALF_BYTES + (tn) * 2048);        \
         }
     // (bf16 -> fp32 is a 16-bit shift: two VALU per packed pair)
 #define P_ROWSUM(half)                                                                                              \
-        if constexpr (WG) { if (do_rowsum) {                                                                        \
+        if constexpr (WG) { if (do_rowsum && (PL == 1 || wc < 3)) {      /* PL 3: wave column wc sums plane wc (h + m + l == x) */ \
             _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                         \
-                const uintx4 f_ = wc == 0 ? fa[t][0] : wc == 1 ? fa[t][1] : wc == 2 ? fa[t][2] : fa[t][3];          \
+                const uintx4 f_ = wc == 0 ? fa[t][0] : wc == 1 ? fa[t][1] : wc == 2 ? fa[t][2] : fa[t][NJ - 1];     \
                 float a_ = 0.f;                                                                                     \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                       \
                     a_ += __uint_as_float(f_[e] << 16) + __uint_as_float(f_[e] & 0xffff0000u);                      \
@@ -248,24 +303,40 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     // LDS-DMA issue costs ~60 cycles among bare MFMAs but 100-185 in a segment that also carries the fragment reads — MI355X_MICROARCH.md;
     // round 4's first version issued them in the LOAD segment and ran 534 instead of ~300 cycles per half-phase).  sched_barrier pins the order.
 #define P_MM(half, tn, FB, j, t) if (!(P_DBG & 4)) acc[(half) * 2 + (t)][tn] = P_MFMA(FB[j], fa[t][j], acc[(half) * 2 + (t)][tn]);
+    // PL 3: product of B plane pb with A plane pa (planes 0 / 1 / 2 = h / m / l)
+#define P_MM3(half, tn, FB, pb, pa, t) if (!(P_DBG & 4)) acc[(half) * 2 + (t)][tn] = P_MFMA(FB[pb], fa[t][pa], acc[(half) * 2 + (t)][tn]);
+#define P_PIN(half, tn) asm volatile("" : "+v"(acc[(half) * 2][tn]), "+v"(acc[(half) * 2 + 1][tn]));
+#define P_DMA(piece, i, MORE)                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if (MORE && !(P_DBG & 1) && ((i) == 0 || second))                                                           \
+            p_glds16(voff[piece][i], ((piece) == 0 || (piece) == 3) ? baseA : baseB, dst[piece][i] + nxt);          \
+        __builtin_amdgcn_sched_barrier(0);
 #define P_MATH(half, tn, FB, piece, MORE)                                                                           \
         __builtin_amdgcn_s_barrier();                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                              \
-        P_MM(half, tn, FB, 0, 0) P_MM(half, tn, FB, 0, 1)                                                           \
-        asm volatile("" : "+v"(acc[(half) * 2][tn]), "+v"(acc[(half) * 2 + 1][tn]));                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                          \
-        if (MORE && !(P_DBG & 1)) p_glds16(voff[piece][0], ((piece) == 0 || (piece) == 3) ? baseA : baseB, dst[piece][0] + nxt); \
-        __builtin_amdgcn_sched_barrier(0);                                                                          \
-        P_MM(half, tn, FB, 1, 0) P_MM(half, tn, FB, 1, 1) P_MM(half, tn, FB, 2, 0)                                  \
-        asm volatile("" : "+v"(acc[(half) * 2][tn]), "+v"(acc[(half) * 2 + 1][tn]));                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                          \
-        if (MORE && !(P_DBG & 1)) p_glds16(voff[piece][1], ((piece) == 0 || (piece) == 3) ? baseA : baseB, dst[piece][1] + nxt); \
-        __builtin_amdgcn_sched_barrier(0);                                                                          \
-        P_MM(half, tn, FB, 2, 1) P_MM(half, tn, FB, 3, 0) P_MM(half, tn, FB, 3, 1)                                  \
+        if constexpr (PL == 1) {                                                                                    \
+            P_MM(half, tn, FB, 0, 0) P_MM(half, tn, FB, 0, 1)                                                       \
+            P_PIN(half, tn)                                                                                         \
+            P_DMA(piece, 0, MORE)                                                                                   \
+            P_MM(half, tn, FB, 1, 0) P_MM(half, tn, FB, 1, 1) P_MM(half, tn, FB, 2, 0)                              \
+            P_PIN(half, tn)                                                                                         \
+            P_DMA(piece, 1, MORE)                                                                                   \
+            P_MM(half, tn, FB, 2, 1) P_MM(half, tn, FB, 3, 0) P_MM(half, tn, FB, 3, 1)                              \
+        } else {                                                                                                    \
+            /* six products per accumulator, smallest terms first, in the order of gemm3_kernel<ARITH = 1> (gemm.hip GEMM3_PRODUCT) */ \
+            P_MM3(half, tn, FB, 2, 0, 0) P_MM3(half, tn, FB, 2, 0, 1)                                               \
+            P_PIN(half, tn)                                                                                         \
+            P_DMA(piece, 0, MORE)                                                                                   \
+            P_MM3(half, tn, FB, 0, 2, 0) P_MM3(half, tn, FB, 0, 2, 1) P_MM3(half, tn, FB, 1, 1, 0) P_MM3(half, tn, FB, 1, 1, 1) \
+            P_PIN(half, tn)                                                                                         \
+            P_DMA(piece, 1, MORE)                                                                                   \
+            P_MM3(half, tn, FB, 1, 0, 0) P_MM3(half, tn, FB, 1, 0, 1) P_MM3(half, tn, FB, 0, 1, 0) P_MM3(half, tn, FB, 0, 1, 1) \
+            P_MM3(half, tn, FB, 0, 0, 0) P_MM3(half, tn, FB, 0, 0, 1)                                               \
+        }                                                                                                           \
         /* (MFMAs are pure register operations: the IR optimizer SINKS them towards their next use, across setprio and the barrier, \
            into the next segment — an empty volatile asm that claims to rewrite the two accumulators pins them here) */             \
-        asm volatile("" : "+v"(acc[(half) * 2][tn]), "+v"(acc[(half) * 2 + 1][tn]));                                \
+        P_PIN(half, tn)                                                                                             \
         __builtin_amdgcn_s_setprio(0);                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
         __builtin_amdgcn_s_barrier();                                                                               \
@@ -273,10 +344,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     // LOAD ends with the counted wait: MORE = 1 leaves ONE piece (two DMA) in flight across the barrier — the piece issued in the MATH
     // segment before this LOAD; everything older has landed, so what the NEXT phase reads is complete for every wave after the barrier.
     // The last k-tile (MORE = 0, peeled) only drains.
-#define P_WAIT(MORE) if (MORE) p_wait_vmcnt<2>(); else p_wait_vmcnt<0>();
+#define P_WAIT(MORE) if (MORE) { if (second) p_wait_vmcnt<2>(); else p_wait_vmcnt<1>(); } else p_wait_vmcnt<0>();
 #define P_KTILE(MORE)                                                                                               \
     {                                                                                                               \
-        const unsigned nxt = cur ^ (unsigned)STAGE_BYTES;                                                           \
+        const unsigned nxt = cur ^ (unsigned)STG;                                                                   \
         /* phase 1: quadrant (rows 0-63, cols 0-31); piece A0 of the next k-tile */                                \
         P_READ_A(0) P_READ_B(fb0, 0) P_WAIT(MORE) P_MATH(0, 0, fb0, 0, MORE) P_ROWSUM(0)                            \
         /* phase 2: (rows 0-63, cols 32-63); piece B0 */                                                           \
@@ -296,6 +367,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
 #undef P_ROWSUM
 #undef P_MATH
 #undef P_MM
+#undef P_MM3
+#undef P_PIN
+#undef P_DMA
 #undef P_WAIT
 #undef P_ISSUE
     if (wr == 0) __builtin_amdgcn_s_barrier();          // the first half waits for the second: the tile buffers become epilogue staging
@@ -396,10 +470,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
                     if (!((w1 >> (sh - 3)) & 1u)) v1.w = 0.f;
                 }
                 if (m < g.M && nb8 < g.N) {
-                    uintx4 pk;
-                    pk[0] = p_cvt_pk_bf16(v0.x, v0.y); pk[1] = p_cvt_pk_bf16(v0.z, v0.w);
-                    pk[2] = p_cvt_pk_bf16(v1.x, v1.y); pk[3] = p_cvt_pk_bf16(v1.z, v1.w);
-                    *(uintx4*)(g.Cb + m * g.ldcb + nb8) = pk;
+                    if constexpr (PL == 1) {
+                        uintx4 pk;
+                        pk[0] = p_cvt_pk_bf16(v0.x, v0.y); pk[1] = p_cvt_pk_bf16(v0.z, v0.w);
+                        pk[2] = p_cvt_pk_bf16(v1.x, v1.y); pk[3] = p_cvt_pk_bf16(v1.z, v1.w);
+                        *(uintx4*)(g.Cb + m * g.ldcb + nb8) = pk;
+                    } else {
+                        uintx4 ph, pm, pl;
+                        { unsigned h_, m_, l_; p_split2(v0.x, v0.y, h_, m_, l_); ph[0] = h_; pm[0] = m_; pl[0] = l_; } { unsigned h_, m_, l_; p_split2(v0.z, v0.w, h_, m_, l_); ph[1] = h_; pm[1] = m_; pl[1] = l_; }
+                        { unsigned h_, m_, l_; p_split2(v1.x, v1.y, h_, m_, l_); ph[2] = h_; pm[2] = m_; pl[2] = l_; } { unsigned h_, m_, l_; p_split2(v1.z, v1.w, h_, m_, l_); ph[3] = h_; pm[3] = m_; pl[3] = l_; }
+                        unsigned short* cb = g.Cb + m * g.ldcb + nb8;
+                        *(uintx4*)cb = ph; *(uintx4*)(cb + g.planeC) = pm; *(uintx4*)(cb + 2 * g.planeC) = pl;
+                    }
                 }
             }
         } else
@@ -436,8 +518,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
             }
             if (Cz) *(float4*)(Cz + m * g.ldc + nb) = v;
             if (g.Cb) {
-                uint2 pk; pk.x = p_cvt_pk_bf16(v.x, v.y); pk.y = p_cvt_pk_bf16(v.z, v.w);
-                *(uint2*)(g.Cb + m * g.ldcb + nb) = pk;
+                if constexpr (PL == 1) {
+                    uint2 pk; pk.x = p_cvt_pk_bf16(v.x, v.y); pk.y = p_cvt_pk_bf16(v.z, v.w);
+                    *(uint2*)(g.Cb + m * g.ldcb + nb) = pk;
+                } else {
+                    uint2 ph, pm, pl;
+                    { unsigned h_, m_, l_; p_split2(v.x, v.y, h_, m_, l_); ph.x = h_; pm.x = m_; pl.x = l_; } { unsigned h_, m_, l_; p_split2(v.z, v.w, h_, m_, l_); ph.y = h_; pm.y = m_; pl.y = l_; }
+                    unsigned short* cb = g.Cb + m * g.ldcb + nb;
+                    *(uint2*)cb = ph; *(uint2*)(cb + g.planeC) = pm; *(uint2*)(cb + 2 * g.planeC) = pl;
+                }
             }
         }
         if (g.bits_out) {
@@ -450,9 +539,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
 
 }  // namespace
 
-static void phased_attr(const void* fn, bool& done) {
+constexpr int LDS_PL1 = 2 * STAGE_BYTES;              // 128 KiB: one workgroup per CU
+constexpr int LDS_PL3 = 2 * 2 * (3 * 256 * 32);       //  96 KiB (>= the 72 KiB of epilogue staging + bias-gradient partials)
+static void phased_attr(const void* fn, bool& done, int bytes = LDS_PL1) {
     if (!done) {
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);      // 128 KiB: one workgroup per CU
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         done = true;
     }
 }
@@ -482,8 +573,41 @@ int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t ld
 #endif
     g.wide16 = (wide && Cb && !C && !addend && N % 8 == 0 && ldcb % 8 == 0 && dlrm_aligned16(Cb) && (!bias || dlrm_aligned16(bias))) ? 1 : 0;
     static bool attr_done[DLRM_MAX_DEVICES] = {};
-    phased_attr((const void*)gemm_bf16_phased_kernel<false>, attr_done[dlrm_current_device()]);
-    hipLaunchKernelGGL(gemm_bf16_phased_kernel<false>, dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), 2 * STAGE_BYTES, st, g);
+    phased_attr((const void*)gemm_bf16_phased_kernel<false, 1>, attr_done[dlrm_current_device()]);
+    hipLaunchKernelGGL((gemm_bf16_phased_kernel<false, 1>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS_PL1, st, g);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- "bf16x6" from pre-split planes (PL = 3).  No fallback kernel reads planes: the host mirror asks dlrm_gemm_bf16x6_ok first and keeps the
+// fp32-storage path (gemm3_kernel<ARITH = 1>, which splits in its k-loop) for shapes outside these preconditions.
+bool dlrm_gemm_bf16x6_ok(int64_t M, int N, int K, int64_t lda, int64_t ldb) {
+    return phased_enabled() && K >= 16 && K % 16 == 0 && N % 4 == 0 && N >= 192 && M >= 256 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K;
+}
+// the planes of an operand travel in the 32-bit lane offset of the LDS-DMA: two plane strides + one tile of rows must stay below 4 GiB
+static bool planes_reachable(int64_t plane_elems, int64_t ld, int64_t rows_in_flight) {
+    return plane_elems >= 0 && plane_elems % 8 == 0 && (2 * plane_elems + rows_in_flight * ld + 64) * 2 < (int64_t)0xffffffffll;
+}
+int dlrm_gemm_bf16x6_phased(int64_t M, int N, int K, const uint16_t* A, int64_t lda, int64_t planeA, const uint16_t* B, int64_t ldb, int64_t planeB,
+                            const float* bias, int act, uint64_t* relu_bits_out, const uint64_t* relu_bits_in, float* C, int64_t ldc, uint16_t* Cp,
+                            int64_t ldcp, int64_t planeC, hipStream_t st) {
+    if (!dlrm_gemm_bf16x6_ok(M, N, K, lda, ldb) || !planes_reachable(planeA, lda, 256) || !planes_reachable(planeB, ldb, 256)) return DLRM_E_ALIGN;
+    if (bias && !dlrm_aligned16(bias)) return DLRM_E_ALIGN;
+    if (Cp && (planeC % 4 || ldcp % 4)) return DLRM_E_ALIGN;
+    BfArgs g = {};
+    g.M = M; g.N = N; g.K = K;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.Cb = Cp; g.ldcb = ldcp;
+    g.planeA = planeA * 2; g.planeB = planeB * 2; g.planeC = planeC;
+    g.bias = bias; g.act = act;
+    g.bits_out = (unsigned*)relu_bits_out; g.bits_in = (const unsigned*)relu_bits_in; g.bits_nblk = ((long long)N + 63) / 64;
+    g.tiles_m = (int)((M + PBM - 1) / PBM); g.tiles_n = (int)((N + PBN - 1) / PBN);
+#ifdef DLRM_TUNING
+    { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 7); g.debug = dbg; }
+#endif
+    g.wide16 = (Cp && !C && N % 8 == 0 && ldcp % 8 == 0 && planeC % 8 == 0 && dlrm_aligned16(Cp)) ? 1 : 0;
+    static bool attr_done[DLRM_MAX_DEVICES] = {};
+    phased_attr((const void*)gemm_bf16_phased_kernel<false, 3>, attr_done[dlrm_current_device()], LDS_PL3);
+    hipLaunchKernelGGL((gemm_bf16_phased_kernel<false, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS_PL3, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
 }
@@ -513,8 +637,10 @@ void dlrm_gemm_bf16_wgrad_plan(int64_t Mb, int N_out, int K_in, int* splits_out,
     *splits_out = (int)((Mb + kchunk - 1) / kchunk);
     *kchunk_out = kchunk;
 }
+// planes = 0: bf16 operands; planes = 1: each operand is three bf16 planes planeZ / planeX elements apart (bf16x6)
 int dlrm_gemm_bf16_wgrad_phased(int64_t Mb, int N_out, int K_in, const uint16_t* dZ, int64_t lddz, const uint16_t* X, int64_t ldx,
-                                float* slabs, int64_t ldc, int64_t slab_stride, float* rowsum_parts, int splits, int64_t kchunk, hipStream_t st) {
+                                float* slabs, int64_t ldc, int64_t slab_stride, float* rowsum_parts, int splits, int64_t kchunk, hipStream_t st,
+                                int planes, int64_t planeZ, int64_t planeX) {
     if (!dlrm_gemm_bf16_wgrad_ok(Mb, N_out, K_in, lddz, ldx) || !dZ || !X || !slabs || ldc % 4 || !dlrm_aligned16(slabs) || !dlrm_aligned16(dZ) ||
         !dlrm_aligned16(X) || kchunk % PBK || splits < 1)
         return DLRM_E_ARG;
@@ -524,9 +650,19 @@ int dlrm_gemm_bf16_wgrad_phased(int64_t Mb, int N_out, int K_in, const uint16_t*
     g.act = DLRM_ACT_NONE;
     g.kchunk = kchunk; g.c_split_stride = slab_stride; g.rowsum = rowsum_parts;
     g.tiles_m = (N_out + PBM - 1) / PBM; g.tiles_n = (K_in + PBN - 1) / PBN;
+    if (planes) {
+        // (a k-tile of the k-strided form holds 16 batch rows of every plane)
+        if (!planes_reachable(planeZ, lddz, 16) || !planes_reachable(planeX, ldx, 16)) return DLRM_E_ALIGN;
+        g.planeA = planeZ * 2; g.planeB = planeX * 2;
+        static bool attr3_done[DLRM_MAX_DEVICES] = {};
+        phased_attr((const void*)gemm_bf16_phased_kernel<true, 3>, attr3_done[dlrm_current_device()], LDS_PL3);
+        hipLaunchKernelGGL((gemm_bf16_phased_kernel<true, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), dim3(512), LDS_PL3, st, g);
+        DLRM_LAUNCH_CHECK();
+        return 0;
+    }
     static bool attr_done[DLRM_MAX_DEVICES] = {};
-    phased_attr((const void*)gemm_bf16_phased_kernel<true>, attr_done[dlrm_current_device()]);
-    hipLaunchKernelGGL(gemm_bf16_phased_kernel<true>, dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), dim3(512), 2 * STAGE_BYTES, st, g);
+    phased_attr((const void*)gemm_bf16_phased_kernel<true, 1>, attr_done[dlrm_current_device()]);
+    hipLaunchKernelGGL((gemm_bf16_phased_kernel<true, 1>), dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), dim3(512), LDS_PL1, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
 }

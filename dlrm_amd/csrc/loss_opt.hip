@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void clamp_bwd_kernel(long long n, const float
 
 }  // namespace
 
-extern "C" int dlrm_hip_abi_version(void) { return 9; }
+extern "C" int dlrm_hip_abi_version(void) { return 10; }
 
 extern "C" const char* dlrm_hip_build_info(void) {
     return "libdlrm_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " clang " __clang_version__;
@@ -415,6 +415,9 @@ extern "C" int dlrm_copy_blocks(int64_t M, int nblk, const void* const* src_host
 }
 
 static inline unsigned ew_blocks(int64_t n) { long long b = (n + 255) / 256; if (b > 2048) b = 2048; if (b < 1) b = 1; return (unsigned)b; }
+// streaming kernels over hundreds of MB (the DCN-v2 elementwise halves): ONE item per thread — the copy sweep of round 4 measured 6.18 TB/s for that
+// shape against 4.3-5.7 TB/s for grid-stride loops of any grid / unroll (profiles/round4/hbm_copy_sweep.txt); the kernels keep their loops, so any grid is valid
+static inline unsigned ew_blocks_full(int64_t n) { long long b = (n + 255) / 256; if (b > 0x7fffffffll) b = 0x7fffffffll; if (b < 1) b = 1; return (unsigned)b; }
 
 extern "C" int dlrm_bce_elementwise(int64_t n, const float* p, const float* target, float* loss, void* stream) {
     if (n <= 0 || !p || !target || !loss) return DLRM_E_ARG;
@@ -451,7 +454,7 @@ static inline bool vec4_ok(int64_t n, const void* a, const void* b, const void* 
 extern "C" int dlrm_cross_fwd(int64_t n, const float* x0, const float* u, const float* xl, float* out, uint16_t* out16, void* stream) {
     if (n <= 0 || !x0 || !u || !xl || !out) return DLRM_E_ARG;
     if (!vec4_ok(n, x0, u, xl, out, nullptr) || (out16 && (((uintptr_t)out16) & 7u))) return DLRM_E_ALIGN;
-    hipLaunchKernelGGL(cross_fwd_kernel, dim3(ew_blocks(n / 4) * 2), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)x0,
+    hipLaunchKernelGGL(cross_fwd_kernel, dim3(ew_blocks_full(n / 4)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)x0,
                        (const float4*)u, (const float4*)xl, (float4*)out, (uint2*)out16);
     DLRM_LAUNCH_CHECK();
     return 0;
@@ -461,7 +464,7 @@ extern "C" int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const 
                               void* stream) {
     if (n <= 0 || !g || !x0 || !u || (!du && !du16) || !dx0) return DLRM_E_ARG;
     if (!vec4_ok(n, g, x0, u, du, dx0) || (du16 && (((uintptr_t)du16) & 7u))) return DLRM_E_ALIGN;
-    hipLaunchKernelGGL(cross_bwd_kernel, dim3(ew_blocks(n / 4) * 2), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)g,
+    hipLaunchKernelGGL(cross_bwd_kernel, dim3(ew_blocks_full(n / 4)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)g,
                        (const float4*)x0, (const float4*)u, (float4*)du, (uint2*)du16, (float4*)dx0, accumulate ? 1 : 0);
     DLRM_LAUNCH_CHECK();
     return 0;
@@ -470,7 +473,7 @@ extern "C" int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const 
 extern "C" int dlrm_add(int64_t n, const float* a, const float* b, float* out, void* stream) {
     if (n <= 0 || !a || !b || !out) return DLRM_E_ARG;
     if (!vec4_ok(n, a, b, out, nullptr, nullptr)) return DLRM_E_ALIGN;
-    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n / 4) * 2), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)a,
+    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks_full(n / 4)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)a,
                        (const float4*)b, (float4*)out);
     DLRM_LAUNCH_CHECK();
     return 0;

@@ -36,7 +36,52 @@ RELU_BITS = os.environ.get("DLRM_RELU_BITS", "1") == "1"
 BF16_STORAGE = os.environ.get("DLRM_BF16_STORAGE", "1") == "1"
 # bf16 storage, LEAN: hidden activations / gradients exist only as bf16 (+ ReLU sign bits) wherever every consumer reads bf16 (MLPFunction)
 BF16_LEAN = os.environ.get("DLRM_BF16_LEAN", "1") == "1"
+# arith "bf16x6": activations / gradients / weights of the GEMM layers travel as three bf16 planes (split once by their producer) and the GEMMs
+# are the planes form of the bf16-shaped kernel (dlrm_gemm_bf16x6), wherever its shapes hold (DLRM_BF16X6_PLANES=0: every GEMM splits its fp32
+# operands inside its k-loop, the kernels of rounds 1-3; the k-contiguous products are bit-identical either way)
+BF16X6_PLANES = os.environ.get("DLRM_BF16X6_PLANES", "1") == "1"
 _side_streams = {}
+
+
+class _Bf16Store:
+    """how MLPFunction keeps the reduced-width copies of arith "bf16": one bf16 matrix per tensor"""
+    planes = False
+    kround = staticmethod(ops.round_bf16_k)
+    cast = staticmethod(ops.cast_bf16)
+    cast_t = staticmethod(ops.cast_bf16_transposed)
+    gemm = staticmethod(ops.gemm_bf16)
+    wgrad = staticmethod(ops.linear_bwd_weight_bf16)
+    wgrad_ok = staticmethod(ops.linear_bwd_weight_bf16_ok)
+
+    @staticmethod
+    def empty(M, N, device):
+        return torch.empty((M, N), dtype=torch.bfloat16, device=device)
+
+    @staticmethod
+    def fwd_ok(M, N, K):        # (dlrm_gemm_bf16 keeps the fp32-shaped kernel for shapes the bf16-shaped one does not take)
+        return True
+
+
+class _PlaneStore:
+    """... and of arith "bf16x6": the three bf16 planes of the fp32 tensor, [3, rows, cols] (ops.split_bf16x3)"""
+    planes = True
+    kround = staticmethod(ops.round_x6_k)
+    cast = staticmethod(ops.split_bf16x3)
+    cast_t = staticmethod(ops.split_bf16x3_transposed)
+    gemm = staticmethod(ops.gemm_bf16x6)
+    wgrad = staticmethod(ops.linear_bwd_weight_bf16x6)
+
+    @staticmethod
+    def wgrad_ok(M, N, K, dZ3, X3):
+        return ops.linear_bwd_weight_bf16_ok(M, N, K, dZ3[0], X3[0])
+
+    @staticmethod
+    def empty(M, N, device):
+        return torch.empty((3, M, N), dtype=torch.bfloat16, device=device)
+
+    @staticmethod
+    def fwd_ok(M, N, K):        # no other kernel reads planes: exactly the preconditions of dlrm_gemm_bf16x6
+        return ops.gemm_bf16x6_ok(M, N, K)
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
@@ -151,7 +196,8 @@ class MLPFunction(Function):
         # sign bits: a forward that will be differentiated (Function.forward itself runs grad-free), and not a SMALL batch — there the GEMMs run
         # on 64 x 64 tiles that neither write nor read the bits (the bits would come from a stand-alone kernel: one more launch per layer of a
         # launch-bound step) and the data gradient reads the fp32 activation, which small batches keep in cache anyway
-        need_bits = RELU_BITS and need_grad and (M > SMALL_BATCH_BITS or (BF16_STORAGE and arith == ops.arith_code("bf16")))
+        need_bits = RELU_BITS and need_grad and (M > SMALL_BATCH_BITS or (BF16_STORAGE and arith == ops.arith_code("bf16")) or
+                                                 (BF16X6_PLANES and arith == ops.arith_code("bf16x6")))
         # arith "bf16" with bf16 STORAGE (default; DLRM_BF16_STORAGE=0 restores the in-loop rounding of rounds 1-2): every GEMM layer reads a
         # bf16 copy of its input and of its weight (dlrm_gemm_bf16: no conversion in the k-loop).  LEAN (default, DLRM_BF16_LEAN=0 turns it
         # off): a hidden activation is written ONLY as bf16 + ReLU sign bits when every consumer reads those — the next layer's forward
@@ -159,32 +205,37 @@ class MLPFunction(Function):
         # fp32 copy (4 of the 6 bytes written per element) exists only where something reads it: the tower's output, the input of a
         # matrix-vector layer, layers whose shapes the bf16 weight gradient does not take.  Same operand rounding and accumulation
         # order as the in-loop path for every product.
+        # arith "bf16x6" with PLANES (default): the same plan with every bf16 copy replaced by the three planes of the fp32 tensor (always lean)
+        st = _Bf16Store
         store16 = BF16_STORAGE and arith == ops.arith_code("bf16")
         lean = store16 and BF16_LEAN
+        if BF16X6_PLANES and arith == ops.arith_code("bf16x6") and M >= 256 and RELU_BITS and os.environ.get("DLRM_BF16_PHASED", "1") != "0":
+            st, store16, lean = _PlaneStore, True, True
+        ctx.st = st
         widths = [params[2 * i].size(0) for i in range(L)]                                   # N_i
         kin = [W0p.size(1) if (i == 0 and W0p is not None) else params[2 * i].size(1) for i in range(L)]
         out_last = out_slot.get() if out_slot is not None else None
-        use16 = [store16 and widths[i] % 4 == 0 and widths[i] != 1 for i in range(L)]
+        kb = [st.kround(kin[i]) for i in range(L)]
+        use16 = [store16 and widths[i] % 4 == 0 and widths[i] != 1 and st.fwd_ok(M, widths[i], kb[i]) for i in range(L)]
         if out_last is not None and use16[L - 1] and not (_ld(out_last) % 4 == 0 and out_last.data_ptr() % 16 == 0):
             use16[L - 1] = False
-        kb = [ops.round_bf16_k(kin[i]) for i in range(L)]
         # weight gradient of layer i from bf16 operands as stored (X16_i = the bf16 input of its forward GEMM, dZ16_i)
         wg16 = [lean and need_grad and use16[i] and M >= 256 and M % 64 == 0 and widths[i] % 8 == 0 and widths[i] >= 64 and kin[i] >= 64
                 and os.environ.get("DLRM_BF16_PHASED", "1") != "0" for i in range(L)]
         # data gradient of layer i (dX = dZ . W) on bf16 operands: reduction over widths[i]
         # (its epilogue applies the derivative of the activation BELOW it: none, or ReLU through that layer's sign bits)
-        dg16 = [store16 and use16[i] and widths[i] % 32 == 0 and kin[i] % 4 == 0 and
+        dg16 = [store16 and use16[i] and widths[i] % 32 == 0 and kin[i] % 4 == 0 and st.fwd_ok(M, kin[i], widths[i]) and
                 (i == 0 or acts[i - 1] == ACT_NONE or (acts[i - 1] == ACT_RELU and need_bits)) for i in range(L)]
         need32 = []
         for i in range(L):
-            n32 = (not lean) or i == L - 1 or not use16[i + 1] or kb[i + 1] != widths[i]
+            n32 = (not lean) or i == L - 1 or not use16[i] or not use16[i + 1] or kb[i + 1] != widths[i]
             if not n32 and need_grad:
                 # backward consumers of the fp32 activation: the next layer's weight gradient when it is not the bf16 one; the ReLU
                 # derivative when there are no sign bits; any other activation's derivative
                 n32 = (not wg16[i + 1]) or (acts[i] == ACT_RELU and not need_bits) or acts[i] not in (ACT_RELU, ACT_NONE)
             need32.append(n32)
         cur16 = None                                                  # bf16 copy of the current activation, [M, kb of the next layer]
-        outs, outs16, bits, x16_0 = [], [], [], None
+        outs, in16, bits = [], [], []                                   # in16[i]: the reduced-width input of layer i's GEMM, kept for its weight gradient
         for i in range(L):
             W, b = params[2 * i], params[2 * i + 1]
             if i == 0 and W0p is not None:
@@ -196,27 +247,25 @@ class MLPFunction(Function):
             rb = ops.relu_bits_alloc(M, N, x.device) if (i < L - 1 and acts[i] == ACT_RELU and need_bits) else None
             y16 = None
             if use16[i]:
-                a16 = cur16 if (cur16 is not None and cur16.size(1) == kb[i]) else ops.cast_bf16(cur, kb[i], category="linear_fwd")
-                if i == 0:
-                    x16_0 = a16
-                w16 = ops.cast_bf16(W, kb[i], category="linear_fwd")
+                a16 = cur16 if (cur16 is not None and cur16.size(-1) == kb[i]) else st.cast(cur, kb[i], category="linear_fwd")
+                in16.append(a16 if (lean and need_grad and wg16[i]) else None)
+                w16 = st.cast(W, kb[i], category="linear_fwd")
                 # the bf16 copy of this activation, if the NEXT layer is a GEMM that can take it as it is
                 nxt = i + 1 < L and use16[i + 1] and kb[i + 1] == N
-                y16 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device) if (nxt or not need32[i]) else None
-                ops.gemm_bf16(a16, w16, b, acts[i], y, y16, relu_bits_out=rb, category="linear_fwd")
+                y16 = st.empty(M, N, x.device) if (nxt or not need32[i]) else None
+                st.gemm(a16, w16, b, acts[i], y, y16, relu_bits_out=rb, category="linear_fwd")
             else:
+                in16.append(None)
                 ops.linear_fwd(cur, W, b, acts[i], y, arith, relu_bits=rb)
             cur16 = y16
             outs.append(y)
-            outs16.append(y16 if lean else None)
             bits.append(rb)
             cur = y
         ctx.bits = bits
         ctx.acts = acts
         ctx.padded = W0p is not None
         ctx.plan = (use16, wg16, dg16, need32, kb) if store16 else None
-        ctx.x16_0 = x16_0 if (lean and need_grad and wg16[0]) else None
-        ctx.outs16 = outs16 if (lean and need_grad) else [None] * L
+        ctx.in16 = in16
         ctx.have32 = [o is not None for o in outs]
         ctx.save_for_backward(x, *params, *[o for o in outs if o is not None], *([W0p] if W0p is not None else []))
         return outs[-1]
@@ -232,11 +281,11 @@ class MLPFunction(Function):
         it32 = iter(saved[1 + 2 * L:1 + 2 * L + n32])
         outs = [next(it32) if h else None for h in ctx.have32]          # fp32 activations (None: the layer kept bf16 + sign bits only)
         W0p = saved[1 + 2 * L + n32] if ctx.padded else None
-        outs16 = ctx.outs16
         M = x.size(0)
         dY = _rowmajor(dY)
         grads: List[Optional[torch.Tensor]] = [None] * (2 * L)
         store16 = ctx.plan is not None
+        st = ctx.st
         use16, wg16, dg16, need32, kb = ctx.plan if store16 else ([False] * L,) * 4 + ([0] * L,)
 
         # last layer: activation backward (its dY comes from outside, e.g. the loss or the interaction)
@@ -259,19 +308,19 @@ class MLPFunction(Function):
         for i in range(L - 1, -1, -1):
             W = params[2 * i] if not (i == 0 and W0p is not None) else W0p
             X_i = x if i == 0 else outs[i - 1]
-            X16_i = (ctx.x16_0 if i == 0 else outs16[i - 1]) if wg16[i] else None
+            X16_i = ctx.in16[i] if wg16[i] else None
             # first layer on a zero-padded input: the gradient is written at the parameter's true width (the padding
             # columns of X are dropped inside the kernel) — contiguous, no slicing / re-packing afterwards
             dW = _grad_out(params[2 * i])
             db = _grad_out(params[2 * i + 1])
             N_i, K_i = W.size(0), W.size(1)
-            do16 = wg16[i] and X16_i is not None and ops.linear_bwd_weight_bf16_ok(M, N_i, dW.size(1), dZ16 if dZ16 is not None else X16_i, X16_i)
+            do16 = wg16[i] and X16_i is not None and st.wgrad_ok(M, N_i, dW.size(1), dZ16 if dZ16 is not None else X16_i, X16_i)
             if do16 and dZ16 is None:
-                dZ16 = ops.cast_bf16(dZ, N_i, category="linear_bwd_weight")          # (the tower's last layer: its dZ comes from act_bwd in fp32)
+                dZ16 = st.cast(dZ, N_i, category="linear_bwd_weight")                # (the tower's last layer: its dZ comes from act_bwd in fp32)
 
             def wgrad():
                 if do16:
-                    ops.linear_bwd_weight_bf16(dZ16, X16_i, dW, db)               # bf16 operands as stored, k-strided reads
+                    st.wgrad(dZ16, X16_i, dW, db)                                 # bf16 operands (or planes) as stored, k-strided reads
                 else:
                     ops.linear_bwd_weight(dZ, X_i, dW, db, arith=arith)           # dW and db (row sums of dZ^T) in one GEMM
             if side is not None:
@@ -297,10 +346,10 @@ class MLPFunction(Function):
                 ok16 = False
             if ok16:
                 # bf16 storage: dX = dZ . W as a <k-contiguous, k-contiguous> GEMM over a transposed bf16 copy of W
-                a16 = dZ16 if dZ16 is not None else ops.cast_bf16(dZ, N_i, category="linear_bwd_data")
-                wT16 = ops.cast_bf16_transposed(W, N_i, category="linear_bwd_data")
-                d16 = torch.empty((M, K_i), dtype=torch.bfloat16, device=x.device) if want16 else None
-                ops.gemm_bf16(a16, wT16, None, ACT_NONE, dprev, d16, relu_bits_in=rbits, category="linear_bwd_data")
+                a16 = dZ16 if dZ16 is not None else st.cast(dZ, N_i, category="linear_bwd_data")
+                wT16 = st.cast_t(W, N_i, category="linear_bwd_data")
+                d16 = st.empty(M, K_i, x.device) if want16 else None
+                st.gemm(a16, wT16, None, ACT_NONE, dprev, d16, relu_bits_in=rbits, category="linear_bwd_data")
                 dZ16 = d16
             else:
                 # dgrad GEMM with the previous layer's activation derivative fused into the epilogue

@@ -750,6 +750,101 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], ac
     _lib.check(rc, "dlrm_gemm_bf16")
 
 
+# ---- arith "bf16x6" from pre-split operands: an fp32 tensor travels as a contiguous [3, rows, cols] bf16 tensor = its planes h, m, l ----
+
+def _planes(t: torch.Tensor, name: str) -> None:
+    if t.dtype != torch.bfloat16 or not t.is_cuda or t.dim() != 3 or t.size(0) != 3 or not t.is_contiguous():
+        raise RuntimeError(f"dlrm_amd: {name} must be a contiguous [3, rows, cols] bf16 GPU tensor (the planes of an fp32 matrix)")
+
+
+def round_x6_k(K: int) -> int:
+    """reduction length an operand's planes are padded to: the 16-k tile of the planes kernel"""
+    return (K + 15) & ~15
+
+
+def gemm_bf16x6_ok(M: int, N: int, K: int) -> bool:
+    """preconditions of dlrm_gemm_bf16x6 for contiguous planes [3, M, K] x [3, N, K]"""
+    return bool(_lib.load().dlrm_gemm_bf16x6_supported(M, N, K, K, K)) and 3 * max(M, N) * K < (1 << 31)
+
+
+def split_bf16x3(src: torch.Tensor, Npad: Optional[int] = None, category: str = "cast_bf16") -> torch.Tensor:
+    """[M, N] fp32 -> [3, M, Npad] bf16: the truncation planes h, m, l with src == h + m + l exactly (zero columns N..Npad-1)"""
+    lib = _lib.load()
+    _req(src, "src", ndim=2)
+    M, N = src.shape
+    Npad = (N + 7) & ~7 if Npad is None else int(Npad)
+    dst = torch.empty((3, M, Npad), dtype=torch.bfloat16, device=src.device)
+    with _timed(category):
+        rc = lib.dlrm_split_bf16x3(M, N, Npad, C.c_void_p(src.data_ptr()), _ld(src), C.c_void_p(dst.data_ptr()), Npad, M * Npad, _stream(dst))
+    _lib.check(rc, "dlrm_split_bf16x3")
+    return dst
+
+
+def split_bf16x3_transposed(src: torch.Tensor, Rpad: Optional[int] = None, category: str = "cast_bf16") -> torch.Tensor:
+    """[R, C] fp32 -> [3, C, Rpad] bf16: the planes of its transpose (zero columns R..Rpad-1)"""
+    lib = _lib.load()
+    _req(src, "src", ndim=2)
+    R, Cc = src.shape
+    Rpad = R if Rpad is None else int(Rpad)
+    dst = torch.empty((3, Cc, Rpad), dtype=torch.bfloat16, device=src.device)
+    with _timed(category):
+        rc = lib.dlrm_split_bf16x3_transposed(R, Cc, Rpad, C.c_void_p(src.data_ptr()), _ld(src), C.c_void_p(dst.data_ptr()), Rpad, Cc * Rpad, _stream(dst))
+    _lib.check(rc, "dlrm_split_bf16x3_transposed")
+    return dst
+
+
+def gemm_bf16x6(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], act: int, Cf: Optional[torch.Tensor],
+                Cp: Optional[torch.Tensor], relu_bits_out: Optional[torch.Tensor] = None, relu_bits_in: Optional[torch.Tensor] = None,
+                category: str = "linear_fwd") -> None:
+    """Cf (fp32 [M, N]) and/or Cp (planes [3, M, N]) = epilogue(A @ B^T) for operands given as planes A [3, M, K], B [3, N, K] (dlrm_gemm_bf16x6)."""
+    lib = _lib.load()
+    _planes(A, "A"); _planes(B, "B")
+    _, M, K = A.shape
+    N = B.size(1)
+    if B.size(2) != K:
+        raise RuntimeError("dlrm_amd: gemm_bf16x6 reduction lengths differ")
+    if Cf is not None:
+        _req(Cf, "C", ndim=2)
+    if Cp is not None:
+        _planes(Cp, "Cp")
+        if tuple(Cp.shape) != (3, M, N):
+            raise RuntimeError("dlrm_amd: gemm_bf16x6 planes output must be [3, M, N]")
+    out = Cf if Cf is not None else Cp
+    with _timed(category):
+        rc = lib.dlrm_gemm_bf16x6(M, N, K, C.c_void_p(A.data_ptr()), K, M * K, C.c_void_p(B.data_ptr()), K, N * K,
+                                  C.c_void_p(bias.data_ptr()) if bias is not None else None, int(act),
+                                  C.c_void_p(relu_bits_out.data_ptr()) if relu_bits_out is not None else None,
+                                  C.c_void_p(relu_bits_in.data_ptr()) if relu_bits_in is not None else None,
+                                  C.c_void_p(Cf.data_ptr()) if Cf is not None else None, _ld(Cf) if Cf is not None else 0,
+                                  C.c_void_p(Cp.data_ptr()) if Cp is not None else None, N if Cp is not None else 0, M * N if Cp is not None else 0,
+                                  _stream(out))
+    _lib.check(rc, "dlrm_gemm_bf16x6")
+
+
+def linear_bwd_weight_bf16x6(dZ3: torch.Tensor, X3: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor] = None,
+                             accumulate: bool = False) -> torch.Tensor:
+    """dW [N, K_store] fp32 = dZ^T @ X[:, :K_store], dbias = column sums of dZ, from the planes dZ3 [3, M, N], X3 [3, M, K] (read k-strided).
+    X3's columns dW.size(1) .. round8(dW.size(1)) must be zero padding."""
+    lib = _lib.load()
+    _planes(dZ3, "dZ3"); _planes(X3, "X3")
+    _req(dW, "dW", ndim=2)
+    _, M, N = dZ3.shape
+    Kx = X3.size(2)
+    K_store = dW.size(1)
+    K = (K_store + 7) & ~7
+    if X3.size(1) != M or dW.size(0) != N or Kx < K:
+        raise RuntimeError("dlrm_amd: linear_bwd_weight_bf16x6 shape mismatch")
+    if dbias is not None:
+        _req(dbias, "dbias", ndim=1)
+    ws = _wgrad_workspace(lib.dlrm_linear_bwd_weight_bf16_workspace_bytes(M, N, K), dW.device)
+    with _timed("linear_bwd_weight"):
+        rc = lib.dlrm_linear_bwd_weight_bf16x6(M, N, K, K_store, C.c_void_p(dZ3.data_ptr()), N, M * N, C.c_void_p(X3.data_ptr()), Kx, M * Kx,
+                                               C.c_void_p(dW.data_ptr()), _ld(dW), C.c_void_p(dbias.data_ptr()) if dbias is not None else None,
+                                               int(bool(accumulate)), C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dW))
+    _lib.check(rc, "dlrm_linear_bwd_weight_bf16x6")
+    return dW
+
+
 _wgrad_ws = {}   # (device, stream) -> cached split-K workspace (kernels of one stream are ordered, so one slab set suffices)
 
 

@@ -256,6 +256,31 @@ int dlrm_linear_bwd_weight_bf16(int64_t M, int N, int K, int K_store, const uint
                                 float* dW, int64_t lddw, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,
                                 void* stream);
 
+/* ---- arith "bf16x6" from PRE-SPLIT operands.  An fp32 tensor is held as THREE bf16 planes h, m, l (truncation split: x == h + m + l exactly,
+ * each plane an [rows, ld] bf16 matrix, the planes `plane` ELEMENTS apart inside one allocation); a product is the six bf16 MFMAs per 16 k of
+ * DLRM_ARITH_BF16X6 (h.h, h.m, m.h, m.m, h.l, l.h; fp32 accumulation) — the same values, in the same order, as dlrm_linear_fwd / _bwd_data
+ * compute when they split fp32 operands inside their k-loops: results are BIT-IDENTICAL to those, i.e. the fp32 round-off class of the
+ * reference's addmm (dlrm_s_pytorch.py:399-405, AddmmBackward :1613).  What changes is the cost: operands are split once by their producer
+ * (dlrm_split_bf16x3, or the Cp output of the previous GEMM) instead of by every k-loop that reads them, and the k-loop is the bf16-shaped
+ * four-phase pipeline of csrc/gemm_bf16.hip with no VALU work in it.
+ *   dlrm_split_bf16x3            [M, N] fp32 -> planes of [M, Npad] (zero columns N..Npad-1; Npad, ldd, plane % 8 == 0)
+ *   dlrm_split_bf16x3_transposed [R, C] fp32 -> planes of its transpose [C, Rpad] (W^T for the data gradient)
+ *   dlrm_gemm_bf16x6             C (fp32, nullable) / Cp (planes of the result, nullable) = epilogue(A . B^T): bias, activation, ReLU sign bits
+ *                                out / mask in as dlrm_gemm_bf16.  Preconditions (dlrm_gemm_bf16x6_supported; DLRM_E_ALIGN otherwise — there is
+ *                                no other kernel that reads planes, the caller keeps fp32 storage): K % 16 == 0, N % 4 == 0, N >= 192, M >= 256,
+ *                                lda, ldb % 8 == 0, plane strides % 8 == 0 and below 2^30 elements.
+ *   dlrm_linear_bwd_weight_bf16x6  dW (+)= dZ^T . X, dbias (+)= column sums of dZ from the planes of dZ [M, N] and X [M, K], read k-strided;
+ *                                preconditions and workspace of dlrm_linear_bwd_weight_bf16. */
+int dlrm_split_bf16x3(int64_t M, int N, int Npad, const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t plane, void* stream);
+int dlrm_split_bf16x3_transposed(int R, int C, int Rpad, const float* src, int64_t lds, uint16_t* dstT, int64_t ldd, int64_t plane, void* stream);
+int dlrm_gemm_bf16x6_supported(int64_t M, int N, int K, int64_t lda, int64_t ldb);
+int dlrm_gemm_bf16x6(int64_t M, int N, int K, const uint16_t* A, int64_t lda, int64_t planeA, const uint16_t* B, int64_t ldb, int64_t planeB,
+                     const float* bias, int act, uint64_t* relu_bits_out, const uint64_t* relu_bits_in, float* C, int64_t ldc,
+                     uint16_t* Cp, int64_t ldcp, int64_t planeC, void* stream);
+int dlrm_linear_bwd_weight_bf16x6(int64_t M, int N, int K, int K_store, const uint16_t* dZ, int64_t lddz, int64_t planeZ, const uint16_t* X,
+                                  int64_t ldx, int64_t planeX, float* dW, int64_t lddw, float* dbias, int accumulate, void* workspace,
+                                  int64_t workspace_bytes, void* stream);
+
 int64_t dlrm_relu_bits_bytes(int64_t M, int N);
 int dlrm_linear_fwd(int64_t M, int N, int K,
                     const float* X, int64_t ldx, const float* W, int64_t ldw,

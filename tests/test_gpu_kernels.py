@@ -551,12 +551,121 @@ def test_linear_bwd_weight_bf16_from_stored_operands(M, N, K):
     np.testing.assert_allclose(dW.cpu().numpy(), dW4.cpu().numpy(), rtol=1e-4, atol=2e-4 * np.sqrt(M))
 
 
+def test_bf16x3_split_is_exact_and_padded():
+    """dlrm_split_bf16x3 / _transposed: the three truncation planes of an fp32 matrix (gemm.hip split3) — h + m + l == x EXACTLY for every
+    finite value (tiny, huge, negative, zero), h = the upper 16 bits of x; padding columns are zero in all planes; the 8-wide and the
+    scalar kernel, ragged widths."""
+    from dlrm_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for M, N, Np in ((300, 13, 16), (65, 479, 480), (1000, 256, 256), (513, 3456, 3456), (129, 480, 512), (3, 8, 64)):
+        x = torch.randn(M, N, generator=g) * torch.exp(torch.randn(M, N, generator=g) * 8)          # 30 binary orders of magnitude
+        x[0, 0], x[-1, -1] = 0.0, -1.00390625
+        x = x.to(dev())
+        p = ops.split_bf16x3(x, Np)
+        assert tuple(p.shape) == (3, M, Np)
+        assert torch.equal((p[0, :, :N].float() + p[1, :, :N].float()) + p[2, :, :N].float(), x), (M, N, Np)
+        assert torch.equal(p[0, :, :N].view(torch.int16).int() & 0xffff, (x.view(torch.int32) >> 16) & 0xffff)
+        assert not p[:, :, N:].view(torch.int16).any()
+    for R, C_, Rp in ((1024, 480, 1024), (100, 37, 128), (1, 256, 32)):
+        w = torch.randn(R, C_, generator=g).to(dev())
+        p = ops.split_bf16x3_transposed(w, Rp)
+        assert tuple(p.shape) == (3, C_, Rp)
+        assert torch.equal((p[0, :, :R].float() + p[1, :, :R].float()) + p[2, :, :R].float(), w.t())
+        assert not p[:, :, R:].view(torch.int16).any()
+
+
+@pytest.mark.parametrize("M,N,K,act", [(512, 256, 512, 1), (1000, 320, 192, 1), (4100, 1024, 1024, 0), (65536, 512, 256, 1), (777, 452, 208, 1),
+                                       (2048, 512, 3456, 0), (256, 192, 64, 2), (16384, 1024, 480, 1), (8192, 512, 16, 1)])
+def test_gemm_bf16x6_from_planes_equals_in_loop_split(M, N, K, act):
+    """dlrm_gemm_bf16x6 (csrc/gemm_bf16.hip PL = 3: operands as three pre-split bf16 planes, six MFMAs per 16 k in the four-phase pipeline)
+    is BIT-IDENTICAL to dlrm_linear_fwd / dlrm_linear_bwd_data with DLRM_ARITH_BF16X6, which split the same fp32 operands inside their
+    k-loops (same six products, same order, same k partition) — and therefore inherits their parity with the fp64 oracle (test_linear_fwd_bwd):
+      * forward: bias, activation, fp32 result, the planes of the result (== split of the fp32 result), ReLU sign bits;
+      * planes-only output (the lean tower's hidden layers, 16-byte stores);
+      * data gradient: product with a transposed-weight planes operand, masked by the sign bits.
+    Shapes: ragged M / N, one tile, K = 3456, K = 480 (the padded interaction width), K = 16 (ONE k-tile: the 13 -> 16 dense-feature layer)."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    assert ops.gemm_bf16x6_ok(M, N, K)
+    X = to_dev(rng.standard_normal((M, K)).astype(np.float32))
+    W = to_dev((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    bias = to_dev(rng.standard_normal(N).astype(np.float32))
+    Y_ref = torch.empty((M, N), device=dev())
+    bits_ref = ops.relu_bits_alloc(M, N, dev()).zero_() if act == 1 else None          # (zeroed: words of ragged edge blocks are compared too)
+    ops.linear_fwd(X, W, bias, act, Y_ref, "bf16x6", relu_bits=bits_ref)
+    X3, W3 = ops.split_bf16x3(X, K), ops.split_bf16x3(W, K)
+    Y = torch.full((M, N), 7.0, device=dev())
+    Y3 = torch.zeros((3, M, N), dtype=torch.bfloat16, device=dev())
+    bits = ops.relu_bits_alloc(M, N, dev()).zero_() if act == 1 else None
+    ops.gemm_bf16x6(X3, W3, bias, act, Y, Y3, relu_bits_out=bits)
+    torch.cuda.synchronize()
+    assert torch.equal(Y, Y_ref)
+    assert torch.equal(Y3, ops.split_bf16x3(Y, N))
+    if bits is not None and M % 32 == 0 and N % 64 == 0:       # (bits of rows / columns past the edge are unspecified; ragged shapes: checked through the data gradient below)
+        assert torch.equal(bits, bits_ref)
+    if N % 8 == 0:
+        Y3b = torch.zeros((3, M, N), dtype=torch.bfloat16, device=dev())
+        bits_b = ops.relu_bits_alloc(M, N, dev()).zero_() if act == 1 else None
+        ops.gemm_bf16x6(X3, W3, bias, act, None, Y3b, relu_bits_out=bits_b)
+        assert torch.equal(Y3b, Y3)
+        if bits_b is not None and M % 32 == 0 and N % 64 == 0:
+            assert torch.equal(bits_b, bits)
+    if act == 1:
+        # data gradient of the NEXT layer: dX = (dY . W2) * (Y > 0) with Y [M, N], dY [M, N2], W2 [N2, N]
+        N2 = 256
+        dY = to_dev(rng.standard_normal((M, N2)).astype(np.float32))
+        W2 = to_dev((rng.standard_normal((N2, N)) / 16).astype(np.float32))
+        dX_ref = torch.empty((M, N), device=dev())
+        ops.linear_bwd_data(dY, W2, Y_ref, 1, dX_ref, "bf16x6", relu_bits=bits_ref)      # (small shapes mask by the fp32 activation, large ones by the bits)
+        dX = torch.empty((M, N), device=dev())
+        dX3 = torch.zeros((3, M, N), dtype=torch.bfloat16, device=dev())
+        ops.gemm_bf16x6(ops.split_bf16x3(dY, N2), ops.split_bf16x3_transposed(W2, N2), None, 0, dX, dX3, relu_bits_in=bits, category="linear_bwd_data")
+        torch.cuda.synchronize()
+        assert torch.equal(dX, dX_ref)
+        assert torch.equal(dX3, ops.split_bf16x3(dX, N))
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1024, 1024), (65536, 512, 256), (1024, 320, 192), (8192, 128, 256), (2048, 3456, 512), (256, 64, 64),
+                                   (16384, 1024, 480), (4096, 1024, 479)])
+def test_linear_bwd_weight_bf16x6_from_planes(M, N, K):
+    """dlrm_linear_bwd_weight_bf16x6 (weight-gradient form of the planes kernel: both operands k-strided through ds_read_b64_tr_b16, six MFMAs per
+    16 batch rows, fp32 slabs summed in slice order) against a float64 product of the fp32 operands (AddmmBackward's weight / bias branch,
+    dlrm_s_pytorch.py:1613) at the tolerance the fp32 MFMA weight gradient is held to, and against the in-loop-split kernel; overwrite /
+    accumulate; run-to-run bit-identical."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    dZ = to_dev(rng.standard_normal((M, N)).astype(np.float32))
+    Kp = (K + 15) & ~15
+    X = torch.zeros((M, Kp), device=dev())
+    X[:, :K] = to_dev(rng.standard_normal((M, K)).astype(np.float32))
+    dZ3, X3 = ops.split_bf16x3(dZ, N), ops.split_bf16x3(X, Kp)
+    dW = torch.full((N, K), 7.0, device=dev())
+    db = torch.full((N,), 7.0, device=dev())
+    ops.linear_bwd_weight_bf16x6(dZ3, X3, dW, db)
+    torch.cuda.synchronize()
+    want = dZ.double().cpu().numpy().T @ X[:, :K].double().cpu().numpy()
+    wdb = dZ.double().cpu().numpy().sum(0)
+    np.testing.assert_allclose(dW.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.sqrt(M))
+    np.testing.assert_allclose(db.cpu().numpy(), wdb, rtol=1e-4, atol=1e-5 * np.sqrt(M))
+    dW2, db2 = dW.clone(), db.clone()
+    ops.linear_bwd_weight_bf16x6(dZ3, X3, dW2, db2, accumulate=True)
+    dW3, db3 = torch.empty_like(dW), torch.empty_like(db)
+    ops.linear_bwd_weight_bf16x6(dZ3, X3, dW3, db3)
+    torch.cuda.synchronize()
+    assert torch.equal(dW3, dW) and torch.equal(db3, db)                       # deterministic
+    np.testing.assert_allclose(dW2.cpu().numpy(), 2 * want, rtol=1e-4, atol=2e-5 * np.sqrt(M))
+    np.testing.assert_allclose(db2.cpu().numpy(), 2 * wdb, rtol=1e-4, atol=2e-5 * np.sqrt(M))
+    dW4 = torch.empty((N, K), device=dev())
+    ops.linear_bwd_weight(dZ, X[:, :K].contiguous() if K % 4 else X[:, :K], dW4, None, arith="bf16x6")
+    np.testing.assert_allclose(dW.cpu().numpy(), dW4.cpu().numpy(), rtol=1e-4, atol=1e-5 * np.sqrt(M))
+
+
 def test_bf16_casts_are_round_to_nearest_even_and_padded():
     """dlrm_cast_bf16 / dlrm_cast_bf16_transposed against torch's fp32 -> bfloat16 conversion (round to nearest even), including the
     zero padding columns and odd shapes"""
     from dlrm_amd import ops
     g = torch.Generator(device="cpu").manual_seed(3)
-    for M, N, Np in ((300, 13, 32), (65, 479, 480), (1000, 256, 256), (7, 1, 2)):
+    for M, N, Np in ((300, 13, 32), (65, 479, 480), (1000, 256, 256), (7, 1, 2), (513, 3456, 3456), (129, 480, 512), (3, 8, 64)):   # last three: the 8-wide kernel, with padding groups
         x = (torch.randn(M, N, generator=g) * 3).to(dev())
         x[0, 0] = 1.00390625          # exactly half way between two bf16 values: ties to even
         got = ops.cast_bf16(x, Np)
@@ -625,6 +734,62 @@ def test_bf16_storage_tower_is_bit_identical_to_in_loop_rounding(ln, B):
         h = h @ params[2 * i].detach().double().cpu().numpy().T + params[2 * i + 1].detach().double().cpu().numpy()
         h = 1 / (1 + np.exp(-h)) if acts[i] == ops.ACT_SIGMOID else np.maximum(h, 0)
     np.testing.assert_allclose(y1.cpu().numpy(), h, rtol=6e-2, atol=6e-2 * float(np.abs(h).max()))
+
+
+@pytest.mark.parametrize("ln,B", [([13, 512, 256, 128], 65536), ([479, 1024, 1024, 512, 256, 1], 4096), ([480, 1024, 512, 256], 2048), ([96, 64, 32], 512),
+                                  ([256, 320, 192, 64], 1000)])
+def test_bf16x6_planes_tower_equals_in_loop_split(ln, B):
+    """arith "bf16x6" with PLANES (functional.BF16X6_PLANES: activations / gradients / weights of the GEMM layers travel as three pre-split bf16
+    planes, hidden layers keep planes + sign bits only, weight gradients from the planes as stored) against the same tower with every GEMM
+    splitting its fp32 operands in its k-loop (the kernels of rounds 1-3): every forward and data-gradient product has the same six bf16
+    terms in the same order -> output and input gradient BIT-IDENTICAL; weight / bias gradients sum the same products in another slice
+    order -> fp32 round-off apart.  Towers: the two Terabyte towers (13 -> 16 first layer on the small-K kernel, a 128-wide and a 1-wide
+    layer on the fp32-storage kernels in between planes layers), widths the planes kernel refuses (N < 192), ragged batch."""
+    from dlrm_amd import functional, ops
+    from dlrm_amd.functional import MLPFunction
+    rng = np.random.default_rng(sum(ln) + B)
+    L = len(ln) - 1
+    params = []
+    for i in range(L):
+        params += [to_dev((rng.standard_normal((ln[i + 1], ln[i])) * np.sqrt(2 / (ln[i] + ln[i + 1]))).astype(np.float32)).requires_grad_(True),
+                   to_dev((rng.standard_normal(ln[i + 1]) * 0.1).astype(np.float32)).requires_grad_(True)]
+    acts = tuple([ops.ACT_RELU] * (L - 1) + [ops.ACT_SIGMOID if ln[-1] == 1 else ops.ACT_RELU])
+    x0 = to_dev(rng.random((B, ln[0])).astype(np.float32))
+    dy = to_dev(rng.standard_normal((B, ln[-1])).astype(np.float32))
+    results = []
+    saved = functional.BF16X6_PLANES, functional._PlaneStore.gemm
+    calls = [0]
+
+    def counting_gemm(*a, **k):
+        calls[0] += 1
+        return ops.gemm_bf16x6(*a, **k)
+    try:
+        functional._PlaneStore.gemm = staticmethod(counting_gemm)
+        for planes in (False, True):
+            functional.BF16X6_PLANES = planes
+            x = x0.clone().requires_grad_(True)
+            for p in params:
+                p.grad = None
+            y = MLPFunction.apply(x, acts, None, ops.arith_code("bf16x6"), *params)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            results.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in params]))
+    finally:
+        functional.BF16X6_PLANES, functional._PlaneStore.gemm = saved[0], staticmethod(saved[1])
+    eligible = sum(1 for i in range(L) if ln[i + 1] >= 192 and B >= 256)
+    assert (calls[0] > 0) == (eligible > 0), (calls, eligible)              # the planes kernels really ran (forward + data gradients)
+    (y0, dx0, g0), (y1, dx1, g1) = results
+    assert torch.equal(y0, y1), float((y0 - y1).abs().max())
+    assert torch.equal(dx0, dx1), float((dx0 - dx1).abs().max())
+    for k, (a, b) in enumerate(zip(g0, g1)):
+        scale = float(a.abs().max())
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=2e-6 * scale * max(1.0, np.sqrt(B / 256)), err_msg="param %d" % k)
+    # and against fp64: the fp32 round-off class
+    h = x0.double().cpu().numpy()
+    for i in range(L):
+        h = h @ params[2 * i].detach().double().cpu().numpy().T + params[2 * i + 1].detach().double().cpu().numpy()
+        h = 1 / (1 + np.exp(-h)) if acts[i] == ops.ACT_SIGMOID else np.maximum(h, 0)
+    np.testing.assert_allclose(y1.cpu().numpy(), h, rtol=1e-5, atol=1e-5 * float(np.abs(h).max()))
 
 
 @pytest.mark.parametrize("M,N,K0", [(5000, 512, 13), (300, 64, 479), (4096, 1024, 479), (33, 8, 5), (8192, 128, 14)])
