@@ -73,6 +73,24 @@ __device__ __forceinline__ void adagrad_apply(float* __restrict__ wrow, float* _
     if (lig == 0) *mom_r = m;
 }
 
+// Pass 1.  A lookup's gradient row is found through a chain of dependent loads — sorted key, sorted value (= lookup position), bag of
+// that position, row of dOut — and rounds 1-3 walked that chain once per ENTRY: 64 entries x 4 memory latencies per lane group, with one
+// 512-byte row in flight per group (1.85 TB/s for the 14 M lookups of the MLPerf-v2 batch: latency-bound, not HBM-bound; more rows per step
+// only lengthened the chains: DLRM_ADAGRAD_KC 1 / 2 / 4 = 5.28 / 5.55 / 5.8 ms).  Now the GROUP resolves all of its 64 entries at once: lane l
+// loads the keys and values of entries l, l + LPB, ... (coalesced), gathers their bags (and pooling weights) — two latencies for the whole
+// group — and the walk then takes (key, bag, weight) of entry j from lane j % LPB by a cross-lane read: the row loads depend on registers
+// only and kC of them are in flight per group.  Same entries, same order, same sums: results are bit-identical to the old walk.
+// Measured (round 4): emb_bwd_adagrad of the MLPerf-v2 batch 4.85 -> 3.62 ms, of the Terabyte batch 0.685 -> 0.56 ms.  (Also requesting the table
+// row and accumulator of a run when it STARTS, so that its end waits for nothing, changed nothing — 3.69-3.76 ms: the walk is at ~0.7 of the copy
+// rate on its real traffic by then, the rest of the category is the sort.)
+template <typename T> __device__ __forceinline__ T group_bcast(T v, int src_lane);
+template <> __device__ __forceinline__ unsigned group_bcast<unsigned>(unsigned v, int src_lane) { return (unsigned)__shfl((int)v, src_lane, 64); }
+template <> __device__ __forceinline__ unsigned long long group_bcast<unsigned long long>(unsigned long long v, int src_lane) {
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src_lane, 64), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src_lane, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <> __device__ __forceinline__ float group_bcast<float>(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+
 template <int VEC, int LPB, int NCH, typename KT, int kC>
 __global__ __launch_bounds__(256) void adagrad_groups_kernel(SortedArgs sa, AdagradArgs aa, long long L, int D, int row_bits,
                                                              const KT* __restrict__ keys, const unsigned* __restrict__ vals,
@@ -83,7 +101,22 @@ __global__ __launch_bounds__(256) void adagrad_groups_kernel(SortedArgs sa, Adag
     using VT = typename Vec<VEC>::T;
     constexpr int DP = NCH * LPB * VEC;                  // padded row length of the edge buffers
     constexpr int GPB = 256 / LPB;
+    constexpr int NS = kG / LPB;                         // entries a lane resolves for its group (LPB is a power of two <= 64)
+    static_assert(kG % LPB == 0 && LPB % kC == 0, "group geometry");
+    // per-table arguments are indexed by a lane-dependent table id: staged in LDS (a by-value kernel argument array indexed that way is
+    // copied to scratch memory by the compiler)
+    __shared__ long long s_w[DLRM_MAX_TABLES_PER_LAUNCH], s_state[DLRM_MAX_TABLES_PER_LAUNCH], s_psw[DLRM_MAX_TABLES_PER_LAUNCH],
+        s_base[DLRM_MAX_TABLES_PER_LAUNCH];
+    __shared__ int s_slot[DLRM_MAX_TABLES_PER_LAUNCH];
+#pragma unroll
+    for (int k = 0; k < DLRM_MAX_TABLES_PER_LAUNCH; ++k)
+        if (threadIdx.x == k) {
+            s_w[k] = (long long)sa.w[k]; s_state[k] = (long long)aa.state[k]; s_psw[k] = (long long)sa.psw[k]; s_base[k] = sa.base[k];
+            s_slot[k] = sa.slot[k];
+        }
+    __syncthreads();
     const int g = threadIdx.x / LPB, lig = threadIdx.x % LPB;
+    const int lane0 = (threadIdx.x & 63) & ~(LPB - 1);   // first lane of this group inside its wave
     const long long grp = (long long)blockIdx.x * GPB + g;
     const long long g0 = grp * kG;
     if (g0 >= L) return;
@@ -92,10 +125,35 @@ __global__ __launch_bounds__(256) void adagrad_groups_kernel(SortedArgs sa, Adag
     const bool cont_in = g0 > 0 && keys[g0 - 1] == keys[g0];
     const bool tail_cont = g0 + kG < L && keys[g0 + kG - 1] == keys[g0 + kG];
 
+    // ---- resolve: entry g0 + s * LPB + lig for s = 0 .. NS-1
+    KT e_key[NS];
+    unsigned e_bag[NS];
+    float e_sc[NS];                                      // pooling weight of the lookup; < 0 is never used as a marker: e_w says whether it applies
+    bool e_w[NS];
+    {
+        unsigned pos[NS];
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const long long e = g0 + s_ * LPB + lig;
+            const bool live = e < g_end;
+            e_key[s_] = live ? keys[e] : (KT)0;
+            pos[s_] = live ? vals[e] : 0u;
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const bool live = g0 + s_ * LPB + lig < g_end;
+            const int t = (int)(e_key[s_] >> row_bits);
+            e_bag[s_] = live ? bag_of[pos[s_]] : DLRM_DEAD_BAG;
+            const float* psw = (const float*)s_psw[t];
+            e_w[s_] = live && psw != nullptr;
+            e_sc[s_] = e_w[s_] ? psw[(long long)pos[s_] - s_base[t]] : 1.f;
+        }
+    }
+
     VT acc[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) v_zero(acc[c]);
-    KT run_key = keys[g0];
+    KT run_key = group_bcast<KT>(e_key[0], lane0);       // key of entry g0
     bool run_first = true, run_empty = true;
 
     auto finish = [&](bool is_last) {
@@ -108,48 +166,55 @@ __global__ __launch_bounds__(256) void adagrad_groups_kernel(SortedArgs sa, Adag
         } else {
             const int t = (int)(run_key >> row_bits);
             const long long row = (long long)(run_key & row_mask);
-            adagrad_apply<VEC, LPB, NCH>(sa.w[t] + row * D, aa.state[t] + row, D, lig, acc, clr, eps);
+            adagrad_apply<VEC, LPB, NCH>((float*)s_w[t] + row * D, (float*)s_state[t] + row, D, lig, acc, clr, eps);
         }
     };
 
-    for (long long c0 = g0; c0 < g_end; c0 += kC) {
-        KT k[kC];
-        VT gr[kC][NCH];
-        float sc[kC];
-        bool live[kC], weighted[kC];
 #pragma unroll
-        for (int j = 0; j < kC; ++j) {
-            live[j] = c0 + j < g_end;
-            k[j] = live[j] ? keys[c0 + j] : run_key;
-            const unsigned pos = live[j] ? vals[c0 + j] : 0u;
-            const int t = (int)(k[j] >> row_bits);
-            unsigned bag = live[j] ? bag_of[pos] : 0u;
-            const bool dead = bag == DLRM_DEAD_BAG;            // out-of-range lookup (expand_kernel): zero gradient
-            if (dead) bag = 0u;
-            const float* psw = sa.psw[t];
-            weighted[j] = live[j] && psw != nullptr && !dead;
-            sc[j] = weighted[j] ? psw[(long long)pos - sa.base[t]] : 1.f;
-            const float* grow = dout + (long long)bag * dout_ld + (long long)sa.slot[t] * D;
+    for (int s_ = 0; s_ < NS; ++s_) {
+        const long long s0 = g0 + s_ * LPB;
+        if (s0 >= g_end) break;
+        for (int j0 = 0; j0 < LPB; j0 += kC) {
+            if (s0 + j0 >= g_end) break;
+            KT k[kC];
+            VT gr[kC][NCH];
+            float sc[kC];
+            bool live[kC], weighted[kC];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int col = (c * LPB + lig) * VEC;
-                v_zero(gr[j][c]);
-                if (live[j] && !dead && col < D) gr[j][c] = *(const VT*)(grow + col);
-            }
-        }
+            for (int j = 0; j < kC; ++j) {
+                const int src = lane0 + j0 + j;
+                live[j] = s0 + j0 + j < g_end;
+                k[j] = group_bcast<KT>(e_key[s_], src);
+                unsigned bag = group_bcast<unsigned>(e_bag[s_], src);
+                sc[j] = group_bcast<float>(e_sc[s_], src);
+                const bool w_ = __shfl((int)e_w[s_], src, 64) != 0;
+                const int t = (int)(k[j] >> row_bits);
+                const bool dead = bag == DLRM_DEAD_BAG;            // out-of-range lookup (expand_kernel): zero gradient
+                if (dead) bag = 0u;
+                weighted[j] = live[j] && w_ && !dead;
+                const float* grow = dout + (long long)bag * dout_ld + (long long)s_slot[t] * D;
 #pragma unroll
-        for (int j = 0; j < kC; ++j) {
-            if (!live[j]) break;
-            if (k[j] != run_key) {
-                finish(false);
-                run_key = k[j]; run_first = false; run_empty = true;
+                for (int c = 0; c < NCH; ++c) {
+                    const int col = (c * LPB + lig) * VEC;
+                    v_zero(gr[j][c]);
+                    if (live[j] && !dead && col < D) gr[j][c] = *(const VT*)(grow + col);
+                }
             }
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const VT v = weighted[j] ? v_scale(sc[j], gr[j][c]) : gr[j][c];
-                acc[c] = run_empty ? v : v_add(acc[c], v);
+            for (int j = 0; j < kC; ++j) {
+                if (!live[j]) break;
+                if (k[j] != run_key) {
+                    finish(false);
+                    run_key = k[j]; run_first = false; run_empty = true;
+                }
+
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const VT v = weighted[j] ? v_scale(sc[j], gr[j][c]) : gr[j][c];
+                    acc[c] = run_empty ? v : v_add(acc[c], v);
+                }
+                run_empty = false;
             }
-            run_empty = false;
         }
     }
     finish(true);
@@ -258,10 +323,9 @@ static int run_adagrad(int n, const int* ids, int64_t B, int D, void* const* wei
     Shape s;
     rc = pick(D, vec_ok, &s);
     if (rc) return rc;
-    static int kc = -1;        // gradient rows requested together per lane group; env DLRM_ADAGRAD_KC = 1 (default) | 2 | 4.  Measured on one box:
-                               // 0.667 / 0.719 / 0.736 ms at Criteo-Terabyte shapes, 5.28 / 5.55 / 5.8 ms for the 214-lookup multi-hot batch —
-                               // the kernel wants waves, not deeper per-wave prefetch (a variant that also prefetched the table rows: 0.88 ms)
-    if (kc < 0) { const char* e = getenv("DLRM_ADAGRAD_KC"); kc = e ? atoi(e) : 1; }
+    static int kc = -1;        // gradient rows in flight per lane group (env DLRM_ADAGRAD_KC = 1 | 2 | 4 | 8, default 2: measured 3.62 / 3.68 / 3.98 ms for 2 / 4 / 8 on the MLPerf-v2 batch): with the group-level resolve the
+                               // rows depend on registers only, so more in flight is more bandwidth (before it, 1 was best: see the kernel's comment)
+    if (kc < 0) { const char* e = getenv("DLRM_ADAGRAD_KC"); kc = e ? atoi(e) : 2; }
     const size_t groups = (L + kG - 1) / kG;
     const int gpb = 256 / s.lpb;
     dim3 grid((unsigned)((groups + gpb - 1) / gpb), 1, 1), block(256);
@@ -270,6 +334,8 @@ static int run_adagrad(int n, const int* ids, int64_t B, int D, void* const* wei
         if (kc == 1) hipLaunchKernelGGL((adagrad_groups_kernel<V, LP, NC, KT, 1>), grid, block, 0, st, sa, aa, (long long)L, D, row_bits, keys, \
                            vals, bag_of, dout, (long long)dout_ld, clr, eps, ef, el);                                          \
         else if (kc == 2) hipLaunchKernelGGL((adagrad_groups_kernel<V, LP, NC, KT, 2>), grid, block, 0, st, sa, aa, (long long)L, D, row_bits, keys, \
+                           vals, bag_of, dout, (long long)dout_ld, clr, eps, ef, el);                                          \
+        else if (kc == 8) hipLaunchKernelGGL((adagrad_groups_kernel<V, LP, NC, KT, (LP >= 8 ? 8 : 4)>), grid, block, 0, st, sa, aa, (long long)L, D, row_bits, keys, \
                            vals, bag_of, dout, (long long)dout_ld, clr, eps, ef, el);                                          \
         else hipLaunchKernelGGL((adagrad_groups_kernel<V, LP, NC, KT, 4>), grid, block, 0, st, sa, aa, (long long)L, D, row_bits, keys, \
                            vals, bag_of, dout, (long long)dout_ld, clr, eps, ef, el);                                          \
