@@ -2,7 +2,7 @@
 # Round-4 build, evidence at HEAD after the fused lookup + interaction became the default forward / backward: the default bench line (both
 # baseline legs), rocprofv3 kernel statistics + step trace, the two PMC passes of the same command, the secondary workloads.
 # (The whole GPU suite runs separately: tools/gpu_r4_suite.sh.)
-OUT=gpurun_out/r4final
+OUT=gpurun_out/${1:-r4final}
 mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== smoke";  timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
@@ -34,6 +34,7 @@ find $OUT -name "p_counter_collection.csv" -size +8M -delete; find $OUT -name "*
 echo "== secondary workloads"
 timeout 300 python bench.py --steps 20 --warmup 5 $FLAGS --optimizer rwsadagrad > $OUT/bench_tb_rwsadagrad.json 2> /dev/null
 timeout 300 python bench.py --steps 20 --warmup 5 $FLAGS --mlp-arith bf16 > $OUT/bench_tb_bf16.json 2> /dev/null
+timeout 300 python bench.py --steps 20 --warmup 5 $FLAGS --mlp-arith bf16x6 > $OUT/bench_tb_bf16x6.json 2> /dev/null
 timeout 300 python bench.py --steps 20 --warmup 5 $FLAGS --graph > $OUT/bench_tb_graph.json 2> /dev/null
 timeout 300 python bench.py --workload criteo_kaggle --steps 300 --warmup 20 $FLAGS > $OUT/bench_kaggle_eager.json 2> /dev/null
 timeout 300 python bench.py --workload criteo_kaggle --steps 300 --warmup 20 $FLAGS --graph > $OUT/bench_kaggle_graph.json 2> /dev/null
@@ -41,7 +42,7 @@ timeout 400 python bench.py --workload mlperf_v2_multihot --interaction dot --st
 timeout 400 python bench.py --workload mlperf_v2_multihot --interaction dcn --steps 10 --warmup 3 > $OUT/bench_mlperf_v2_dcn.json 2> /dev/null
 python - <<PY
 import json
-for n in ("bench_tb_rwsadagrad","bench_tb_bf16","bench_tb_graph","bench_kaggle_eager","bench_kaggle_graph","bench_mlperf_v2_dot","bench_mlperf_v2_dcn"):
+for n in ("bench_tb_rwsadagrad","bench_tb_bf16","bench_tb_bf16x6","bench_tb_graph","bench_kaggle_eager","bench_kaggle_graph","bench_mlperf_v2_dot","bench_mlperf_v2_dcn"):
     try:
         d=json.load(open("$OUT/%s.json" % n)); p=d.get("parity_check") or {}
         print("%-28s ms %.3f  update=%s lookup=%s" % (n, d["ms_per_step"], d["config"]["embedding_update"][:20], d["config"].get("embedding_interaction", "")[:12]))
