@@ -172,6 +172,27 @@ def measure_box(device, quick=False):
     torch.cuda.synchronize(device)
     out["hbm_copy_gbps"] = 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del a, b
+    # 512-byte rows at random places of 16 GiB (the embedding kernels' access pattern: what page-table / channel effects do to a box shows
+    # here, not in the streaming probes)
+    tbytes = 16 << 30
+    t = torch.empty(tbytes, dtype=torch.uint8, device=device)
+    t.zero_()
+    nb = C.c_double(0.0)
+    rows = 1 << 23                                          # 4 GiB per launch
+    reps = 4 if quick else 12
+    total = 0.0
+    for r in range(reps + 1):
+        if r == 1:
+            torch.cuda.synchronize(device)
+            e0.record()
+        _lib.check(lib.dlrm_calib_hbm_gather(C.c_void_p(t.data_ptr()), tbytes, rows, 12345 + r, C.c_void_p(scratch.data_ptr()), C.byref(nb), st),
+                   "dlrm_calib_hbm_gather")
+        if r >= 1:
+            total += nb.value
+    e1.record()
+    torch.cuda.synchronize(device)
+    out["hbm_gather_gbps"] = total / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del t
     return out
 
 
@@ -180,8 +201,9 @@ def merge_box(b0, b1):
     box = {k: (0.5 * (b0[k] + b1[k]) if isinstance(b0[k], float) else b0[k]) for k in b0}
     box["before"] = {k: round(v, 2) for k, v in b0.items() if isinstance(v, float)}
     box["after"] = {k: round(v, 2) for k, v in b1.items() if isinstance(v, float)}
-    box["note"] = ("measured in this run by dlrm_calib_mfma / dlrm_calib_hbm_copy right before and right after the timed region "
-                   "(mean); frac_of_measured_peak is priced against these, frac against the spec peaks")
+    box["note"] = ("measured in this run by dlrm_calib_mfma / dlrm_calib_hbm_copy / dlrm_calib_hbm_gather right before and right after the timed "
+                   "region (mean); frac_of_measured_peak is priced against the MFMA and copy rates, frac against the spec peaks; hbm_gather_gbps = "
+                   "512-byte rows at random places of 16 GiB, the embedding kernels' access pattern (reported, not priced against)")
     return box
 
 

@@ -35,6 +35,7 @@ SIGNATURES = {
     "dlrm_hip_device_info": (_i32, [_i32, C.POINTER(_i32), C.POINTER(_i32), _pi64, C.c_char_p, _i32]),
     "dlrm_calib_mfma": (_i32, [_i32, _i32, _vp, C.POINTER(C.c_double), _vp]),
     "dlrm_calib_hbm_copy": (_i32, [_vp, _vp, _i64, _vp]),
+    "dlrm_calib_hbm_gather": (_i32, [_vp, _i64, _i64, C.c_uint32, _vp, _vp, _vp]),
     "dlrm_stream_create_cu_range": (_i32, [_i32, _i32, C.POINTER(C.c_void_p)]),
     "dlrm_stream_destroy": (_i32, [_vp]),
     "dlrm_emb_fwd": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64, _vp, _vp]),

@@ -3,7 +3,11 @@
 // regression.  Two probes, ~50 ms each, timed by the caller with HIP events on `stream`:
 //   dlrm_calib_mfma       back-to-back v_mfma_f32_32x32x2_f32 (kind 0) or v_mfma_f32_32x32x16_bf16 (kind 1) on every SIMD, no memory
 //                         traffic -> the matrix rate this chip sustains at its power budget (and the implied clock);
-//   dlrm_calib_hbm_copy   float4 copy src -> dst, one float4 per thread (the access pattern MI355X_MICROARCH.md quotes 6.29 TB/s for).
+//   dlrm_calib_hbm_copy   float4 copy src -> dst, one float4 per thread (the access pattern MI355X_MICROARCH.md quotes 6.29 TB/s for);
+//   dlrm_calib_hbm_gather 512-byte rows at pseudo-random places of a multi-GiB buffer, one row per half-wave, eight in flight — the access
+//                         pattern of the embedding kernels.  Added after a visit whose MFMA and copy probes read 156.6 TFLOP/s / 6.30 TB/s (the
+//                         fastest seen) while its embedding kernels ran 17-22 % and its GEMMs 3 % slower than on other boxes
+//                         (profiles/round4/box_classes.md): streaming probes do not see whatever separates those boxes.
 // Not on the training path; nothing here is called by the model.
 #include "common.h"
 
@@ -44,7 +48,35 @@ __global__ __launch_bounds__(256) void calib_copy_kernel(const float4* __restric
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) b[i] = a[i];
 }
+// one 512-byte row per half-wave and step, 8 independent rows in flight per half-wave; rows by a 64-bit mix of (half-wave, step)
+__global__ __launch_bounds__(256) void calib_gather_kernel(const float4* __restrict__ t, unsigned long long nrows, float* out, unsigned seed) {
+    const unsigned long long hw = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int l = threadIdx.x & 31;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        unsigned long long x = (hw * 8 + r) * 0x9E3779B97F4A7C15ull + seed;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        const float4 v = t[(x % nrows) * 32 + l];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (s.x + s.y + s.z + s.w == 123.456f) out[0] = s.x;      // never true for a zero-filled buffer: keeps the loads live
+}
 }  // namespace
+
+// reads `rows_to_read` (rounded down to a multiple of 64) pseudo-random 512-byte rows of table[0 .. table_bytes); *bytes_out = bytes read
+extern "C" int dlrm_calib_hbm_gather(const void* table, int64_t table_bytes, int64_t rows_to_read, uint32_t seed, float* scratch, double* bytes_out,
+                                     void* stream) {
+    if (!table || !scratch || !bytes_out || table_bytes < 512 || rows_to_read < 64) return DLRM_E_ARG;
+    if (!dlrm_aligned16(table)) return DLRM_E_ALIGN;
+    const unsigned long long nrows = (unsigned long long)(table_bytes / 512);
+    const long long blocks = rows_to_read / 64;                // 8 half-waves x 8 rows per block
+    if (blocks > 0x7fffffffll) return DLRM_E_RANGE;
+    hipLaunchKernelGGL(calib_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)table, nrows, scratch, seed);
+    DLRM_LAUNCH_CHECK();
+    *bytes_out = (double)blocks * 64.0 * 512.0;
+    return 0;
+}
 
 extern "C" int dlrm_calib_mfma(int kind, int iters, float* scratch, double* flop_out, void* stream) {
     if (iters <= 0 || !scratch || !flop_out || (kind != 0 && kind != 1)) return DLRM_E_ARG;

@@ -60,6 +60,9 @@ int         dlrm_hip_device_info(int device, int* cu_count, int* lds_bytes,
  *   dlrm_calib_hbm_copy: float4 copy (one float4 per thread) of `bytes` (multiple of 16) from src to dst; HBM rate = 2 * bytes / time. */
 int dlrm_calib_mfma(int kind, int iters, float* scratch, double* flop_out, void* stream);
 int dlrm_calib_hbm_copy(const void* src, void* dst, int64_t bytes, void* stream);
+/* 512-byte rows at pseudo-random places of table[0 .. table_bytes), one per half-wave, eight in flight: the embedding kernels' access pattern
+ * (bench.py's `box.hbm_gather_gbps`; zero-fill the buffer first).  *bytes_out = bytes read by the launch. */
+int dlrm_calib_hbm_gather(const void* table, int64_t table_bytes, int64_t rows_to_read, uint32_t seed, float* scratch, double* bytes_out, void* stream);
 /* CU-partitioned streams for composition experiments (tools/probes/cu_mask_probe.py; not used by the training path): a stream restricted to
  * CUs [first, first + count) of the current device (hipExtStreamCreateWithCUMask).  The caller destroys it. */
 int dlrm_stream_create_cu_range(int first, int count, void** stream_out);
