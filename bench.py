@@ -196,6 +196,40 @@ def measure_box(device, quick=False):
     return out
 
 
+def node_state():
+    """What the NODE looks like around the run (never fatal): the current shader clock of every GPU the driver exposes under /sys/class/drm
+    (the pool's nodes are shared: the other seven GPUs of a box may be running somebody else's job — `cards_at_high_clock` counts them,
+    including this process's own GPU once it is busy), and this GPU's identity / power state from rocm-smi.  Recorded because visits of
+    the same commit differ by 5 % (memory-bound kernels by 17-22 %) with all three calibration probes nominal (profiles/round4/box_classes.md):
+    whatever separates those visits is outside what a probe on this GPU sees, so the line at least says which GPU it ran on and how busy
+    its neighbours were."""
+    import glob
+    import re
+    import subprocess
+    out = {}
+    try:
+        clocks = []
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            cur = None
+            for line in open(f):
+                if "*" in line:
+                    m = re.search(r"(\d+)\s*Mhz", line, re.I)
+                    cur = int(m.group(1)) if m else None
+            clocks.append(cur)
+        out["sclk_mhz_all_cards"] = clocks
+        out["cards_at_high_clock"] = sum(1 for c in clocks if c and c >= 1500)
+    except Exception as e:                                   # noqa: BLE001 — diagnostics only
+        out["sysfs_error"] = repr(e)[:120]
+    try:
+        r = subprocess.run(["rocm-smi", "--showuniqueid", "--showmaxpower", "--showpower", "--showtemp", "--showclocks", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        cards = json.loads(r.stdout[r.stdout.index("{"):])
+        out["smi"] = {name: {k.strip().rstrip(":"): v for k, v in card.items()} for name, card in cards.items() if isinstance(card, dict)}
+    except Exception as e:                                   # noqa: BLE001
+        out["smi_error"] = repr(e)[:120]
+    return out
+
+
 def merge_box(b0, b1):
     """mean of the calibration before and after the timed region (+ the two readings, so drift inside a run is visible)"""
     box = {k: (0.5 * (b0[k] + b1[k]) if isinstance(b0[k], float) else b0[k]) for k in b0}
@@ -660,6 +694,7 @@ def main():
             torch.cuda.synchronize()
             watchdog(args.hang_timeout + 20 * (args.warmup + args.steps), "warm-up + timed region")
     box0 = measure_box(device) if not args.no_box_calibration else None
+    node0 = node_state() if (box0 is not None and int(os.environ.get("RANK", "0")) == 0) else None
     if box0 is not None:
         step(args.warmup)                # one more untimed step: the timed region starts from the step's own steady state, not the probe's
     if N > 1:
@@ -683,7 +718,10 @@ def main():
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
+    node1 = node_state() if node0 is not None else None       # (right after the timed region: this GPU still counts among the busy ones)
     box = merge_box(box0, measure_box(device)) if box0 is not None else None
+    if box is not None and node0 is not None:
+        box["node"] = {"before": node0, "after": node1}
     ms = dt / args.steps * 1e3
     value = B / (dt / args.steps)
     final_loss = float(loss.detach())

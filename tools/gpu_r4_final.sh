@@ -32,14 +32,14 @@ cd $GRAFT_REPO_ROOT
 python tools/pmc_fold.py $OUT
 find $OUT -name "p_counter_collection.csv" -size +8M -delete; find $OUT -name "*kernel_trace.csv" -size +8M -delete; find $OUT -name "*.db" -size +8M -delete
 echo "== secondary workloads"
+timeout 400 python bench.py --workload mlperf_v2_multihot --interaction dot --steps 10 --warmup 3 > $OUT/bench_mlperf_v2_dot.json 2> /dev/null
+timeout 400 python bench.py --workload mlperf_v2_multihot --interaction dcn --steps 10 --warmup 3 > $OUT/bench_mlperf_v2_dcn.json 2> /dev/null
 timeout 300 python bench.py --steps 20 --warmup 5 $FLAGS --optimizer rwsadagrad > $OUT/bench_tb_rwsadagrad.json 2> /dev/null
 timeout 300 python bench.py --steps 20 --warmup 5 $FLAGS --mlp-arith bf16 > $OUT/bench_tb_bf16.json 2> /dev/null
 timeout 300 python bench.py --steps 20 --warmup 5 $FLAGS --mlp-arith bf16x6 > $OUT/bench_tb_bf16x6.json 2> /dev/null
-timeout 300 python bench.py --steps 20 --warmup 5 $FLAGS --graph > $OUT/bench_tb_graph.json 2> /dev/null
-timeout 300 python bench.py --workload criteo_kaggle --steps 300 --warmup 20 $FLAGS > $OUT/bench_kaggle_eager.json 2> /dev/null
 timeout 300 python bench.py --workload criteo_kaggle --steps 300 --warmup 20 $FLAGS --graph > $OUT/bench_kaggle_graph.json 2> /dev/null
-timeout 400 python bench.py --workload mlperf_v2_multihot --interaction dot --steps 10 --warmup 3 > $OUT/bench_mlperf_v2_dot.json 2> /dev/null
-timeout 400 python bench.py --workload mlperf_v2_multihot --interaction dcn --steps 10 --warmup 3 > $OUT/bench_mlperf_v2_dcn.json 2> /dev/null
+timeout 300 python bench.py --workload criteo_kaggle --steps 300 --warmup 20 $FLAGS > $OUT/bench_kaggle_eager.json 2> /dev/null
+timeout 300 python bench.py --steps 20 --warmup 5 $FLAGS --graph > $OUT/bench_tb_graph.json 2> /dev/null
 python - <<PY
 import json
 for n in ("bench_tb_rwsadagrad","bench_tb_bf16","bench_tb_bf16x6","bench_tb_graph","bench_kaggle_eager","bench_kaggle_graph","bench_mlperf_v2_dot","bench_mlperf_v2_dcn"):
