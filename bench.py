@@ -148,7 +148,9 @@ def measure_box(device, quick=False):
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     out = {"cu_count": cus}
-    for kind, key, iters in ((0, "mfma_f32_tflops", 4000 if quick else 15000), (1, "mfma_bf16_tflops", 8000 if quick else 30000)):
+    # (kinds 2 / 3: the same probes on RANDOM operands — a GEMM's bit toggling, which is where GPUs of the pool differ: csrc/calib.hip)
+    for kind, key, iters in ((0, "mfma_f32_tflops", 4000 if quick else 15000), (1, "mfma_bf16_tflops", 8000 if quick else 30000),
+                             (2, "mfma_f32_random_tflops", 4000 if quick else 15000), (3, "mfma_bf16_random_tflops", 8000 if quick else 30000)):
         flop = C.c_double(0.0)
         _lib.check(lib.dlrm_calib_mfma(kind, 200, C.c_void_p(scratch.data_ptr()), C.byref(flop), st), "dlrm_calib_mfma")     # warm
         torch.cuda.synchronize(device)
@@ -236,7 +238,8 @@ def merge_box(b0, b1):
     box["before"] = {k: round(v, 2) for k, v in b0.items() if isinstance(v, float)}
     box["after"] = {k: round(v, 2) for k, v in b1.items() if isinstance(v, float)}
     box["note"] = ("measured in this run by dlrm_calib_mfma / dlrm_calib_hbm_copy / dlrm_calib_hbm_gather right before and right after the timed "
-                   "region (mean); frac_of_measured_peak is priced against the MFMA and copy rates, frac against the spec peaks; hbm_gather_gbps = "
+                   "region (mean); frac_of_measured_peak is priced against the constant-operand MFMA and copy rates, frac against the spec peaks; "
+                   "mfma_*_random_tflops = the MFMA probes on random operands (what the chip holds under a GEMM's bit toggling); hbm_gather_gbps = "
                    "512-byte rows at random places of 16 GiB, the embedding kernels' access pattern (reported, not priced against)")
     return box
 

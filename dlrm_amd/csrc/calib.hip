@@ -15,6 +15,49 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// RANDOM operands (kinds 2 / 3): eight different pseudo-random operand register sets per lane, rotated through the unrolled loop, so that
+// consecutive MFMAs multiply different bit patterns the way a GEMM's operand stream does.  Constant operands barely toggle the multiplier
+// array: a GPU that holds 2.4 GHz on kinds 0 / 1 may not hold it here — round 4 met a GPU whose constant-operand probes read the pool's best
+// (156.6 / 2472 TFLOP/s) while its bf16 GEMM step ran 26 % and its fp32 step 5 % slower than on other GPUs (profiles/round4/box_classes.md).
+__device__ __forceinline__ unsigned calib_mix(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+template <int KIND>
+__global__ __launch_bounds__(256) void calib_mfma_random_kernel(float* out, int iters, unsigned seed) {
+    floatx16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const unsigned tid = blockIdx.x * 256 + threadIdx.x;
+    float af[8], bf[8];
+    bf16x8 av[8], bv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        // values in (-1, 1), both signs: the accumulators do a bounded random walk
+        af[k] = (float)(int)(calib_mix(seed + tid * 16 + k) >> 8) * (1.f / 8388608.f) - 1.f;
+        bf[k] = (float)(int)(calib_mix(seed + tid * 16 + 8 + k) >> 8) * (1.f / 8388608.f) - 1.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            av[k][r] = (__bf16)((float)(int)(calib_mix(seed + (tid * 16 + k) * 8 + r) >> 8) * (1.f / 8388608.f) - 1.f);
+            bv[k][r] = (__bf16)((float)(int)(calib_mix(~seed + (tid * 16 + k) * 8 + r) >> 8) * (1.f / 8388608.f) - 1.f);
+        }
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (KIND == 0) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k], bf[(k + i) & 7], acc[i], 0, 0, 0);
+                else           acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[k], bv[(k + i) & 7], acc[i], 0, 0, 0);
+            }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 123.456f) out[0] = s;          // (practically) never true: keeps the accumulators live
+}
+
 template <int KIND>
 __global__ __launch_bounds__(256) void calib_mfma_kernel(float* out, int iters, float a, float b) {
     floatx16 acc[8];
@@ -79,16 +122,18 @@ extern "C" int dlrm_calib_hbm_gather(const void* table, int64_t table_bytes, int
 }
 
 extern "C" int dlrm_calib_mfma(int kind, int iters, float* scratch, double* flop_out, void* stream) {
-    if (iters <= 0 || !scratch || !flop_out || (kind != 0 && kind != 1)) return DLRM_E_ARG;
+    if (iters <= 0 || !scratch || !flop_out || kind < 0 || kind > 3) return DLRM_E_ARG;     // 0 fp32 / 1 bf16 on constant operands, 2 / 3 the same on random ones
     hipDeviceProp_t p;
     hipError_t e = hipGetDeviceProperties(&p, dlrm_current_device());
     if (e != hipSuccess) return (int)e;
     const int grid = p.multiProcessorCount * 2;                 // 2 waves per SIMD
-    if (kind == 0) hipLaunchKernelGGL(calib_mfma_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, scratch, iters, 1.0f, 2.0f);
-    else           hipLaunchKernelGGL(calib_mfma_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, scratch, iters, 1.0f, 2.0f);
+    if (kind == 0)      hipLaunchKernelGGL(calib_mfma_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, scratch, iters, 1.0f, 2.0f);
+    else if (kind == 1) hipLaunchKernelGGL(calib_mfma_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, scratch, iters, 1.0f, 2.0f);
+    else if (kind == 2) hipLaunchKernelGGL(calib_mfma_random_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, scratch, iters, 0x9e3779b9u);
+    else                hipLaunchKernelGGL(calib_mfma_random_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, scratch, iters, 0x9e3779b9u);
     DLRM_LAUNCH_CHECK();
     // per wave and iteration: 64 MFMAs of 32 x 32 x {2, 16} multiply-adds
-    *flop_out = (double)grid * 4.0 * iters * 64.0 * (2.0 * 32 * 32 * (kind == 0 ? 2 : 16));
+    *flop_out = (double)grid * 4.0 * iters * 64.0 * (2.0 * 32 * 32 * ((kind & 1) == 0 ? 2 : 16));
     return 0;
 }
 

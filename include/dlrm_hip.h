@@ -54,7 +54,8 @@ int         dlrm_hip_device_info(int device, int* cu_count, int* lds_bytes,
                                  int64_t* hbm_bytes, char* name, int name_len);
 
 /* In-run calibration of the box (bench.py `box`; not on the training path).  The caller times the launch with HIP events on `stream`.
- *   dlrm_calib_mfma:     kind 0 = v_mfma_f32_32x32x2_f32, kind 1 = v_mfma_f32_32x32x16_bf16, back to back on every SIMD, no memory traffic;
+ *   dlrm_calib_mfma:     kind 0 = v_mfma_f32_32x32x2_f32, kind 1 = v_mfma_f32_32x32x16_bf16, back to back on every SIMD, no memory traffic, CONSTANT
+ *                        operands; kinds 2 / 3 = the same instructions on eight rotating sets of pseudo-random operands (a GEMM's bit toggling);
  *                        *flop_out = FLOPs the launch executes (so rate = flop / time; implied clock = rate / (CUs * 256 [* 16] FLOP/clk)).
  *                        scratch: device float[1].  iters = 15000 is ~50 ms of fp32, ~3 ms of bf16 work on MI355X.
  *   dlrm_calib_hbm_copy: float4 copy (one float4 per thread) of `bytes` (multiple of 16) from src to dst; HBM rate = 2 * bytes / time. */
