@@ -28,6 +28,13 @@
 //     (fp32) / 8-byte (bf16) row segments; bias, activation, sign bits out (one 4-byte word per lane and 32 x 64 block), sign-bit mask in.
 // Preconditions (checked by the host; otherwise the caller keeps gemm3_kernel): K % 64 == 0, N % 4 == 0, N >= 192, M >= 256, 16-byte aligned
 // operand rows.  Rows / columns past the matrix edge are clamped to a valid address and never stored.
+//
+// The same kernel template carries two more forms:
+//   WG = true   the WEIGHT GRADIENT dW = dZ^T X from the stored bf16 operands (both k-strided: fragments by ds_read_b64_tr_b16, split-K slabs);
+//   PL = 3      arith "bf16x6": every operand is THREE bf16 planes of an fp32 tensor, six MFMAs per 16 k (dlrm_gemm_bf16x6,
+//               dlrm_linear_bwd_weight_bf16x6; K % 16 == 0) — see the comment at the kernel.
+// Measured context for every rate quoted against "the bf16 peak": on random operands the matrix pipe of this part holds 1.88 of its nominal
+// 2.46 PFLOP/s (bench.py box.mfma_bf16_random_tflops, profiles/round4/box_classes.md).
 #include "common.h"
 
 namespace {

@@ -393,3 +393,150 @@ def test_product_library_has_no_work_skipping_switches():
         assert name not in blob, name
     mk = open(os.path.join(_lib.CSRC, "Makefile")).read()
     assert "DLRM_TUNING" in mk and "TUNING" in mk
+
+
+@pytest.mark.parametrize("ln,B,arith", [([13, 512, 256, 128], 4096, "bf16x6"), ([479, 1024, 1024, 512, 256, 1], 4096, "bf16x6"),
+                                        ([480, 1024, 512, 256], 2048, "bf16x6"), ([96, 64, 32], 512, "bf16x6"), ([256, 320, 192, 64], 1000, "bf16x6"),
+                                        ([13, 512, 256, 128], 4096, "bf16"), ([479, 1024, 1024, 512, 256, 1], 4096, "bf16")])
+def test_mlp_storage_plan_hands_every_consumer_what_it_reads(monkeypatch, ln, B, arith):
+    """MLPFunction's storage plan (functional.py: which layer keeps fp32, which keeps only the reduced-width copy — bf16, or the three planes
+    of arith "bf16x6" — and which kernel form every forward / data-gradient / weight-gradient product takes) with the device operators
+    replaced by plain torch on the CPU: every operator asserts that the operands it is handed exist in the form it reads, and the tower's
+    output and all gradients must equal torch autograd's.  The kernels themselves are tested on the GPU; this is the HOST logic around
+    them — the towers of the Terabyte model (13 -> 16 padded first layer, a 128-wide and a 1-wide layer between reduced-width layers), a
+    tower the planes kernel refuses entirely, and a batch that is not a multiple of 64 (fp32 weight gradients beside planes)."""
+    from dlrm_amd import functional, ops
+    from dlrm_amd.functional import MLPFunction
+    masks = {}
+
+    def act(v, a):
+        return torch.relu(v) if a == ops.ACT_RELU else torch.sigmoid(v) if a == ops.ACT_SIGMOID else v
+
+    def linear_fwd(X, W, b, a, Y, arith_, relu_bits=None):
+        assert Y is not None and X is not None and X.dtype == torch.float32
+        y = act(X[:, :W.size(1)] @ W.t() + (b if b is not None else 0), a)
+        Y.copy_(y)
+        if relu_bits is not None:
+            masks[relu_bits.data_ptr()] = y > 0
+
+    def act_bwd(dY, Y, a, dZ, db):
+        dZ.copy_(dY * (Y > 0) if a == ops.ACT_RELU else dY * Y * (1 - Y) if a == ops.ACT_SIGMOID else dY)
+
+    def linear_bwd_weight(dZ, X, dW, db, accumulate=False, arith=None, **_):
+        assert dZ is not None and X is not None
+        dW.copy_((dZ.t() @ X)[:, :dW.size(1)])
+        if db is not None:
+            db.copy_(dZ.sum(0))
+
+    def linear_bwd_data(dZ, W, Xprev, mask_act, dprev, arith_, relu_bits=None):
+        assert dZ is not None
+        d = dZ @ W
+        if mask_act == ops.ACT_RELU:
+            d = d * (masks[relu_bits.data_ptr()] if relu_bits is not None else (Xprev > 0))
+        dprev.copy_(d[:, :dprev.size(1)])
+
+    def reduced(shape3):                       # stand-in for a reduced-width tensor: right shape / dtype, the fp32 values ride along
+        return torch.zeros(shape3, dtype=torch.bfloat16)
+
+    def cast_like(planes):
+        def cast(src, Npad=None, category=None):
+            M, N = src.shape
+            Npad = Npad or N
+            t = reduced((3, M, Npad) if planes else (M, Npad))
+            t.f32 = torch.zeros((M, Npad)); t.f32[:, :N] = src
+            return t
+        return cast
+
+    def cast_t_like(planes):
+        return lambda src, Rpad=None, category=None: cast_like(planes)(src.t().contiguous(), Rpad)
+
+    def gemm_like(planes):
+        def gemm(A, Bm, bias, a, Cf, Cr, relu_bits_out=None, relu_bits_in=None, category=None, **_):
+            assert A.dim() == (3 if planes else 2) and Bm.dim() == A.dim() and A.size(-1) == Bm.size(-1), (A.shape, Bm.shape)
+            if planes:
+                assert ops.gemm_bf16x6_ok(A.size(1), Bm.size(1), A.size(2)), (A.shape, Bm.shape)      # no other kernel reads planes
+            y = act(A.f32 @ Bm.f32.t() + (bias if bias is not None else 0), a)
+            if relu_bits_out is not None:
+                masks[relu_bits_out.data_ptr()] = y > 0
+            if relu_bits_in is not None:
+                y = y * masks[relu_bits_in.data_ptr()]
+            assert Cf is not None or Cr is not None
+            if Cf is not None:
+                Cf.copy_(y[:, :Cf.size(1)])
+            if Cr is not None:
+                assert tuple(Cr.shape[-2:]) == (A.size(-2), Bm.size(-2))
+                Cr.f32 = y
+        return gemm
+
+    def wgrad_like(dZr, Xr, dW, db, accumulate=False):
+        assert dZr.size(-2) == Xr.size(-2)
+        dW.copy_((dZr.f32.t() @ Xr.f32)[:, :dW.size(1)])
+        if db is not None:
+            db.copy_(dZr.f32.sum(0))
+
+    def pad_cols(src, Kp):
+        t = torch.zeros((src.size(0), Kp)); t[:, :src.size(1)] = src
+        return t
+
+    for name, fn in (("linear_fwd", linear_fwd), ("act_bwd", act_bwd), ("linear_bwd_weight", linear_bwd_weight), ("linear_bwd_data", linear_bwd_data),
+                     ("pad_cols", pad_cols)):
+        monkeypatch.setattr(ops, name, fn)
+    for store, planes in ((functional._PlaneStore, True), (functional._Bf16Store, False)):
+        monkeypatch.setattr(store, "cast", staticmethod(cast_like(planes)))
+        monkeypatch.setattr(store, "cast_t", staticmethod(cast_t_like(planes)))
+        monkeypatch.setattr(store, "gemm", staticmethod(gemm_like(planes)))
+        monkeypatch.setattr(store, "wgrad", staticmethod(wgrad_like))
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a: None)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+
+    rng = np.random.default_rng(0)
+    L = len(ln) - 1
+    params = []
+    for i in range(L):
+        params += [torch.tensor((rng.standard_normal((ln[i + 1], ln[i])) * np.sqrt(2 / (ln[i] + ln[i + 1]))).astype(np.float32), requires_grad=True),
+                   torch.tensor((rng.standard_normal(ln[i + 1]) * 0.1).astype(np.float32), requires_grad=True)]
+    acts = tuple([ops.ACT_RELU] * (L - 1) + [ops.ACT_SIGMOID if ln[-1] == 1 else ops.ACT_RELU])
+    x = torch.tensor(rng.random((B, ln[0])).astype(np.float32), requires_grad=True)
+    dy = torch.tensor(rng.standard_normal((B, ln[-1])).astype(np.float32))
+    y = MLPFunction.apply(x, acts, None, ops.arith_code(arith), *params)
+    y.backward(dy)
+    got = [y.detach(), x.grad] + [p.grad for p in params]
+    ps = [p.detach().clone().requires_grad_(True) for p in params]
+    xr = x.detach().clone().requires_grad_(True)
+    h = xr
+    for i in range(L):
+        h = act(h @ ps[2 * i].t() + ps[2 * i + 1], acts[i])
+    h.backward(dy)
+    ref = [h.detach(), xr.grad] + [p.grad for p in ps]
+    for k, (a, b) in enumerate(zip(got, ref)):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-3, atol=2e-3 * float(b.abs().max()), err_msg=str((ln, k)))
+
+
+def test_bench_node_state_never_raises_and_reads_the_sysfs_format(tmp_path, monkeypatch):
+    """bench.py's `box.node` diagnostics: on a machine without GPUs (here) it returns error notes instead of raising; the shader-clock parser
+    reads the `pp_dpm_sclk` format the GPU boxes expose (captured in profiles/round4/visit_slow_box/sysfs_clocks.txt)."""
+    import glob as _glob
+    import bench
+    out = bench.node_state()
+    assert isinstance(out, dict)
+    d = tmp_path / "card0" / "device"
+    d.mkdir(parents=True)
+    (d / "pp_dpm_sclk").write_text("0: 500Mhz\n1: 2393Mhz *\n2: 2400Mhz\n")
+    d2 = tmp_path / "card8" / "device"
+    d2.mkdir(parents=True)
+    (d2 / "pp_dpm_sclk").write_text("S: 94Mhz *\n0: 500Mhz\n1: 2400Mhz\n")
+    real = _glob.glob
+    monkeypatch.setattr(_glob, "glob", lambda pat: sorted(real(str(tmp_path / "card*" / "device" / "pp_dpm_sclk"))) if "pp_dpm_sclk" in pat else real(pat))
+    out = bench.node_state()
+    assert out["sclk_mhz_all_cards"] == [2393, 94] and out["cards_at_high_clock"] == 1
+
+
+def test_planes_kernel_preconditions_are_host_side():
+    """dlrm_gemm_bf16x6_supported answers without touching a GPU (the host mirror asks it for every layer of every tower)."""
+    from dlrm_amd import ops
+    assert ops.round_x6_k(479) == 480 and ops.round_x6_k(16) == 16 and ops.round_x6_k(13) == 16
+    assert ops.gemm_bf16x6_ok(65536, 1024, 480) and ops.gemm_bf16x6_ok(65536, 512, 16) and ops.gemm_bf16x6_ok(256, 192, 64)
+    assert not ops.gemm_bf16x6_ok(65536, 128, 256)          # N < 192
+    assert not ops.gemm_bf16x6_ok(128, 512, 256)            # M < 256
+    assert not ops.gemm_bf16x6_ok(65536, 512, 24)           # K % 16
+    assert not ops.gemm_bf16x6_ok(65536, 1, 256)
