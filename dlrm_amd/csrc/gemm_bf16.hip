@@ -56,7 +56,7 @@ struct BfArgs {
     unsigned* bits_out; const unsigned* bits_in; long long bits_nblk;
     int tiles_m, tiles_n;
     int wide16;                              // bf16-only output through 16-byte stores (set by the host when its preconditions hold)
-    int debug;                               // tuning build only (make TUNING=1, env DLRM_BF16_DEBUG): 1 no DMA in the k-loop, 2 fragments read once, 4 no MFMAs — WRONG results
+    int debug;                               // tuning build only (make TUNING=1, env DLRM_BF16_DEBUG): 1 no DMA in the k-loop, 2 fragments read once, 4 no MFMAs, 8 no epilogue — WRONG results
     // weight-gradient form (WG): the reduction runs over the ROWS of both operands (A = dZ [K, M], B = X [K, N], C = A^T B), split in
     // gridDim.z slices of kchunk rows; slice z stores its fp32 partial at C + z * c_split_stride and the row sums of A^T (the bias
     // gradient) at rowsum + z * M
@@ -381,6 +381,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
 #undef P_ISSUE
     if (wr == 0) __builtin_amdgcn_s_barrier();          // the first half waits for the second: the tile buffers become epilogue staging
     __builtin_amdgcn_s_barrier();
+#ifdef DLRM_TUNING
+    if (P_DBG & 8) {                                    // timing only: NO epilogue (what prologue + k-loop cost without the band staging and the stores)
+        float s_ = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_ += acc[i][j][r];
+        if (s_ == 123.456f && g.C) g.C[0] = s_;         // keeps the accumulators live
+        return;
+    }
+#endif
 
     if constexpr (WG) {
         if (do_rowsum) {
@@ -576,7 +589,7 @@ int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t ld
     static int wide = -1;               // tuning aid: DLRM_BF16_WIDE_STORE=0 keeps the 8-byte bf16 stores
     if (wide < 0) { const char* e = getenv("DLRM_BF16_WIDE_STORE"); wide = e ? atoi(e) : 1; }
 #ifdef DLRM_TUNING
-    { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 7); g.debug = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 15); g.debug = dbg; }
 #endif
     g.wide16 = (wide && Cb && !C && !addend && N % 8 == 0 && ldcb % 8 == 0 && dlrm_aligned16(Cb) && (!bias || dlrm_aligned16(bias))) ? 1 : 0;
     static bool attr_done[DLRM_MAX_DEVICES] = {};
@@ -609,7 +622,7 @@ int dlrm_gemm_bf16x6_phased(int64_t M, int N, int K, const uint16_t* A, int64_t 
     g.bits_out = (unsigned*)relu_bits_out; g.bits_in = (const unsigned*)relu_bits_in; g.bits_nblk = ((long long)N + 63) / 64;
     g.tiles_m = (int)((M + PBM - 1) / PBM); g.tiles_n = (int)((N + PBN - 1) / PBN);
 #ifdef DLRM_TUNING
-    { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 7); g.debug = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 15); g.debug = dbg; }
 #endif
     g.wide16 = (Cp && !C && N % 8 == 0 && ldcp % 8 == 0 && planeC % 8 == 0 && dlrm_aligned16(Cp)) ? 1 : 0;
     static bool attr_done[DLRM_MAX_DEVICES] = {};
