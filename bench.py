@@ -367,7 +367,7 @@ def parity_check(args, device):
         reduced = None
         if args.mlp_arith == "bf16":
             # bf16 operand rounding is an opt-in arithmetic, not the north_star fp32 path: the fp32 run below stays the parity claim for this
-            # configuration; the bf16 run itself is held to its own stated bar on the loss (measured: <= 2e-4; predictions differ by ~5e-4)
+            # configuration; the bf16 run itself is held to its own stated bar on the loss (1e-3; its predictions were measured ~5e-4 relative off the reference's)
             rel16 = golden_tb.run_on_gpu(device, arith="bf16", mode=mode, check=False, overlap=bool(args.overlap) and not args.no_overlap,
                                          fuse=bool(args.fuse), name=args.parity_fixture)
             reduced = {"mlp_arith": "bf16", "rel_err_per_step": rel16, "bar": 1e-3, "pass": bool(max(rel16) <= 1e-3),
