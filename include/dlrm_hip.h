@@ -218,7 +218,8 @@ int dlrm_interact_bwd_gather(int64_t B, int F, int D, const void* const* feat_ho
  *   DLRM_ARITH_F32    v_mfma_f32_32x32x2_f32: every product and sum in fp32 (157 TFLOP/s matrix peak).
  *   DLRM_ARITH_BF16X6 fp32 operands split EXACTLY into three bf16 terms inside the kernel (x = h + m + l), the six
  *                     products of order >= 2^-16 issued on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; dropped
- *                     terms total <= 2^-23 |a*b| (one fp32 rounding).  Inputs, outputs and accumulators stay fp32.
+ *                     terms total <= 2^-21 |a*b| in the worst case and 2^-24 |a*b| rms — the rms of ONE fp32 rounding (oracle/oracle.py product_bf16x6,
+ *                     tests/test_oracle_golden.py).  Inputs, outputs and accumulators stay fp32.
  * Only operands that meet the fast-path preconditions (16-byte alignment, k % 16 == 0) use BF16X6; others run F32. */
 #define DLRM_ARITH_F32    0
 #define DLRM_ARITH_BF16X6 1

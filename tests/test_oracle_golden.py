@@ -409,3 +409,26 @@ def test_mlperf_v2_fixture_agrees_with_the_numpy_oracle_at_step_0():
         o += B * h
     logits = ref.forward(X[:n], off, idx)
     np.testing.assert_allclose(logits.reshape(-1), z["s0.logits"][:n], rtol=2e-5, atol=2e-6)
+
+
+def test_bf16x6_split_is_exact_and_the_dropped_terms_are_one_fp32_rounding():
+    """The arithmetic claim behind `--mlp-arith bf16x6` (include/dlrm_hip.h): an fp32 value IS the sum of its three truncation planes, each
+    plane is a bfloat16 value, and the six products the kernels keep miss the exact product by at most 2^-21 of its magnitude (m.l + l.m:
+    2 x 2^-7 x 2^-15) and by 2^-24 rms — the rms of one fp32 rounding of the product — over 30 binary orders of magnitude, both signs, zero."""
+    rng = np.random.default_rng(7)
+    a = (rng.standard_normal(200000) * np.exp(rng.standard_normal(200000) * 8)).astype(np.float32)
+    b = (rng.standard_normal(200000) * np.exp(rng.standard_normal(200000) * 8)).astype(np.float32)
+    a[:3] = [0.0, -1.00390625, 3.0e-30]
+    for x in (a, b):
+        h, m, l = O.split_bf16x3(x)
+        assert np.array_equal((h.astype(np.float64) + m.astype(np.float64)) + l.astype(np.float64), x.astype(np.float64))
+        assert np.array_equal((h + m) + l, x)                                   # also in fp32, in this order
+        for p in (h, m, l):
+            assert not (p.view(np.uint32) & np.uint32(0xffff)).any()            # bfloat16 values
+    kept, dropped = O.product_bf16x6(a, b)
+    exact = a.astype(np.float64) * b.astype(np.float64)
+    assert np.array_equal(kept + dropped, exact)
+    nz = exact != 0
+    ratio = np.abs(dropped[nz]) / np.abs(exact[nz])
+    assert ratio.max() <= 2.0 ** -21 * 1.01
+    assert np.sqrt(np.mean(ratio ** 2)) <= 2.0 ** -23.5
