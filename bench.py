@@ -177,7 +177,11 @@ def measure_box(device, quick=False):
     # 512-byte rows at random places of 16 GiB (the embedding kernels' access pattern: what page-table / channel effects do to a box shows
     # here, not in the streaming probes)
     tbytes = 16 << 30
-    t = torch.empty(tbytes, dtype=torch.uint8, device=device)
+    try:
+        t = torch.empty(tbytes, dtype=torch.uint8, device=device)
+    except Exception as e:                                  # noqa: BLE001 — (a configuration that fills the HBM: the other probes stand)
+        out["hbm_gather_error"] = repr(e)[:120]
+        return out
     t.zero_()
     nb = C.c_double(0.0)
     rows = 1 << 23                                          # 4 GiB per launch
@@ -196,6 +200,19 @@ def measure_box(device, quick=False):
     out["hbm_gather_gbps"] = total / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del t
     return out
+
+
+def measure_box_or_none(device):
+    """the calibration must never cost a run its headline: any failure is reported on stderr and the line goes out without `box`"""
+    try:
+        return measure_box(device)
+    except Exception as e:                                   # noqa: BLE001
+        sys.stderr.write("bench.py: box calibration failed (%r): continuing without it\n" % (e,))
+        try:
+            torch.cuda.empty_cache()
+        except Exception:                                    # noqa: BLE001
+            pass
+        return None
 
 
 def node_state():
@@ -234,7 +251,9 @@ def node_state():
 
 def merge_box(b0, b1):
     """mean of the calibration before and after the timed region (+ the two readings, so drift inside a run is visible)"""
-    box = {k: (0.5 * (b0[k] + b1[k]) if isinstance(b0[k], float) else b0[k]) for k in b0}
+    box = {k: (0.5 * (b0[k] + b1[k]) if (isinstance(b0[k], float) and isinstance(b1.get(k), float)) else b0[k]) for k in b0}
+    for k in b1:
+        box.setdefault(k, b1[k])
     box["before"] = {k: round(v, 2) for k, v in b0.items() if isinstance(v, float)}
     box["after"] = {k: round(v, 2) for k, v in b1.items() if isinstance(v, float)}
     box["note"] = ("measured in this run by dlrm_calib_mfma / dlrm_calib_hbm_copy / dlrm_calib_hbm_gather right before and right after the timed "
@@ -696,9 +715,9 @@ def main():
         if i == 0 and N > 1:
             torch.cuda.synchronize()
             watchdog(args.hang_timeout + 20 * (args.warmup + args.steps), "warm-up + timed region")
-    box0 = measure_box(device) if not args.no_box_calibration else None
+    box0 = measure_box_or_none(device) if not args.no_box_calibration else None
     node0 = node_state() if (box0 is not None and int(os.environ.get("RANK", "0")) == 0) else None
-    if box0 is not None:
+    if not args.no_box_calibration:      # (every rank, whether or not ITS probes succeeded: the step contains collectives)
         step(args.warmup)                # one more untimed step: the timed region starts from the step's own steady state, not the probe's
     if N > 1:
         torch.distributed.barrier()
@@ -722,7 +741,8 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     node1 = node_state() if node0 is not None else None       # (right after the timed region: this GPU still counts among the busy ones)
-    box = merge_box(box0, measure_box(device)) if box0 is not None else None
+    box1 = measure_box_or_none(device) if box0 is not None else None
+    box = merge_box(box0, box1) if (box0 is not None and box1 is not None) else None
     if box is not None and node0 is not None:
         box["node"] = {"before": node0, "after": node1}
     ms = dt / args.steps * 1e3
