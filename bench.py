@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--overlap", action="store_true",
                     help="headline on two HIP streams: the HBM-bound embedding kernels (pooled lookups; fused sparse update) beside the "
                          "MFMA-bound bottom-MLP GEMMs they do not depend on (DLRM_Net.overlap_streams).  Default: single stream — the "
-                         "gain is 0.2-1.7 % (profiles/r03/ceilings.md) and overlapped kernels stretch each other's event times, which "
+                         "gain is 0.2-1.7 %% (profiles/r03/ceilings.md) and overlapped kernels stretch each other's event times, which "
                          "would blur the per-kernel roofline; the 2-stream schedule is measured in the same run as alt_stream_overlap")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-alt-overlap", action="store_true", help="do not also measure the 2-stream schedule (profiling runs: keeps the "

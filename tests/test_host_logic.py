@@ -556,3 +556,11 @@ def test_bench_calibration_failures_do_not_cost_the_headline(monkeypatch, capsys
     box = bench.merge_box(b0, b1)
     assert box["mfma_f32_tflops"] == 157.0 and box["hbm_copy_gbps"] == 6250.0 and box["hbm_gather_gbps"] == 6100.0
     assert box["hbm_gather_error"] == "OOM" and box["before"]["hbm_gather_gbps"] == 6100.0 and "hbm_gather_gbps" not in box["after"]
+
+
+def test_bench_help_renders():
+    """`python bench.py --help` (argparse expands %-formats in help strings: a bare "1.7 % (" in one of them made --help raise for two rounds)"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--mlp-arith" in r.stdout, r.stderr[-500:]
