@@ -79,6 +79,19 @@ def parse():
                          "gain is 0.2-1.7 %% (profiles/r03/ceilings.md) and overlapped kernels stretch each other's event times, which "
                          "would blur the per-kernel roofline; the 2-stream schedule is measured in the same run as alt_stream_overlap")
     ap.add_argument("--no-overlap", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--alts", action="store_true",
+                    help="also measure the alternative schedules beside the headline (bf16x6 arithmetic, two-kernel lookups, 2 HIP streams; "
+                         "N > 1: the other all-to-all schedule and the other dense-gradient all-reduce).  Off by default: the default run is "
+                         "the headline + roofline + cpu_baseline only")
+    ap.add_argument("--offsets", default="fresh", choices=["fresh", "tagged", "resident"],
+                    help="what the timed steps receive as bag offsets.  fresh (default): a NEW untagged offsets tensor object every step, as the "
+                         "reference loop's loader + dlrm_wrap deliver (dlrm_s_pytorch.py:129-145,1541-1548) — the fused lookup path then "
+                         "proves one-lookup-per-bag on the device with a stream synchronisation INSIDE the timed region, every step; tagged: "
+                         "new tensor objects carrying the producer's proof (dlrm_amd.datagen / CriteoBinBatches tag what their kernels "
+                         "wrote: no device pass, no synchronisation); resident: four batches reused (their proof is cached after warm-up)")
+    ap.add_argument("--no-high-row-check", action="store_true", help="skip the top-eighth-of-every-table check of the embedding kernels after the timed region")
+    ap.add_argument("--no-standalone-emb", action="store_true", help="skip the stand-alone dlrm_emb_fwd measurement (profiling runs)")
+    ap.add_argument("--no-rccl-selfcheck", action="store_true", help="skip the one-rank RCCL self-check child process (N = 1)")
     ap.add_argument("--no-alt-overlap", action="store_true", help="do not also measure the 2-stream schedule (profiling runs: keeps the "
                                                                     "rocprofv3 / PMC statistics to the single-stream headline steps)")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false", default=True,
@@ -282,9 +295,12 @@ def make_batches(n, B, rows, device, seed, hot=None, local_rows=None):
         mh = Multihot(hot, rows, B, dist_type="uniform", device=device, seed=0)
     out = []
     for k in range(n):
+        if mh is None:
+            out.append(gen.batch(B, batch_no=k, stacked=True))            # [T, B] offsets / indices; offsets tagged by their producer
+            continue
         X, lS_o, lS_i, T = gen.batch(B, batch_no=k)
         if mh is None:
-            out.append((X, torch.stack(lS_o), torch.stack(lS_i), T))
+            pass
         elif local_rows is not None:
             ids = torch.stack(lS_i)[:, local_rows].contiguous()
             mh.expand(ids, want_global_offsets=False)                     # warm
@@ -448,6 +464,85 @@ KERNEL_SOURCES = {
     "linear_fwd": ["gemm.hip", "gemv.hip", "common.h"], "linear_bwd_data": ["gemm.hip", "gemv.hip", "common.h"],
     "linear_bwd_weight": ["gemm.hip", "gemv.hip", "smallk.hip", "common.h"],
 }
+
+
+def high_row_check(model, D, device, B=4096, seed=99):
+    """The headline's embedding kernels on the benchmark's OWN tables at their full size, lookups drawn from the TOP EIGHTH of every table
+    (byte offsets of up to 20 GB from a table base; tools/visualize.py:1195-1223 sizes): dlrm_emb_fwd and the fused lookup + interaction
+    kernels against torch's index_select + the plain interaction kernels (bit-identical), and the sorted fused SGD update on distinct
+    rows against w - lr*g computed by torch on the gathered rows (exact for lr = 0.5), the touched rows restored afterwards.  Runs
+    after the timed region; tests/test_gpu_bigtables.py is the thorough version (closed-form tables, whole-table comparison)."""
+    from dlrm_amd import ops
+    Ws = [e.weight.detach() for e in model.emb_l]
+    T = len(Ws)
+    g_ = torch.Generator(device="cpu").manual_seed(seed)
+    idx = []
+    for W in Ws:
+        n = W.size(0)
+        span = max(n // 8, 1)
+        if span >= B:                                  # distinct rows of the top eighth, the last row included
+            r = n - 1 - torch.randperm(span, generator=g_)[:B]
+        else:
+            r = n - 1 - torch.randint(0, span, (B,), generator=g_)
+        idx.append(r.to(torch.int64))
+    I = torch.stack(idx).to(device)
+    Ofs = torch.arange(B, device=device).repeat(T, 1)
+    bags = ops.BagBatch(Ofs, I)
+    F = T + 1
+    x = torch.randn((B, D), device=device)
+    feat = torch.empty((B, F * D), device=device)
+    feat[:, :D] = x
+    for t in range(T):
+        feat[:, (1 + t) * D:(2 + t) * D] = Ws[t].index_select(0, I[t])
+    pooled = torch.empty((B, T * D), device=device)
+    ops.emb_fwd(Ws, bags, pooled)
+    out = {"rows": "top eighth of each of the %d full-size tables (max row %d), %d lookups per table" % (T, max(w.size(0) for w in Ws) - 1, B),
+           "emb_fwd": bool(torch.equal(pooled, feat[:, D:]))}
+    ldr = (ops.interact_out_width(F, D, False) + 3) & ~3
+    R0, R1 = torch.empty((B, ldr), device=device), torch.empty((B, ldr), device=device)
+    ops.interact_fwd([feat[:, :D], feat[:, D:]], D, False, R0)
+    ops.interact_fwd_gather(x, Ws, bags, D, False, R1)
+    out["fused_lookup_interaction_fwd"] = bool(torch.equal(R0, R1))
+    dR = torch.randn((B, ldr), device=device)
+    d0 = torch.empty((B, F * D), device=device)
+    ops.interact_bwd([feat[:, :D], feat[:, D:]], D, False, dR, [d0[:, :D], d0[:, D:]])
+    dx, dE = torch.empty((B, D), device=device), torch.empty((B, T * D), device=device)
+    ops.interact_bwd_gather(x, Ws, bags, D, False, dR, dx, dE)
+    out["fused_lookup_interaction_bwd"] = bool(torch.equal(d0[:, :D], dx) and torch.equal(d0[:, D:], dE))
+    big = [t for t in range(T) if Ws[t].size(0) // 8 >= B]                  # tables whose drawn rows are distinct
+    before = {t: Ws[t].index_select(0, I[t]) for t in big}
+    gsel = torch.randn((B, len(big) * D), device=device)
+    ops.emb_bwd_sgd([Ws[t] for t in big], ops.BagBatch(Ofs[:len(big)], torch.stack([I[t] for t in big])), gsel, 0.5, ops.UPD_SORTED)
+    ok = True
+    for j, t in enumerate(big):
+        ok = ok and bool(torch.equal(Ws[t].index_select(0, I[t]), before[t] - 0.5 * gsel[:, j * D:(j + 1) * D]))
+        Ws[t].index_copy_(0, I[t], before[t])                               # the tables leave as they came
+    out["sorted_sgd_update"] = ok
+    ops.check_index_errors(sync=True)
+    out["ok"] = bool(out["emb_fwd"] and out["fused_lookup_interaction_fwd"] and out["fused_lookup_interaction_bwd"] and ok)
+    return out
+
+
+def rccl_selfcheck(timeout=300):
+    """`python -m dlrm_amd.selfcheck` in a child process: a one-rank RCCL group forced through the distributed code path, compared with
+    the single-process steps (see that module).  A child, so that nothing RCCL does can hold up or break the headline line."""
+    import socket
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    env["MASTER_PORT"], env["MASTER_ADDR"] = str(sk.getsockname()[1]), "127.0.0.1"
+    sk.close()
+    try:
+        r = subprocess.run([sys.executable, "-m", "dlrm_amd.selfcheck"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if lines:
+            return json.loads(lines[-1])
+        return {"ok": False, "error": "no JSON line (exit code %d): %s" % (r.returncode, r.stderr[-400:])}
+    except subprocess.TimeoutExpired:
+        return {"ok": False, "error": "timed out after %d s" % timeout}
+    except Exception as e:                                  # noqa: BLE001 - a report, never allowed to break the headline line
+        return {"ok": False, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
 
 def source_hashes():
@@ -649,11 +744,23 @@ def main():
                                           local_rows=ext_dist.get_my_slice(B) if sharded else None)
     else:
         batches = make_batches(4, B, rows, device, seed=727)     # every rank reads the whole global batch (reference :1541)
-        if N == 1:
-            # the fused lookup + interaction path proves "one lookup per bag" once per offsets tensor (one device pass + one stream
-            # synchronisation, ops.offsets_are_iota): paid here for the four resident batches, whatever --warmup is
-            for b_ in batches:
-                ops.offsets_are_iota(b_[1])
+    # ---- what the steps receive as bag offsets (--offsets).  The fused lookup + interaction path is only valid for one lookup per bag
+    # and proves it per offsets tensor OBJECT (ops.offsets_are_iota).  The reference loop hands the module a brand-new tensor every
+    # iteration (loader -> dlrm_wrap's .to(device), dlrm_s_pytorch.py:129-145), so the default here does the same: every step gets a
+    # fresh, untagged copy made BEFORE the timed region (input production is outside the reference's timed region too) and pays the
+    # device pass + stream synchronisation of the proof INSIDE it.
+    fresh_off = None
+    if N == 1 and not hot and args.offsets != "resident":
+        n_fresh = args.warmup + args.steps + 2
+        if n_fresh * batches[0][1].numel() * batches[0][1].element_size() > (8 << 30):
+            sys.exit("ERROR: --offsets %s with %d steps needs more than 8 GiB of offsets copies; use --offsets resident" % (args.offsets, n_fresh))
+        fresh_off = []
+        for i in range(n_fresh):
+            o_ = batches[i % len(batches)][1].clone()             # a new tensor object: no cached verdict, no tag
+            if args.offsets == "tagged":
+                ops.mark_one_lookup_per_bag(o_)                    # (a copy of rows dlrm_amd.datagen wrote as 0..B-1: the producer's proof)
+            fresh_off.append(o_)
+        torch.cuda.synchronize()
     my_rows = ext_dist.get_my_slice(B) if N > 1 else slice(0, B)
     if sharded:
         local_tables = list(model.tw_mine)           # + a 1/N row range of every row-wise table (accounted below)
@@ -664,6 +771,8 @@ def main():
 
     def eager_step(i):
         X, off, idx, T = batches[i % len(batches)]
+        if fresh_off is not None and i < len(fresh_off):
+            off = fresh_off[i]
         if sharded:                                   # (X, values, None, T): this rank's samples only
             Z = model(X, off)
             E = model.loss_fn(Z, T)
@@ -687,6 +796,8 @@ def main():
         if graphed is None:
             return eager_step(i)
         X, off, idx, T = batches[i % len(batches)]
+        if fresh_off is not None and i < len(fresh_off):
+            off = fresh_off[i]
         return graphed(X, off, idx, T)
 
     dist_info = None
@@ -723,17 +834,19 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     ops.timers = None if args.no_kernel_timers else ops.KernelTimers()
+    iota0 = dict(ops.IOTA_STATS)
     t0 = time.perf_counter()
     timed_steps = 0
     for i in range(args.steps):
         if ops.timers is not None:
             ops.timers.enabled = (i % max(args.timer_every, 1) == 0)
             timed_steps += int(ops.timers.enabled)
-        loss = step(args.warmup + i)
+        loss = step(args.warmup + 1 + i)          # (index args.warmup was the extra untimed step above: every timed step sees a NEW offsets object)
     torch.cuda.synchronize()
     if N > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    iota = {k: ops.IOTA_STATS[k] - iota0[k] for k in iota0}
     ksum = ops.timers.summary() if ops.timers is not None else {}
     ops.timers = None
     if N > 1:
@@ -808,6 +921,20 @@ def main():
         if name in ksum:
             kernels[name] = {"ms_per_step": ksum[name]["total_ms"] / max(timed_steps, 1),
                              "launches_per_step": ksum[name]["calls"] / max(timed_steps, 1)}
+    # ---- counter-byte rates beside the algorithmic ones (SURVEY 8d "report both"): HBM bytes per call from the committed
+    # rocprofv3 PMC passes of this workload x the calls of one step / the category's measured time.  For the embedding categories the
+    # algorithmic figure counts bytes the caches serve (small tables, duplicate rows), so `achieved` can exceed what the HBM interface
+    # moved: `traffic_gbps` is the rate the memory system really sustained and `frac_traffic` prices THAT against the 8 TB/s peak.
+    # Nothing is capped: an algorithmic frac_of_measured_peak above 1 means cache hits, and the traffic columns show it.
+    pmc = load_pmc_traffic() if (N == 1 and args.workload == "criteo_terabyte" and not args.batch and not args.row_cap) else None
+    for name, k in kernels.items():
+        t = pmc["kernels"].get(name) if pmc else None
+        if t and not t.get("stale") and t.get("traffic_bytes") and "ms_per_step" in k:
+            per_step = t["traffic_bytes"] * t.get("calls_per_step", 1)
+            k["traffic_bytes_per_step"] = per_step
+            k["traffic_gbps"] = per_step / (k["ms_per_step"] * 1e-3) / 1e9
+            k["frac_traffic"] = k["traffic_gbps"] / HBM_PEAK_GBS
+            k["frac_traffic_of_measured_peak"] = k["traffic_gbps"] / hbm_measured
     heavy = [n for n in kernels if "achieved" in kernels[n]]
     dom = max(heavy, key=lambda n: kernels[n]["ms_per_step"]) if heavy else None
     kname = {"linear_fwd": "gemm3_kernel<KC,KC> (Y = X*W^T + bias, act; LDS-DMA ring, 256x128x16 tiles)",
@@ -818,7 +945,6 @@ def main():
              "interact_fwd": "interact_fwd_dma_kernel", "interact_bwd": "interact_bwd_dma_kernel",
              "emb_interact_fwd": "interact_fwd_dma_kernel<gather>: one-hot embedding lookups fetched by the interaction kernel (K1 + K6 fused)",
              "emb_interact_bwd": "interact_bwd_dma_kernel<gather>"}
-    pmc = load_pmc_traffic() if (N == 1 and args.workload == "criteo_terabyte" and not args.batch and not args.row_cap) else None
     if hot:
         result_extra = {"multihot": {"lookups_per_sample": L, "index_dtype": "int32", "lookup_table_bytes": int(sum(4 * r * h for r, h in zip(rows, hot))),
                                      "expand_ms_per_batch": sum(expand_ms) / len(expand_ms),
@@ -860,7 +986,9 @@ def main():
         # the whole per-category table travels INSIDE `roofline` (the driver's record keeps this object): [ms per step, frac of the
         # spec peak, frac of this box's measured peak]; categories without an algorithmic-work figure carry None fractions
         by_cat = {c: [round(v["ms_per_step"], 4), round(v["frac"], 4) if "frac" in v else None,
-                      round(v["frac_of_measured_peak"], 4) if "frac_of_measured_peak" in v else None] for c, v in kernels.items()}
+                      round(v["frac_of_measured_peak"], 4) if "frac_of_measured_peak" in v else None,
+                      round(v["traffic_gbps"], 1) if "traffic_gbps" in v else None,
+                      round(v["frac_traffic"], 4) if "frac_traffic" in v else None] for c, v in kernels.items()}
         return {"kernel": kname.get(n, n), "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"],
                 "peak_note": None if k["unit"] == "GB/s" else
                 {"f32": "dense fp32 MFMA peak", "bf16": "dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)",
@@ -869,8 +997,18 @@ def main():
                 "frac_of_measured_peak": k["achieved"] / measured_peak, "measured_peak": measured_peak,
                 "traffic": t["traffic_bytes"] if (t and not stale) else None, "traffic_note": note,
                 "avg_launch_ms": k["avg_launch_ms"], "ms_per_step": k["ms_per_step"],
-                "by_category": by_cat, "by_category_columns": ["ms_per_step", "frac", "frac_of_measured_peak"], "box": box}
+                "traffic_gbps": k.get("traffic_gbps"), "frac_traffic": k.get("frac_traffic"),
+                "by_category": by_cat,
+                "by_category_columns": ["ms_per_step", "frac (algorithmic work / spec peak)", "frac_of_measured_peak",
+                                        "traffic_gbps (PMC HBM bytes / time)", "frac_traffic (traffic_gbps / 8000)"],
+                "embedding_hbm_gbps": emb_gbps, "box": box}
 
+    emb_gbps = {"fwd": kernels.get("emb_fwd", {}).get("achieved"), "bwd_sgd": kernels.get("emb_bwd_sgd", {}).get("achieved"),
+                "fwd_fused_with_interaction": kernels.get("emb_interact_fwd", {}).get("achieved"),
+                "fwd_traffic": kernels.get("emb_interact_fwd", kernels.get("emb_fwd", {})).get("traffic_gbps"),
+                "bwd_sgd_traffic": kernels.get("emb_bwd_sgd", {}).get("traffic_gbps"),
+                "note": "BASELINE.json's second metric.  fwd / bwd_sgd / fwd_fused_with_interaction: algorithmic bytes (SURVEY 8d) / kernel time; "
+                        "*_traffic: rocprofv3 PMC HBM bytes / kernel time (cache hits excluded)"}
     result = {
         "metric": "samples/sec (global batch) + embedding HBM GB/s, Criteo-TB config",
         "value": value, "unit": "samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
@@ -914,13 +1052,18 @@ def main():
                          "is one event pair; dlrm_amd.ops.KernelTimers), on %d of the %d timed steps" % (timed_steps, args.steps),
         "roofline": roof(dom) if dom else None,
         "roofline_embedding": roof("emb_fwd") if "emb_fwd" in kernels else None,
-        "embedding_hbm_gbps": {"fwd": kernels.get("emb_fwd", {}).get("achieved"),
-                               "bwd_sgd": kernels.get("emb_bwd_sgd", {}).get("achieved")},
+        "embedding_hbm_gbps": emb_gbps,
+        "iota_proof": None if (N > 1 or hot) else {
+            "offsets": args.offsets, "device_proofs_in_timed_region": iota["checked"], "tagged": iota["tagged"], "cached": iota["cached"],
+            "us_per_step": iota["host_us"] / max(args.steps, 1),
+            "note": "host time inside ops.offsets_are_iota per timed step (kernel launch + stream synchronisation + pinned flag read); with "
+                    "--offsets fresh every timed step hands the module a new untagged offsets tensor, as the reference loop does, and the "
+                    "proof runs inside the timed region; a synchronisation also ends the host's run-ahead, which ms_per_step contains"},
         "kernels": kernels,
     }
     result.update(result_extra)
     partial["json"] = json.dumps(result)            # from here on a hang in an optional measurement cannot lose the headline
-    if N == 1 and "emb_fwd" not in kernels:
+    if N == 1 and "emb_fwd" not in kernels and not args.no_standalone_emb:
         # fused forward: no separate embedding kernel ran inside the step.  BASELINE.json's second metric is the embedding kernel's
         # HBM rate, so the stand-alone dlrm_emb_fwd (what the unfused / multi-hot / distributed paths launch) is measured here.
         from dlrm_amd.ops import BagBatch, emb_fwd
@@ -942,10 +1085,24 @@ def main():
                                                            "the step itself runs the lookups inside the interaction kernels",
                                                  "ms": ems, "achieved": ach, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS,
                                                  "frac_of_measured_peak": ach / hbm_measured, "algorithmic_bytes": emb_fwd_bytes}
-        result["embedding_hbm_gbps"]["fwd"] = ach
-        result["embedding_hbm_gbps"]["fwd_fused_with_interaction"] = kernels.get("emb_interact_fwd", {}).get("achieved")
+        emb_gbps["fwd"] = ach
+        if pmc and pmc["kernels"].get("emb_fwd") and not pmc["kernels"]["emb_fwd"].get("stale"):
+            tb_ = pmc["kernels"]["emb_fwd"]["traffic_bytes"]
+            result["embedding_kernel_standalone"].update({"traffic_bytes": tb_, "traffic_gbps": tb_ / (ems * 1e-3) / 1e9,
+                                                          "frac_traffic": tb_ / (ems * 1e-3) / 1e9 / HBM_PEAK_GBS})
+            emb_gbps["fwd_standalone_traffic"] = tb_ / (ems * 1e-3) / 1e9
+        partial["json"] = json.dumps(result)
         del out0
-    if N == 1 and args.mlp_arith == "f32" and not args.no_alt_arith:
+    if N == 1 and fused_active and graphed is None and not args.no_high_row_check:
+        try:
+            result["high_row_check"] = high_row_check(model, D, device)
+        except Exception as e:                              # noqa: BLE001 - a report beside the headline
+            result["high_row_check"] = {"ok": False, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        partial["json"] = json.dumps(result)
+    if N == 1 and not args.no_rccl_selfcheck:
+        result["rccl_selfcheck"] = rccl_selfcheck()
+        partial["json"] = json.dumps(result)
+    if args.alts and N == 1 and args.mlp_arith == "f32" and not args.no_alt_arith:
         # the same step with the opt-in bf16x6 MLP arithmetic (fp32 round-off class, see include/dlrm_hip.h): reported
         # beside the headline value, never instead of it
         model.set_mlp_arith("bf16x6")
@@ -963,7 +1120,7 @@ def main():
                                    "note": "opt-in (--mlp-arith bf16x6); parity-tested at the fp32 tolerances; GEMM layers on pre-split bf16 planes (csrc/gemm_bf16.hip PL = 3; "
                                            "DLRM_BF16X6_PLANES=0: split inside every k-loop, bit-identical products)"}
         del loss_alt
-    if N == 1 and graphed is None and not hot and args.fuse and getattr(model, "fuse_emb_interact", False) and not args.no_alt_fuse:
+    if args.alts and N == 1 and graphed is None and not hot and args.fuse and getattr(model, "fuse_emb_interact", False) and not args.no_alt_fuse:
         # the same step with the lookups and the interaction as two kernels (rounds 1-2's forward; what multi-hot and distributed runs launch)
         model.fuse_emb_interact = False
         for i in range(3):
@@ -978,7 +1135,7 @@ def main():
         result["alt_two_kernel_lookup"] = {"value": B / dtu, "unit": "samples/s", "ms_per_step": dtu * 1e3, "final_loss": float(loss_u.detach()),
                                            "note": "--no-fuse: dlrm_emb_fwd + dlrm_interact_fwd / _bwd through the pooled-embedding buffer; bit-identical results"}
         del loss_u
-    if N == 1 and graphed is None and not hot and not (args.overlap and not args.no_overlap) and not args.no_alt_overlap:
+    if args.alts and N == 1 and graphed is None and not hot and not (args.overlap and not args.no_overlap) and not args.no_alt_overlap:
         # the same step on two HIP streams (embedding kernels beside the bottom-MLP GEMMs): beside the headline, never instead
         model.overlap_streams = True
         for i in range(3):
@@ -1026,7 +1183,7 @@ def main():
     elif N > 1:
         # ---- the OTHER exchange schedule, same process, same model: never instead of the headline ------------------------
         alt_c = 1 if model_a2a_chunks > 1 else (args.alt_a2a_chunks or {2: 4, 4: 2, 8: 2}.get(N, 2))
-        if alt_c == 1 or (B // N) % alt_c == 0:
+        if args.alts and (alt_c == 1 or (B // N) % alt_c == 0):
             watchdog(args.hang_timeout + 20 * args.steps, "alternative all-to-all schedule (%d chunk(s))" % alt_c)
             model.a2a_chunks = alt_c
             for i in range(2):
@@ -1048,7 +1205,7 @@ def main():
             del loss_alt
             model.a2a_chunks = model_a2a_chunks
         # ---- the OTHER dense-gradient synchronisation, same process, same parameters -------------------------------------------
-        if not hot:
+        if args.alts and not hot:
             try:
                 import gc
                 other = "flat" if args.dense_sync == "ddp" else "ddp"

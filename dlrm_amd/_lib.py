@@ -20,6 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED = 0, 1, 2
 ARITH_F32, ARITH_BF16X6, ARITH_BF16 = 0, 1, 2
+EXPECTED_ABI = 10          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
 
 _lock = threading.Lock()
 _lib = None
@@ -150,6 +151,12 @@ def load():
                     "libdlrm_hip.so is missing and hipcc is not available; the HIP extension is required "
                     "(there is no fallback path). Run `python -c 'import __graft_entry__ as g; g.build()'`.")
         lib = C.CDLL(LIB_PATH)
+        lib.dlrm_hip_abi_version.restype = C.c_int
+        got = int(lib.dlrm_hip_abi_version())
+        if got != EXPECTED_ABI:
+            # a stale or foreign build (DLRM_HIP_LIB, or a prebuilt .so without hipcc to refresh it) would be called with shifted arguments
+            raise RuntimeError("%s reports C-ABI version %d, these bindings need %d (include/dlrm_hip.h); rebuild it: "
+                               "python -c 'import __graft_entry__ as g; g.build()'" % (LIB_PATH, got, EXPECTED_ABI))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res

@@ -21,7 +21,7 @@ from typing import Iterator, Tuple
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 TOT_FEA, DEN_FEA, SPA_FEA = 40, 13, 26          # data_loader_terabyte.py:209-213
 
@@ -96,6 +96,8 @@ class CriteoBinBatches:
         ev = torch.cuda.Event()
         ev.record(cur)
         self._free[slot] = ev
+        # criteo_bin_transform_kernel writes off[t, b] = b: the producer's proof of "one lookup per bag" (no device pass / sync later)
+        ops.mark_one_lookup_per_bag(off)
         return X, off, idx, tgt
 
     def batch(self, i: int):

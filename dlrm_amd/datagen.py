@@ -14,7 +14,7 @@ from typing import List, Sequence, Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 
 class UniformBatchGenerator:
@@ -38,7 +38,11 @@ class UniformBatchGenerator:
         z ^= z >> 31
         return z & (2 ** 64 - 1)
 
-    def batch(self, B: int, batch_no: int = 0) -> Tuple[torch.Tensor, List[torch.Tensor], List[torch.Tensor], torch.Tensor]:
+    def batch(self, B: int, batch_no: int = 0, stacked: bool = False):
+        """-> (X, lS_o, lS_i, T): lS_o / lS_i lists of per-table tensors, or (stacked=True, fixed bag lengths only) the reference
+        collate layout, one [T, B] tensor each (dlrm_data_pytorch.py:686,337)."""
+        if stacked and not self.fixed:
+            raise RuntimeError("dlrm_amd.datagen: stacked=True needs num_indices_per_lookup_fixed (equal nnz per table)")
         lib = _lib.load()
         dev, T = self.device, len(self.rows)
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -73,6 +77,18 @@ class UniformBatchGenerator:
             _lib.check(rc, "dlrm_gen_uniform_bags")
             counts = [B] * n if onehot else nnz.tolist()             # variable bag lengths: one small D2H copy per batch
             for k in range(n):
-                lS_o.append(off[k])
+                o_k = off[k]
+                if onehot:
+                    # gen_onehot_kernel writes bag start b for bag b: the producer's own proof of "one lookup per bag"
+                    # (ops.offsets_are_iota then needs no device pass and no synchronisation for this tensor object)
+                    ops.mark_one_lookup_per_bag(o_k)
+                lS_o.append(o_k)
                 lS_i.append(idx[k, :counts[k]])
+            if onehot and T <= 32 and stacked:
+                return X, ops.mark_one_lookup_per_bag(off), idx, tgt
+        if stacked:
+            so = torch.stack(lS_o)
+            if onehot:
+                ops.mark_one_lookup_per_bag(so)          # a copy of rows this generator wrote as 0..B-1
+            return X, so, torch.stack(lS_i), tgt
         return X, lS_o, lS_i, tgt

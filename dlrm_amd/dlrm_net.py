@@ -167,7 +167,7 @@ class DLRM_Net(nn.Module):
         tables = nn.ModuleList()
         pool_w = []
         for i in range(ln.size):
-            if ext_dist.my_size > 1 and i not in self.local_emb_indices:
+            if ext_dist.is_distributed() and i not in self.local_emb_indices:
                 continue
             n = int(ln[i])
             if getattr(self, "qr_flag", False) and n > self.qr_threshold:
@@ -237,7 +237,7 @@ class DLRM_Net(nn.Module):
             self.md_threshold = md_threshold
         self.m_spa = m_spa
 
-        if ext_dist.my_size > 1:
+        if ext_dist.is_distributed():
             n_emb = len(ln_emb)
             if n_emb < ext_dist.my_size:
                 sys.exit("only (%d) sparse features for (%d) devices, table partitions will fail"
@@ -437,7 +437,7 @@ class DLRM_Net(nn.Module):
 
     # ---------------------------------------------------------------- forward paths
     def forward(self, dense_x, lS_o, lS_i):
-        if ext_dist.my_size > 1:
+        if ext_dist.is_distributed():        # more than one rank (or a forced one-rank RCCL group: ext_dist.force_distributed)
             return self.distributed_forward(dense_x, lS_o, lS_i)
         return self.sequential_forward(dense_x, lS_o, lS_i)
 

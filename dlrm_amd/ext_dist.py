@@ -33,6 +33,11 @@ my_size = -1
 my_local_rank = -1
 my_local_size = -1
 alltoall_supported = False
+# True: a ONE-rank process group takes the distributed code path too (distributed_forward, alltoall, FlatDDP's all-reduce,
+# reduce_scatter_rows, kjt_input_dist) — every collective runs, on RCCL, as a self-exchange.  Set by
+# init_distributed(..., force=True) or DLRM_DIST_FORCE=1; exists so that the backend-specific branches (async work handles,
+# ReduceOp.AVG, reduce_scatter_tensor, device all_to_all_single) can be executed and checked on a one-GPU box.
+force_distributed = False
 a2a_impl = os.environ.get("DLRM_ALLTOALL_IMPL", "")  # parsed for CLI parity; only "alltoall" exists here
 
 _orig_print = builtins.print
@@ -49,6 +54,11 @@ def _env_int(names: Sequence[str], default: int = -1) -> int:
             if iv >= 0:
                 return iv
     return default
+
+
+def is_distributed() -> bool:
+    """the table-sharded / batch-split path is active: more than one rank, or a forced one-rank group (see force_distributed)"""
+    return my_size > 1 or (force_distributed and my_size == 1 and dist.is_initialized())
 
 
 def get_my_slice(n: int) -> slice:
@@ -78,9 +88,12 @@ def print_all(*args, **kwargs):
     _orig_print(*args, **kwargs)
 
 
-def init_distributed(rank: int = -1, local_rank: int = -1, size: int = -1, use_gpu: bool = False, backend: str = ""):
-    """Discover rank/size from torchrun or MPI-style environment variables and create the process group."""
-    global my_rank, my_size, my_local_rank, my_local_size, alltoall_supported
+def init_distributed(rank: int = -1, local_rank: int = -1, size: int = -1, use_gpu: bool = False, backend: str = "",
+                     force: bool = False):
+    """Discover rank/size from torchrun or MPI-style environment variables and create the process group.
+    force (or DLRM_DIST_FORCE=1): create the group even for ONE rank and route a one-rank run through the distributed path."""
+    global my_rank, my_size, my_local_rank, my_local_size, alltoall_supported, force_distributed
+    force = force or os.environ.get("DLRM_DIST_FORCE", "0") == "1"
     env_size = _env_int(["WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "MV2_COMM_WORLD_SIZE"])
     env_rank = _env_int(["RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "MV2_COMM_WORLD_RANK"])
     env_lrank = _env_int(["LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "MV2_COMM_WORLD_LOCAL_RANK"])
@@ -91,7 +104,10 @@ def init_distributed(rank: int = -1, local_rank: int = -1, size: int = -1, use_g
         rank = env_rank
     if local_rank < 0:
         local_rank = env_lrank
-    if size > 1 and rank >= 0:
+    if force and size <= 1:
+        size, rank = 1, 0
+    if (size > 1 or force) and rank >= 0:
+        force_distributed = force and size == 1
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ["RANK"] = str(rank)
@@ -124,7 +140,7 @@ def init_distributed(rank: int = -1, local_rank: int = -1, size: int = -1, use_g
 
 
 def barrier():
-    if my_size > 1:
+    if is_distributed():
         dist.barrier()
 
 
@@ -260,7 +276,7 @@ def alltoall(inputs: Sequence[torch.Tensor], per_rank_table_splits: Optional[Lis
     Reference form (extend_distributed.py:541-576): `inputs` = one [B, D] tensor per local table.
     Zero-copy form: a single packed [B, T_loc*D] block plus `emb_dim=D` (what the embedding kernel
     writes), which is sent without any cat/copy."""
-    if my_size <= 1:
+    if not is_distributed():
         raise RuntimeError("alltoall called without an initialised multi-rank process group")
     batch = inputs[0].size(0)
     width = sum(t.size(1) for t in inputs)
@@ -334,7 +350,7 @@ class FlatDDP(torch.nn.Module):
         dev = self._params[0].device
         if any(p.device != dev or p.dtype != torch.float32 for p in self._params):
             raise RuntimeError("FlatDDP: all parameters must be fp32 tensors on one device")
-        if my_size > 1 and broadcast:
+        if is_distributed() and broadcast:
             with torch.no_grad():
                 for p in self._params:
                     dist.broadcast(p, 0)
@@ -346,7 +362,7 @@ class FlatDDP(torch.nn.Module):
         self._ready = 0
         self._work = None
         self._callback_queued = False
-        self._avg = my_size > 1 and dist.get_backend() == "nccl"
+        self._avg = is_distributed() and dist.get_backend() == "nccl"
         from . import functional
         self._hooks = []
         on_grad = weakref.WeakMethod(self._on_grad)             # the parameters must not keep their wrapper alive
@@ -397,7 +413,7 @@ class FlatDDP(torch.nn.Module):
                 if p.grad.data_ptr() != v.data_ptr():      # produced elsewhere (or accumulated): move it into the flat buffer
                     v.copy_(p.grad)
                     p.grad = v
-        if my_size > 1:
+        if is_distributed():
             _mark()
             self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, async_op=True)
 

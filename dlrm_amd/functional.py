@@ -232,7 +232,10 @@ class MLPFunction(Function):
             if not n32 and need_grad:
                 # backward consumers of the fp32 activation: the next layer's weight gradient when it is not the bf16 one; the ReLU
                 # derivative when there are no sign bits; any other activation's derivative
-                n32 = (not wg16[i + 1]) or (acts[i] == ACT_RELU and not need_bits) or acts[i] not in (ACT_RELU, ACT_NONE)
+                # ... and the next layer's DATA gradient when it is not the bf16 one (widths the bf16 / plane GEMM refuses, e.g. 200 or 72):
+                # the fp32-storage fallback masks with this activation (ops.linear_bwd_data), the sign bits alone would not do
+                n32 = ((not wg16[i + 1]) or (not dg16[i + 1]) or (acts[i] == ACT_RELU and not need_bits)
+                       or acts[i] not in (ACT_RELU, ACT_NONE))
             need32.append(n32)
         cur16 = None                                                  # bf16 copy of the current activation, [M, kb of the next layer]
         outs, in16, bits = [], [], []                                   # in16[i]: the reduced-width input of layer i's GEMM, kept for its weight gradient
@@ -314,7 +317,13 @@ class MLPFunction(Function):
             dW = _grad_out(params[2 * i])
             db = _grad_out(params[2 * i + 1])
             N_i, K_i = W.size(0), W.size(1)
-            do16 = wg16[i] and X16_i is not None and st.wgrad_ok(M, N_i, dW.size(1), dZ16 if dZ16 is not None else X16_i, X16_i)
+            do16 = wg16[i] and X16_i is not None
+            if do16 and not st.wgrad_ok(M, N_i, dW.size(1), dZ16 if dZ16 is not None else X16_i, X16_i):
+                # forward already dropped the fp32 operands on the strength of this plan: a run-time disagreement (DLRM_BF16_PHASED changed
+                # between forward and backward, an unaligned gradient slot) must not fall into the fp32 branch with operands that no longer exist
+                raise RuntimeError("dlrm_amd: the bf16 weight gradient planned at forward time for layer %d (M=%d, N=%d, K=%d) is refused at "
+                                   "backward time (environment switched between forward and backward, or unaligned gradient storage)"
+                                   % (i, M, N_i, dW.size(1)))
             if do16 and dZ16 is None:
                 dZ16 = st.cast(dZ, N_i, category="linear_bwd_weight")                # (the tower's last layer: its dZ comes from act_bwd in fp32)
 

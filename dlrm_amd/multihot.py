@@ -84,6 +84,8 @@ class Multihot:
                                               C.c_void_p(off_l.data_ptr()), C.c_void_p(ops._err_block(ids.device).data_ptr()),
                                               ops._stream(ids))
         _lib.check(rc, "dlrm_multihot_expand")
+        if self.lookups_per_sample == T:                 # every hot size is 1: multihot_expand_kernel wrote off_l[t, b] = b * 1
+            ops.mark_one_lookup_per_bag(off_l)
         return values, off_g, off_l
 
     def to_model_inputs(self, ids: torch.Tensor):

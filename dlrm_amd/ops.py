@@ -494,7 +494,21 @@ def gather_ok(F: int, D: int) -> bool:
 # address can never alias) together with its in-place version counter.
 _iota_cache: dict = {}          # id(tensor) -> (weakref, _version, verdict)
 _iota_flags: dict = {}          # device index -> pinned host int32[1]
-IOTA_STATS = {"checked": 0, "cached": 0}
+IOTA_STATS = {"checked": 0, "cached": 0, "tagged": 0, "host_us": 0.0}
+_IOTA_TAG = "_dlrm_one_lookup_per_bag"      # attribute a PRODUCER sets on an offsets tensor it wrote as 0, 1, ..., B-1 (value: t._version)
+
+
+def mark_one_lookup_per_bag(t: torch.Tensor) -> torch.Tensor:
+    """Producer-side proof: whoever WROTE the bag starts as 0, 1, ..., B-1 (dlrm_amd.datagen with one fixed lookup per bag,
+    CriteoBinBatches, Multihot over all-ones hot sizes — by construction of their kernels) tags the tensor object, and
+    `offsets_are_iota` then needs neither a device pass nor a synchronisation for it.  The tag holds the tensor's in-place version
+    counter, so a later versioned write voids it; views and copies are new objects and carry no tag (they take the device proof)."""
+    setattr(t, _IOTA_TAG, t._version)
+    return t
+
+
+def _iota_tagged(t: torch.Tensor) -> bool:
+    return getattr(t, _IOTA_TAG, None) == t._version
 
 
 def _iota_cached(t: torch.Tensor):
@@ -520,13 +534,18 @@ def offsets_are_iota(lS_o):
     graph is being captured no synchronisation is possible: returns None (undecided) unless every tensor is already cached —
     GraphedTrainStep proves it on the incoming batch before every replay instead."""
     srcs = [lS_o] if isinstance(lS_o, torch.Tensor) else list(lS_o)
-    verdicts = [_iota_cached(t) for t in srcs]
+    if all(_iota_tagged(t) for t in srcs):
+        IOTA_STATS["tagged"] += 1
+        return True
+    verdicts = [True if _iota_tagged(t) else _iota_cached(t) for t in srcs]
     if all(v is not None for v in verdicts):
         IOTA_STATS["cached"] += 1
         return all(verdicts)
     dev = srcs[0].device
     if torch.cuda.is_current_stream_capturing():
         return None
+    import time as _time
+    t_host0 = _time.perf_counter()
     ptrs, keep = [], []
     for t in srcs:
         if not t.is_cuda or t.dtype not in (torch.int64, torch.int32) or t.dtype != srcs[0].dtype:
@@ -555,6 +574,7 @@ def offsets_are_iota(lS_o):
     # the same objects come back, and then it is False again)
     for t in srcs:
         _iota_remember(t, ok)
+    IOTA_STATS["host_us"] += (_time.perf_counter() - t_host0) * 1e6
     return ok
 
 
@@ -680,6 +700,11 @@ def linear_bwd_data(dY: torch.Tensor, W: torch.Tensor, Xact: Optional[torch.Tens
         raise RuntimeError("dlrm_amd: linear_bwd_data shape mismatch")
     if Xact is not None:
         _req(Xact, "Xact", ndim=2)
+    elif xact_kind != ACT_NONE:
+        # (the sign bits alone are not enough here: only the fast GEMM path reads them, every other path of dlrm_linear_bwd_data masks
+        # with the fp32 activation — a caller that kept bits only must take dlrm_gemm_bf16's relu_bits_in, functional.MLPFunction)
+        raise RuntimeError("dlrm_amd: linear_bwd_data with an activation derivative needs the fp32 activation Xact "
+                           "(got xact_kind=%d, Xact=None%s)" % (xact_kind, ", relu_bits given" if relu_bits is not None else ""))
     with _timed("linear_bwd_data"):
         rc = lib.dlrm_linear_bwd_data(M, N, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(W.data_ptr()), _ld(W),
                                       C.c_void_p(Xact.data_ptr()) if Xact is not None else None,

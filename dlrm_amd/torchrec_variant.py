@@ -163,12 +163,13 @@ class ShardedDLRM(DLRM_Net):
         Bl = dense_x.size(0)
         B = Bl * N
         ops.check_index_errors()
-        if N > 1:
+        dist_on = N > 1 or ext_dist.is_distributed()         # (a forced one-rank RCCL group runs every collective as a self-exchange)
+        if dist_on:
             tw, rw = ext_dist.kjt_input_dist(values, self.hot, self.tw_owner, self.rw_tables)
         else:                                                # one rank: every table is "mine", nothing is exchanged
             seg, tw, rw = 0, {}, {}
             for t, h in enumerate(self.hot):
-                tw[t] = values[seg:seg + Bl * h]
+                (rw if t in self.rw_tables else tw)[t] = values[seg:seg + Bl * h]
                 seg += Bl * h
         n_tw = len(self.tw_mine)
         w_tw = [self.emb_l[j].weight for j in range(n_tw)]
@@ -176,7 +177,7 @@ class ShardedDLRM(DLRM_Net):
         bags = ops.BagBatch([self._bag_starts(B, self.hot[t], values) for t in self.tw_mine], [tw[t] for t in self.tw_mine])
         E_tw = EmbeddingBagsFunction.apply(self._stash_embedding_grad, bags, None, *w_tw)          # [B, n_tw * D]
         blocks = []
-        if N > 1:
+        if dist_on:
             req = ext_dist.alltoall([E_tw], self.tw_per_rank, emb_dim=D)
         if self.rw_tables:
             ids = []
@@ -189,7 +190,7 @@ class ShardedDLRM(DLRM_Net):
             E_rw = EmbeddingBagsFunction.apply(self._stash_embedding_grad, bags_rw, None, *w_rw)   # partial sums, whole batch
             E_rw = ext_dist.reduce_scatter_rows(E_rw)                                              # [B/N, n_rw * D]
         x = self.apply_mlp(dense_x, self.bot_l)
-        blocks = [x] + (list(req.wait()) if N > 1 else [E_tw]) + ([E_rw] if self.rw_tables else [])
+        blocks = [x] + (list(req.wait()) if dist_on else [E_tw]) + ([E_rw] if self.rw_tables else [])
         z = InteractFunction.apply(D, self._interaction_mode(), True, list(self.feature_order), *blocks)
         return self.apply_mlp(z, self.top_l)
 

@@ -364,3 +364,48 @@ def test_flat_ddp_equals_ddp(size):
         assert "parameters received a gradient" in results[r]["partial"]
         for pa, pb in zip(results[0]["params"], results[r]["params"]):
             assert np.array_equal(pa, pb)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a ONE-rank group forced through the distributed path (ext_dist.init_distributed(force=True); tests/test_gpu_rccl.py runs the same
+# switch on RCCL): every collective is a self-exchange, i.e. the identity
+# ---------------------------------------------------------------------------------------------------------------------
+def _forced_one_rank_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    from dlrm_amd import ext_dist
+    assert not ext_dist.is_distributed()
+    ext_dist.init_distributed(rank=0, local_rank=0, size=1, use_gpu=False, backend="gloo", force=True)
+    res = {"dist": ext_dist.is_distributed(), "size": ext_dist.my_size, "slice": ext_dist.get_my_slice(26),
+           "split": ext_dist.get_split_lengths(26)}
+    B, D, T = 6, 4, 3
+    packed = torch.arange(B * T * D, dtype=torch.float32).view(B, T * D).requires_grad_(True)
+    outs = ext_dist.alltoall([packed], None, emb_dim=D).wait()
+    (2.0 * outs[0]).sum().backward()
+    res["a2a"] = bool(len(outs) == 1 and torch.equal(outs[0], packed.detach()) and torch.equal(packed.grad, torch.full_like(packed, 2.0)))
+    x = torch.randn(4, 5, requires_grad=True)
+    y = ext_dist.reduce_scatter_rows(x)
+    y.sum().backward()
+    res["rs"] = bool(torch.equal(y.detach(), x.detach()) and torch.equal(x.grad, torch.ones_like(x)))
+    hot = [2, 1]
+    vals = torch.arange(3 * 3, dtype=torch.int32)
+    tw, rw = ext_dist.kjt_input_dist(vals, hot, [0, -1], [1])
+    res["kjt"] = bool(torch.equal(tw[0], vals[:6]) and torch.equal(rw[1], vals[6:]))
+    lin = torch.nn.Linear(3, 2)
+    f = ext_dist.FlatDDP(lin)
+    f(torch.ones(5, 3)).sum().backward()
+    res["flat"] = bool(torch.allclose(lin.weight.grad, torch.full((2, 3), 5.0)))
+    q.put(res)
+    ext_dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_forced_one_rank_group_takes_the_distributed_path():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=180)
+    p.join(60)
+    assert p.exitcode == 0
+    assert res["dist"] and res["size"] == 1 and res["slice"] == slice(0, 26, 1) and res["split"] == (26, None)
+    assert res["a2a"] and res["rs"] and res["kjt"] and res["flat"]

@@ -388,7 +388,7 @@ def _run_bench_n2(extra_env, extra_args, timeout):
 def test_bench_two_rank_control_flow(dense_sync):
     """headline (reference exchange schedule) + alternative exchange schedule + the other dense-gradient synchronisation + collective
     timings + process-group report, end to end through torchrun, as the driver launches it"""
-    d, _ = _run_bench_n2({}, ["--steps", "3", "--hang-timeout", "120", "--dense-sync", dense_sync], 600)
+    d, _ = _run_bench_n2({}, ["--steps", "3", "--hang-timeout", "120", "--dense-sync", dense_sync, "--alts"], 600)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and "selftest" in d
     assert dense_sync in d["config"]["parallelism"] and d["config"]["a2a_chunks"] == 1
     assert d["alt_a2a_pipelined"]["value"] > 0 and d["alt_a2a_pipelined"]["a2a_chunks"] > 1
@@ -411,7 +411,7 @@ def test_bench_two_rank_self_launch_with_bf16_lean_towers_and_flat_allreduce():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(DLRM_BENCH_SELFTEST_GLOO="1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4096", "--row-cap", "50000",
-                        "--hang-timeout", "120", "--mlp-arith", "bf16", "--dense-sync", "flat"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+                        "--hang-timeout", "120", "--mlp-arith", "bf16", "--dense-sync", "flat", "--alts"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and lines, (r.returncode, r.stderr[-3000:])
     d = json.loads(lines[-1])
@@ -437,6 +437,6 @@ def test_bench_two_rank_sharded_multihot_control_flow():
 def test_bench_prints_its_headline_when_an_optional_measurement_hangs():
     """DLRM_BENCH_SELFTEST_HANG=alt blocks inside the optional dense-sync measurement: the watchdog must print the finished headline
     line (marked "incomplete") and exit 0 instead of losing the run"""
-    d, err = _run_bench_n2({"DLRM_BENCH_SELFTEST_HANG": "alt"}, ["--steps", "1", "--hang-timeout", "3"], 300)
+    d, err = _run_bench_n2({"DLRM_BENCH_SELFTEST_HANG": "alt"}, ["--steps", "1", "--hang-timeout", "3", "--alts"], 300)
     assert d["value"] > 0 and "incomplete" in d and "alt_dense_sync" not in d
     assert "watchdog expired" in err

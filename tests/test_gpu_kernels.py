@@ -801,6 +801,45 @@ def test_bf16x6_planes_tower_equals_in_loop_split(ln, B):
     np.testing.assert_allclose(y1.cpu().numpy(), h, rtol=1e-5, atol=1e-5 * float(np.abs(h).max()))
 
 
+@pytest.mark.parametrize("arith", ["bf16", "bf16x6"])
+@pytest.mark.parametrize("ln", [[128, 256, 200, 64], [128, 256, 72, 64], [64, 320, 200, 72, 32]])
+def test_lean_towers_keep_the_fp32_activation_where_the_data_gradient_falls_back(ln, arith):
+    """hidden widths the bf16 / plane DATA-gradient GEMM refuses (200, 72: multiples of 8 that are not multiples of 32)
+    while the bf16 WEIGHT gradient takes them.  The lean plan used to drop the fp32 activation below such a layer on the strength of
+    the weight gradient alone; the fp32-storage data-gradient fallback then ran without its ReLU mask and every gradient below was
+    wrong.  The plan now keeps the fp32 copy (need32 looks at dg16 as well) and ops.linear_bwd_data refuses a derivative without its
+    activation.  Against an fp64 restatement with the ReLU masks applied: input gradient and all parameter gradients."""
+    from dlrm_amd import ops
+    from dlrm_amd.functional import MLPFunction
+    rng = np.random.default_rng(sum(ln))
+    B, L = 2048, len(ln) - 1
+    params = []
+    for i in range(L):
+        params += [to_dev((rng.standard_normal((ln[i + 1], ln[i])) * np.sqrt(2 / (ln[i] + ln[i + 1]))).astype(np.float32)).requires_grad_(True),
+                   to_dev((rng.standard_normal(ln[i + 1]) * 0.1).astype(np.float32)).requires_grad_(True)]
+    acts = tuple([ops.ACT_RELU] * L)
+    x = to_dev(rng.random((B, ln[0])).astype(np.float32)).requires_grad_(True)
+    dy = to_dev(rng.standard_normal((B, ln[-1])).astype(np.float32))
+    y = MLPFunction.apply(x, acts, None, ops.arith_code(arith), *params)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    hs = [x.detach().double().cpu().numpy()]
+    for i in range(L):
+        hs.append(np.maximum(hs[-1] @ params[2 * i].detach().double().cpu().numpy().T + params[2 * i + 1].detach().double().cpu().numpy(), 0))
+    g = dy.double().cpu().numpy()
+    tol = 4e-2 if arith == "bf16" else 2e-5
+    np.testing.assert_allclose(y.detach().cpu().numpy(), hs[-1], rtol=tol, atol=tol * float(np.abs(hs[-1]).max()))
+    for i in range(L - 1, -1, -1):
+        g = g * (hs[i + 1] > 0)
+        dW, db = g.T @ hs[i], g.sum(0)
+        np.testing.assert_allclose(params[2 * i].grad.cpu().numpy(), dW, rtol=tol, atol=tol * float(np.abs(dW).max()), err_msg="dW %d" % i)
+        np.testing.assert_allclose(params[2 * i + 1].grad.cpu().numpy(), db, rtol=tol, atol=tol * float(np.abs(db).max()), err_msg="db %d" % i)
+        g = g @ params[2 * i].detach().double().cpu().numpy()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g, rtol=tol, atol=tol * float(np.abs(g).max()))
+    with pytest.raises(RuntimeError, match="needs the fp32 activation"):
+        ops.linear_bwd_data(dy, params[2 * (L - 1)].detach(), None, ops.ACT_RELU, torch.empty((B, ln[-2]), device=dev()))
+
+
 @pytest.mark.parametrize("M,N,K0", [(5000, 512, 13), (300, 64, 479), (4096, 1024, 479), (33, 8, 5), (8192, 128, 14)])
 def test_linear_weight_gradient_of_padded_input(M, N, K0):
     """First MLP layers run on a zero-padded input (13 -> 16 dense features, 479 -> 480 interaction outputs):
