@@ -464,12 +464,18 @@ class DLRM_Net(nn.Module):
             # nnz == B does not prove one lookup per bag (an empty bag next to a two-lookup bag is legal EmbeddingBag input and the
             # reference computes it): ops.offsets_are_iota proves offsets == arange(B) on the device, once per offsets tensor
             # object (None = undecided, only while a HIP graph is being captured: GraphedTrainStep proves every incoming batch).
-            if (all(n == B for n in bags.nnz) and all(e.weight.data_ptr() % 16 == 0 for e in self.emb_l)
-                    and ops.offsets_are_iota(lS_o) is not False):
-                x = self.apply_mlp(dense_x, self.bot_l)
-                z = GatherInteractFunction.apply(self._stash_embedding_grad, D, self._interaction_mode(), bags, x,
-                                                 *self._emb_weights(self.emb_l))
-                return self._clamp(self.apply_mlp(z, self.top_l))
+            if all(n == B for n in bags.nnz) and all(e.weight.data_ptr() % 16 == 0 for e in self.emb_l):
+                # the proof of a tensor nobody vouched for is a device pass the HOST waits for: it is started first (on its own stream,
+                # behind what this stream holds now), the bottom tower is enqueued, and only then the host waits for the verdict — the
+                # GPU has the tower's GEMMs to run while the host catches up, so the wait does not drain the stream
+                proof = ops.offsets_are_iota_start(lS_o)
+                if proof is not False:
+                    x = self.apply_mlp(dense_x, self.bot_l)
+                    if ops.offsets_are_iota_finish(proof) is not False:
+                        z = GatherInteractFunction.apply(self._stash_embedding_grad, D, self._interaction_mode(), bags, x,
+                                                         *self._emb_weights(self.emb_l))
+                        return self._clamp(self.apply_mlp(z, self.top_l))
+                    del x        # a ragged batch with nnz == B after all: the two kernels below (the bottom tower runs again, into its slot)
         feat = torch.empty((B, n_out + T * D), dtype=torch.float32, device=dense_x.device)
         if self.overlap_streams and dense_x.is_cuda:
             # pooled lookups (HBM-bound) on the side stream beside the bottom-MLP GEMMs (MFMA-bound): they only meet at the

@@ -568,4 +568,6 @@ class _ReduceScatterRows(Function):
 
 
 def reduce_scatter_rows(x: torch.Tensor) -> torch.Tensor:
+    if not is_distributed():                 # one process, no group: the one "rank" already holds the whole sum of its whole batch
+        return x
     return _ReduceScatterRows.apply(x)

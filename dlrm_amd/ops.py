@@ -493,8 +493,7 @@ def gather_ok(F: int, D: int) -> bool:
 # synchronisation, paid once per distinct offsets tensor: the verdict is cached on the tensor OBJECT (weak reference, so a recycled
 # address can never alias) together with its in-place version counter.
 _iota_cache: dict = {}          # id(tensor) -> (weakref, _version, verdict)
-_iota_flags: dict = {}          # device index -> pinned host int32[1]
-IOTA_STATS = {"checked": 0, "cached": 0, "tagged": 0, "host_us": 0.0}
+IOTA_STATS = {"checked": 0, "cached": 0, "tagged": 0, "host_us": 0.0, "wait_us": 0.0}
 _IOTA_TAG = "_dlrm_one_lookup_per_bag"      # attribute a PRODUCER sets on an offsets tensor it wrote as 0, 1, ..., B-1 (value: t._version)
 
 
@@ -528,11 +527,23 @@ def _iota_remember(t: torch.Tensor, verdict: bool) -> None:
     _iota_cache[id(t)] = (weakref.ref(t), t._version, verdict)
 
 
-def offsets_are_iota(lS_o):
-    """True iff every table's bag starts are 0, 1, ..., B-1 (with nnz == B: exactly one lookup per bag).  `lS_o` is what the caller
-    passed to the module (a stacked [T, B] tensor or a list of [B] tensors): the verdict is remembered per tensor object.  While a HIP
-    graph is being captured no synchronisation is possible: returns None (undecided) unless every tensor is already cached —
-    GraphedTrainStep proves it on the incoming batch before every replay instead."""
+class _IotaProof:
+    """a proof in flight: the check kernel runs on the proof stream behind `entry` (an event of the caller's stream recorded when
+    the proof was requested); `done` fires when the verdict is in `flag` (pinned host memory the kernel counts violations into)"""
+    __slots__ = ("srcs", "keep", "flag", "done", "t0")
+
+
+_proof_streams: dict = {}        # device index -> the (high-priority) stream the check kernels run on
+_iota_flag_pool: dict = {}       # device index -> list of free pinned int32[1] flags
+
+
+def offsets_are_iota_start(lS_o):
+    """First half of the proof.  Returns True / False when the verdict is already known (producer tag, cached per tensor object), None
+    while a HIP graph is being captured (undecided: GraphedTrainStep proves every incoming batch before the replay), else a handle for
+    `offsets_are_iota_finish`.  The check kernel is NOT put on the caller's stream: it runs on a proof stream that waits only for what
+    the caller's stream holds at this moment (the tensor's producer, by torch's stream convention), so everything the caller enqueues
+    AFTER this call — DLRM_Net runs the whole bottom tower here — is queued behind nothing of the proof and keeps the GPU busy while
+    the host waits for the verdict."""
     srcs = [lS_o] if isinstance(lS_o, torch.Tensor) else list(lS_o)
     if all(_iota_tagged(t) for t in srcs):
         IOTA_STATS["tagged"] += 1
@@ -545,7 +556,8 @@ def offsets_are_iota(lS_o):
     if torch.cuda.is_current_stream_capturing():
         return None
     import time as _time
-    t_host0 = _time.perf_counter()
+    h = _IotaProof()
+    h.t0 = _time.perf_counter()
     ptrs, keep = [], []
     for t in srcs:
         if not t.is_cuda or t.dtype not in (torch.int64, torch.int32) or t.dtype != srcs[0].dtype:
@@ -559,23 +571,52 @@ def offsets_are_iota(lS_o):
             ptrs.append(t.data_ptr())
         keep.append(t)
     B = srcs[0].size(-1)
-    flag = _iota_flags.get(dev.index)
-    if flag is None:
-        flag = _iota_flags[dev.index] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    pool = _iota_flag_pool.setdefault(dev.index, [])
+    flag = pool.pop() if pool else torch.zeros(1, dtype=torch.int32).pin_memory()
     flag[0] = 0
-    st = torch.cuda.current_stream(dev)
+    cur = torch.cuda.current_stream(dev)
+    ps = _proof_streams.get(dev.index)
+    if ps is None:
+        ps = _proof_streams[dev.index] = torch.cuda.Stream(device=dev, priority=-1)
+    ps.wait_event(cur.record_event())
     rc = _lib.load().dlrm_offsets_are_iota(len(ptrs), B, _lib.ptr_array(ptrs), 64 if srcs[0].dtype == torch.int64 else 32,
-                                           C.c_void_p(flag.data_ptr()), C.c_void_p(st.cuda_stream))
+                                           C.c_void_p(flag.data_ptr()), C.c_void_p(ps.cuda_stream))
     _lib.check(rc, "dlrm_offsets_are_iota")
-    st.synchronize()
-    ok = int(flag[0]) == 0
+    h.srcs, h.keep, h.flag, h.done = srcs, keep, flag, ps.record_event()
+    IOTA_STATS["host_us"] += (_time.perf_counter() - h.t0) * 1e6
+    return h
+
+
+def offsets_are_iota_finish(h) -> bool:
+    """Second half: wait for the check kernel alone (an event of the proof stream, not a stream synchronisation of the caller's) and
+    read the verdict.  The offsets tensors stayed alive in the handle until here."""
+    if not isinstance(h, _IotaProof):
+        return h
+    import time as _time
+    t0 = _time.perf_counter()
+    h.done.synchronize()
+    ok = int(h.flag[0]) == 0
+    _iota_flag_pool[h.srcs[0].device.index].append(h.flag)
     IOTA_STATS["checked"] += 1
     # one verdict for the whole set: each tensor of a list is remembered with it (a False verdict of the set is re-examined only if
     # the same objects come back, and then it is False again)
-    for t in srcs:
+    for t in h.srcs:
         _iota_remember(t, ok)
-    IOTA_STATS["host_us"] += (_time.perf_counter() - t_host0) * 1e6
+    IOTA_STATS["wait_us"] += (_time.perf_counter() - t0) * 1e6
+    h.keep = h.srcs = None
     return ok
+
+
+def offsets_are_iota(lS_o):
+    """True iff every table's bag starts are 0, 1, ..., B-1 (with nnz == B: exactly one lookup per bag).  `lS_o` is what the caller
+    passed to the module (a stacked [T, B] tensor or a list of [B] tensors).  Free for tensors their PRODUCER tagged
+    (`mark_one_lookup_per_bag`: dlrm_amd.datagen, CriteoBinBatches, Multihot know it by construction) and for tensor objects seen
+    before (verdict cached per object + in-place version; a write that does not bump `_version` — `t.data.copy_`, a collective or a
+    custom kernel writing into a reused buffer — is not noticed here: the fused kernels still verify every bag start themselves and
+    report a violation through the index-error block, so reused offsets buffers must be updated through versioned in-place ops).
+    Any other tensor takes one device pass + a host wait for it (`offsets_are_iota_start` / `_finish`).  While a HIP graph is being
+    captured no wait is possible: returns None (undecided) — GraphedTrainStep proves the incoming batch before every replay."""
+    return offsets_are_iota_finish(offsets_are_iota_start(lS_o))
 
 
 def _gather_desc(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: BagBatch, D: int):
