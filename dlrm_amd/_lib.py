@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED = 0, 1, 2
 ARITH_F32, ARITH_BF16X6, ARITH_BF16 = 0, 1, 2
-EXPECTED_ABI = 10          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
+EXPECTED_ABI = 11          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
 
 _lock = threading.Lock()
 _lib = None
@@ -95,7 +95,8 @@ SIGNATURES = {
     "dlrm_bce_elementwise": (_i32, [_i64, _vp, _vp, _vp, _vp]),
     "dlrm_bce_elementwise_bwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp]),
     "dlrm_cross_fwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "dlrm_cross_bwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "dlrm_cross_bwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "dlrm_gemm_bf16_cross": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_add": (_i32, [_i64, _vp, _vp, _vp, _vp]),
     "dlrm_clamp": (_i32, [_i64, _vp, _f32, _f32, _vp, _vp]),
     "dlrm_clamp_bwd": (_i32, [_i64, _vp, _f32, _f32, _vp, _vp, _vp]),

@@ -121,7 +121,8 @@ int dlrm_smallk_bwd_weight(int64_t M, int N, int K, int K_store, const float* dY
 // gemm_bf16.hip: the bf16-shaped (256 x 256 x 64, four phases per k-tile) GEMM; 0 = handled, DLRM_GEMV_NOT_HANDLED = outside its preconditions
 int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, int act,
                           uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd, const float* addend2,
-                          int64_t ldadd2, float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, hipStream_t st);
+                          int64_t ldadd2, float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, hipStream_t st, const float* mul = nullptr,
+                          int64_t ldmul = 0, uint16_t* Ub = nullptr, int64_t ldub = 0);
 bool dlrm_gemm_bf16_wgrad_ok(int64_t Mb, int N_out, int K_in, int64_t lddz, int64_t ldx);
 void dlrm_gemm_bf16_wgrad_plan(int64_t Mb, int N_out, int K_in, int* splits_out, int64_t* kchunk_out);
 int dlrm_gemm_bf16_wgrad_phased(int64_t Mb, int N_out, int K_in, const uint16_t* dZ, int64_t lddz, const uint16_t* X, int64_t ldx,

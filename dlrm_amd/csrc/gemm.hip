@@ -1331,6 +1331,24 @@ extern "C" int dlrm_gemm_bf16(int64_t M, int N, int K, const uint16_t* A, int64_
     return big ? launch_gemm3<true, true, 4, 3>(g, 1, (hipStream_t)stream) : launch_gemm3<true, true, 2, 3>(g, 1, (hipStream_t)stream);
 }
 
+// DCN-v2 cross layer, second product WITH its Hadamard half (torchrec LowRankCrossNet, torchrec_dlrm/dlrm_main.py:608-619):
+//   u = A . B^T + bias (A = v_l bf16 [M, K], B = W_l bf16 [N, K]);  Ub (bf16, nullable) = u;  C (fp32) = fma(x0, u, xl);  Cb (bf16, nullable) = bf16(C)
+// — what dlrm_gemm_bf16 + dlrm_cross_fwd computed in two passes (the fp32 u written by one and re-read by the other), same operation order.
+// Only where the bf16-shaped kernel runs (DLRM_E_MODE otherwise: the caller keeps the two kernels).
+extern "C" int dlrm_gemm_bf16_cross(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
+                                    const float* x0, int64_t ldx0, const float* xl, int64_t ldxl, uint16_t* Ub, int64_t ldub,
+                                    float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !x0 || !xl || !C) return DLRM_E_ARG;
+    if (lda < K || ldb < K || ldc < N || ldx0 < N || ldxl < N || (Cb && ldcb < N) || (Ub && ldub < N)) return DLRM_E_ARG;
+    if (K % 32 || N % 4 || lda % 8 || ldb % 8 || !dlrm_aligned16(A) || !dlrm_aligned16(B) || !dlrm_aligned16(C) || ldc % 4 ||
+        !dlrm_aligned16(x0) || ldx0 % 4 || !dlrm_aligned16(xl) || ldxl % 4 || (Cb && ((((uintptr_t)Cb) & 7u) || ldcb % 4)) ||
+        (Ub && ((((uintptr_t)Ub) & 7u) || ldub % 4)))
+        return DLRM_E_ALIGN;
+    const int rc = dlrm_gemm_bf16_phased(M, N, K, A, lda, B, ldb, bias, DLRM_ACT_NONE, nullptr, nullptr, xl, ldxl, nullptr, 0, C, ldc, Cb, ldcb,
+                                         (hipStream_t)stream, x0, ldx0, Ub, ldub);
+    return rc == DLRM_GEMV_NOT_HANDLED ? DLRM_E_MODE : rc;
+}
+
 extern "C" int64_t dlrm_relu_bits_bytes(int64_t M, int N) {
     if (M <= 0 || N <= 0) return 0;
     return ((M + 31) / 32) * (((int64_t)N + 63) / 64) * 32 * 8;

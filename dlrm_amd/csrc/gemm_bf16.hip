@@ -53,6 +53,10 @@ struct BfArgs {
     const float* bias; int act;
     const float* addend; long long ldadd;    // nullable: fp32 [M, N] added to the result (after bias / activation / mask); may alias C
     const float* addend2; long long ldadd2;  // nullable: a second one (the DCN-v2 backward's last sum: dx0 + g + dv.V in one epilogue)
+    // DCN-v2 cross layer with its Hadamard half in the epilogue (dlrm_gemm_bf16_cross): u = A.B^T + bias is stored as bf16 in Ub (nullable) and
+    // the result becomes fma(mul, u, addend) = x0 * u + xl (the operation order of cross_fwd_kernel: bit-identical)
+    const float* mul; long long ldmul;       // nullable; needs addend
+    unsigned short* Ub; long long ldub;      // nullable
     unsigned* bits_out; const unsigned* bits_in; long long bits_nblk;
     int tiles_m, tiles_n;
     int wide16;                              // bf16-only output through 16-byte stores (set by the host when its preconditions hold)
@@ -528,7 +532,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
                 if (!((wv >> (31 - (it * 4 + 2))) & 1u)) v.z = 0.f;
                 if (!((wv >> (31 - (it * 4 + 3))) & 1u)) v.w = 0.f;
             }
-            if (g.addend) {
+            if constexpr (PL == 1) {
+                if (g.Ub) {                  // the cross layer's u, as the backward pass reads it
+                    uint2 pk; pk.x = p_cvt_pk_bf16(v.x, v.y); pk.y = p_cvt_pk_bf16(v.z, v.w);
+                    *(uint2*)(g.Ub + m * g.ldub + nb) = pk;
+                }
+            }
+            if (g.mul) {                     // x_{l+1} = fma(x0, u, xl)
+                const float4 x0 = *(const float4*)(g.mul + m * g.ldmul + nb);
+                const float4 a = *(const float4*)(g.addend + m * g.ldadd + nb);
+                v.x = __builtin_fmaf(x0.x, v.x, a.x); v.y = __builtin_fmaf(x0.y, v.y, a.y);
+                v.z = __builtin_fmaf(x0.z, v.z, a.z); v.w = __builtin_fmaf(x0.w, v.w, a.w);
+            } else if (g.addend) {
                 const float4 a = *(const float4*)(g.addend + m * g.ldadd + nb);
                 v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
             }
@@ -577,13 +592,15 @@ static int phased_enabled() {           // DLRM_BF16_PHASED=0: keep the fp32-sha
 // returns 0 when the phased kernel took the call, DLRM_GEMV_NOT_HANDLED when the shape is outside its preconditions (the caller keeps gemm3_kernel)
 int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, int act,
                           uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd, const float* addend2,
-                          int64_t ldadd2, float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, hipStream_t st) {
+                          int64_t ldadd2, float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, hipStream_t st, const float* mul, int64_t ldmul,
+                          uint16_t* Ub, int64_t ldub) {
     if (!phased_enabled() || K % PBK || N % 4 || N < 192 || M < 256 || lda % 8 || ldb % 8) return DLRM_GEMV_NOT_HANDLED;
     if (bias && !dlrm_aligned16(bias)) return DLRM_GEMV_NOT_HANDLED;
     BfArgs g = {};
     g.M = M; g.N = N; g.K = K;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.Cb = Cb; g.ldcb = ldcb;
     g.bias = bias; g.act = act; g.addend = addend; g.ldadd = ldadd; g.addend2 = addend2; g.ldadd2 = ldadd2;
+    g.mul = mul; g.ldmul = ldmul; g.Ub = Ub; g.ldub = ldub;
     g.bits_out = (unsigned*)relu_bits_out; g.bits_in = (const unsigned*)relu_bits_in; g.bits_nblk = ((long long)N + 63) / 64;
     g.tiles_m = (int)((M + PBM - 1) / PBM); g.tiles_n = (int)((N + PBN - 1) / PBN);
     static int wide = -1;               // tuning aid: DLRM_BF16_WIDE_STORE=0 keeps the 8-byte bf16 stores
@@ -591,7 +608,7 @@ int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t ld
 #ifdef DLRM_TUNING
     { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 15); g.debug = dbg; }
 #endif
-    g.wide16 = (wide && Cb && !C && !addend && N % 8 == 0 && ldcb % 8 == 0 && dlrm_aligned16(Cb) && (!bias || dlrm_aligned16(bias))) ? 1 : 0;
+    g.wide16 = (wide && Cb && !C && !addend && !mul && !Ub && N % 8 == 0 && ldcb % 8 == 0 && dlrm_aligned16(Cb) && (!bias || dlrm_aligned16(bias))) ? 1 : 0;
     static bool attr_done[DLRM_MAX_DEVICES] = {};
     phased_attr((const void*)gemm_bf16_phased_kernel<false, 1>, attr_done[dlrm_current_device()]);
     hipLaunchKernelGGL((gemm_bf16_phased_kernel<false, 1>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS_PL1, st, g);

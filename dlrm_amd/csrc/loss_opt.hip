@@ -243,11 +243,20 @@ __global__ __launch_bounds__(256) void cross_fwd_kernel(long long n4, const floa
     }
 }
 // du = g * x0 (fp32, nullable) and / or du16 = bf16(g * x0) (nullable);  dx0 (+)= g * u
+// (u as stored by the forward pass: fp32, or — U16 — the bf16 copy the fused cross GEMM wrote: a bf16 value IS the upper half of its fp32 form)
+template <bool U16>
 __global__ __launch_bounds__(256) void cross_bwd_kernel(long long n4, const float4* __restrict__ g, const float4* __restrict__ x0,
-                                                        const float4* __restrict__ u, float4* __restrict__ du, uint2* __restrict__ du16,
+                                                        const void* __restrict__ uv, float4* __restrict__ du, uint2* __restrict__ du16,
                                                         float4* __restrict__ dx0, int accumulate) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const float4 gg = g[i], a = x0[i], b = u[i];
+        const float4 gg = g[i], a = x0[i];
+        float4 b;
+        if constexpr (U16) {
+            const uint2 w = ((const uint2*)uv)[i];
+            b = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u));
+        } else {
+            b = ((const float4*)uv)[i];
+        }
         const float4 r = make_float4(gg.x * a.x, gg.y * a.y, gg.z * a.z, gg.w * a.w);
         if (du) du[i] = r;
         if (du16) du16[i] = make_uint2(lo_cvt_pk_bf16(r.x, r.y), lo_cvt_pk_bf16(r.z, r.w));
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(256) void clamp_bwd_kernel(long long n, const float
 
 }  // namespace
 
-extern "C" int dlrm_hip_abi_version(void) { return 10; }
+extern "C" int dlrm_hip_abi_version(void) { return 11; }
 
 extern "C" const char* dlrm_hip_build_info(void) {
     return "libdlrm_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " clang " __clang_version__;
@@ -460,12 +469,16 @@ extern "C" int dlrm_cross_fwd(int64_t n, const float* x0, const float* u, const 
     return 0;
 }
 
-extern "C" int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const float* u, float* du, uint16_t* du16, float* dx0, int accumulate,
-                              void* stream) {
-    if (n <= 0 || !g || !x0 || !u || (!du && !du16) || !dx0) return DLRM_E_ARG;
-    if (!vec4_ok(n, g, x0, u, du, dx0) || (du16 && (((uintptr_t)du16) & 7u))) return DLRM_E_ALIGN;
-    hipLaunchKernelGGL(cross_bwd_kernel, dim3(ew_blocks_full(n / 4)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)g,
-                       (const float4*)x0, (const float4*)u, (float4*)du, (uint2*)du16, (float4*)dx0, accumulate ? 1 : 0);
+extern "C" int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const float* u, const uint16_t* u16, float* du, uint16_t* du16, float* dx0,
+                              int accumulate, void* stream) {
+    if (n <= 0 || !g || !x0 || (!u == !u16) || (!du && !du16) || !dx0) return DLRM_E_ARG;
+    if (!vec4_ok(n, g, x0, u, du, dx0) || (du16 && (((uintptr_t)du16) & 7u)) || (u16 && (((uintptr_t)u16) & 7u))) return DLRM_E_ALIGN;
+    if (u16)
+        hipLaunchKernelGGL(cross_bwd_kernel<true>, dim3(ew_blocks_full(n / 4)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)g,
+                           (const float4*)x0, (const void*)u16, (float4*)du, (uint2*)du16, (float4*)dx0, accumulate ? 1 : 0);
+    else
+        hipLaunchKernelGGL(cross_bwd_kernel<false>, dim3(ew_blocks_full(n / 4)), dim3(256), 0, (hipStream_t)stream, (long long)(n / 4), (const float4*)g,
+                           (const float4*)x0, (const void*)u, (float4*)du, (uint2*)du16, (float4*)dx0, accumulate ? 1 : 0);
     DLRM_LAUNCH_CHECK();
     return 0;
 }

@@ -36,6 +36,8 @@ RELU_BITS = os.environ.get("DLRM_RELU_BITS", "1") == "1"
 BF16_STORAGE = os.environ.get("DLRM_BF16_STORAGE", "1") == "1"
 # bf16 storage, LEAN: hidden activations / gradients exist only as bf16 (+ ReLU sign bits) wherever every consumer reads bf16 (MLPFunction)
 BF16_LEAN = os.environ.get("DLRM_BF16_LEAN", "1") == "1"
+# DCN-v2 (bf16 storage): the elementwise half of a cross layer inside the epilogue of its second product (dlrm_gemm_bf16_cross); 0 = two kernels
+CROSS_FUSE = os.environ.get("DLRM_CROSS_FUSE", "1") == "1"
 # arith "bf16x6": activations / gradients / weights of the GEMM layers travel as three bf16 planes (split once by their producer) and the GEMMs
 # are the planes form of the bf16-shaped kernel (dlrm_gemm_bf16x6), wherever its shapes hold (DLRM_BF16X6_PLANES=0: every GEMM splits its fp32
 # operands inside its k-loop, the kernels of rounds 1-3; the k-contiguous products are bit-identical either way)
@@ -518,9 +520,18 @@ class LowRankCrossNetFunction(Function):
                 V, W, b = params[3 * l], params[3 * l + 1], params[3 * l + 2]
                 v16 = torch.empty((M, V.size(0)), dtype=torch.bfloat16, device=x0.device)
                 ops.gemm_bf16(xl16, ops.cast_bf16(V, n_in, category="linear_fwd"), None, ACT_NONE, None, v16, category="linear_fwd")
+                W16 = ops.cast_bf16(W, V.size(0), category="linear_fwd")
+                xs16.append(xl16); vs16.append(v16)
+                # x_{l+1} = x0 * (v W^T + b) + x_l inside the GEMM's epilogue (DLRM_CROSS_FUSE=0: the two kernels of round 4): the fp32 u
+                # never goes through HBM, its bf16 copy is all the backward pass reads
+                fused = ops.gemm_bf16_cross(v16, W16, b, x0, xl, want16=(l + 1 < L)) if CROSS_FUSE else None
+                if fused is not None:
+                    xl, xl16, u = fused
+                    us.append(u)
+                    continue
                 u = torch.empty((M, n_in), dtype=torch.float32, device=x0.device)
-                ops.gemm_bf16(v16, ops.cast_bf16(W, V.size(0), category="linear_fwd"), b, ACT_NONE, u, None, category="linear_fwd")
-                xs16.append(xl16); vs16.append(v16); us.append(u)
+                ops.gemm_bf16(v16, W16, b, ACT_NONE, u, None, category="linear_fwd")
+                us.append(u)
                 if l + 1 < L:
                     xl, xl16 = ops.cross_fwd(x0, u, xl, want16=True)
                 else:

@@ -1246,13 +1246,48 @@ def cross_fwd(x0: torch.Tensor, u: torch.Tensor, xl: torch.Tensor, want16: bool 
     return (out, out16) if want16 else out
 
 
+def gemm_bf16_cross(v16: torch.Tensor, W16: torch.Tensor, bias: Optional[torch.Tensor], x0: torch.Tensor, xl: torch.Tensor,
+                    want16: bool, category: str = "linear_fwd"):
+    """DCN-v2 cross layer, second product with the elementwise half in its epilogue (dlrm_gemm_bf16_cross):
+    u = v16 . W16^T + bias;  returns (x_next = x0 * u + xl fp32, bf16(x_next) or None, bf16(u)), or None when the bf16-shaped kernel does not take
+    the shape (the caller keeps gemm_bf16 + cross_fwd)."""
+    lib = _lib.load()
+    M, K = v16.shape
+    N = W16.size(0)
+    if v16.dtype != torch.bfloat16 or W16.dtype != torch.bfloat16 or W16.size(1) != K or x0.shape != (M, N) or xl.shape != (M, N):
+        raise RuntimeError("dlrm_amd: gemm_bf16_cross shape / dtype mismatch")
+    _req(x0, "x0", ndim=2); _req(xl, "xl", ndim=2)
+    out = torch.empty((M, N), dtype=torch.float32, device=x0.device)
+    out16 = torch.empty((M, N), dtype=torch.bfloat16, device=x0.device) if want16 else None
+    u16 = torch.empty((M, N), dtype=torch.bfloat16, device=x0.device)
+    with _timed(category):
+        rc = lib.dlrm_gemm_bf16_cross(M, N, K, C.c_void_p(v16.data_ptr()), v16.stride(0), C.c_void_p(W16.data_ptr()), W16.stride(0),
+                                      C.c_void_p(bias.data_ptr()) if bias is not None else None,
+                                      C.c_void_p(x0.data_ptr()), _ld(x0), C.c_void_p(xl.data_ptr()), _ld(xl),
+                                      C.c_void_p(u16.data_ptr()), u16.stride(0), C.c_void_p(out.data_ptr()), _ld(out),
+                                      C.c_void_p(out16.data_ptr()) if out16 is not None else None, out16.stride(0) if out16 is not None else 0,
+                                      _stream(out))
+    if rc == -4:                       # DLRM_E_MODE: outside the bf16-shaped kernel's preconditions
+        return None
+    _lib.check(rc, "dlrm_gemm_bf16_cross")
+    return out, out16, u16
+
+
 def cross_bwd(g: torch.Tensor, x0: torch.Tensor, u: torch.Tensor, dx0: torch.Tensor, accumulate: bool, out: str = "f32"):
-    """du = g * x0 (out "f32": fp32 tensor; "bf16": only its bf16 rounding — what a bf16-storage weight / data gradient reads); dx0 (+)= g * u"""
-    n = _flat3(g, x0, u, dx0)
+    """du = g * x0 (out "f32": fp32 tensor; "bf16": only its bf16 rounding — what a bf16-storage weight / data gradient reads); dx0 (+)= g * u
+    (u: the fp32 tensor, or the bf16 copy gemm_bf16_cross stored)"""
+    n = _flat3(g, x0, dx0)
+    if u.dtype == torch.bfloat16:
+        if not u.is_contiguous() or u.numel() != n:
+            raise RuntimeError("dlrm_amd: elementwise operands must be contiguous and of equal size")
+    else:
+        _flat3(g, u)
     du = torch.empty_like(g) if out == "f32" else None
     du16 = torch.empty(g.shape, dtype=torch.bfloat16, device=g.device) if out == "bf16" else None
     with _timed("cross_ew"):
-        rc = _lib.load().dlrm_cross_bwd(n, C.c_void_p(g.data_ptr()), C.c_void_p(x0.data_ptr()), C.c_void_p(u.data_ptr()),
+        rc = _lib.load().dlrm_cross_bwd(n, C.c_void_p(g.data_ptr()), C.c_void_p(x0.data_ptr()),
+                                        C.c_void_p(u.data_ptr()) if u.dtype != torch.bfloat16 else None,
+                                        C.c_void_p(u.data_ptr()) if u.dtype == torch.bfloat16 else None,
                                         C.c_void_p(du.data_ptr()) if du is not None else None,
                                         C.c_void_p(du16.data_ptr()) if du16 is not None else None,
                                         C.c_void_p(dx0.data_ptr()), int(bool(accumulate)), _stream(g))

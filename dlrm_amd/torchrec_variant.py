@@ -111,12 +111,12 @@ class ShardedDLRM(DLRM_Net):
         ln_bot = np.asarray([dense_in_features] + list(dense_arch_layer_sizes))
         ln_top = np.asarray([D + F * (F - 1) // 2] + list(over_arch_layer_sizes))
         local_rows = [rows[t] for t in self.tw_mine] + [self.rw_range[t][1] - self.rw_range[t][0] for t in self.rw_tables]
-        saved = ext_dist.my_size
-        ext_dist.my_size = 1                                 # create_emb: build exactly the listed (local) tables
+        saved = ext_dist.my_size, ext_dist.force_distributed
+        ext_dist.my_size, ext_dist.force_distributed = 1, False     # create_emb: build exactly the listed (local) tables
         try:
             self.emb_l, self.v_W_l = self.create_emb(D, np.asarray(local_rows), None)
         finally:
-            ext_dist.my_size = saved
+            ext_dist.my_size, ext_dist.force_distributed = saved
         self.bot_l = self.create_mlp(ln_bot, -1)
         top = self.create_mlp(ln_top, -1)
         self.top_l = FusedMLP(*list(top.children())[:-1])    # bare last Linear -> logits

@@ -446,8 +446,16 @@ int dlrm_bce_elementwise_bwd(int64_t n, const float* p, const float* target, con
  *   (n % 4 == 0, 16-byte aligned):  dlrm_cross_fwd  out = x0 * u + xl;   dlrm_cross_bwd  du = g * x0,  dx0 (+)= g * u
  *   (accumulate != 0 adds into dx0);  dlrm_add  out = a + b  (the gradient reaching x_l through the V product joins g). */
 int dlrm_cross_fwd(int64_t n, const float* x0, const float* u, const float* xl, float* out, uint16_t* out16 /* nullable: bf16(out) */, void* stream);
-int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const float* u, float* du /* nullable */, uint16_t* du16 /* nullable: bf16(g * x0) */,
-                   float* dx0, int accumulate, void* stream);
+int dlrm_cross_bwd(int64_t n, const float* g, const float* x0, const float* u /* fp32 u ... */, const uint16_t* u16 /* ... or its bf16 copy: exactly one */,
+                   float* du /* nullable */, uint16_t* du16 /* nullable: bf16(g * x0) */, float* dx0, int accumulate, void* stream);
+/* The second product of a cross layer WITH its elementwise half in the GEMM epilogue (bf16-storage towers; replaces dlrm_gemm_bf16 + dlrm_cross_fwd,
+ * whose fp32 u made a round trip through HBM):  u = A . B^T + bias (A = bf16 v_l [M, K], B = bf16 W_l [N, K], fp32 accumulation);
+ * Ub (bf16 [M, N], nullable) = u — what dlrm_cross_bwd(u16) reads;  C (fp32) = fma(x0, u, xl) = x_{l+1};  Cb (bf16, nullable) = bf16(C), the next
+ * layer's GEMM operand.  Same operation order as the two kernels (bit-identical x_{l+1}).  Preconditions of the bf16-shaped kernel (K % 64 == 0,
+ * N >= 192, M >= 256, 16-byte aligned rows); DLRM_E_MODE otherwise — the caller keeps the two kernels. */
+int dlrm_gemm_bf16_cross(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias,
+                         const float* x0, int64_t ldx0, const float* xl, int64_t ldxl, uint16_t* Ub, int64_t ldub,
+                         float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, void* stream);
 int dlrm_add(int64_t n, const float* a, const float* b, float* out, void* stream);
 
 /* torch.clamp(p, lo, hi) of the predictions and its backward (--loss-threshold, dlrm_s_pytorch.py:580-583, 607-610):

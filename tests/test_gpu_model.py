@@ -661,10 +661,10 @@ def test_dcn_v2_cross_network_bf16_storage_equals_in_loop_rounding():
                  torch.from_numpy((rng.standard_normal((n, r)) / np.sqrt(r)).astype(np.float32)).to(device),
                  torch.from_numpy((rng.standard_normal(n) * 0.1).astype(np.float32)).to(device)]
     res = []
-    saved = functional.BF16_STORAGE
+    saved = functional.BF16_STORAGE, functional.CROSS_FUSE
     try:
-        for storage in (False, True):
-            functional.BF16_STORAGE = storage
+        for storage, fuse in ((False, False), (True, False), (True, True)):
+            functional.BF16_STORAGE, functional.CROSS_FUSE = storage, fuse
             tx0 = x0.clone().requires_grad_(True)
             ps = [p.clone().requires_grad_(True) for p in base]
             out = LowRankCrossNetFunction.apply(ops.arith_code("bf16"), tx0, *ps)
@@ -672,8 +672,8 @@ def test_dcn_v2_cross_network_bf16_storage_equals_in_loop_rounding():
             torch.cuda.synchronize()
             res.append((out.detach(), tx0.grad, [p.grad for p in ps]))
     finally:
-        functional.BF16_STORAGE = saved
-    (o0, d0, g0), (o1, d1, g1) = res
+        functional.BF16_STORAGE, functional.CROSS_FUSE = saved
+    (o0, d0, g0), (o1, d1, g1), (o2, d2, g2) = res
     sc = lambda a: float(a.abs().max())      # noqa: E731
     assert float((o0 - o1).abs().max()) <= 1e-5 * sc(o0)
     assert float((d0 - d1).abs().max()) <= 2e-5 * sc(d0)
@@ -681,6 +681,14 @@ def test_dcn_v2_cross_network_bf16_storage_equals_in_loop_rounding():
         # (bias gradients: column sums of bf16-ROUNDED du — 8192 terms with an independent relative rounding of up to 2^-9 each — against
         # sums of the fp32 du: a random walk of ~1e-3 of the sum's own scale, a few times that at the worst of 3456 columns)
         assert float((a - b).abs().max()) <= (6e-3 if k % 3 == 2 else 1e-4) * sc(a), k
+    # the FUSED form (round 5, dlrm_gemm_bf16_cross: x_{l+1} = fma(x0, u, xl) in the epilogue of the second product, u kept as bf16 only): the
+    # forward is the same operations in the same order -> BIT-identical output; the backward reads the bf16 copy of u for dx0 += g * u, one
+    # more bf16 rounding (2^-9 relative per term) on a factor that is itself the result of bf16-operand products -> dx0 within 4e-3 of its
+    # scale, and through g_l = g + dv.V + ... every parameter gradient of the layers below within the bf16 class
+    assert torch.equal(o1, o2), float((o1 - o2).abs().max())
+    assert float((d1 - d2).abs().max()) <= 4e-3 * sc(d1)
+    for k, (a, b) in enumerate(zip(g1, g2)):
+        assert float((a - b).abs().max()) <= (6e-3 if k % 3 == 2 else 4e-3) * sc(a), k
 
 
 def test_dlrm_dcn_model_trains_like_a_torch_composition():
