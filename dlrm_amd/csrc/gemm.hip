@@ -1388,8 +1388,11 @@ extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, in
 static void wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* kchunk_out) {
     // split the batch reduction so that >= ~4 workgroups per CU exist; slices of >= 512 rows
     const int tiles = (int)(((N + BM - 1) / BM) * ((K + BN - 1) / BN));
-    int splits = (1024 + tiles - 1) / tiles;
-    const int64_t max_splits = (M + 511) / 512;
+    static int target_wgs = -1, min_rows = -1;   // tuning aids: DLRM_WGRAD_WGS (workgroups a launch aims at), DLRM_WGRAD_MINROWS (shortest batch slice)
+    if (target_wgs < 0) { const char* e = getenv("DLRM_WGRAD_WGS"); target_wgs = e && atoi(e) > 0 ? atoi(e) : 1024; }
+    if (min_rows < 0) { const char* e = getenv("DLRM_WGRAD_MINROWS"); min_rows = e && atoi(e) >= 128 ? atoi(e) : 512; }
+    int splits = (target_wgs + tiles - 1) / tiles;
+    const int64_t max_splits = (M + min_rows - 1) / min_rows;
     if (splits > max_splits) {
         // small batches (Criteo-Kaggle: 2048 rows): slices down to 128 rows while the launch still has fewer workgroups than the chip has CUs
         const int64_t max128 = (M + 127) / 128;

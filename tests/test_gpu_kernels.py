@@ -827,7 +827,10 @@ def test_lean_towers_keep_the_fp32_activation_where_the_data_gradient_falls_back
     for i in range(L):
         hs.append(np.maximum(hs[-1] @ params[2 * i].detach().double().cpu().numpy().T + params[2 * i + 1].detach().double().cpu().numpy(), 0))
     g = dy.double().cpu().numpy()
-    tol = 4e-2 if arith == "bf16" else 2e-5
+    # bf16: operands rounded to 8 bits; a pre-activation within that rounding of zero flips its ReLU mask against the fp64 restatement, which
+    # moves single gradient entries by a few per cent of the largest one (measured: 2 of 51200 entries off by 0.048 of the maximum); the bug
+    # this test guards against (a data gradient without its ReLU mask) moves EVERY entry below the layer by its own size
+    tol = 1e-1 if arith == "bf16" else 2e-5
     np.testing.assert_allclose(y.detach().cpu().numpy(), hs[-1], rtol=tol, atol=tol * float(np.abs(hs[-1]).max()))
     for i in range(L - 1, -1, -1):
         g = g * (hs[i + 1] > 0)

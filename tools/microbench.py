@@ -73,6 +73,22 @@ def gemm(shapes):
     return out
 
 
+def wgrad(shapes):
+    """weight gradient only (tuning sweeps: DLRM_WGRAD_WGS / DLRM_WGRAD_MINROWS / DLRM_WGRAD_TM are read once per process)"""
+    tot = 0.0
+    for (M, N, K) in shapes:
+        ldk = (K + 3) & ~3
+        X = torch.randn(M, ldk, device=DEV)[:, :K]
+        dY = torch.randn(M, N, device=DEV)
+        dW = torch.empty(N, K, device=DEV)
+        db = torch.zeros(N, device=DEV)
+        t = timeit(lambda: ops.linear_bwd_weight(dY, X, dW, db, arith=ARITH))
+        tot += t
+        print("wgrad M=%d N=%d K=%d  %.1f us  %.1f TF" % (M, N, K, t * 1e3, 2.0 * M * N * K / t / 1e9), flush=True)
+    print("wgrad sum %.1f us  [WGS=%s MINROWS=%s TM=%s]" % (tot * 1e3, os.environ.get("DLRM_WGRAD_WGS", "-"), os.environ.get("DLRM_WGRAD_MINROWS", "-"),
+                                                        os.environ.get("DLRM_WGRAD_TM", "-")), flush=True)
+
+
 def emb(B=65536, D=128, cap=0):
     rows = [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155, 4, 976, 14,
             39979771, 25641295, 39664984, 585935, 12972, 108, 36]
@@ -135,7 +151,7 @@ ARITH = "f32"
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "gemm_big", "emb", "emb_classes", "all"])
+    ap.add_argument("what", choices=["gemm", "gemm_big", "wgrad", "emb", "emb_classes", "all"])
     ap.add_argument("--arith", default="f32")
     a = ap.parse_args()
     ARITH = a.arith
@@ -143,6 +159,8 @@ if __name__ == "__main__":
     layer_shapes = [(B, 512, 16), (B, 256, 512), (B, 128, 256), (B, 1024, 480), (B, 1024, 1024), (B, 512, 1024), (B, 256, 512), (B, 1, 256)]
     if a.what in ("gemm", "all"):
         gemm(layer_shapes)
+    if a.what == "wgrad":
+        wgrad(layer_shapes[1:7])
     if a.what == "gemm_big":
         gemm([(B, 1024, 1024), (B, 512, 1024)])
     if a.what in ("emb", "all"):
