@@ -827,18 +827,25 @@ def test_lean_towers_keep_the_fp32_activation_where_the_data_gradient_falls_back
     for i in range(L):
         hs.append(np.maximum(hs[-1] @ params[2 * i].detach().double().cpu().numpy().T + params[2 * i + 1].detach().double().cpu().numpy(), 0))
     g = dy.double().cpu().numpy()
-    # bf16: operands rounded to 8 bits; a pre-activation within that rounding of zero flips its ReLU mask against the fp64 restatement, which
-    # moves single gradient entries by a few per cent of the largest one (measured: 2 of 51200 entries off by 0.048 of the maximum); the bug
-    # this test guards against (a data gradient without its ReLU mask) moves EVERY entry below the layer by its own size
-    tol = 1e-1 if arith == "bf16" else 2e-5
-    np.testing.assert_allclose(y.detach().cpu().numpy(), hs[-1], rtol=tol, atol=tol * float(np.abs(hs[-1]).max()))
+    # bf16: operands rounded to 8 bits; a pre-activation within that rounding of zero flips its ReLU unit against the fp64 restatement, which
+    # moves that SAMPLE's input-gradient row by O(1) and single parameter-gradient entries by a few per cent (measured: 0.1 % of the dx
+    # entries, 2 of 51200 dW entries) — so bf16 is compared in the Frobenius norm; the bug this test guards against (a data gradient
+    # without its ReLU mask) changes about half of ALL entries below the layer by their own size (relative norm error ~0.7).  The bar of 0.2:
+    # these gradients are sums of 2048 random-sign terms, which amplifies the 2^-9 operand rounding — bf16 vs fp32 arithmetic of the SAME
+    # kernels differs by 0.04-0.10 in this norm for every tensor, at widths 192 / 224 as at 200 (tools/probes/lean_width_probe.py)
+    def close(got, want, what):
+        if arith == "bf16":
+            err = float(np.linalg.norm(got.astype(np.float64) - want) / max(np.linalg.norm(want), 1e-30))
+            assert err <= 0.2, (what, err)
+        else:
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * float(np.abs(want).max()), err_msg=what)
+    close(y.detach().cpu().numpy(), hs[-1], "y")
     for i in range(L - 1, -1, -1):
         g = g * (hs[i + 1] > 0)
-        dW, db = g.T @ hs[i], g.sum(0)
-        np.testing.assert_allclose(params[2 * i].grad.cpu().numpy(), dW, rtol=tol, atol=tol * float(np.abs(dW).max()), err_msg="dW %d" % i)
-        np.testing.assert_allclose(params[2 * i + 1].grad.cpu().numpy(), db, rtol=tol, atol=tol * float(np.abs(db).max()), err_msg="db %d" % i)
+        close(params[2 * i].grad.cpu().numpy(), g.T @ hs[i], "dW %d" % i)
+        close(params[2 * i + 1].grad.cpu().numpy(), g.sum(0), "db %d" % i)
         g = g @ params[2 * i].detach().double().cpu().numpy()
-    np.testing.assert_allclose(x.grad.cpu().numpy(), g, rtol=tol, atol=tol * float(np.abs(g).max()))
+    close(x.grad.cpu().numpy(), g, "dx")
     with pytest.raises(RuntimeError, match="needs the fp32 activation"):
         ops.linear_bwd_data(dy, params[2 * (L - 1)].detach(), None, ops.ACT_RELU, torch.empty((B, ln[-2]), device=dev()))
 
