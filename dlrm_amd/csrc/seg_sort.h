@@ -32,7 +32,10 @@
 
 namespace {
 
-constexpr int SEG_TILE = 2048;           // entries per wave-tile (measured at Criteo-Terabyte shapes: 4096 -> 134 us per sort, 2048 -> 120 us)
+#ifndef DLRM_SEG_TILE
+#define DLRM_SEG_TILE 2048
+#endif
+constexpr int SEG_TILE = DLRM_SEG_TILE;  // entries per wave-tile (measured at Criteo-Terabyte shapes: 4096 -> 134 us per sort, 2048 -> 120 us; -DDLRM_SEG_TILE: tools/build_variant_lib.sh)
 constexpr int SEG_MAX_DBITS = 13;        // 8192 bins: 32 KB of LDS per wave
 constexpr int SEG_GROUP_TILES = 128;     // tiles whose counts ONE thread of seg_colscan_kernel prefixes (262144 lookups); longer segments: several groups
 constexpr int SEG_MAX_GROUPS = 256;      // per table segment (67 M lookups)
