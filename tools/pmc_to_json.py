@@ -42,8 +42,11 @@ def load(path):
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
-    steps = 6      # bench.py --steps 4 --warmup 2 under the profiler
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 4 --warmup 2",
+    fetch_rows = load(f"{src}/pmc_FETCH_SIZE.csv")
+    # training steps the profiled process ran = launches of the ONE dense-SGD kernel of a step (warm-up + timed steps + bench.py's comparison
+    # legs: counted, not assumed — round 5's tagged-offsets leg doubled the step count and a fixed 6 doubled every figure)
+    steps = sum(c for k, c, _ in fetch_rows if "sgd_dense_multi_kernel" in k) or 6
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 4 --warmup 2 (%d training steps in the process)" % steps,
            "units": "bytes per C-ABI call (average over the calls of one training step)",
            "fetch_correction": "FETCH_SIZE x 2 (gfx950: 128-B requests counted as 64 B)", "kernels": {}}
     # stamp: SHA-256 of every kernel source the counters were collected on (bench.py refuses a stale file per category) + commit
@@ -56,7 +59,7 @@ def main():
         out["git_head"] = subprocess.run(["git", "-C", root, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
     except Exception:
         out["git_head"] = None
-    fetch, write = load(f"{src}/pmc_FETCH_SIZE.csv"), load(f"{src}/pmc_WRITE_SIZE.csv")
+    fetch, write = fetch_rows, load(f"{src}/pmc_WRITE_SIZE.csv")
     for cat, pats in CATS.items():
         f_kb = sum(c * v for k, c, v in fetch if in_cat(cat, pats, k)) / steps
         w_kb = sum(c * v for k, c, v in write if in_cat(cat, pats, k)) / steps
