@@ -158,6 +158,15 @@ class GraphedTrainStep:
         model = self.model
         if not getattr(model, "fuse_emb_interact", False):
             return
+        # (a model that cannot take the fused path anyway — Criteo-Kaggle's D = 16, a cat interaction, pooling weights — needs no proof: a
+        # per-replay host wait doubled that launch-bound step when every replay brought a new offsets tensor)
+        try:
+            D = model.emb_l[0].weight.size(1)
+            if (getattr(model, "arch_interaction_op", "dot") != "dot" or not ops.gather_ok(1 + len(model.emb_l), D)
+                    or any(w is not None for w in (getattr(model, "v_W_l", None) or []))):
+                return
+        except (AttributeError, IndexError, TypeError):
+            pass
         n_i = lS_i.size(-1) if isinstance(lS_i, torch.Tensor) else None
         n_o = lS_o.size(-1) if isinstance(lS_o, torch.Tensor) else None
         if isinstance(lS_i, torch.Tensor) != isinstance(lS_o, torch.Tensor) or (n_i is not None and n_i != n_o):
