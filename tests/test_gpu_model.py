@@ -401,6 +401,53 @@ def test_ragged_batch_with_one_lookup_per_bag_on_average_takes_the_two_kernels()
     assert ops.offsets_are_iota(o) is False
 
 
+def test_producer_tags_and_the_proof_stream():
+    """Round 5: (a) tensors whose PRODUCER wrote 0..B-1 carry its proof (dlrm_amd.datagen with one fixed lookup per bag — list and stacked
+    forms —, Multihot over all-ones hot sizes): ops.offsets_are_iota answers without a device pass; a versioned in-place write voids the
+    tag, a copy carries none; a generator with variable bag lengths tags nothing.  (b) the two-phase proof (offsets_are_iota_start /
+    _finish: the check kernel on its own stream, the host waits for ITS event) — work enqueued on the caller's stream between the two
+    halves does not disturb it, the verdict is cached per tensor object afterwards, and a ragged tensor is refused."""
+    from dlrm_amd import ops
+    from dlrm_amd.datagen import UniformBatchGenerator
+    from dlrm_amd.multihot import Multihot
+    device = torch.device("cuda:0")
+    rows, B = [50, 300, 7, 100000], 512
+    gen = UniformBatchGenerator(13, rows, 1, True, seed=3, device=device)
+    s0 = dict(ops.IOTA_STATS)
+    _, lS_o, _, _ = gen.batch(B, 0)
+    assert ops.offsets_are_iota(lS_o) is True
+    _, so, si, _ = gen.batch(B, 1, stacked=True)
+    assert so.shape == (len(rows), B) and si.shape == (len(rows), B) and ops.offsets_are_iota(so) is True
+    assert ops.IOTA_STATS["tagged"] == s0["tagged"] + 2 and ops.IOTA_STATS["checked"] == s0["checked"]      # no device pass so far
+    assert torch.equal(so, torch.arange(B, device=device).repeat(len(rows), 1))                               # ... and the tag tells the truth
+    c = so.clone()                                   # a copy is a new object: it takes the device proof
+    assert ops.offsets_are_iota(c) is True and ops.IOTA_STATS["checked"] == s0["checked"] + 1
+    so[2, 7] = 9                                     # a versioned write voids the tag; the device pass then sees the ragged bags
+    assert ops.offsets_are_iota(so) is False and ops.IOTA_STATS["checked"] == s0["checked"] + 2
+    ragged_gen = UniformBatchGenerator(13, rows, 3, False, seed=3, device=device)
+    _, ro, _, _ = ragged_gen.batch(B, 0)
+    assert not any(getattr(o, ops._IOTA_TAG, None) is not None for o in ro)
+    mh = Multihot([1, 1, 1], [50, 300, 7], B, device=device)
+    _, _, off_l = mh.expand(torch.randint(0, 7, (3, B), device=device, dtype=torch.int32), want_global_offsets=False)
+    assert ops.offsets_are_iota(off_l) is True and ops.IOTA_STATS["checked"] == s0["checked"] + 2            # tagged: no pass
+    mh2 = Multihot([2, 1, 1], [50, 300, 7], B, device=device)
+    _, _, off2 = mh2.expand(torch.randint(0, 7, (3, B), device=device, dtype=torch.int32), want_global_offsets=False)
+    assert getattr(off2, ops._IOTA_TAG, None) is None
+    # (b) two-phase proof with caller-stream work in between
+    fresh = torch.arange(B, device=device).repeat(len(rows), 1)
+    h = ops.offsets_are_iota_start(fresh)
+    assert not isinstance(h, bool) and h is not None
+    a = torch.randn(2048, 2048, device=device)
+    for _ in range(8):
+        a = a @ a * 1e-3                             # the caller's stream is busy while the proof runs on its own
+    assert ops.offsets_are_iota_finish(h) is True
+    assert ops.offsets_are_iota_start(fresh) is True                     # cached per object now
+    bad = fresh.clone(); bad[0, 3] = 2
+    assert ops.offsets_are_iota_finish(ops.offsets_are_iota_start(bad)) is False
+    assert ops.offsets_are_iota_finish(True) is True and ops.offsets_are_iota_finish(False) is False and ops.offsets_are_iota_finish(None) is None
+    torch.cuda.synchronize()
+
+
 def test_coo_escape_hatch_refuses_row_wise_shards_and_checks_indices_synchronously():
     """ADVICE r2 fixes that had no test: (a) DLRM_Net._materialize_coo_grads exits with the reference-style ERROR when the bags
     belong to a row-wise shard (ignore_oob: out-of-range ids are other ranks' rows, a COO gradient would scatter them);
