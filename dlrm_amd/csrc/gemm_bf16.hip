@@ -35,6 +35,7 @@
 //               dlrm_linear_bwd_weight_bf16x6; K % 16 == 0) — see the comment at the kernel.
 // Measured context for every rate quoted against "the bf16 peak": on random operands the matrix pipe of this part holds 1.88 of its nominal
 // 2.46 PFLOP/s (bench.py box.mfma_bf16_random_tflops, profiles/round4/box_classes.md).
+#include <cstring>
 #include "common.h"
 
 namespace {
@@ -60,7 +61,7 @@ struct BfArgs {
     unsigned* bits_out; const unsigned* bits_in; long long bits_nblk;
     int tiles_m, tiles_n;
     int wide16;                              // bf16-only output through 16-byte stores (set by the host when its preconditions hold)
-    int debug;                               // tuning build only (make TUNING=1, env DLRM_BF16_DEBUG): 1 no DMA in the k-loop, 2 fragments read once, 4 no MFMAs, 8 no epilogue — WRONG results
+    int debug;                               // tuning build only (make TUNING=1, env DLRM_BF16_DEBUG): 1 no DMA in the k-loop, 2 fragments read once, 4 no MFMAs, 8 no epilogue, 16 epilogue without its global stores — WRONG results
     // weight-gradient form (WG): the reduction runs over the ROWS of both operands (A = dZ [K, M], B = X [K, N], C = A^T B), split in
     // gridDim.z slices of kchunk rows; slice z stores its fp32 partial at C + z * c_split_stride and the row sums of A^T (the bias
     // gradient) at rowsum + z * M
@@ -440,9 +441,78 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     if (g.bias && nb < g.N) bv = *(const float4*)(g.bias + nb);      // N % 4 == 0 and nb % 4 == 0: the quad is inside the bias vector
     // (one instantiation per band through a generic lambda: with the second output form the unroller refused the pragma on a plain loop —
     // "unrolled size is too large" — and a rolled loop indexes acc[tm] dynamically, i.e. puts the accumulators into scratch memory)
+    // bias quads of this lane's 2 x 4 column groups (direct epilogue only): columns n0 + wc * 64 + 32 tn + 8 q + 4 h .. + 3
+    float4 bq[2][4];
+    if (!WG && PL == 1 && g.wide16 == 2) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long c_ = n0 + wc * 64 + 32 * tn + 8 * q + 4 * h;
+                bq[tn][q] = (g.bias && c_ < g.N) ? *(const float4*)(g.bias + c_) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    }
     auto band = [&](auto TMC) {
         constexpr int tm = decltype(TMC)::value;
         unsigned myword = 0u;
+        if constexpr (!WG && PL == 1) {
+            if (g.wide16 == 2) {
+                // ---- DIRECT epilogue (round 5; bf16-only output): no LDS round trip of the tile.  profiles/round5/bf16_epilogue_ablation.txt: of the
+                // 35 us a 65536 x 1024 x 1024 call spends in its epilogue, 22 are the staging pass (256 KiB of fp32 written to and read back from LDS
+                // per tile, twice with sign bits) and 13 the stores.  The transposed accumulators already give a lane 4 CONSECUTIVE columns of ITS
+                // row per (tn, q): bias, activation, mask and the bf16 rounding happen in registers, v_permlane32_swap trades the 8-byte pieces of
+                // the two half-waves (lanes l and l + 32 hold the same row) so that every lane owns 16 contiguous bytes per store, and the sign
+                // bits reach their documented owners (dlrm_relu_bits_bytes) as one nibble word per lane through eight cross-lane fetches.
+                const long long m = m0 + wr * 128 + tm * 32 + l31;
+                const int it_ = l31 >> 2, rr_ = l31 & 3;
+                unsigned W = 0u, pk[2][4][2];
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 b_ = bq[tn][q];
+                        const float x0 = acc[tm][tn][4 * q] + b_.x, x1 = acc[tm][tn][4 * q + 1] + b_.y, x2 = acc[tm][tn][4 * q + 2] + b_.z,
+                                    x3 = acc[tm][tn][4 * q + 3] + b_.w;
+                        if (g.bits_out) {
+                            const unsigned nib = (x0 > 0.f ? 8u : 0u) | (x1 > 0.f ? 4u : 0u) | (x2 > 0.f ? 2u : 0u) | (x3 > 0.f ? 1u : 0u);
+                            W |= nib << (4 * (tn * 4 + q));
+                        }
+                        float v0 = p_act(x0, g.act), v1 = p_act(x1, g.act), v2 = p_act(x2, g.act), v3 = p_act(x3, g.act);
+                        if (g.bits_in) {          // the word of the lane that owns (row, column quad): lane 16 (row & 3) + quad, bits 31 - (4 (row >> 2) + c)
+                            const unsigned w_ = (unsigned)__shfl((int)mkb[tm], 16 * rr_ + 8 * tn + 2 * q + h, 64);
+                            const unsigned nm = (w_ >> (28 - 4 * it_)) & 15u;
+                            if (!(nm & 8u)) v0 = 0.f;
+                            if (!(nm & 4u)) v1 = 0.f;
+                            if (!(nm & 2u)) v2 = 0.f;
+                            if (!(nm & 1u)) v3 = 0.f;
+                        }
+                        pk[tn][q][0] = p_cvt_pk_bf16(v0, v1); pk[tn][q][1] = p_cvt_pk_bf16(v2, v3);
+                    }
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        // pieces P[2j] (columns 16 j + 4 h ..) and P[2j + 1] (16 j + 8 + 4 h ..): after the swap the lower half-wave holds both halves'
+                        // P[2j] (columns 16 j .. + 7) and the upper one both halves' P[2j + 1] (16 j + 8 .. + 15): 16 contiguous bytes per lane
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[tn][2 * j][0], pk[tn][2 * j + 1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[tn][2 * j][1], pk[tn][2 * j + 1][1], false, false);
+                        uintx4 o; o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
+                        const long long c_ = n0 + wc * 64 + 32 * tn + 16 * j + 8 * h;
+                        if (m < g.M && c_ < g.N && !(P_DBG & 16)) *(uintx4*)(g.Cb + m * g.ldcb + c_) = o;
+                    }
+                if (g.bits_out) {
+                    const int src0_ = (lane >> 4) + 32 * (lane & 1), sh_ = 4 * ((lane & 15) >> 1);
+#pragma unroll
+                    for (int i8 = 0; i8 < 8; ++i8) {
+                        const unsigned w_ = (unsigned)__shfl((int)W, 4 * i8 + src0_, 64);
+                        myword |= ((w_ >> sh_) & 15u) << (28 - 4 * i8);
+                    }
+                    const long long mb = (m0 + wr * 128 + tm * 32) >> 5, nbk = (n0 + wc * 64) >> 6;
+                    if (mb <= ((g.M - 1) >> 5) && nbk < g.bits_nblk) g.bits_out[(mb * g.bits_nblk + nbk) * 64 + lane] = myword;
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -493,7 +563,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
                     if (!((w1 >> (sh - 2)) & 1u)) v1.z = 0.f;
                     if (!((w1 >> (sh - 3)) & 1u)) v1.w = 0.f;
                 }
-                if (m < g.M && nb8 < g.N) {
+                if (m < g.M && nb8 < g.N && !(P_DBG & 16)) {        // (16: timing only — the whole epilogue EXCEPT its global stores)
                     if constexpr (PL == 1) {
                         uintx4 pk;
                         pk[0] = p_cvt_pk_bf16(v0.x, v0.y); pk[1] = p_cvt_pk_bf16(v0.z, v0.w);
@@ -524,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
                              "v_cmp_lt_f32 vcc, 0, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                              : "+v"(myword) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "vcc");
             }
-            if (!live) continue;
+            if (!live || (P_DBG & 16)) continue;
             if (g.bits_in) {
                 const unsigned wv = mkb[tm];
                 if (!((wv >> (31 - (it * 4 + 0))) & 1u)) v.x = 0.f;
@@ -606,9 +676,12 @@ int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t ld
     static int wide = -1;               // tuning aid: DLRM_BF16_WIDE_STORE=0 keeps the 8-byte bf16 stores
     if (wide < 0) { const char* e = getenv("DLRM_BF16_WIDE_STORE"); wide = e ? atoi(e) : 1; }
 #ifdef DLRM_TUNING
-    { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 15); g.debug = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 31); g.debug = dbg; }
 #endif
     g.wide16 = (wide && Cb && !C && !addend && !mul && !Ub && N % 8 == 0 && ldcb % 8 == 0 && dlrm_aligned16(Cb) && (!bias || dlrm_aligned16(bias))) ? 1 : 0;
+    static int direct = -1;             // DLRM_BF16_EPI=lds keeps the LDS-staged bf16-only epilogue (A/B runs); default: the direct one
+    if (direct < 0) { const char* e = getenv("DLRM_BF16_EPI"); direct = (e && strcmp(e, "lds") == 0) ? 0 : 1; }
+    if (g.wide16 && direct) g.wide16 = 2;
     static bool attr_done[DLRM_MAX_DEVICES] = {};
     phased_attr((const void*)gemm_bf16_phased_kernel<false, 1>, attr_done[dlrm_current_device()]);
     hipLaunchKernelGGL((gemm_bf16_phased_kernel<false, 1>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS_PL1, st, g);
@@ -639,7 +712,7 @@ int dlrm_gemm_bf16x6_phased(int64_t M, int N, int K, const uint16_t* A, int64_t 
     g.bits_out = (unsigned*)relu_bits_out; g.bits_in = (const unsigned*)relu_bits_in; g.bits_nblk = ((long long)N + 63) / 64;
     g.tiles_m = (int)((M + PBM - 1) / PBM); g.tiles_n = (int)((N + PBN - 1) / PBN);
 #ifdef DLRM_TUNING
-    { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 15); g.debug = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 31); g.debug = dbg; }
 #endif
     g.wide16 = (Cp && !C && N % 8 == 0 && ldcp % 8 == 0 && planeC % 8 == 0 && dlrm_aligned16(Cp)) ? 1 : 0;
     static bool attr_done[DLRM_MAX_DEVICES] = {};

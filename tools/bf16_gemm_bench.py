@@ -17,7 +17,7 @@ SHAPES = [(65536, 1024, 1024), (65536, 1024, 512), (65536, 512, 1024), (65536, 5
 def main():
     global SHAPES
     if os.environ.get("BF16_BENCH_SHAPES"):         # ablation runs: the two layer shapes that matter
-        SHAPES = [(65536, 1024, 1024), (65536, 512, 3456)]
+        SHAPES = [(65536, 1024, 1024), (65536, 512, 3456)] if os.environ["BF16_BENCH_SHAPES"] != "3" else [(65536, 1024, 1024), (65536, 3456, 512)]
     from dlrm_amd import ops
     from tools.microbench import timeit
     dev = torch.device("cuda:0")
