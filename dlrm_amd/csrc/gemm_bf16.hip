@@ -35,7 +35,6 @@
 //               dlrm_linear_bwd_weight_bf16x6; K % 16 == 0) — see the comment at the kernel.
 // Measured context for every rate quoted against "the bf16 peak": on random operands the matrix pipe of this part holds 1.88 of its nominal
 // 2.46 PFLOP/s (bench.py box.mfma_bf16_random_tflops, profiles/round4/box_classes.md).
-#include <cstring>
 #include "common.h"
 
 namespace {
@@ -441,78 +440,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     if (g.bias && nb < g.N) bv = *(const float4*)(g.bias + nb);      // N % 4 == 0 and nb % 4 == 0: the quad is inside the bias vector
     // (one instantiation per band through a generic lambda: with the second output form the unroller refused the pragma on a plain loop —
     // "unrolled size is too large" — and a rolled loop indexes acc[tm] dynamically, i.e. puts the accumulators into scratch memory)
-    // bias quads of this lane's 2 x 4 column groups (direct epilogue only): columns n0 + wc * 64 + 32 tn + 8 q + 4 h .. + 3
-    float4 bq[2][4];
-    if (!WG && PL == 1 && g.wide16 == 2) {
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const long long c_ = n0 + wc * 64 + 32 * tn + 8 * q + 4 * h;
-                bq[tn][q] = (g.bias && c_ < g.N) ? *(const float4*)(g.bias + c_) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-    }
     auto band = [&](auto TMC) {
         constexpr int tm = decltype(TMC)::value;
         unsigned myword = 0u;
-        if constexpr (!WG && PL == 1) {
-            if (g.wide16 == 2) {
-                // ---- DIRECT epilogue (round 5; bf16-only output): no LDS round trip of the tile.  profiles/round5/bf16_epilogue_ablation.txt: of the
-                // 35 us a 65536 x 1024 x 1024 call spends in its epilogue, 22 are the staging pass (256 KiB of fp32 written to and read back from LDS
-                // per tile, twice with sign bits) and 13 the stores.  The transposed accumulators already give a lane 4 CONSECUTIVE columns of ITS
-                // row per (tn, q): bias, activation, mask and the bf16 rounding happen in registers, v_permlane32_swap trades the 8-byte pieces of
-                // the two half-waves (lanes l and l + 32 hold the same row) so that every lane owns 16 contiguous bytes per store, and the sign
-                // bits reach their documented owners (dlrm_relu_bits_bytes) as one nibble word per lane through eight cross-lane fetches.
-                const long long m = m0 + wr * 128 + tm * 32 + l31;
-                const int it_ = l31 >> 2, rr_ = l31 & 3;
-                unsigned W = 0u, pk[2][4][2];
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float4 b_ = bq[tn][q];
-                        const float x0 = acc[tm][tn][4 * q] + b_.x, x1 = acc[tm][tn][4 * q + 1] + b_.y, x2 = acc[tm][tn][4 * q + 2] + b_.z,
-                                    x3 = acc[tm][tn][4 * q + 3] + b_.w;
-                        if (g.bits_out) {
-                            const unsigned nib = (x0 > 0.f ? 8u : 0u) | (x1 > 0.f ? 4u : 0u) | (x2 > 0.f ? 2u : 0u) | (x3 > 0.f ? 1u : 0u);
-                            W |= nib << (4 * (tn * 4 + q));
-                        }
-                        float v0 = p_act(x0, g.act), v1 = p_act(x1, g.act), v2 = p_act(x2, g.act), v3 = p_act(x3, g.act);
-                        if (g.bits_in) {          // the word of the lane that owns (row, column quad): lane 16 (row & 3) + quad, bits 31 - (4 (row >> 2) + c)
-                            const unsigned w_ = (unsigned)__shfl((int)mkb[tm], 16 * rr_ + 8 * tn + 2 * q + h, 64);
-                            const unsigned nm = (w_ >> (28 - 4 * it_)) & 15u;
-                            if (!(nm & 8u)) v0 = 0.f;
-                            if (!(nm & 4u)) v1 = 0.f;
-                            if (!(nm & 2u)) v2 = 0.f;
-                            if (!(nm & 1u)) v3 = 0.f;
-                        }
-                        pk[tn][q][0] = p_cvt_pk_bf16(v0, v1); pk[tn][q][1] = p_cvt_pk_bf16(v2, v3);
-                    }
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        // pieces P[2j] (columns 16 j + 4 h ..) and P[2j + 1] (16 j + 8 + 4 h ..): after the swap the lower half-wave holds both halves'
-                        // P[2j] (columns 16 j .. + 7) and the upper one both halves' P[2j + 1] (16 j + 8 .. + 15): 16 contiguous bytes per lane
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[tn][2 * j][0], pk[tn][2 * j + 1][0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[tn][2 * j][1], pk[tn][2 * j + 1][1], false, false);
-                        uintx4 o; o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
-                        const long long c_ = n0 + wc * 64 + 32 * tn + 16 * j + 8 * h;
-                        if (m < g.M && c_ < g.N && !(P_DBG & 16)) *(uintx4*)(g.Cb + m * g.ldcb + c_) = o;
-                    }
-                if (g.bits_out) {
-                    const int src0_ = (lane >> 4) + 32 * (lane & 1), sh_ = 4 * ((lane & 15) >> 1);
-#pragma unroll
-                    for (int i8 = 0; i8 < 8; ++i8) {
-                        const unsigned w_ = (unsigned)__shfl((int)W, 4 * i8 + src0_, 64);
-                        myword |= ((w_ >> sh_) & 15u) << (28 - 4 * i8);
-                    }
-                    const long long mb = (m0 + wr * 128 + tm * 32) >> 5, nbk = (n0 + wc * 64) >> 6;
-                    if (mb <= ((g.M - 1) >> 5) && nbk < g.bits_nblk) g.bits_out[(mb * g.bits_nblk + nbk) * 64 + lane] = myword;
-                }
-                return;
-            }
-        }
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn)
 #pragma unroll
@@ -679,9 +609,8 @@ int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t ld
     { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 31); g.debug = dbg; }
 #endif
     g.wide16 = (wide && Cb && !C && !addend && !mul && !Ub && N % 8 == 0 && ldcb % 8 == 0 && dlrm_aligned16(Cb) && (!bias || dlrm_aligned16(bias))) ? 1 : 0;
-    static int direct = -1;             // DLRM_BF16_EPI=lds keeps the LDS-staged bf16-only epilogue (A/B runs); default: the direct one
-    if (direct < 0) { const char* e = getenv("DLRM_BF16_EPI"); direct = (e && strcmp(e, "lds") == 0) ? 0 : 1; }
-    if (g.wide16 && direct) g.wide16 = 2;
+    // (a DIRECT epilogue — bias / activation / rounding in registers, v_permlane32_swap to 16 contiguous bytes per lane, no LDS round trip — was
+    // built and measured in round 5: correct, 4-6 % slower than this staged one; profiles/round5/bf16_epilogue_ablation.txt)
     static bool attr_done[DLRM_MAX_DEVICES] = {};
     phased_attr((const void*)gemm_bf16_phased_kernel<false, 1>, attr_done[dlrm_current_device()]);
     hipLaunchKernelGGL((gemm_bf16_phased_kernel<false, 1>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS_PL1, st, g);
