@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED = 0, 1, 2
 ARITH_F32, ARITH_BF16X6, ARITH_BF16 = 0, 1, 2
-EXPECTED_ABI = 11          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
+EXPECTED_ABI = 12          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
 
 _lock = threading.Lock()
 _lib = None
@@ -44,6 +44,7 @@ SIGNATURES = {
     "dlrm_emb_sort_kind": (_i32, [_i32, _pi64, _pi64]),
     "dlrm_cast_bf16": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_cast_bf16_transposed": (_i32, [_i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
+    "dlrm_cast_bf16_multi": (_i32, [_i32, _pp, _pi64, C.POINTER(_i32), C.POINTER(_i32), _pp, _pi64, C.POINTER(_i32), _pp, _pi64, C.POINTER(_i32), _vp]),
     "dlrm_gemm_bf16": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_split_bf16x3": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _i64, _vp]),
     "dlrm_split_bf16x3_transposed": (_i32, [_i32, _i32, _i32, _vp, _i64, _vp, _i64, _i64, _vp]),

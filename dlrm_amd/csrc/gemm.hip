@@ -1008,6 +1008,47 @@ __global__ __launch_bounds__(256) void cast_bf16_t_kernel(int R, int C, int Rpad
     }
 }
 
+// ALL weight copies of a bf16 tower in ONE launch (round 5): tensor i = src [R, C] fp32 -> dst [R, Cpad] bf16 (zero columns C..Cpad-1; nullable)
+// and / or dstT [C, Rpad] bf16 = its transpose (zero columns R..Rpad-1; nullable).  A workgroup = one 32 x 32 source tile, read once.  The
+// per-layer launches it replaces were 15 of the 70 kernels of the Terabyte bf16 step at ~5 us each (profiles/round5/step_trace_tb_bf16.txt).
+struct CastMultiArgs {
+    const float* src[DLRM_CAST_MULTI_MAX]; long long lds[DLRM_CAST_MULTI_MAX];
+    unsigned short* dst[DLRM_CAST_MULTI_MAX]; long long ldd[DLRM_CAST_MULTI_MAX];
+    unsigned short* dstT[DLRM_CAST_MULTI_MAX]; long long lddT[DLRM_CAST_MULTI_MAX];
+    int R[DLRM_CAST_MULTI_MAX], C[DLRM_CAST_MULTI_MAX], Cpad[DLRM_CAST_MULTI_MAX], Rpad[DLRM_CAST_MULTI_MAX];
+    int tiles_c[DLRM_CAST_MULTI_MAX], tile_start[DLRM_CAST_MULTI_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void cast_bf16_multi_kernel(CastMultiArgs a) {
+    __shared__ float tile[32][33];
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.tile_start[i + 1]) ++i;
+    const int t = (int)blockIdx.x - a.tile_start[i];
+    const int r0 = (t / a.tiles_c[i]) * 32, c0 = (t % a.tiles_c[i]) * 32;
+    const int R = a.R[i], C = a.C[i];
+    const float* __restrict__ src = a.src[i];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? src[(long long)r * a.lds[i] + c] : 0.f;
+    }
+    __syncthreads();
+    if (a.dst[i]) {
+        unsigned short* __restrict__ d = a.dst[i];
+        for (int k = ty; k < 32; k += 8) {
+            const int r = r0 + k, c = c0 + tx;
+            if (r < R && c < a.Cpad[i]) d[(long long)r * a.ldd[i] + c] = (unsigned short)(cvt_pk_bf16(tile[k][tx], 0.f) & 0xffffu);
+        }
+    }
+    if (a.dstT[i]) {
+        unsigned short* __restrict__ d = a.dstT[i];
+        for (int k = ty; k < 32; k += 8) {
+            const int c = c0 + k, r = r0 + tx;
+            if (c < C && r < a.Rpad[i]) d[(long long)c * a.lddT[i] + r] = (unsigned short)(cvt_pk_bf16(tile[tx][k], 0.f) & 0xffffu);
+        }
+    }
+}
+
 // ---- fp32 -> three bf16 planes (arith "bf16x6" with PRE-SPLIT operands: gemm_bf16.hip PL = 3).  The truncation split of split3 above, done ONCE
 // per tensor instead of in every k-loop that reads it: x == h + m + l exactly.  dst = planes h, m, l of [M, ldd], `plane` elements apart.
 __device__ __forceinline__ void split2_planes(float a, float b, unsigned& ph, unsigned& pm, unsigned& pl) {
@@ -1238,6 +1279,30 @@ extern "C" int dlrm_cast_bf16(int64_t M, int N, int Npad, const float* src, int6
     long long nb = (M * (Npad / 2) + 255) / 256; if (nb > 8192) nb = 8192;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (long long)M, N, Npad, src, (long long)lds_,
                        (unsigned short*)dst, (long long)ldd);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_cast_bf16_multi(int n, const float* const* src, const int64_t* lds_, const int* R, const int* C, uint16_t* const* dst,
+                                    const int64_t* ldd, const int* Cpad, uint16_t* const* dstT, const int64_t* lddT, const int* Rpad, void* stream) {
+    if (n <= 0 || n > DLRM_CAST_MULTI_MAX || !src || !lds_ || !R || !C || !dst || !ldd || !Cpad || !dstT || !lddT || !Rpad) return DLRM_E_ARG;
+    CastMultiArgs a = {};
+    a.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!src[i] || R[i] <= 0 || C[i] <= 0 || lds_[i] < C[i] || (!dst[i] && !dstT[i])) return DLRM_E_ARG;
+        if (dst[i] && (Cpad[i] < C[i] || ldd[i] < Cpad[i])) return DLRM_E_ARG;
+        if (dstT[i] && (Rpad[i] < R[i] || lddT[i] < Rpad[i])) return DLRM_E_ARG;
+        a.src[i] = src[i]; a.lds[i] = lds_[i]; a.R[i] = R[i]; a.C[i] = C[i];
+        a.dst[i] = (unsigned short*)dst[i]; a.ldd[i] = ldd[i]; a.Cpad[i] = dst[i] ? Cpad[i] : 0;
+        a.dstT[i] = (unsigned short*)dstT[i]; a.lddT[i] = lddT[i]; a.Rpad[i] = dstT[i] ? Rpad[i] : 0;
+        const int rows = a.Rpad[i] > R[i] ? a.Rpad[i] : R[i], cols = a.Cpad[i] > C[i] ? a.Cpad[i] : C[i];
+        a.tiles_c[i] = (cols + 31) / 32;
+        a.tile_start[i] = total;
+        total += ((rows + 31) / 32) * a.tiles_c[i];
+    }
+    for (int i = n; i <= DLRM_CAST_MULTI_MAX; ++i) a.tile_start[i] = total;
+    hipLaunchKernelGGL(cast_bf16_multi_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a);
     DLRM_LAUNCH_CHECK();
     return 0;
 }

@@ -38,6 +38,9 @@ BF16_STORAGE = os.environ.get("DLRM_BF16_STORAGE", "1") == "1"
 BF16_LEAN = os.environ.get("DLRM_BF16_LEAN", "1") == "1"
 # DCN-v2 (bf16 storage): the elementwise half of a cross layer inside the epilogue of its second product (dlrm_gemm_bf16_cross); 0 = two kernels
 CROSS_FUSE = os.environ.get("DLRM_CROSS_FUSE", "1") == "1"
+# bf16 towers: the bf16 copies of ALL weights of a tower (W16 for the forward GEMMs, W^T16 for the data gradients) in one launch at the start of
+# the forward pass (dlrm_cast_bf16_multi) instead of one launch per layer and direction; 0 = per-layer casts
+MULTI_CAST = os.environ.get("DLRM_BF16_MULTI_CAST", "1") == "1"
 # arith "bf16x6": activations / gradients / weights of the GEMM layers travel as three bf16 planes (split once by their producer) and the GEMMs
 # are the planes form of the bf16-shaped kernel (dlrm_gemm_bf16x6), wherever its shapes hold (DLRM_BF16X6_PLANES=0: every GEMM splits its fp32
 # operands inside its k-loop, the kernels of rounds 1-3; the k-contiguous products are bit-identical either way)
@@ -51,6 +54,7 @@ class _Bf16Store:
     kround = staticmethod(ops.round_bf16_k)
     cast = staticmethod(ops.cast_bf16)
     cast_t = staticmethod(ops.cast_bf16_transposed)
+    cast_multi = staticmethod(ops.cast_bf16_multi)           # several (copy, transposed copy) pairs in one launch
     gemm = staticmethod(ops.gemm_bf16)
     wgrad = staticmethod(ops.linear_bwd_weight_bf16)
     wgrad_ok = staticmethod(ops.linear_bwd_weight_bf16_ok)
@@ -239,6 +243,21 @@ class MLPFunction(Function):
                 n32 = ((not wg16[i + 1]) or (not dg16[i + 1]) or (acts[i] == ACT_RELU and not need_bits)
                        or acts[i] not in (ACT_RELU, ACT_NONE))
             need32.append(n32)
+        # every weight copy of the tower in ONE launch (bf16 storage; the planes form keeps its per-layer splits): W16 [N, kb] for the forward
+        # GEMM of a use16 layer, W^T16 [K, N] for its data gradient where backward will take the bf16 path (weights do not change in between)
+        pre16, preT16 = [None] * L, [None] * L
+        if store16 and st is _Bf16Store and MULTI_CAST:
+            items, where = [], []
+            for i in range(L):
+                W_i = W0p if (i == 0 and W0p is not None) else params[2 * i]
+                want = kb[i] if use16[i] else None
+                wantT = widths[i] if (need_grad and dg16[i] and (i > 0 or ctx.needs_input_grad[0])) else None
+                if want or wantT:
+                    items.append((W_i, want, wantT)); where.append(i)
+            if len(items) > 1:
+                for i, (d_, dT_) in zip(where, st.cast_multi(items, category="linear_fwd")):
+                    pre16[i], preT16[i] = d_, dT_
+        ctx.preT16 = preT16
         cur16 = None                                                  # bf16 copy of the current activation, [M, kb of the next layer]
         outs, in16, bits = [], [], []                                   # in16[i]: the reduced-width input of layer i's GEMM, kept for its weight gradient
         for i in range(L):
@@ -254,7 +273,7 @@ class MLPFunction(Function):
             if use16[i]:
                 a16 = cur16 if (cur16 is not None and cur16.size(-1) == kb[i]) else st.cast(cur, kb[i], category="linear_fwd")
                 in16.append(a16 if (lean and need_grad and wg16[i]) else None)
-                w16 = st.cast(W, kb[i], category="linear_fwd")
+                w16 = pre16[i] if pre16[i] is not None else st.cast(W, kb[i], category="linear_fwd")
                 # the bf16 copy of this activation, if the NEXT layer is a GEMM that can take it as it is
                 nxt = i + 1 < L and use16[i + 1] and kb[i + 1] == N
                 y16 = st.empty(M, N, x.device) if (nxt or not need32[i]) else None
@@ -358,7 +377,7 @@ class MLPFunction(Function):
             if ok16:
                 # bf16 storage: dX = dZ . W as a <k-contiguous, k-contiguous> GEMM over a transposed bf16 copy of W
                 a16 = dZ16 if dZ16 is not None else st.cast(dZ, N_i, category="linear_bwd_data")
-                wT16 = st.cast_t(W, N_i, category="linear_bwd_data")
+                wT16 = ctx.preT16[i] if ctx.preT16[i] is not None else st.cast_t(W, N_i, category="linear_bwd_data")
                 d16 = st.empty(M, K_i, x.device) if want16 else None
                 st.gemm(a16, wT16, None, ACT_NONE, dprev, d16, relu_bits_in=rbits, category="linear_bwd_data")
                 dZ16 = d16

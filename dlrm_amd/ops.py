@@ -787,6 +787,37 @@ def cast_bf16_transposed(src: torch.Tensor, Rpad: Optional[int] = None, category
     return dst
 
 
+CAST_MULTI_MAX = 16
+
+
+def cast_bf16_multi(items, category: str = "cast_bf16"):
+    """bf16 copies of several fp32 matrices in ONE launch (dlrm_cast_bf16_multi).  items: (src [R, C], Cpad or None, Rpad or None) —
+    Cpad: also return the row-major copy [R, Cpad] (zero columns C..); Rpad: also return the transposed copy [C, Rpad] (zero columns R..).
+    Returns a list of (copy or None, transposed copy or None)."""
+    lib = _lib.load()
+    out = []
+    for k0 in range(0, len(items), CAST_MULTI_MAX):
+        chunk = items[k0:k0 + CAST_MULTI_MAX]
+        n = len(chunk)
+        srcs, lds, R, Cc, dst, ldd, cpad, dstT, lddT, rpad, res = [], [], [], [], [], [], [], [], [], [], []
+        for src, Cpad, Rpad in chunk:
+            _req(src, "src", ndim=2)
+            r_, c_ = src.shape
+            d = torch.empty((r_, int(Cpad)), dtype=torch.bfloat16, device=src.device) if Cpad else None
+            dT = torch.empty((c_, int(Rpad)), dtype=torch.bfloat16, device=src.device) if Rpad else None
+            srcs.append(src.data_ptr()); lds.append(_ld(src)); R.append(r_); Cc.append(c_)
+            dst.append(d.data_ptr() if d is not None else 0); ldd.append(int(Cpad) if Cpad else 0); cpad.append(int(Cpad) if Cpad else 0)
+            dstT.append(dT.data_ptr() if dT is not None else 0); lddT.append(int(Rpad) if Rpad else 0); rpad.append(int(Rpad) if Rpad else 0)
+            res.append((d, dT))
+        ia = lambda v: (C.c_int * n)(*v)            # noqa: E731
+        with _timed(category):
+            rc = lib.dlrm_cast_bf16_multi(n, _lib.ptr_array(srcs), _lib.i64_array(lds), ia(R), ia(Cc), _lib.ptr_array(dst), _lib.i64_array(ldd), ia(cpad),
+                                          _lib.ptr_array(dstT), _lib.i64_array(lddT), ia(rpad), _stream(chunk[0][0]))
+        _lib.check(rc, "dlrm_cast_bf16_multi")
+        out += res
+    return out
+
+
 def gemm_bf16(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], act: int, Cf: Optional[torch.Tensor],
               Cb: Optional[torch.Tensor], relu_bits_out: Optional[torch.Tensor] = None, relu_bits_in: Optional[torch.Tensor] = None,
               category: str = "linear_fwd", addend: Optional[torch.Tensor] = None, addend2: Optional[torch.Tensor] = None) -> None:

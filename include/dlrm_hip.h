@@ -244,6 +244,11 @@ int dlrm_interact_bwd_gather(int64_t B, int F, int D, const void* const* feat_ho
  * weight gradient keeps reading the fp32 copies through dlrm_linear_bwd_weight(arith = DLRM_ARITH_BF16). */
 int dlrm_cast_bf16(int64_t M, int N, int Npad, const float* src, int64_t lds, uint16_t* dst, int64_t ldd, void* stream);
 int dlrm_cast_bf16_transposed(int R, int C, int Rpad, const float* src, int64_t lds, uint16_t* dstT, int64_t ldd, void* stream);
+/* both copies of up to DLRM_CAST_MULTI_MAX tensors in ONE launch (the weights of a tower: W16 for the forward GEMMs, W^T16 for the data
+ * gradients): tensor i = src[i] [R, C] -> dst[i] [R, Cpad] (nullable) and / or dstT[i] [C, Rpad] (nullable), padding zero-filled */
+#define DLRM_CAST_MULTI_MAX 16
+int dlrm_cast_bf16_multi(int n, const float* const* src, const int64_t* lds, const int* R, const int* C, uint16_t* const* dst, const int64_t* ldd,
+                         const int* Cpad, uint16_t* const* dstT, const int64_t* lddT, const int* Rpad, void* stream);
 int dlrm_gemm_bf16(int64_t M, int N, int K, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const float* bias, int act,
                    uint64_t* relu_bits_out, const uint64_t* relu_bits_in, const float* addend, int64_t ldadd, const float* addend2, int64_t ldadd2,
                    float* C, int64_t ldc, uint16_t* Cb, int64_t ldcb, void* stream);

@@ -689,6 +689,32 @@ def test_bf16_casts_are_round_to_nearest_even_and_padded():
         assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (R, C_, Rp)
 
 
+def test_bf16_multi_cast_equals_the_single_casts():
+    """dlrm_cast_bf16_multi (round 5: the bf16 copies of ALL weights of a tower — row-major for the forward GEMMs, transposed for the data
+    gradients — in one launch) against dlrm_cast_bf16 / dlrm_cast_bf16_transposed tensor by tensor: same bits, same zero padding; odd shapes,
+    a strided source, only-one-copy requests, more tensors than one launch holds."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(77)
+    shapes = [(512, 16), (256, 512), (128, 256), (1024, 480), (33, 70), (1, 5), (64, 64)] * 3          # 21 tensors > DLRM_CAST_MULTI_MAX = 16
+    items, want = [], []
+    for k, (R, C_) in enumerate(shapes):
+        wide = to_dev(rng.standard_normal((R, C_ + 3)).astype(np.float32))
+        src = wide[:, 1:1 + C_] if k % 4 == 1 else to_dev(rng.standard_normal((R, C_)).astype(np.float32))
+        cpad = ops.round_bf16_k(C_) if k % 3 != 2 else None
+        rpad = ((R + 7) & ~7) if k % 3 != 1 else None
+        items.append((src, cpad, rpad))
+        want.append((ops.cast_bf16(src.contiguous(), cpad) if cpad else None, ops.cast_bf16_transposed(src.contiguous(), rpad) if rpad else None))
+    got = ops.cast_bf16_multi(items)
+    torch.cuda.synchronize()
+    assert len(got) == len(items)
+    for k, ((d, dT), (w, wT)) in enumerate(zip(got, want)):
+        assert (d is None) == (w is None) and (dT is None) == (wT is None), k
+        if w is not None:
+            assert d.shape == w.shape and torch.equal(d.view(torch.int16), w.view(torch.int16)), k
+        if wT is not None:
+            assert dT.shape == wT.shape and torch.equal(dT.view(torch.int16), wT.view(torch.int16)), k
+
+
 @pytest.mark.parametrize("ln,B", [([13, 512, 256, 128], 4096), ([479, 1024, 1024, 512, 256, 1], 2048), ([13, 64, 48, 16], 300), ([96, 64, 32], 129),
                                   ([64, 256, 128, 64], 65536)])
 def test_bf16_storage_tower_is_bit_identical_to_in_loop_rounding(ln, B):

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.dlrm_hip_abi_version() == 11
+    assert lib.dlrm_hip_abi_version() == 12
     assert b"gfx950" in lib.dlrm_hip_build_info()
 
 
@@ -481,6 +481,9 @@ def test_mlp_storage_plan_hands_every_consumer_what_it_reads(monkeypatch, ln, B,
     for name, fn in (("linear_fwd", linear_fwd), ("act_bwd", act_bwd), ("linear_bwd_weight", linear_bwd_weight), ("linear_bwd_data", linear_bwd_data),
                      ("pad_cols", pad_cols)):
         monkeypatch.setattr(ops, name, fn)
+    def cast_multi_like(items, category=None):           # (round 5: all weight copies of a bf16 tower in one launch)
+        return [(cast_like(False)(s_, cp) if cp else None, cast_t_like(False)(s_, rp) if rp else None) for s_, cp, rp in items]
+    monkeypatch.setattr(functional._Bf16Store, "cast_multi", staticmethod(cast_multi_like))
     for store, planes in ((functional._PlaneStore, True), (functional._Bf16Store, False)):
         monkeypatch.setattr(store, "cast", staticmethod(cast_like(planes)))
         monkeypatch.setattr(store, "cast_t", staticmethod(cast_t_like(planes)))
