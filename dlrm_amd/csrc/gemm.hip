@@ -26,6 +26,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
+#ifndef DLRM_GEMM_FRAG2
+#define DLRM_GEMM_FRAG2 1
+#endif
 
 namespace {
 
@@ -565,9 +568,20 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             }
         }
         if constexpr (ARITH == 0) {
+        // fragments of BOTH 8-k halves of the tile are requested before the first product (round 5; -DDLRM_GEMM_FRAG2=0 restores one set): with one
+        // register set the second half's ds_reads could only be issued when the first half's last MFMA had its operands, i.e. a second LDS
+        // round trip per k-tile sat in front of 16 (TM = 2) / 32 (TM = 4) MFMAs (disassembly: profiles/round5/gemm3_main_loop_isa.txt)
+        // Measured per kernel form (profiles/round5/gemm_frag2_ab.txt, A/B inside one visit): the WEIGHT GRADIENT (256-row tiles, two
+        // waves per SIMD: little else to hide an LDS round trip behind) gains 4 % (1024 x 1024: 1004 -> 965 us); the forward form (three
+        // waves per SIMD) does not move (+1 %), and the data gradient's 172 registers would cost it its third workgroup per CU (-4 to -7 %):
+        // only the weight gradient takes it.
+        constexpr bool F2 = DLRM_GEMM_FRAG2 && !A_KC && !B_KC;
+        float4 fa2[F2 ? 2 : 1][TM], fb2[F2 ? 2 : 1][TN];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            float4 fa[TM], fb[TN];
+            float4 (&fa)[TM] = fa2[F2 ? j : 0];
+            float4 (&fb)[TN] = fb2[F2 ? j : 0];
+            auto load_frags = [&]() {
             if constexpr (A_IL) {           // one vector read per k row feeds all TM sub-tiles (rows TM*r + t)
                 using VA = typename FVec<TM>::T;
                 const char* pa = ldsb + cur + fa_off[j];
@@ -598,6 +612,49 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
                     const float* p = (const float*)(ldsb + cur + fb_off[j]) + t * 32;
                     fb[t] = make_float4(p[0], p[BNt], p[2 * BNt], p[3 * BNt]);
                 }
+            }
+            }
+            };
+            if constexpr (F2) { load_frags(); }
+            else { (void)load_frags; }
+        }
+        if constexpr (F2) __builtin_amdgcn_sched_barrier(0);      // keep all fragment reads of the tile in front of its first MFMA
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 (&fa)[TM] = fa2[F2 ? j : 0];
+            float4 (&fb)[TN] = fb2[F2 ? j : 0];
+            if constexpr (!F2) {
+            if constexpr (A_IL) {
+                using VA = typename FVec<TM>::T;
+                const char* pa = ldsb + cur + fa_off[j];
+                const VA a0 = *(const VA*)(pa), a1 = *(const VA*)(pa + BMt * 4), a2 = *(const VA*)(pa + 2 * BMt * 4), a3 = *(const VA*)(pa + 3 * BMt * 4);
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[t] = make_float4(a0[t], a1[t], a2[t], a3[t]);
+            } else {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                if (A_KC) fa[t] = *(const float4*)(ldsb + cur + fa_off[j] + t * 32 * 64);
+                else {
+                    const float* p = (const float*)(ldsb + cur + fa_off[j]) + t * 32;
+                    fa[t] = make_float4(p[0], p[BMt], p[2 * BMt], p[3 * BMt]);
+                }
+            }
+            }
+            if constexpr (B_IL) {
+                using VB = typename FVec<TN>::T;
+                const char* pb = ldsb + cur + fb_off[j];
+                const VB b0 = *(const VB*)(pb), b1 = *(const VB*)(pb + BNt * 4), b2 = *(const VB*)(pb + 2 * BNt * 4), b3 = *(const VB*)(pb + 3 * BNt * 4);
+#pragma unroll
+                for (int t = 0; t < TN; ++t) fb[t] = make_float4(b0[t], b1[t], b2[t], b3[t]);
+            } else {
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                if (B_KC) fb[t] = *(const float4*)(ldsb + cur + fb_off[j] + t * 32 * 64);
+                else {
+                    const float* p = (const float*)(ldsb + cur + fb_off[j]) + t * 32;
+                    fb[t] = make_float4(p[0], p[BNt], p[2 * BNt], p[3 * BNt]);
+                }
+            }
             }
             }
             if (do_rowsum) {
