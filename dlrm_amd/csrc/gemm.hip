@@ -556,6 +556,8 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             if (kt + 1 < nk) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();   // my share of tile kt has landed
             __builtin_amdgcn_s_barrier();      // everyone's share has; everyone is done reading stage `nxt`
         }
+        // (issued BEFORE this tile's fragment reads: issuing it after them — the reads are on the first MFMA's critical path, the refill is not —
+        // measured 1-2 % slower in every kernel form, profiles/round5/gemm_dma_late_ab.txt: the refill's head start matters more)
         if (kt + 2 < nk && !(g.debug & 1)) GEMM3_ISSUE(nxt);
         if constexpr (MASKED) {
             // no DMA is issued after tile nk-1's (at kt == nk-3), so these loads sit behind every DMA in the in-order
