@@ -29,6 +29,9 @@
 #ifndef DLRM_GEMM_FRAG2
 #define DLRM_GEMM_FRAG2 1
 #endif
+#ifndef DLRM_GEMM_FRAG2_ALL
+#define DLRM_GEMM_FRAG2_ALL 0      /* tuning builds: the two fragment sets in every kernel form */
+#endif
 
 namespace {
 
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
         // waves per SIMD: little else to hide an LDS round trip behind) gains 4 % (1024 x 1024: 1004 -> 965 us); the forward form (three
         // waves per SIMD) does not move (+1 %), and the data gradient's 172 registers would cost it its third workgroup per CU (-4 to -7 %):
         // only the weight gradient takes it.
-        constexpr bool F2 = DLRM_GEMM_FRAG2 && !A_KC && !B_KC;
+        constexpr bool F2 = DLRM_GEMM_FRAG2 && ((!A_KC && !B_KC) || DLRM_GEMM_FRAG2_ALL);
         float4 fa2[F2 ? 2 : 1][TM], fb2[F2 ? 2 : 1][TN];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
