@@ -1106,7 +1106,7 @@ def main():
                                                  "ms": ems, "achieved": ach, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS,
                                                  "frac_of_measured_peak": ach / hbm_measured, "algorithmic_bytes": emb_fwd_bytes}
         emb_gbps["fwd"] = ach
-        if pmc and pmc["kernels"].get("emb_fwd") and not pmc["kernels"]["emb_fwd"].get("stale"):
+        if pmc and (pmc["kernels"].get("emb_fwd") or {}).get("traffic_bytes") and not pmc["kernels"]["emb_fwd"].get("stale"):
             tb_ = pmc["kernels"]["emb_fwd"]["traffic_bytes"]
             result["embedding_kernel_standalone"].update({"traffic_bytes": tb_, "traffic_gbps": tb_ / (ems * 1e-3) / 1e9,
                                                           "frac_traffic": tb_ / (ems * 1e-3) / 1e9 / HBM_PEAK_GBS})

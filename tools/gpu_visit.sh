@@ -50,7 +50,7 @@ for stage in "$@"; do
       find $OUT -name "*kernel_trace.csv" -size +8M -delete; find $OUT -name "*.db" -size +8M -delete ;;
     pmc)
       for c in FETCH_SIZE WRITE_SIZE; do
-        ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $ROOT/$OUT/$c -o p -- python $ROOT/bench.py --steps 4 --warmup 2 $QUICK --no-standalone-emb $arg > $ROOT/$OUT/$c.log 2>&1 ); echo "== pmc $c rc=$?"
+        ( cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $ROOT/$OUT/$c -o p -- python $ROOT/bench.py --steps 4 --warmup 2 ${QUICK/--no-high-row-check/} --no-high-row-check $arg > $ROOT/$OUT/$c.log 2>&1 ); echo "== pmc $c rc=$?"
       done
       python tools/pmc_fold.py $OUT && python tools/pmc_to_json.py $OUT $OUT/pmc_traffic.json
       find $OUT -name "p_counter_collection.csv" -size +8M -delete; find $OUT -name "*kernel_trace.csv" -size +8M -delete ;;

@@ -64,6 +64,13 @@ def main():
         f_kb = sum(c * v for k, c, v in fetch if in_cat(cat, pats, k)) / steps
         w_kb = sum(c * v for k, c, v in write if in_cat(cat, pats, k)) / steps
         n = CALLS_PER_STEP[cat]
+        if cat == "emb_fwd":
+            # the stand-alone lookup kernel is not part of the fused step: bench.py measures it after the timed region (7 launches); one kernel
+            # per call, so its per-call bytes are the launch-weighted mean over its own launches
+            calls = sum(c for k, c, _ in fetch if in_cat(cat, pats, k))
+            if calls:
+                f_kb = sum(c * v for k, c, v in fetch if in_cat(cat, pats, k)) / calls
+                w_kb = sum(c * v for k, c, v in write if in_cat(cat, pats, k)) / max(sum(c for k, c, _ in write if in_cat(cat, pats, k)), 1)
         out["kernels"][cat] = {"fetch_raw_bytes": f_kb * 1024 / n, "fetch_bytes": 2 * f_kb * 1024 / n,
                                "write_bytes": w_kb * 1024 / n, "traffic_bytes": (2 * f_kb + w_kb) * 1024 / n,
                                "calls_per_step": n}
