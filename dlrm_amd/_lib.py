@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED = 0, 1, 2
 ARITH_F32, ARITH_BF16X6, ARITH_BF16 = 0, 1, 2
-EXPECTED_ABI = 12          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
+EXPECTED_ABI = 13          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
 
 _lock = threading.Lock()
 _lib = None

@@ -253,7 +253,10 @@ __global__ __launch_bounds__(256) void interact_bwd_kernel(FeatArgs fa, FeatArgs
                         for (int q = 0; q < 4; ++q) {
                             if (orow[r][q]) {
                                 float v = acc[q];
-                                if (r == 0 && q == 0 && g == 0) v += dRb[d];   // feature 0 also feeds R[:, 0:D]
+                                if (r == 0 && q == 0 && g == 0) {
+                                    v += dRb[d];                               // feature 0 also feeds R[:, 0:D]
+                                    if ((self & 4) && !(my[d] > 0.f)) v = 0.f; // ... and is a ReLU output whose derivative is applied here
+                                }
                                 orow[r][q][d] = v;
                             }
                         }
@@ -504,6 +507,9 @@ __global__ __launch_bounds__(320) void interact_fwd_dma_kernel(FeatArgs fa, Gath
 #pragma unroll
             for (int s = 0; s < IDMA_D / 16; ++s)
                 fr[r][s] = *(const float4*)(my + (16 * r + li) * (IDMA_D * 4) + (((4 * s + g) ^ li) * 16));      // (row & 15) == li
+        // (the scheduler sinks each k-step's two reads to just before its 12 MFMAs — one wave per SIMD, so those LDS round trips are exposed.
+        // Pinning all reads in front of the first MFMA with a scheduling fence was measured: the kernel 195 -> 188 us, the step no faster —
+        // profiles/round5/interact_frags_first_ab.txt; the kernel is bound by its row fetches, 0.85 of the copy rate)
         // the tile pairs advance together, one k-substep at a time: consecutive MFMAs are independent, the two accumulators of a
         // pair (even / odd substeps, summed at the end — the summation order of every version of this kernel) are three issues apart
         floatx4 acc[NPAIR][2];
@@ -695,6 +701,11 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                         if (r == 0 && q == 0 && g == 0) {       // feature 0 also feeds R[:, 0:D]
                             const float4 x = *(const float4*)(dr + (64 * dq + 4 * li) * 4);
                             v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                            if (self & 4) {                     // feature 0 is a ReLU output: its derivative is applied here (image row 0 = x)
+                                const float4 y = *(const float4*)(my + (16 * dq + li) * 16);
+                                v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f;
+                                v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
+                            }
                         }
                         *(float4*)(orow[r][q] + dq * 256) = v;
                     }
@@ -911,7 +922,9 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
     if (B <= 0 || F <= 0 || D <= 0 || !feat_host || !feat_ld_host || !dR || !dfeat_host || !dfeat_ld_host)
         return DLRM_E_ARG;
     if (F > DLRM_MAX_FEATURES) return DLRM_E_RANGE;
-    if (self_interaction < 0 || self_interaction > 2) return DLRM_E_MODE;     // 0 tril, 1 tril + diagonal, 2 torchrec triu order
+    // bits 0-1: 0 tril, 1 tril + diagonal, 2 torchrec triu order; bit 2 (DLRM_INTERACT_RELU_X, backward only): feature 0 is the output of a
+    // ReLU and dfeat_0 is multiplied by its derivative [feature 0 > 0] (the bottom tower's last act_bwd pass, dlrm_s_pytorch.py:238-241)
+    if (self_interaction < 0 || self_interaction > 7 || (self_interaction & 3) > 2) return DLRM_E_MODE;
     const int P = (self_interaction & 1) ? F * (F + 1) / 2 : F * (F - 1) / 2;
     if (ldr < D + P) return DLRM_E_ARG;
     FeatArgs fa, da;
@@ -941,11 +954,11 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
                 if (gidx) {                                                                                  \
                     (void)hipFuncSetAttribute((const void*)interact_bwd_dma_kernel<NIV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma); \
                     hipLaunchKernelGGL((interact_bwd_dma_kernel<NIV, true>), dim3((unsigned)nb), dim3(256), lds_dma, (hipStream_t)stream, fa, da, ga, \
-                                       (long long)B, F, self_interaction & 3, dR, (long long)ldr);       \
+                                       (long long)B, F, self_interaction & 7, dR, (long long)ldr);       \
                 } else {                                                                                     \
                     (void)hipFuncSetAttribute((const void*)interact_bwd_dma_kernel<NIV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma); \
                     hipLaunchKernelGGL((interact_bwd_dma_kernel<NIV, false>), dim3((unsigned)nb), dim3(256), lds_dma, (hipStream_t)stream, fa, da, ga, \
-                                       (long long)B, F, self_interaction & 3, dR, (long long)ldr);       \
+                                       (long long)B, F, self_interaction & 7, dR, (long long)ldr);       \
                 }                                                                                            \
             } while (0)
             switch (ni) {
@@ -973,7 +986,7 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
     do {                                                                                                 \
         (void)hipFuncSetAttribute((const void*)interact_bwd_kernel<NBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(interact_bwd_kernel<NBV>, grid, block, lds, st, fa, da, (long long)B, F, D,   \
-                           self_interaction & 3, dR, (long long)ldr, vec, d4s);                      \
+                           self_interaction & 7, dR, (long long)ldr, vec, d4s);                      \
     } while (0)
     switch (NB) {
         case 1: BWD_LAUNCH(1); break;

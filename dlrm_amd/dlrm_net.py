@@ -30,7 +30,8 @@ from . import ext_dist, ops
 from .functional import (BCEElementwiseFunction, BCELossFunction, CatFunction, ChunkPackFunction, ClampFunction,
                          EmbeddingBagsFunction, GatherInteractFunction, InteractFunction, MLPFunction, MSELossFunction,
                          OutSlot)
-from .functional import _side_stream
+from . import functional as _functional
+from .functional import MLP_CONSUMER_APPLIES_LAST_ACT, _side_stream
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, BagBatch
 
 
@@ -72,9 +73,17 @@ class FusedMLP(nn.Sequential):
             i += 1
         return params, tuple(acts)
 
-    def forward(self, x, out_slot: Optional[OutSlot] = None):
+    def forward(self, x, out_slot: Optional[OutSlot] = None, consumer_applies_last_act: bool = False):
+        """consumer_applies_last_act: the caller promises that the ONLY consumer of the output multiplies the gradient it sends back
+        by the derivative of this tower's last ReLU (the interaction backward kernels do, ops.INTERACT_RELU_X) — the tower's
+        backward then skips that pass.  Ignored (False) for towers that do not end in a ReLU."""
         params, acts = self._layers()
-        return MLPFunction.apply(x, acts, out_slot, ops.arith_code(self.arith), *params)
+        flag = MLP_CONSUMER_APPLIES_LAST_ACT if (consumer_applies_last_act and acts and acts[-1] == ACT_RELU) else 0
+        return MLPFunction.apply(x, acts, out_slot, ops.arith_code(self.arith) | flag, *params)
+
+    def ends_in_relu(self) -> bool:
+        mods = list(self.children())
+        return bool(mods) and isinstance(mods[-1], nn.ReLU)
 
 
 class FusedBCELoss(nn.Module):
@@ -292,10 +301,19 @@ class DLRM_Net(nn.Module):
             getattr(tower, "module", tower).arith = name        # DDP-wrapped towers keep the FusedMLP in .module
 
     # ---------------------------------------------------------------- operators
-    def apply_mlp(self, x, layers, out_slot: Optional[OutSlot] = None):
+    def apply_mlp(self, x, layers, out_slot: Optional[OutSlot] = None, consumer_applies_last_act: bool = False):
+        if consumer_applies_last_act:
+            return layers(x, out_slot=out_slot, consumer_applies_last_act=True)
         if out_slot is not None:
             return layers(x, out_slot=out_slot)
         return layers(x)
+
+    def _relu_x(self) -> int:
+        """ops.INTERACT_RELU_X when the dot interaction's backward may apply the derivative of the bottom tower's last ReLU to its
+        feature-0 gradient (and the tower is told to expect that: apply_mlp(..., consumer_applies_last_act=True)), else 0."""
+        tower = getattr(self.bot_l, "module", self.bot_l)          # DDP / FlatDDP keep the FusedMLP in .module
+        ok = _functional.FUSE_ACT_BWD and self.arch_interaction_op == "dot" and isinstance(tower, FusedMLP) and tower.ends_in_relu()
+        return ops.INTERACT_RELU_X if ok else 0
 
     def _bags(self, lS_o, lS_i, v_W_l) -> BagBatch:
         return BagBatch(lS_o, lS_i, None)        # pooling weights, if any, are gathered on the device inside EmbeddingBagsFunction
@@ -458,6 +476,8 @@ class DLRM_Net(nn.Module):
         n_out = self.bot_l[-2].out_features if isinstance(self.bot_l[-2], nn.Linear) else D
         if self.arch_interaction_op == "dot" and n_out != D:
             sys.exit("ERROR: bottom MLP output (%d) and embedding dimension (%d) differ" % (n_out, D))
+        # the last ReLU of the bottom tower is differentiated inside the interaction backward (which has x staged): see _relu_x
+        rx = self._relu_x() if dense_x.is_cuda else 0
         if (self.fuse_emb_interact and self.arch_interaction_op == "dot" and dense_x.is_cuda and ops.gather_ok(1 + T, D)
                 and not any(w is not None for w in (self.v_W_l or []))):
             bags = self._bags(lS_o, lS_i, None)
@@ -470,9 +490,9 @@ class DLRM_Net(nn.Module):
                 # GPU has the tower's GEMMs to run while the host catches up, so the wait does not drain the stream
                 proof = ops.offsets_are_iota_start(lS_o)
                 if proof is not False:
-                    x = self.apply_mlp(dense_x, self.bot_l)
+                    x = self.apply_mlp(dense_x, self.bot_l, consumer_applies_last_act=bool(rx))
                     if ops.offsets_are_iota_finish(proof) is not False:
-                        z = GatherInteractFunction.apply(self._stash_embedding_grad, D, self._interaction_mode(), bags, x,
+                        z = GatherInteractFunction.apply(self._stash_embedding_grad, D, self._interaction_mode() | rx, bags, x,
                                                          *self._emb_weights(self.emb_l))
                         return self._clamp(self.apply_mlp(z, self.top_l))
                     del x        # a ragged batch with nnz == B after all: the two kernels below (the bottom tower runs again, into its slot)
@@ -485,16 +505,16 @@ class DLRM_Net(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l, out_slot=OutSlot(feat[:, n_out:]))
-            x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :n_out]))
+            x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :n_out]), consumer_applies_last_act=bool(rx))
             ops.timer_mark()
             main.wait_stream(side)
         else:
-            x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :n_out]))
+            x = self.apply_mlp(dense_x, self.bot_l, out_slot=OutSlot(feat[:, :n_out]), consumer_applies_last_act=bool(rx))
             E = self._emb_packed(lS_o, lS_i, self.emb_l, self.v_W_l, out_slot=OutSlot(feat[:, n_out:]))
         if self.arch_interaction_op == "cat":
             z = CatFunction.apply(OutSlot(feat), x, E)      # the feature buffer IS cat([x] + ly, 1): nothing is copied
         else:
-            z = InteractFunction.apply(D, self._interaction_mode(), True, x, E)   # [B, round4(width)], zero padded
+            z = InteractFunction.apply(D, self._interaction_mode() | rx, True, x, E)   # [B, round4(width)], zero padded
         return self._clamp(self.apply_mlp(z, self.top_l))
 
     def distributed_forward(self, dense_x, lS_o, lS_i):
@@ -518,10 +538,11 @@ class DLRM_Net(nn.Module):
         if C > 1 and self.arch_interaction_op == "dot" and (batch_size // ext_dist.my_size) % C == 0:
             return self._pipelined_exchange_forward(dense_x, E, D, batch_size, C)
         req = ext_dist.alltoall([E], self.n_emb_per_rank, emb_dim=D)
-        x = self.apply_mlp(dense_x, self.bot_l)                             # overlaps the exchange
+        rx = self._relu_x() if dense_x.is_cuda else 0                       # (see sequential_forward)
+        x = self.apply_mlp(dense_x, self.bot_l, consumer_applies_last_act=bool(rx))     # overlaps the exchange
         ly = list(req.wait())                                               # N x [B/N, T_s*D], read in place
         if self.arch_interaction_op == "dot":
-            z = InteractFunction.apply(D, self._interaction_mode(), True, x, *ly)
+            z = InteractFunction.apply(D, self._interaction_mode() | rx, True, x, *ly)
         else:
             z = self.interact_features(x, ly)
         return self._clamp(self.apply_mlp(z, self.top_l))
@@ -539,11 +560,12 @@ class DLRM_Net(nn.Module):
         Bc = batch_size // N // C
         sends = ChunkPackFunction.apply(E, N, C)
         reqs = [ext_dist.alltoall([sends[c]], self.n_emb_per_rank, emb_dim=D) for c in range(C)]
-        x = self.apply_mlp(dense_x, self.bot_l)                                 # overlaps the first exchange
+        rx = self._relu_x() if dense_x.is_cuda else 0                           # every chunk's backward masks its own rows of dx
+        x = self.apply_mlp(dense_x, self.bot_l, consumer_applies_last_act=bool(rx))     # overlaps the first exchange
         outs = []
         for c in range(C):
             ly = list(reqs[c].wait())                                           # N x [Bc, T_s*D]
-            z = InteractFunction.apply(D, self._interaction_mode(), True, x[c * Bc:(c + 1) * Bc], *ly)
+            z = InteractFunction.apply(D, self._interaction_mode() | rx, True, x[c * Bc:(c + 1) * Bc], *ly)
             outs.append(self.apply_mlp(z, self.top_l))
         return self._clamp(torch.cat(outs, dim=0))
 

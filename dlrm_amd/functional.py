@@ -38,6 +38,9 @@ BF16_STORAGE = os.environ.get("DLRM_BF16_STORAGE", "1") == "1"
 BF16_LEAN = os.environ.get("DLRM_BF16_LEAN", "1") == "1"
 # DCN-v2 (bf16 storage): the elementwise half of a cross layer inside the epilogue of its second product (dlrm_gemm_bf16_cross); 0 = two kernels
 CROSS_FUSE = os.environ.get("DLRM_CROSS_FUSE", "1") == "1"
+# flag bit of MLPFunction's `arith` argument (see MLPFunction.forward); DLRM_FUSE_ACT_BWD=0 makes DLRM_Net never set it (A/B)
+MLP_CONSUMER_APPLIES_LAST_ACT = 0x100
+FUSE_ACT_BWD = os.environ.get("DLRM_FUSE_ACT_BWD", "1") == "1"
 # bf16 towers: the bf16 copies of ALL weights of a tower (W16 for the forward GEMMs, W^T16 for the data gradients) in one launch at the start of
 # the forward pass (dlrm_cast_bf16_multi) instead of one launch per layer and direction; 0 = per-layer casts
 MULTI_CAST = os.environ.get("DLRM_BF16_MULTI_CAST", "1") == "1"
@@ -182,6 +185,13 @@ class MLPFunction(Function):
     @staticmethod
     def forward(ctx, x, acts, out_slot, arith, *params):
         x = _rowmajor(x)
+        # MLP_CONSUMER_APPLIES_LAST_ACT OR-ed into `arith`: the gradient this tower receives is already multiplied by the derivative of its
+        # LAST activation (a ReLU) — the interaction backward does that to its feature-0 gradient on request (ops.INTERACT_RELU_X), so
+        # backward starts from dY as it comes instead of with an act_bwd pass over [M, N_last]
+        ctx.consumer_applies_last_act = bool(int(arith) & MLP_CONSUMER_APPLIES_LAST_ACT)
+        arith = int(arith) & ~MLP_CONSUMER_APPLIES_LAST_ACT
+        if ctx.consumer_applies_last_act and acts[-1] != ACT_RELU:
+            raise RuntimeError("dlrm_amd: MLP_CONSUMER_APPLIES_LAST_ACT needs a tower that ends in a ReLU")
         ctx.arith = arith
         L = len(acts)
         M = x.size(0)
@@ -314,8 +324,14 @@ class MLPFunction(Function):
 
         # last layer: activation backward (its dY comes from outside, e.g. the loss or the interaction)
         N_last = params[2 * (L - 1)].size(0)
-        dZ = alloc2d(M, N_last, x)
-        ops.act_bwd(dY, outs[L - 1], acts[L - 1], dZ, None)
+        if ctx.consumer_applies_last_act and _ld(dY) % 4 == 0 and dY.data_ptr() % 16 == 0:
+            dZ = dY                                        # already dL/dz of the last layer (see forward)
+        else:
+            dZ = alloc2d(M, N_last, x)
+            if ctx.consumer_applies_last_act:
+                dZ.copy_(dY)                               # (an unaligned gradient view: the GEMMs want 16-byte rows)
+            else:
+                ops.act_bwd(dY, outs[L - 1], acts[L - 1], dZ, None)
         dX = None
         # The weight-gradient GEMM of layer i and the data-gradient GEMM that feeds layer i-1 both consume dZ_i and
         # are independent: wgrad goes to a side HIP stream so the two kernels share the chip (their epilogue
@@ -448,12 +464,18 @@ class InteractFunction(Function):
         blocks = tuple(_rowmajor(b) for b in blocks)
         B = blocks[0].size(0)
         F = sum(b.size(1) // D for b in blocks)
-        Wd = ops.interact_out_width(F, D, self_interaction)
+        # `self_interaction | ops.INTERACT_RELU_X` (backward only): block 0's first feature is a ReLU output whose derivative the backward
+        # kernel applies (the producing MLPFunction was told so: MLP_CONSUMER_APPLIES_LAST_ACT) — never together with a permutation
+        relu_x = int(self_interaction) & ops.INTERACT_RELU_X
+        if relu_x and order is not None:
+            raise RuntimeError("dlrm_amd: INTERACT_RELU_X names feature 0 of the block list; it cannot be combined with a feature permutation")
+        mode = int(self_interaction) & 3
+        Wd = ops.interact_out_width(F, D, mode)
         ldr = _round4(Wd)
         Rfull = torch.empty((B, ldr), dtype=torch.float32, device=blocks[0].device)
-        ops.interact_fwd(blocks, D, self_interaction, Rfull, order=order)
+        ops.interact_fwd(blocks, D, mode, Rfull, order=order)
         ctx.order = order
-        ctx.D, ctx.self_interaction, ctx.width = D, self_interaction, Wd
+        ctx.D, ctx.self_interaction, ctx.width = D, mode | relu_x, Wd
         ctx.save_for_backward(*blocks)
         # padded=True hands out the whole [B, round4(width)] buffer (zero padding columns) for MLPFunction
         return Rfull if (ldr == Wd or padded) else Rfull[:, :Wd]
@@ -487,11 +509,12 @@ class GatherInteractFunction(Function):
     def forward(ctx, sink, D, self_interaction, bags, x, *weights):
         x = _rowmajor(x)
         F = 1 + len(weights)
-        Wd = ops.interact_out_width(F, D, self_interaction)
+        mode = int(self_interaction) & 3                      # (| ops.INTERACT_RELU_X: see InteractFunction.forward)
+        Wd = ops.interact_out_width(F, D, mode)
         R = torch.empty((x.size(0), _round4(Wd)), dtype=torch.float32, device=x.device)
-        ops.interact_fwd_gather(x, weights, bags, D, self_interaction, R)
+        ops.interact_fwd_gather(x, weights, bags, D, mode, R)
         ctx.sink, ctx.bags, ctx.weights = sink, bags, weights
-        ctx.D, ctx.self_interaction = D, self_interaction
+        ctx.D, ctx.self_interaction = D, int(self_interaction) & (3 | ops.INTERACT_RELU_X)
         ctx.save_for_backward(x)
         return R                                   # [B, round4(width)], zero padding columns (what MLPFunction takes as is)
 

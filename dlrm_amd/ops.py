@@ -650,9 +650,13 @@ def interact_fwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: 
     return R
 
 
+INTERACT_RELU_X = 4         # DLRM_INTERACT_RELU_X of include/dlrm_hip.h: OR-ed into the backward kernels' interaction mode
+
+
 def interact_bwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: BagBatch, D: int, self_interaction: bool,
                         dR: torch.Tensor, dx: torch.Tensor, dE: torch.Tensor) -> None:
-    """dx [B, D] = gradient of x; dE [B, T*D] = gradients of the T gathered rows (the dout of the fused embedding update)."""
+    """dx [B, D] = gradient of x; dE [B, T*D] = gradients of the T gathered rows (the dout of the fused embedding update).
+    `self_interaction | INTERACT_RELU_X`: x is a ReLU output and dx comes back multiplied by [x > 0] (see interact_bwd)."""
     lib = _lib.load()
     F, p, ld, gidx, goff, rows = _gather_desc(x, weights, bags, D)
     _req(dR, "dR", ndim=2); _req(dx, "dx", ndim=2); _req(dE, "dE", ndim=2)
@@ -667,6 +671,9 @@ def interact_bwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: 
 
 def interact_bwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool, dR: torch.Tensor,
                  dblocks: Sequence[torch.Tensor], order=None) -> None:
+    """`self_interaction` is the forward's mode, optionally OR-ed with INTERACT_RELU_X: feature 0 (the first D columns of blocks[0],
+    the bottom tower's output) is then taken as a ReLU output and its gradient is multiplied by the derivative [feature 0 > 0] inside
+    the kernel, which has the feature staged anyway — the tower's backward then starts without its act_bwd pass over [B, D]."""
     lib = _lib.load()
     B, ptrs, lds = _feature_table(blocks, D)
     B2, dptrs, dlds = _feature_table(dblocks, D)

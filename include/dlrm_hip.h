@@ -179,7 +179,11 @@ int dlrm_interact_fwd(int64_t B, int F, int D,
                       int self_interaction, float* R, int64_t ldr, void* stream);
 
 /* K6 backward:  dfeat_i = sum_j (dZ[i,j] + dZ[j,i]) * feat_j  (+ dR[:,0:D] for i = 0).
- * dfeat_host/dfeat_ld_host address the gradient rows exactly like feat_host addresses inputs. */
+ * dfeat_host/dfeat_ld_host address the gradient rows exactly like feat_host addresses inputs.
+ * Backward only (both dlrm_interact_bwd and dlrm_interact_bwd_gather): self_interaction | DLRM_INTERACT_RELU_X says that feature 0 is
+ * the output of a ReLU (the bottom tower's last layer, dlrm_s_pytorch.py:238-241) and asks for dfeat_0 * [feature 0 > 0] — the kernel
+ * has x staged anyway, so the tower's first backward pass (dlrm_act_bwd over [B, D]) disappears; same values, bit for bit. */
+#define DLRM_INTERACT_RELU_X 4
 int dlrm_interact_bwd(int64_t B, int F, int D,
                       const void* const* feat_host, const int64_t* feat_ld_host,
                       int self_interaction, const float* dR, int64_t ldr,

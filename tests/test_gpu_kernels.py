@@ -1171,6 +1171,44 @@ def test_gather_interaction_is_bit_identical_to_the_two_kernels(T, B, idx_dtype,
     assert not ops.gather_ok(29, 128) and ops.gather_ok(27, 128)      # the dR row of F > 27 (with self pairs) exceeds the gather backward's image
 
 
+@pytest.mark.parametrize("T,B,D,mode", [(26, 4099, 128, 0), (3, 777, 128, 1), (26, 1000, 128, 2), (26, 300, 16, 0), (8, 513, 64, 1), (2, 5, 36, 0)])
+def test_interaction_backward_applies_the_relu_derivative_of_feature_0(T, B, D, mode):
+    """`mode | INTERACT_RELU_X`: the backward kernels (LDS-DMA form at D = 128 with and without the fused lookups, the generic form
+    elsewhere) multiply the gradient of feature 0 by [feature 0 > 0] — the same bits as dlrm_act_bwd(ReLU) applied afterwards, which
+    is what the bottom tower's backward otherwise starts with (dlrm_s_pytorch.py:238-241, 483-504); every other gradient row unchanged."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(T * B + D)
+    F = T + 1
+    x = torch.relu(to_dev(rng.standard_normal((B, D)).astype(np.float32)))          # a ReLU output: about half zeros
+    x[0, 0] = 0.0; x[B - 1, D - 1] = -0.0
+    E = to_dev(rng.standard_normal((B, T * D)).astype(np.float32))
+    W_ = ops.interact_out_width(F, D, mode)
+    ldr = (W_ + 3) & ~3
+    dR = to_dev(rng.standard_normal((B, ldr)).astype(np.float32))
+    d0 = [torch.empty((B, D), device=dev()), torch.empty((B, T * D), device=dev())]
+    d1 = [torch.full((B, D), 9.0, device=dev()), torch.full((B, T * D), 9.0, device=dev())]
+    ops.interact_bwd([x, E], D, mode, dR, d0)
+    ops.interact_bwd([x, E], D, mode | ops.INTERACT_RELU_X, dR, d1)
+    want = torch.empty_like(d0[0])
+    ops.act_bwd(d0[0], x, ops.ACT_RELU, want, None)
+    assert torch.equal(d1[0], want) and torch.equal(d1[1], d0[1])
+    assert float(want.abs().sum()) > 0 and not torch.equal(want, d0[0])
+    if D == 128 and ops.gather_ok(F, D):
+        rows = [int(r) for r in rng.integers(1, 3000, size=T)]
+        Ws = [to_dev(rng.standard_normal((n, D)).astype(np.float32)) for n in rows]
+        idx = torch.stack([to_dev(rng.integers(0, n, size=B)) for n in rows])
+        bags = ops.BagBatch(torch.arange(B, device=dev()).repeat(T, 1), idx)
+        dx0, dE0 = torch.empty((B, D), device=dev()), torch.empty((B, T * D), device=dev())
+        dx1, dE1 = torch.empty((B, D), device=dev()), torch.empty((B, T * D), device=dev())
+        ops.interact_bwd_gather(x, Ws, bags, D, mode, dR, dx0, dE0)
+        ops.interact_bwd_gather(x, Ws, bags, D, mode | ops.INTERACT_RELU_X, dR, dx1, dE1)
+        ops.act_bwd(dx0, x, ops.ACT_RELU, want, None)
+        assert torch.equal(dx1, want) and torch.equal(dE1, dE0)
+        ops.check_index_errors(sync=True)
+    with pytest.raises(RuntimeError):
+        ops.interact_bwd([x, E], D, 3 | ops.INTERACT_RELU_X, dR, d1)                 # mode 3 does not exist, with or without the flag
+
+
 # ------------------------------------------------------------------------------------------ config 5 inputs: Multihot
 @pytest.mark.parametrize("id_dtype", [torch.int64, torch.int32])
 def test_multihot_expand_matches_reference_class(id_dtype):

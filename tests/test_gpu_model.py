@@ -448,6 +448,59 @@ def test_producer_tags_and_the_proof_stream():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("D,fuse", [(128, True), (128, False), (16, False)], ids=["fused-lookups", "two-kernels-D128", "generic-D16"])
+def test_bottom_tower_relu_derivative_inside_the_interaction_backward(D, fuse, monkeypatch):
+    """The interaction backward applies the derivative of the bottom tower's last ReLU to dx (ops.INTERACT_RELU_X) and the tower's backward
+    skips its act_bwd pass (MLP_CONSUMER_APPLIES_LAST_ACT): two SGD steps give the SAME bits for every parameter, embedding table and
+    prediction as with DLRM_FUSE_ACT_BWD=0, with one C-ABI call per step fewer (dlrm_s_pytorch.py:238-241, 483-504).  A bottom tower
+    that ends in a sigmoid is left alone."""
+    import dlrm_amd
+    from dlrm_amd import functional, ops
+    device = torch.device("cuda:0")
+    rows, B = [50, 7, 3000, 11, 400], 384
+    F = len(rows) + 1
+    ln_bot = np.asarray([13, 64, D])
+    ln_top = np.asarray([D + F * (F - 1) // 2, 96, 1])
+
+    def run(flag, sigmoid_bot=-1):
+        monkeypatch.setattr(functional, "FUSE_ACT_BWD", flag)
+        np.random.seed(11)
+        model = dlrm_amd.DLRM_Net(D, np.asarray(rows), ln_bot, ln_top, "dot", sigmoid_bot=sigmoid_bot, sigmoid_top=ln_top.size - 2,
+                                  loss_function="bce").to(device)
+        model.emb_update_mode = ops.UPD_DETERMINISTIC
+        model.fuse_emb_interact = fuse
+        opt = torch.optim.SGD(model.parameters(), lr=0.3)
+        g = torch.Generator().manual_seed(5)
+        out = []
+        calls0 = ops.CALL_COUNT[0]
+        for _ in range(2):
+            X = torch.rand((B, 13), generator=g).to(device)
+            idx = torch.stack([torch.randint(0, n, (B,), generator=g) for n in rows]).to(device)
+            off = torch.arange(B).repeat(len(rows), 1).to(device)
+            T = torch.randint(0, 2, (B, 1), generator=g).float().to(device)
+            Z = model(X, off, idx)
+            E = model.loss_fn(Z, T)
+            opt.zero_grad()
+            E.backward()
+            opt.step()
+            out.append(Z.detach().clone())
+        calls = ops.CALL_COUNT[0] - calls0
+        out += [p.detach().clone() for p in model.parameters()]
+        torch.cuda.synchronize()
+        ops.check_index_errors(sync=True)
+        return out, calls
+
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert len(ref) == len(got) and all(torch.equal(a, b) for a, b in zip(ref, got))
+    assert n_got == n_ref - 2                                       # one act_bwd call per step gone
+    # a sigmoid at the end of the bottom tower: nothing to fuse (same calls, same bits) — and a different model
+    ref_s, n_ref_s = run(False, sigmoid_bot=ln_bot.size - 2)
+    got_s, n_got_s = run(True, sigmoid_bot=ln_bot.size - 2)
+    assert n_ref_s == n_got_s and all(torch.equal(a, b) for a, b in zip(ref_s, got_s))
+    assert not all(torch.equal(a, b) for a, b in zip(ref, ref_s))
+
+
 def test_coo_escape_hatch_refuses_row_wise_shards_and_checks_indices_synchronously():
     """ADVICE r2 fixes that had no test: (a) DLRM_Net._materialize_coo_grads exits with the reference-style ERROR when the bags
     belong to a row-wise shard (ignore_oob: out-of-range ids are other ranks' rows, a COO gradient would scatter them);

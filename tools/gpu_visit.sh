@@ -10,6 +10,7 @@
 #   pmcm             MFMA-busy / LDS-conflict passes -> pmc_mfma_lds.md
 #   secondary        rwsadagrad / bf16 / bf16x6 / graph / Kaggle / MLPerf-v2 dot + dcn lines
 #   ab=ENV           alternating A/B of the quick bench: A = no env, B = ENV (e.g. ab=DLRM_FOO=1), two rounds each
+#   abx[=ROUNDS]     like ab for any number of configurations: ABX="name:ENV=v ..;name2:.." (empty ENV = HEAD), interleaved ROUNDS times
 #   run=CMD          any command (quoted), output to run_<n>.log
 OUT=gpurun_out/${1:?out tag}; shift
 mkdir -p $OUT
@@ -73,6 +74,14 @@ for stage in "$@"; do
       for r in 1 2; do
         timeout 300 python bench.py --steps 30 --warmup 5 $QUICK $AB_FLAGS > $OUT/A$r.json 2> $OUT/A$r.err; echo "== A$r"; summ $OUT/A$r.json
         env $arg timeout 300 python bench.py --steps 30 --warmup 5 $QUICK $AB_FLAGS > $OUT/B$r.json 2> $OUT/B$r.err; echo "== B$r ($arg)"; summ $OUT/B$r.json
+      done ;;
+    abx)   # several configurations interleaved: ABX="name:ENV=..;name2:ENV2=.. ENV3=.." (empty ENV = HEAD), arg = rounds (default 2)
+      for r in $(seq 1 ${arg:-2}); do
+        IFS=';' read -ra cfgs <<< "$ABX"
+        for c in "${cfgs[@]}"; do
+          t=${c%%:*}; e=${c#*:}
+          env $e timeout 300 python bench.py --steps ${ABX_STEPS:-30} --warmup 5 $QUICK $AB_FLAGS > $OUT/$t$r.json 2> $OUT/$t$r.err; echo "== $t$r ($e)"; summ $OUT/$t$r.json
+        done
       done ;;
     run) bash -c "$arg" > $OUT/run_$n.log 2>&1; echo "== run rc=$? ($arg)"; tail -${RUN_TAIL:-12} $OUT/run_$n.log ;;
     *) echo "unknown stage $stage" ;;
