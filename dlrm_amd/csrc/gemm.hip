@@ -1516,7 +1516,7 @@ static void wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* kchunk
     // split the batch reduction so that >= ~4 workgroups per CU exist; slices of >= 512 rows
     const int tiles = (int)(((N + BM - 1) / BM) * ((K + BN - 1) / BN));
     static int target_wgs = -1, min_rows = -1;   // tuning aids: DLRM_WGRAD_WGS (workgroups a launch aims at), DLRM_WGRAD_MINROWS (shortest batch slice)
-    if (target_wgs < 0) { const char* e = getenv("DLRM_WGRAD_WGS"); target_wgs = e && atoi(e) > 0 ? atoi(e) : 1024; }
+    if (target_wgs < 0) { const char* e = getenv("DLRM_WGRAD_WGS"); target_wgs = e && atoi(e) > 0 ? atoi(e) : 768; }
     if (min_rows < 0) { const char* e = getenv("DLRM_WGRAD_MINROWS"); min_rows = e && atoi(e) >= 128 ? atoi(e) : 512; }
     int splits = (target_wgs + tiles - 1) / tiles;
     const int64_t max_splits = (M + min_rows - 1) / min_rows;
