@@ -99,6 +99,10 @@ SIGNATURES = {
     "dlrm_cross_bwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "dlrm_gemm_bf16_cross": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_add": (_i32, [_i64, _vp, _vp, _vp, _vp]),
+    "dlrm_tower_fwd": (_i32, [_i64, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _i64, _pp, _pi64, _pp, _pp, _pi64, _vp]),
+    "dlrm_tower_bwd": (_i32, [_i64, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _i64, _i32, _pp, _pi64, _pp, _pi64, _pp, _pi64, _vp, _i64, _vp]),
+    "dlrm_tower_wgrad_workspace_bytes": (_i64, [_i64, _i32, C.POINTER(_i32)]),
+    "dlrm_tower_wgrad": (_i32, [_i64, _i32, C.POINTER(_i32), C.POINTER(_i32), _pp, _pi64, _pp, _pi64, _pp, _pi64, _pp, _vp, _i64, _vp]),
     "dlrm_clamp": (_i32, [_i64, _vp, _f32, _f32, _vp, _vp]),
     "dlrm_clamp_bwd": (_i32, [_i64, _vp, _f32, _f32, _vp, _vp, _vp]),
 }

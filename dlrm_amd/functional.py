@@ -39,6 +39,11 @@ BF16_LEAN = os.environ.get("DLRM_BF16_LEAN", "1") == "1"
 # DCN-v2 (bf16 storage): the elementwise half of a cross layer inside the epilogue of its second product (dlrm_gemm_bf16_cross); 0 = two kernels
 CROSS_FUSE = os.environ.get("DLRM_CROSS_FUSE", "1") == "1"
 # flag bit of MLPFunction's `arith` argument (see MLPFunction.forward); DLRM_FUSE_ACT_BWD=0 makes DLRM_Net never set it (A/B)
+# small batches: a whole fp32 tower per launch (csrc/tower.hip) for up to DLRM_TOWER_ROWS rows (0 = never, the default until the kernels
+# beat the per-layer GEMMs: profiles/round5/kaggle_towers.md) while the weight traffic of its 16-row workgroups stays under
+# DLRM_TOWER_L2_MB; see _tower_applies
+TOWER_ROWS = int(os.environ.get("DLRM_TOWER_ROWS", "0"))
+TOWER_L2_BYTES = int(os.environ.get("DLRM_TOWER_L2_MB", "384")) << 20
 MLP_CONSUMER_APPLIES_LAST_ACT = 0x100
 FUSE_ACT_BWD = os.environ.get("DLRM_FUSE_ACT_BWD", "1") == "1"
 # bf16 towers: the bf16 copies of ALL weights of a tower (W16 for the forward GEMMs, W^T16 for the data gradients) in one launch at the start of
@@ -169,6 +174,25 @@ class OutSlot:
         return self._view[:]  # fresh tensor object sharing the storage (gets its own grad_fn)
 
 
+def _tower_applies(x, arith, params, L) -> bool:
+    """the small-batch tower kernels take this MLP: native fp32, a batch of at most TOWER_ROWS rows, widths the kernels hold in LDS, and
+    little enough weight traffic — every 16-row workgroup streams ALL weights, (M / 16) x parameters x 4 bytes through L2, which is what
+    bounds the path to small batches x small towers (Criteo-Kaggle: 128 x 1.3 MB; the Criteo-Terabyte towers at 2048 rows would move 1.1 GB)"""
+    if TOWER_ROWS <= 0 or not x.is_cuda or arith != ops.arith_code("f32"):
+        return False
+    M = x.size(0)
+    K0 = params[0].size(1)
+    if M < 1 or M > TOWER_ROWS or x.size(1) not in (K0, _round4(K0)) or L > ops.TOWER_MAX_LAYERS:
+        return False
+    widths = [x.size(1)] + [params[2 * i].size(0) for i in range(L)]
+    if not ops.tower_ok(M, widths):
+        return False
+    if any(params[2 * i].size(1) != (K0 if i == 0 else widths[i]) for i in range(L)):
+        return False
+    weight_bytes = 4 * sum(widths[i] * widths[i + 1] for i in range(L))
+    return ((M + 15) // 16) * weight_bytes <= TOWER_L2_BYTES
+
+
 class MLPFunction(Function):
     """nn.Sequential(Linear, act, Linear, act, ...) as one chain of fused GEMM(+bias+act) kernels.
 
@@ -198,6 +222,9 @@ class MLPFunction(Function):
         W0 = params[0]
         K0, Kp = W0.size(1), _round4(W0.size(1))
         ctx.in_width = x.size(1)
+        ctx.tower = False
+        if _tower_applies(x, arith, params, L):
+            return MLPFunction._tower_forward(ctx, x, acts, out_slot, params)
         W0p = None
         if Kp != K0:
             if x.size(1) != Kp:
@@ -305,7 +332,48 @@ class MLPFunction(Function):
         return outs[-1]
 
     @staticmethod
+    def _tower_forward(ctx, x, acts, out_slot, params):
+        """small batches, native fp32: the whole tower in ONE launch (csrc/tower.hip) — activations of 16 batch rows stay in LDS from layer
+        to layer; every layer's output is still written once, for the backward pass.  Nothing is padded: an input that arrives unpadded (13
+        dense features) is read with element loads; an input that arrives padded to a multiple of 4 (the interaction's 367 -> 368 columns)
+        meets a zero-padded copy of the first weight, as in the per-layer path."""
+        L = len(acts)
+        M = x.size(0)
+        W0 = params[0]
+        K0 = W0.size(1)
+        W0p = ops.pad_cols(W0, x.size(1)) if x.size(1) != K0 else None
+        Ws = [W0p if (i == 0 and W0p is not None) else params[2 * i] for i in range(L)]
+        outs = [(out_slot.get() if (i == L - 1 and out_slot is not None) else alloc2d(M, params[2 * i].size(0), x)) for i in range(L)]
+        ops.tower_fwd(x, Ws, [params[2 * i + 1] for i in range(L)], acts, outs)
+        ctx.tower, ctx.acts, ctx.padded = True, acts, W0p is not None
+        ctx.save_for_backward(x, *params, *outs, *([W0p] if W0p is not None else []))
+        return outs[-1]
+
+    @staticmethod
+    def _tower_backward(ctx, dY):
+        acts = ctx.acts
+        L = len(acts)
+        saved = ctx.saved_tensors
+        x, params, outs = saved[0], saved[1:1 + 2 * L], list(saved[1 + 2 * L:1 + 3 * L])
+        W0p = saved[1 + 3 * L] if ctx.padded else None
+        M = x.size(0)
+        dY = _rowmajor(dY)
+        Ws = [W0p if (i == 0 and W0p is not None) else params[2 * i] for i in range(L)]
+        dZs = [alloc2d(M, params[2 * i].size(0), x) for i in range(L)]
+        dX = alloc2d(M, x.size(1), x) if ctx.needs_input_grad[0] else None
+        ops.tower_bwd(dY, Ws, acts, outs, dZs, dX, last_act_applied=ctx.consumer_applies_last_act)
+        dWs = [_grad_out(params[2 * i]) for i in range(L)]              # (the first layer's at the parameter's true width)
+        dbs = [_grad_out(params[2 * i + 1]) for i in range(L)]
+        ops.tower_wgrad(dZs, [x] + outs[:-1], dWs, dbs)
+        grads = []
+        for i in range(L):
+            grads += [dWs[i], dbs[i]]
+        return (dX, None, None, None, *grads)
+
+    @staticmethod
     def backward(ctx, dY):
+        if ctx.tower:
+            return MLPFunction._tower_backward(ctx, dY)
         acts, arith = ctx.acts, ctx.arith
         L = len(acts)
         saved = ctx.saved_tensors

@@ -54,12 +54,19 @@ def _clone_struct(x: TensorOrList):
     return out
 
 
-def _copy_struct(dst: TensorOrList, src: TensorOrList) -> None:
+def _copy_struct(dst: TensorOrList, src: TensorOrList, pairs: Optional[list] = None) -> None:
+    """static buffers <- the caller's tensors.  With `pairs` the (dst, src) tensor pairs are only COLLECTED (after the shape checks):
+    _flush_copies then moves all of them in one launch."""
+    def put(d, s_):
+        if pairs is not None:
+            pairs.append((d, s_))
+        else:
+            d.copy_(s_, non_blocking=True)
     if isinstance(dst, torch.Tensor):
         if not isinstance(src, torch.Tensor) or src.shape != dst.shape or src.dtype != dst.dtype:
             raise RuntimeError("dlrm_amd.graph: input shape/dtype differs from the captured step")
         if src.data_ptr() != dst.data_ptr():
-            dst.copy_(src, non_blocking=True)
+            put(dst, src)
         return
     if isinstance(src, torch.Tensor) or len(src) != len(dst):
         raise RuntimeError("dlrm_amd.graph: input structure differs from the captured step")
@@ -71,9 +78,32 @@ def _copy_struct(dst: TensorOrList, src: TensorOrList) -> None:
         if id(d) in done or s_.data_ptr() == d.data_ptr():
             continue
         done.add(id(d))
-        # one copy_ per distinct tensor.  (torch._foreach_copy_ on int64 lists raised GPU memory faults on
+        # one copy per distinct tensor.  (torch._foreach_copy_ on int64 lists raised GPU memory faults on
         # torch 2.10 + ROCm 7 at B = 65536 — profiles/r02/graph_probe.md; pass stacked [T, B] index / offset tensors to
         # make this a single copy.)
+        put(d, s_)
+
+
+def _flush_copies(pairs: list) -> None:
+    """All input copies of a replay in ONE launch of the library's strided block copy (dlrm_copy_blocks, every tensor seen as a row of
+    32-bit words) instead of one ATen copy kernel per tensor: at Criteo-Kaggle shapes the four copy_ calls (dense features, offsets,
+    indices, targets) were 45 us of a 390 us step, nearly all of it host time between four 2-us kernels
+    (profiles/round5/step_trace_kaggle_graph.txt).  Tensors the block copy cannot take (non-contiguous, other devices, element sizes
+    other than 4 / 8 bytes, more than 2^31 words) keep their copy_."""
+    words, rest = [], []
+    for d, s_ in pairs:
+        ok = (d.is_cuda and s_.is_cuda and d.device == s_.device and d.is_contiguous() and s_.is_contiguous() and d.element_size() in (4, 8)
+              and d.dtype == s_.dtype and 0 < d.numel() * d.element_size() // 4 < (1 << 31) and d.data_ptr() % 4 == 0 and s_.data_ptr() % 4 == 0)
+        (words if ok else rest).append((d, s_))
+    if len(words) > 1:
+        def w32(t):
+            t = t.detach().reshape(-1)
+            t = t.view(torch.int32) if t.element_size() == 8 else t
+            return (t if t.dtype == torch.float32 else t.view(torch.float32)).view(1, -1)
+        ops.copy_blocks([w32(s_) for _, s_ in words], [w32(d) for d, _ in words])
+    else:
+        rest = words + rest
+    for d, s_ in rest:
         d.copy_(s_, non_blocking=True)
 
 
@@ -219,6 +249,7 @@ class GraphedTrainStep:
         # the graph holds raw pointers into the cached scratch workspaces: pin those tensors so that a later, larger
         # request elsewhere (which replaces the cache entry) cannot free memory the replays still use
         self._pinned_ws = [w for (d_, _), w in list(ops._emb_ws.items()) + list(ops._wgrad_ws.items()) if d_ == dev]
+        self._pinned_ws += [w for (d_, _), w in ops._tower_ws.items() if d_ == dev]
         self.captures += 1
         torch.cuda.current_stream(dev).wait_stream(self.stream)
 
@@ -242,10 +273,12 @@ class GraphedTrainStep:
             self.static = (X.clone(), _clone_struct(lS_o), _clone_struct(lS_i), T.clone())
         else:
             xs, os_, is_, ts = self.static
-            _copy_struct(xs, X)
-            _copy_struct(os_, lS_o)
-            _copy_struct(is_, lS_i)
-            _copy_struct(ts, T)
+            pairs = []
+            _copy_struct(xs, X, pairs)
+            _copy_struct(os_, lS_o, pairs)
+            _copy_struct(is_, lS_i, pairs)
+            _copy_struct(ts, T, pairs)
+            _flush_copies(pairs)
         dev = X.device
         if self._eager_calls < self.warmup:
             # the first calls are ordinary eager steps, issued on the stream the capture will use so that kernel

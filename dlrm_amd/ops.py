@@ -1042,6 +1042,104 @@ def pad_cols(src: torch.Tensor, Kp: int) -> torch.Tensor:
     return dst
 
 
+# ------------------------------------------------------------------------------------------------
+# small-batch towers (csrc/tower.hip): all layers of an MLP in one launch per direction
+# ------------------------------------------------------------------------------------------------
+TOWER_MAX_LAYERS, TOWER_MAX_WIDTH = 8, 1024          # DLRM_TOWER_MAX_LAYERS / DLRM_TOWER_MAX_WIDTH of include/dlrm_hip.h
+_tower_ws = {}     # (device, stream) -> slab workspace of tower_wgrad
+
+
+def _int_array(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def tower_ok(M: int, widths: Sequence[int]) -> bool:
+    return 0 < M and 1 <= len(widths) - 1 <= TOWER_MAX_LAYERS and all(0 < w <= TOWER_MAX_WIDTH for w in widths)
+
+
+def tower_fwd(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], acts: Sequence[int],
+              outs: Sequence[torch.Tensor]) -> None:
+    """outs[l] = act_l(in_l @ weights[l]^T + biases[l]) for the whole tower, in_0 = x, in_l = outs[l-1]: ONE launch (dlrm_tower_fwd).
+    weights[l] is [N_l, K_l] with K_0 == x.size(1) and K_l == N_{l-1}; every outs[l] [M, N_l] is written (backward reads them)."""
+    lib = _lib.load()
+    L = len(weights)
+    _req(x, "x", ndim=2)
+    M = x.size(0)
+    widths = [x.size(1)] + [w.size(0) for w in weights]
+    for l, (w, o) in enumerate(zip(weights, outs)):
+        _req(w, "W", ndim=2); _req(o, "out", ndim=2)
+        if w.size(1) != widths[l] or o.size(0) != M or o.size(1) != widths[l + 1] or (biases[l] is not None and biases[l].numel() != widths[l + 1]):
+            raise RuntimeError("dlrm_amd: tower_fwd shape mismatch at layer %d" % l)
+    if len(outs) != L or len(biases) != L or len(acts) != L or not tower_ok(M, widths):
+        raise RuntimeError("dlrm_amd: tower_fwd: %d layers of widths %s are outside the small-batch tower kernels" % (L, widths))
+    with _timed("linear_fwd"):
+        rc = lib.dlrm_tower_fwd(M, L, _int_array(widths), _int_array(acts), C.c_void_p(x.data_ptr()), _ld(x),
+                                _lib.ptr_array([w.data_ptr() for w in weights]), _lib.i64_array([_ld(w) for w in weights]),
+                                _lib.ptr_array([b.data_ptr() if b is not None else 0 for b in biases]),
+                                _lib.ptr_array([o.data_ptr() for o in outs]), _lib.i64_array([_ld(o) for o in outs]), _stream(x))
+    _lib.check(rc, "dlrm_tower_fwd")
+
+
+def tower_bwd(dY: torch.Tensor, weights: Sequence[torch.Tensor], acts: Sequence[int], outs: Sequence[torch.Tensor],
+              dZs: Sequence[torch.Tensor], dX: Optional[torch.Tensor], last_act_applied: bool = False) -> None:
+    """The data-gradient chain of the tower in ONE launch (dlrm_tower_bwd): dZs[l] [M, N_l] = dL/dz_l of every layer (the operands of
+    tower_wgrad) and, when dX is given, the gradient of the tower's input [M, K_0]."""
+    lib = _lib.load()
+    L = len(weights)
+    _req(dY, "dY", ndim=2)
+    M = dY.size(0)
+    widths = [weights[0].size(1)] + [w.size(0) for w in weights]
+    if len(outs) != L or len(dZs) != L or len(acts) != L or dY.size(1) != widths[L] or not tower_ok(M, widths):
+        raise RuntimeError("dlrm_amd: tower_bwd argument mismatch")
+    for l in range(L):
+        _req(outs[l], "out", ndim=2); _req(dZs[l], "dZ", ndim=2)
+        if outs[l].shape != (M, widths[l + 1]) or dZs[l].shape != (M, widths[l + 1]) or weights[l].size(1) != widths[l]:
+            raise RuntimeError("dlrm_amd: tower_bwd shape mismatch at layer %d" % l)
+    if dX is not None:
+        _req(dX, "dX", ndim=2)
+        if dX.shape != (M, widths[0]):
+            raise RuntimeError("dlrm_amd: tower_bwd dX shape mismatch")
+    with _timed("linear_bwd_data"):
+        rc = lib.dlrm_tower_bwd(M, L, _int_array(widths), _int_array(acts), C.c_void_p(dY.data_ptr()), _ld(dY), int(bool(last_act_applied)),
+                                _lib.ptr_array([w.data_ptr() for w in weights]), _lib.i64_array([_ld(w) for w in weights]),
+                                _lib.ptr_array([o.data_ptr() for o in outs]), _lib.i64_array([_ld(o) for o in outs]),
+                                _lib.ptr_array([z.data_ptr() for z in dZs]), _lib.i64_array([_ld(z) for z in dZs]),
+                                C.c_void_p(dX.data_ptr()) if dX is not None else None, _ld(dX) if dX is not None else 0, _stream(dY))
+    _lib.check(rc, "dlrm_tower_bwd")
+
+
+def tower_wgrad(dZs: Sequence[torch.Tensor], ins: Sequence[torch.Tensor], dWs: Sequence[torch.Tensor],
+                dbs: Sequence[Optional[torch.Tensor]]) -> None:
+    """dWs[l] [N_l, K_store_l] = dZs[l]^T @ ins[l] (K_store_l = dWs[l].size(1) <= ins[l].size(1): trailing padding columns of the input
+    are dropped) and dbs[l] = column sums of dZs[l], for ALL layers in one launch, deterministic (dlrm_tower_wgrad)."""
+    lib = _lib.load()
+    L = len(dZs)
+    M = dZs[0].size(0)
+    widths = [ins[0].size(1)] + [z.size(1) for z in dZs]
+    for l in range(L):
+        _req(dZs[l], "dZ", ndim=2); _req(ins[l], "in", ndim=2); _req(dWs[l], "dW", ndim=2)
+        if (ins[l].size(0) != M or dZs[l].size(0) != M or ins[l].size(1) != widths[l] or dWs[l].size(0) != widths[l + 1]
+                or dWs[l].size(1) > widths[l] or (dbs[l] is not None and (dbs[l].numel() != widths[l + 1] or not dbs[l].is_contiguous()))):
+            raise RuntimeError("dlrm_amd: tower_wgrad shape mismatch at layer %d" % l)
+    if len(ins) != L or len(dWs) != L or len(dbs) != L or not tower_ok(M, widths):
+        raise RuntimeError("dlrm_amd: tower_wgrad argument mismatch")
+    wa = _int_array(widths)
+    need = int(lib.dlrm_tower_wgrad_workspace_bytes(M, L, wa))
+    dev = dZs[0].device
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    ws = _tower_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _tower_ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    with _timed("linear_bwd_weight"):
+        rc = lib.dlrm_tower_wgrad(M, L, wa, _int_array([w.size(1) for w in dWs]),
+                                  _lib.ptr_array([z.data_ptr() for z in dZs]), _lib.i64_array([_ld(z) for z in dZs]),
+                                  _lib.ptr_array([i.data_ptr() for i in ins]), _lib.i64_array([_ld(i) for i in ins]),
+                                  _lib.ptr_array([w.data_ptr() for w in dWs]), _lib.i64_array([_ld(w) for w in dWs]),
+                                  _lib.ptr_array([b.data_ptr() if b is not None else 0 for b in dbs]),
+                                  C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dZs[0]))
+    _lib.check(rc, "dlrm_tower_wgrad")
+
+
 def act_bwd(dY: torch.Tensor, Y: torch.Tensor, act: int, dZ: torch.Tensor, dbias: Optional[torch.Tensor]) -> torch.Tensor:
     lib = _lib.load()
     _req(dY, "dY", ndim=2); _req(Y, "Y", ndim=2); _req(dZ, "dZ", ndim=2)

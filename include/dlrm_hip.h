@@ -336,6 +336,35 @@ int dlrm_linear_bwd_weight_padded(int64_t M, int N, int K, int K_store,
 /* dst[m, 0:K] = src[m, 0:K], dst[m, K:Kp] = 0   (builds those padded operands: no ATen fill/copy on the hot path) */
 int dlrm_pad_cols(int64_t M, int K, int Kp, const float* src, int64_t ld_src, float* dst, int64_t ld_dst, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * K5 for SMALL batches: a whole tower (nn.Sequential(Linear, act, ...), dlrm_s_pytorch.py:208-246, 399-405; native fp32 MFMA) in
+ * four launches — forward, data-gradient chain, all weight / bias gradients (+ their slab sums) — instead of one GEMM launch per layer and direction.
+ * A workgroup owns 16 batch rows whose activations stay in LDS between the layers; every workgroup streams all weights, so this is
+ * for batches of a few thousand rows (Criteo-Kaggle: 2048), where the per-layer GEMMs are launch- and latency-bound.  csrc/tower.hip.
+ *   widths[0..L]      widths[0] = the tower's input width, widths[l + 1] = outputs of layer l (all <= DLRM_TOWER_MAX_WIDTH)
+ *   acts[l]           DLRM_ACT_* of layer l
+ *   W_host[l]         [widths[l + 1], widths[l]] at pitch ldw_host[l]; bias_host[l] nullable
+ *   Y_host[l]         [M, widths[l + 1]]: every layer's activated output is WRITTEN by dlrm_tower_fwd (the backward pass reads them)
+ * dlrm_tower_bwd: dY [M, widths[L]] = gradient of the tower's output (last_act_applied != 0: already multiplied by the last
+ *   activation's derivative — DLRM_INTERACT_RELU_X); writes dZ_host[l] [M, widths[l + 1]] = dL/dz of every layer and, when dX != NULL,
+ *   the gradient of the tower's input.
+ * dlrm_tower_wgrad: dW_host[l] [widths[l + 1], kstore[l]] = dZ_l^T . In_l (In_0 = the tower's input, In_l = Y_{l-1}; kstore[l] <=
+ *   widths[l]: trailing alignment-padding columns of the input are dropped), db_host[l] (nullable) = column sums of dZ_l; both
+ *   OVERWRITTEN.  64 x 64 tiles x batch slices into slabs (`workspace`, dlrm_tower_wgrad_workspace_bytes), then a second launch adds
+ *   every tile's slabs in slice order (deterministic).
+ * Unaligned operands (13 dense features: rows of 52 bytes) take element loads; nothing needs padding. */
+#define DLRM_TOWER_MAX_LAYERS 8
+#define DLRM_TOWER_MAX_WIDTH 1024
+int dlrm_tower_fwd(int64_t M, int L, const int* widths, const int* acts, const float* X, int64_t ldx, const void* const* W_host,
+                   const int64_t* ldw_host, const void* const* bias_host, void* const* Y_host, const int64_t* ldy_host, void* stream);
+int dlrm_tower_bwd(int64_t M, int L, const int* widths, const int* acts, const float* dY, int64_t lddy, int last_act_applied,
+                   const void* const* W_host, const int64_t* ldw_host, const void* const* Y_host, const int64_t* ldy_host,
+                   void* const* dZ_host, const int64_t* lddz_host, float* dX, int64_t lddx, void* stream);
+int64_t dlrm_tower_wgrad_workspace_bytes(int64_t M, int L, const int* widths);
+int dlrm_tower_wgrad(int64_t M, int L, const int* widths, const int* kstore, const void* const* dZ_host, const int64_t* lddz_host,
+                     const void* const* In_host, const int64_t* ldin_host, void* const* dW_host, const int64_t* lddw_host,
+                     void* const* db_host, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* activation backward for a layer whose dY does not come out of dlrm_linear_bwd_data (i.e. the last
  * layer of a tower):  dZ = dY ⊙ act'(Y);  optionally dbias[N] += column sums of dZ (dbias != NULL; the
  * caller zeroes it — normally NULL because dlrm_linear_bwd_weight produces the bias gradient). */

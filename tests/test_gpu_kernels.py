@@ -372,6 +372,76 @@ def _linear_fwd_bwd(M, N, K, act, arith):
     np.testing.assert_allclose(dXd.cpu().numpy(), dX, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("M,widths,acts,need_dx", [
+    (2048, [13, 512, 256, 64, 16], [1, 1, 1, 1], False),          # Criteo-Kaggle bottom tower: unaligned input rows (52 bytes)
+    (2048, [368, 512, 256, 1], [1, 1, 2], True),                  # ... top tower (the interaction's padded 367 columns), sigmoid head
+    (128, [13, 512, 16], [1, 1], False), (128, [22, 512, 256, 1], [1, 1, 2], True),
+    (1000, [7, 33, 130, 5], [1, 0, 2], True),                     # nothing aligned, ragged batch (1000 = 62 * 16 + 8), mixed activations
+    (17, [64, 1024, 1024, 64], [1, 1, 1], True), (1, [4, 4], [0], True), (4096, [16, 64, 48], [2, 1], True)])
+def test_small_batch_tower_kernels_match_oracle(M, widths, acts, need_dx):
+    """dlrm_tower_fwd / _bwd / _wgrad (csrc/tower.hip: a whole MLP per launch, activations of 16 rows in LDS, the weight gradients of all
+    layers from one launch with an in-order slice sum) against the float64 oracle applied layer by layer (O.linear_fwd / O.linear_bwd,
+    dlrm_s_pytorch.py:208-246, 399-405), at the tolerances of the per-layer GEMM test; the weight gradient twice: same bits (deterministic)."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + sum(widths))
+    L = len(acts)
+    X = rng.standard_normal((M, widths[0])).astype(np.float32)
+    Ws = [(rng.standard_normal((widths[l + 1], widths[l])) / np.sqrt(widths[l])).astype(np.float32) for l in range(L)]
+    bs = [rng.standard_normal(widths[l + 1]).astype(np.float32) for l in range(L)]
+    Xd = to_dev(X)
+    Wd, bd = [to_dev(w) for w in Ws], [to_dev(b) for b in bs]
+    outs = [torch.full((M, widths[l + 1]), 7.0, device=dev()) for l in range(L)]
+    ops.tower_fwd(Xd, Wd, bd, acts, outs)
+    torch.cuda.synchronize()
+    cur = X
+    for l in range(L):          # every layer checked on the input the GPU actually fed it (errors do not compound into the bars)
+        want = O.linear_fwd(cur, Ws[l], bs[l], acts[l])
+        np.testing.assert_allclose(outs[l].cpu().numpy(), want, rtol=1e-5, atol=1e-5, err_msg="layer %d forward" % l)
+        cur = outs[l].cpu().numpy()
+    dY = rng.standard_normal((M, widths[L])).astype(np.float32)
+    dZs = [torch.full((M, widths[l + 1]), 7.0, device=dev()) for l in range(L)]
+    dX = torch.full((M, widths[0]), 7.0, device=dev()) if need_dx else None
+    ops.tower_bwd(to_dev(dY), Wd, acts, outs, dZs, dX)
+    dWs = [torch.full((widths[l + 1], widths[l]), 7.0, device=dev()) for l in range(L)]
+    dbs = [torch.full((widths[l + 1],), 7.0, device=dev()) for l in range(L)]
+    ops.tower_wgrad(dZs, [Xd] + outs[:-1], dWs, dbs)
+    dWs2 = [torch.empty_like(w) for w in dWs]
+    dbs2 = [torch.empty_like(b) for b in dbs]
+    ops.tower_wgrad(dZs, [Xd] + outs[:-1], dWs2, dbs2)
+    torch.cuda.synchronize()
+    g = dY
+    for l in range(L - 1, -1, -1):
+        inp = X if l == 0 else outs[l - 1].cpu().numpy()
+        dXo, dWo, dbo = O.linear_bwd(inp, Ws[l], acts[l], outs[l].cpu().numpy(), g)
+        # dZ of this layer as the GPU has it (mask from the GPU's own forward output, as in the per-layer test)
+        y = outs[l].cpu().numpy().astype(np.float64)
+        dz = g * ((y > 0) if acts[l] == 1 else (y * (1 - y)) if acts[l] == 2 else 1.0)
+        np.testing.assert_allclose(dZs[l].cpu().numpy(), dz, rtol=1e-5, atol=1e-5, err_msg="layer %d dZ" % l)
+        scale = max(1.0, float(np.abs(dWo).max()))
+        np.testing.assert_allclose(dWs[l].cpu().numpy(), dWo, rtol=1e-4, atol=1e-5 * scale, err_msg="layer %d dW" % l)
+        np.testing.assert_allclose(dbs[l].cpu().numpy(), dbo, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(dbo).max())), err_msg="layer %d db" % l)
+        assert torch.equal(dWs[l], dWs2[l]) and torch.equal(dbs[l], dbs2[l])
+        if l == 0:
+            if need_dx:
+                np.testing.assert_allclose(dX.cpu().numpy(), dXo, rtol=1e-5, atol=1e-5)
+        else:
+            g = dZs[l].cpu().numpy().astype(np.float64) @ Ws[l].astype(np.float64)       # the gradient the next (lower) layer receives, from the GPU's dZ
+            g = g.astype(np.float32)
+    # the consumer-applied form: dY taken as dL/dz of the last layer
+    dZb = [torch.empty_like(z) for z in dZs]
+    ops.tower_bwd(dZs[L - 1].clone(), Wd, acts, outs, dZb, None, last_act_applied=True)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(dZs, dZb))
+    # a narrower first weight gradient: the input's trailing padding columns are dropped
+    if widths[0] > 4:
+        dW0 = torch.full((widths[1], widths[0] - 1), 7.0, device=dev())
+        ops.tower_wgrad(dZs, [Xd] + outs[:-1], [dW0] + dWs2[1:], dbs2)
+        torch.cuda.synchronize()
+        assert torch.equal(dW0, dWs[0][:, :widths[0] - 1])
+    with pytest.raises(RuntimeError):
+        ops.tower_fwd(Xd, Wd, bd, acts, outs[:-1])
+
+
 @pytest.mark.parametrize("M,N,K,Nn", [(65536, 512, 256, 128), (1000, 256, 64, 96), (4100, 200, 48, 64), (333, 130, 36, 16), (4096, 1, 256, 32)])
 def test_relu_sign_bits_replace_the_fp32_mask(M, N, K, Nn):
     """dlrm_linear_fwd(relu_bits=...) stores one sign bit per output element in the documented 32 x 64-block layout (fast

@@ -41,9 +41,15 @@ def build_model(meta, init, device, deterministic=True, mode=None):
 
 
 @pytest.mark.parametrize("name", FIXTURES)
-@pytest.mark.parametrize("mode,arith", [(1, "f32"), (2, "f32"), (0, "f32"), (2, "bf16x6")],
-                         ids=["deterministic", "sorted", "atomic", "sorted-bf16x6"])
-def test_training_matches_reference_golden(name, mode, arith):
+@pytest.mark.parametrize("mode,arith", [(1, "f32"), (2, "f32"), (0, "f32"), (2, "bf16x6"), (1, "f32-per-layer"), (1, "f32-towers")],
+                         ids=["deterministic", "sorted", "atomic", "sorted-bf16x6", "deterministic-per-layer-gemms", "deterministic-towers"])
+def test_training_matches_reference_golden(name, mode, arith, monkeypatch):
+    # (the fixtures are small batches: "f32-towers" runs fp32 towers on the whole-tower kernels of csrc/tower.hip, "f32-per-layer" on the
+    # per-layer GEMMs whatever the default is — both paths are held to the same reference values)
+    if arith in ("f32-per-layer", "f32-towers"):
+        from dlrm_amd import functional
+        monkeypatch.setattr(functional, "TOWER_ROWS", 0 if arith == "f32-per-layer" else 4096)
+        arith = "f32"
     d, meta = load_golden(name)
     device = torch.device("cuda:0")
     model = build_model(meta, params_with_prefix(d, "init"), device, mode=mode)
@@ -448,8 +454,9 @@ def test_producer_tags_and_the_proof_stream():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("towers", [False, True], ids=["per-layer", "towers"])
 @pytest.mark.parametrize("D,fuse", [(128, True), (128, False), (16, False)], ids=["fused-lookups", "two-kernels-D128", "generic-D16"])
-def test_bottom_tower_relu_derivative_inside_the_interaction_backward(D, fuse, monkeypatch):
+def test_bottom_tower_relu_derivative_inside_the_interaction_backward(D, fuse, towers, monkeypatch):
     """The interaction backward applies the derivative of the bottom tower's last ReLU to dx (ops.INTERACT_RELU_X) and the tower's backward
     skips its act_bwd pass (MLP_CONSUMER_APPLIES_LAST_ACT): two SGD steps give the SAME bits for every parameter, embedding table and
     prediction as with DLRM_FUSE_ACT_BWD=0, with one C-ABI call per step fewer (dlrm_s_pytorch.py:238-241, 483-504).  A bottom tower
@@ -461,6 +468,9 @@ def test_bottom_tower_relu_derivative_inside_the_interaction_backward(D, fuse, m
     F = len(rows) + 1
     ln_bot = np.asarray([13, 64, D])
     ln_top = np.asarray([D + F * (F - 1) // 2, 96, 1])
+
+    # (towers: the small-batch path, csrc/tower.hip, where the derivative is a flag of the one backward launch instead of a pass of its own)
+    monkeypatch.setattr(functional, "TOWER_ROWS", 4096 if towers else 0)
 
     def run(flag, sigmoid_bot=-1):
         monkeypatch.setattr(functional, "FUSE_ACT_BWD", flag)
@@ -493,7 +503,7 @@ def test_bottom_tower_relu_derivative_inside_the_interaction_backward(D, fuse, m
     ref, n_ref = run(False)
     got, n_got = run(True)
     assert len(ref) == len(got) and all(torch.equal(a, b) for a, b in zip(ref, got))
-    assert n_got == n_ref - 2                                       # one act_bwd call per step gone
+    assert n_got == n_ref - (0 if towers else 2)                    # per-layer path: one act_bwd call per step gone
     # a sigmoid at the end of the bottom tower: nothing to fuse (same calls, same bits) — and a different model
     ref_s, n_ref_s = run(False, sigmoid_bot=ln_bot.size - 2)
     got_s, n_got_s = run(True, sigmoid_bot=ln_bot.size - 2)
@@ -836,12 +846,15 @@ def test_dlrm_dcn_model_trains_like_a_torch_composition():
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=2e-4, atol=1e-5, err_msg=k)
 
 
-def test_kernel_timers_runs_partition_the_step():
+@pytest.mark.parametrize("towers", [False, True], ids=["per-layer", "towers"])
+def test_kernel_timers_runs_partition_the_step(towers, monkeypatch):
     """bench.py's per-kernel timers (ops.KernelTimers): one HIP event per change of launch category.  The category runs of an
-    instrumented step must account for every launch (call counts) and add up to the step's GPU time (they share their boundary events)."""
+    instrumented step must account for every launch (call counts) and add up to the step's GPU time (they share their boundary events).
+    Small batches: one call per tower and direction (csrc/tower.hip) instead of one per layer."""
     import dlrm_amd
-    from dlrm_amd import ops
+    from dlrm_amd import functional, ops
     from dlrm_amd.optim import FusedSGD
+    monkeypatch.setattr(functional, "TOWER_ROWS", 4096 if towers else 0)
     dev = torch.device("cuda:0")
     np.random.seed(1)
     m = dlrm_amd.DLRM_Net(16, np.asarray([50, 60, 70]), np.asarray([13, 32, 16]), np.asarray([22, 32, 1]), "dot", sigmoid_top=1,
@@ -875,7 +888,10 @@ def test_kernel_timers_runs_partition_the_step():
     finally:
         ops.timers = None
     wall = a.elapsed_time(b)
-    assert s["linear_fwd"]["calls"] == 4 and s["linear_bwd_weight"]["calls"] == 4 and s["linear_bwd_data"]["calls"] == 3
+    if towers:
+        assert s["linear_fwd"]["calls"] == 2 and s["linear_bwd_weight"]["calls"] == 2 and s["linear_bwd_data"]["calls"] == 2
+    else:
+        assert s["linear_fwd"]["calls"] == 4 and s["linear_bwd_weight"]["calls"] == 4 and s["linear_bwd_data"]["calls"] == 3
     assert s["emb_fwd"]["calls"] == 1 and s["emb_bwd_sgd"]["calls"] == 1 and s["interact_fwd"]["calls"] == 1
     total = sum(v["total_ms"] for v in s.values())
     assert 0.5 * wall <= total <= 1.05 * wall, (total, wall, s)

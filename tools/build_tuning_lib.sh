@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OBJ=${TMPDIR:-/tmp}/dlrm_tuning_objs
 mkdir -p "$OBJ"
 FLAGS="-O3 -std=c++17 -fPIC -munsafe-fp-atomics --offload-arch=gfx950 -Wno-unused-result -DDLRM_TUNING -I$ROOT/dlrm_amd/csrc -I$ROOT/include"
-for s in emb emb_sorted interact gemm loss_opt adagrad metrics datagen gemv smallk multihot calib gemm_bf16; do
+for s in emb emb_sorted interact gemm loss_opt adagrad metrics datagen gemv smallk multihot calib gemm_bf16 tower; do
   if [ ! -f "$OBJ/$s.o" ] || [ "$ROOT/dlrm_amd/csrc/$s.hip" -nt "$OBJ/$s.o" ]; then
     /opt/rocm/bin/hipcc $FLAGS -c "$ROOT/dlrm_amd/csrc/$s.hip" -o "$OBJ/$s.o" &
   fi

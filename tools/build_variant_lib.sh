@@ -10,7 +10,7 @@ mkdir -p "$OBJ"
 make -C "$ROOT/dlrm_amd/csrc" -j8 > /dev/null
 FLAGS="-O3 -std=c++17 -fPIC -munsafe-fp-atomics --offload-arch=gfx950 -Wno-unused-result $DEFS -I$ROOT/dlrm_amd/csrc -I$ROOT/include"
 objs=""
-for s in emb emb_sorted interact gemm loss_opt adagrad metrics datagen gemv smallk multihot calib gemm_bf16; do
+for s in emb emb_sorted interact gemm loss_opt adagrad metrics datagen gemv smallk multihot calib gemm_bf16 tower; do
   if [[ " $* " == *" $s "* ]]; then
     /opt/rocm/bin/hipcc $FLAGS -c "$ROOT/dlrm_amd/csrc/$s.hip" -o "$OBJ/$s.o" &
     objs="$objs $OBJ/$s.o"
