@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED = 0, 1, 2
 ARITH_F32, ARITH_BF16X6, ARITH_BF16 = 0, 1, 2
-EXPECTED_ABI = 13          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
+EXPECTED_ABI = 14          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
 
 _lock = threading.Lock()
 _lib = None
@@ -99,6 +99,7 @@ SIGNATURES = {
     "dlrm_cross_bwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "dlrm_gemm_bf16_cross": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_add": (_i32, [_i64, _vp, _vp, _vp, _vp]),
+    "dlrm_graph_replay": (_i32, [_i32, _pp, _pp, _pi64, _vp, _i32, _vp]),
     "dlrm_tower_fwd": (_i32, [_i64, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _i64, _pp, _pi64, _pp, _pp, _pi64, _vp]),
     "dlrm_tower_bwd": (_i32, [_i64, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _i64, _i32, _pp, _pi64, _pp, _pi64, _pp, _pi64, _vp, _i64, _vp]),
     "dlrm_tower_wgrad_workspace_bytes": (_i64, [_i64, _i32, C.POINTER(_i32)]),

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void clamp_bwd_kernel(long long n, const float
 
 }  // namespace
 
-extern "C" int dlrm_hip_abi_version(void) { return 13; }
+extern "C" int dlrm_hip_abi_version(void) { return 14; }
 
 extern "C" const char* dlrm_hip_build_info(void) {
     return "libdlrm_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " clang " __clang_version__;
@@ -304,6 +304,27 @@ extern "C" int dlrm_hip_device_info(int device, int* cu_count, int* lds_bytes, i
     if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
     if (name && name_len > 0) { snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName); }
     return 0;
+}
+
+// One replay of a captured training step (dlrm_amd.graph.GraphedTrainStep) from ONE host call: wait for the previous replay, copy the
+// step's inputs into the graph's static buffers, launch.  At Criteo-Kaggle shapes the GPU finishes a replay in ~0.3 ms and then waits for
+// the host; the same sequence issued from Python (stream.synchronize(), one copy_ per input, CUDAGraph.replay()) was ~60 us of that wait.
+extern "C" int dlrm_graph_replay(int n, void* const* dst_host, const void* const* src_host, const int64_t* bytes_host, void* graph_exec,
+                                 int sync_first, void* stream) {
+    if (n < 0 || !graph_exec || (n > 0 && (!dst_host || !src_host || !bytes_host))) return DLRM_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (sync_first) {
+        hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return (int)e;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!dst_host[i] || !src_host[i] || bytes_host[i] < 0) return DLRM_E_ARG;
+        if (dst_host[i] == src_host[i] || bytes_host[i] == 0) continue;
+        hipError_t e = hipMemcpyAsync(dst_host[i], src_host[i], (size_t)bytes_host[i], hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, st);
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 extern "C" int64_t dlrm_loss_workspace_bytes(int64_t B) {

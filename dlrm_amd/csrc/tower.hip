@@ -1,21 +1,24 @@
 // tower.hip — an MLP tower (nn.Sequential(Linear, act, Linear, act, ...), dlrm_s_pytorch.py:208-246, 399-405) for SMALL batches as
 // four launches instead of one GEMM launch per layer and direction (plus a reduction launch per weight gradient):
-//   tower_fwd_kernel     all layers forward: a workgroup owns 16 batch rows, the activations of those rows stay in LDS from layer to
-//                        layer (each is also written out: the backward pass reads them), weights stream from L2 / HBM
-//   tower_bwd_kernel     the data-gradient chain dZ_L -> dZ_{L-1} -> ... (-> dX), same ownership; every layer's dZ is written out
-//   tower_wgrad_kernel   the weight / bias gradients of ALL layers in one launch: 64 x 64 output tiles x batch slices into slabs,
-//                        + tower_wgrad_finish_kernel: the slices of every tile summed in slice order (deterministic)
+//   tower_fwd_kernel           all layers forward: a workgroup (1024 threads) owns 16 batch rows whose activations stay in LDS from layer
+//                              to layer (each is also written out: the backward pass reads them); the weights stream through LDS panels
+//   tower_bwd_kernel           the data-gradient chain dZ_L -> dZ_{L-1} -> ... (-> dX), same ownership; every layer's dZ is written out
+//   tower_wgrad_kernel         the weight / bias gradients of ALL layers in one launch: 64 x 64 output tiles x batch slices into slabs
+//   tower_wgrad_finish_kernel  the slices of every tile summed in slice order (deterministic)
 // Why: at Criteo-Kaggle shapes (BASELINE.json configs[1]: batch 2048, widths 13-512-256-64-16 / 367-512-256-1) a training step is
-// ~45 dependent kernels of 4-25 us, most of it dependency latency: the per-layer GEMMs (64 x 64 tiles, split-k slabs + a reduction
-// kernel per weight gradient) occupy a fraction of the chip for a few microseconds each (profiles/round5/step_trace_kaggle_graph.txt).
-// Large batches keep the per-layer LDS-DMA GEMMs of gemm.hip: here every workgroup re-reads all weights, which only pays while
-// (M / 16) x sum(N_l x K_l) x 4 bytes of L2 traffic is small.
+// ~45 dependent kernels of 4-25 us: the per-layer GEMMs (64 x 64 tiles, split-k slabs + a reduction kernel per weight gradient) occupy
+// a fraction of the chip for a few microseconds each, and a replayed HIP graph pays per node (profiles/round5/step_trace_kaggle_graph.txt).
+// With these kernels the step is 19 kernels.  What they are NOT is fast per kernel: a batch of 2048 rows is 128 workgroups — half the
+// chip — and every workgroup streams ALL weights for its 16 rows (no reuse beyond one MFMA row block), so the forward / backward
+// launches run at about a third of the MFMA rate and the step gains 3 % rather than the 30 % the launch count suggests
+// (profiles/round5/kaggle_towers.md has the four versions that were measured).  Large batches keep the per-layer LDS-DMA GEMMs of
+// gemm.hip: (M / 16) x sum(N_l x K_l) x 4 bytes of weight traffic only pays while it is small (functional._tower_applies).
 //
 // MFMA use (v_mfma_f32_16x16x4_f32; lane l: li = l & 15, g = l >> 4; A[i = li][k = g], B[k = g][j = li], D[i = 4g + r][j = li]):
 // a lane loads FOUR consecutive floats of an operand row with one 16-byte load and feeds them to four MFMAs — the k index of a
 // product only has to agree between A and B, so MFMA c of a 16-wide k-step multiplies the k values {4g + c}.  Where the four floats
-// run along an OUTPUT dimension instead (backward: W rows, weight gradient: both operands) they select four different output
-// columns / rows: output j of MFMA c stands for column 4j + c, which makes a lane's four results of consecutive c a float4 again.
+// run along an OUTPUT dimension instead (weight gradient: both operands) they select four different output rows / columns: output j
+// of MFMA c stands for column 4j + c, which makes a lane's four results of consecutive c a float4 again.
 #include "common.h"
 
 namespace {
@@ -24,14 +27,11 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int TW_MAXL = DLRM_TOWER_MAX_LAYERS;
 constexpr int TW_ROWS = 16;            // batch rows per workgroup (one MFMA row block)
-constexpr int TW_NW = 16;              // forward / backward: waves per workgroup (1024 threads: four waves per SIMD hide the L2 latency of the weight loads)
+constexpr int TW_NW = 16;              // forward / backward: waves per workgroup (1024 threads)
 constexpr int TW_THREADS = 64 * TW_NW;
-constexpr int TW_TPW = 2;              // forward / backward: output column tiles (16 wide) a wave advances together
-constexpr int TW_KU = 2;               // forward / backward: 16-wide reduction steps per chunk (the next chunk's operands are in flight meanwhile)
-constexpr int TW_KUB = 1;              // ... of the backward loop (four 4-byte loads per step and tile: one step per chunk keeps it inside 128 registers)
+constexpr int TW_TPW = 2;              // forward / backward: output column tiles (16 wide) per wave and pass
 constexpr int TW_WU = 4;               // weight gradient: 4-row groups per chunk
-constexpr int TW_UNR = 8;              // pipeline stages per loop body
-constexpr int TW_UNRB = 4;             // ... of the backward loop (register budget of 1024 threads)
+constexpr int TW_UNR = 8;              // weight gradient: pipeline stages per loop body
 
 // one pipeline stage of the hand-pipelined loops: the loads of the NEXT chunk first, back to back, then the products of the current one.
 // Left alone the scheduler sinks every load to just before its first use in the next stage, i.e. one exposed L2 round trip per load.
@@ -80,89 +80,103 @@ __device__ __forceinline__ float4 tw_load4(const float* __restrict__ p, long lon
     if (VEC) return *(const float4*)(q + (c + 3 < cols ? c : 0));
     return make_float4(q[c < cols ? c : 0], q[c + 1 < cols ? c + 1 : 0], q[c + 2 < cols ? c + 2 : 0], q[c + 3 < cols ? c + 3 : 0]);
 }
+// ------------------------------------------------------------------------------------------------ forward / backward products
+// Weights reach the MFMAs through LDS: per chunk of the reduction all 1024 threads fetch a [rows x 32 k] (forward) / [32 n x K] (backward)
+// panel of W with full-line, row-contiguous 16-byte loads into registers WHILE earlier panels are multiplied, then park it in LDS
+// between two barriers.  (Fragments loaded straight from global memory were measured first — a tile's B operand is 16 rows x 16 bytes
+// per instruction, i.e. 16 half-used cache lines — with the same result within 20 % either way: profiles/round5/kaggle_towers.md.)
+// Panel elements outside W are stored as ZEROS, so the activation buffers only have to hold finite values wherever they are read
+// (they are cleared when the kernel starts).
+constexpr int TW_CK = 32;                          // reduction elements per chunk
+constexpr int TW_PASS = 512;                       // forward: output columns per pass (32 tiles: two per wave)
+constexpr int TW_WLD_F = TW_CK + 4;                // forward panel [512][36]: rows 144 bytes apart (16-byte fragments, conflict free)
+constexpr int TW_WLD_B = DLRM_TOWER_MAX_WIDTH + 4; // backward panel [32][516]: four k-groups two banks apart
+constexpr int TW_WST_FLOATS = (TW_PASS * TW_WLD_F > TW_CK * TW_WLD_B) ? TW_PASS * TW_WLD_F : TW_CK * TW_WLD_B;
+
+// four floats W[r][c .. c+3] (zeros outside [rows, cols]); clamped address + select: no branch (see tw_load4)
 template <bool VEC>
-__device__ __forceinline__ void tw_store4(float* __restrict__ p, long long ld, int r, int c, int rows, int cols, float4 v) {
-    if (r >= rows) return;
-    float* q = p + (long long)r * ld + c;
-    if (VEC) { if (c + 3 < cols) *(float4*)q = v; return; }
-    if (c < cols) q[0] = v.x;
-    if (c + 1 < cols) q[1] = v.y;
-    if (c + 2 < cols) q[2] = v.z;
-    if (c + 3 < cols) q[3] = v.w;
+__device__ __forceinline__ float4 tw_panel_quad(const float* __restrict__ W, long long ldw, int r, int c, int rows, int cols) {
+    const bool rok = r < rows;
+    const float4 v = tw_load4<VEC>(W, ldw, r, c, rows, cols);
+    return make_float4((rok && c < cols) ? v.x : 0.f, (rok && c + 1 < cols) ? v.y : 0.f, (rok && c + 2 < cols) ? v.z : 0.f, (rok && c + 3 < cols) ? v.w : 0.f);
 }
 
-// ------------------------------------------------------------------------------------------------ forward
-// one layer: nxt[16][N] = act(cur[16][K] . W[N, K]^T + b), also to Y.  Waves take column tiles t = wave*TPW + 4*TPW*pass + j.
+// one layer forward: nxt[16][N] = act(cur[16][K] . W[N, K]^T + b), also to Y
 template <bool VEC>
-__device__ __forceinline__ void tw_fwd_layer(const TowerArgs& a, int l, const float* cur, float* nxt, int m0, int lane, int wave) {
-    const int li = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void tw_fwd_layer(const TowerArgs& a, int l, const float* cur, float* nxt, float* wst, int m0, int lane, int wave) {
+    const int li = lane & 15, g = lane >> 4, tid = threadIdx.x;
     const int K = a.width[l], N = a.width[l + 1];
-    const int Kp = (K + 15) & ~15, ntiles = (N + 15) >> 4;
     const int LD = a.ld_lds;
     const float* __restrict__ W = a.W[l];
     const long long ldw = a.ldw[l];
-    // a pass covers NW * TPW tiles: wave w takes tiles tb + w, tb + w + NW, ... (narrow layers still spread over the waves)
-    for (int tb = 0; tb < ntiles; tb += TW_NW * TW_TPW) {
-        const int t0 = tb + wave;                        // tile j of this wave: t0 + NW * j
-        if (t0 >= ntiles) break;
+    const int pr = tid >> 3, pq = (tid & 7) * 4;              // panel element of this thread: rows pr + 128 i, k-quad pq
+    for (int nb = 0; nb < N; nb += TW_PASS) {
+        const int rows = (N - nb < TW_PASS) ? N - nb : TW_PASS;          // output columns of this pass
+        const int nload = (rows + 127) >> 7;                               // 128-row slabs of the panel that hold anything
+        const bool t1 = (wave + TW_NW) * 16 < rows;                        // this wave's second tile exists
+        const bool t0 = wave * 16 < rows;
         floatx4 acc[TW_TPW];
 #pragma unroll
         for (int j = 0; j < TW_TPW; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
-        // one wave per SIMD and operands that come from L2: the k loop runs in chunks of TW_KU 16-wide steps and the NEXT chunk's
-        // loads are issued before the current chunk's products (explicit double buffering; the compiler does not pipeline this loop)
-        float4 a4[2][TW_KU], b4[2][TW_KU][TW_TPW];
-        bool kv[2][TW_KU];                                   // 16-wide step inside the reduction (a chunk may end past Kp: zeroed AT USE)
-        auto load = [&](int k0, float4 (&av)[TW_KU], float4 (&bv)[TW_KU][TW_TPW], bool (&ok)[TW_KU]) {
+        // panels travel global -> registers -> LDS, requested TWO chunks ahead (one chunk of products does not cover an L2 round trip):
+        // while chunk c is multiplied, chunk c+1 waits in one register set and chunk c+2 is in flight into the other.  The body handles
+        // two chunks so that the sets keep their names (no copies); requests past the end are clamped and never parked.
+        float4 preA[4], preB[4];
+        auto fetch = [&](int kc, float4 (&pre)[4]) {
 #pragma unroll
-            for (int u = 0; u < TW_KU; ++u) {
-                const int k = k0 + 16 * u;
-                // (k in [K, Kp): the activation columns read from LDS are zeros — every producer of a buffer zero-fills up to the next
-                // multiple of 16 — so whatever the clamped weight load returns adds nothing; tiles past the layer's last one compute
-                // columns that the epilogue drops)
-                ok[u] = k < Kp;
-                av[u] = *(const float4*)(cur + li * LD + (ok[u] ? k : 0) + 4 * g);
-#pragma unroll
-                for (int j = 0; j < TW_TPW; ++j)
-                    bv[u][j] = tw_load4<VEC>(W, ldw, (t0 + TW_NW * j) * 16 + li, k + 4 * g, N, K);
-            }
+            for (int i = 0; i < 4; ++i)
+                if (i < nload) pre[i] = tw_panel_quad<VEC>(W, ldw, nb + pr + 128 * i, kc + pq, N, K);        // (wave-uniform condition)
         };
-        auto mma = [&](const float4 (&av)[TW_KU], const float4 (&bv)[TW_KU][TW_TPW], const bool (&ok)[TW_KU]) {
+        auto park = [&](const float4 (&pre)[4]) {
 #pragma unroll
-            for (int u = 0; u < TW_KU; ++u) {
-                const float ax = ok[u] ? av[u].x : 0.f, ay = ok[u] ? av[u].y : 0.f, az = ok[u] ? av[u].z : 0.f, aw = ok[u] ? av[u].w : 0.f;
+            for (int i = 0; i < 4; ++i)
+                if (i < nload) *(float4*)(wst + (pr + 128 * i) * TW_WLD_F + pq) = pre[i];
+        };
+        auto products = [&](int kc) {
+            if (!t0) return;
 #pragma unroll
-                for (int j = 0; j < TW_TPW; ++j) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bv[u][j].x, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, bv[u][j].y, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bv[u][j].z, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bv[u][j].w, acc[j], 0, 0, 0);
+            for (int u = 0; u < TW_CK / 16; ++u) {
+                const float4 a4 = *(const float4*)(cur + li * LD + kc + 16 * u + 4 * g);
+                const float4 b0 = *(const float4*)(wst + (wave * 16 + li) * TW_WLD_F + 16 * u + 4 * g);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0.x, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b0.y, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b0.z, acc[0], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b0.w, acc[0], 0, 0, 0);
+                if (t1) {
+                    const float4 b1 = *(const float4*)(wst + ((wave + TW_NW) * 16 + li) * TW_WLD_F + 16 * u + 4 * g);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b1.x, acc[1], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b1.y, acc[1], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b1.z, acc[1], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b1.w, acc[1], 0, 0, 0);
                 }
             }
         };
-        // TW_UNR stages per loop body, the pipeline drained at the body's end: the compiler's wait-count insertion is exact inside a body
-        // but conservative across a loop back-edge (it would make every stage wait for the loads it has just issued)
-        constexpr int CH = 16 * TW_KU;
-        for (int kb = 0; kb < Kp; kb += TW_UNR * CH) {
-            load(kb, a4[0], b4[0], kv[0]);
-#pragma unroll
-            for (int u = 0; u < TW_UNR; ++u) {
-                // the next chunk is requested UNCONDITIONALLY (past the end: clamped addresses, dropped): a load under a condition makes
-                // the wait-count insertion merge "issued" and "not issued" at the join and wait for the newest loads as well
-                if (u + 1 < TW_UNR) load(kb + (u + 1) * CH, a4[(u + 1) & 1], b4[(u + 1) & 1], kv[(u + 1) & 1]);
-                mma(a4[u & 1], b4[u & 1], kv[u & 1]);
-                TW_STAGE_ORDER((VEC ? 1 : 4) * TW_KU * TW_TPW, TW_KU, 4 * TW_KU * TW_TPW);
-                if (kb + (u + 1) * CH >= Kp) break;
-            }
+        fetch(0, preA);
+        fetch(TW_CK, preB);
+        park(preA);
+        __syncthreads();
+        for (int kc = 0; kc < K; kc += 2 * TW_CK) {
+            fetch(kc + 2 * TW_CK, preA);                                   // chunk c+2
+            products(kc);                                                  // chunk c
+            __syncthreads();                                               // everyone is done with this panel
+            park(preB);                                                    // chunk c+1 (requested one chunk of products ago)
+            __syncthreads();
+            if (kc + TW_CK >= K) break;
+            fetch(kc + 3 * TW_CK, preB);                                   // chunk c+3
+            products(kc + TW_CK);                                          // chunk c+1
+            __syncthreads();
+            park(preA);                                                    // chunk c+2
+            __syncthreads();
         }
 #pragma unroll
         for (int j = 0; j < TW_TPW; ++j) {
-            if (t0 + TW_NW * j >= ntiles) continue;
-            const int n = (t0 + TW_NW * j) * 16 + li;
+            if (!(j ? t1 : t0)) continue;
+            const int n = nb + (wave + TW_NW * j) * 16 + li;
             const float b = (n < N && a.bias[l]) ? a.bias[l][n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * g + r;
-                const float v = n < N ? tw_act(acc[j][r] + b, a.act[l]) : 0.f;     // columns N .. 16*ntiles-1: the next layer's k padding
+                const float v = n < N ? tw_act(acc[j][r] + b, a.act[l]) : 0.f;
                 nxt[row * LD + n] = v;
                 if (n < N && m0 + row < a.M) a.Y[l][(long long)(m0 + row) * a.ldy[l] + n] = v;
             }
@@ -177,97 +191,100 @@ __global__ __launch_bounds__(TW_THREADS) void tower_fwd_kernel(TowerArgs a) {
     const int LD = a.ld_lds;
     float* cur = lds;
     float* nxt = lds + TW_ROWS * LD;
-    {   // the tower's input rows, zero beyond the batch and up to the next multiple of 16 columns
-        const int K0 = a.width[0], K0p = (K0 + 15) & ~15;
-        for (int e = threadIdx.x; e < TW_ROWS * K0p; e += TW_THREADS) {
-            const int r = e / K0p, c = e - r * K0p;
-            cur[r * LD + c] = (m0 + r < a.M && c < K0) ? a.X[(long long)(m0 + r) * a.ldx + c] : 0.f;
+    float* wst = lds + 2 * TW_ROWS * LD;
+    for (int e = threadIdx.x; e < 2 * TW_ROWS * LD; e += TW_THREADS) lds[e] = 0.f;       // finite everywhere (see above)
+    __syncthreads();
+    {   // the tower's input rows (zero beyond the batch)
+        const int K0 = a.width[0];
+        for (int e = threadIdx.x; e < TW_ROWS * K0; e += TW_THREADS) {
+            const int r = e / K0, c = e - r * K0;
+            if (m0 + r < a.M) cur[r * LD + c] = a.X[(long long)(m0 + r) * a.ldx + c];
         }
     }
     __syncthreads();
     for (int l = 0; l < a.L; ++l) {
-        if (tw_vec_ok(a.W[l], a.ldw[l], a.width[l])) tw_fwd_layer<true>(a, l, cur, nxt, m0, lane, wave);
-        else tw_fwd_layer<false>(a, l, cur, nxt, m0, lane, wave);
+        if (tw_vec_ok(a.W[l], a.ldw[l], a.width[l])) tw_fwd_layer<true>(a, l, cur, nxt, wst, m0, lane, wave);
+        else tw_fwd_layer<false>(a, l, cur, nxt, wst, m0, lane, wave);
         __syncthreads();
         float* t = cur; cur = nxt; nxt = t;
     }
 }
 
-// ------------------------------------------------------------------------------------------------ backward (data gradients)
-// one layer: dA[16][K] = cur[16][N] (= dZ_l) . W[N, K]; then dZ_{l-1} = dA * act'_{l-1}(Y_{l-1}) -> nxt and dZ[l-1]   (l > 0)
-//                                                       or dX = dA                                              (l == 0)
-// Waves take 16-column tiles of dA.  A = dZ rows (one 16-byte LDS read feeds the four MFMAs of a 16-wide step, MFMA s multiplying
-// the reduction indices n0 + 4g + s), B[k = g][j = li] = W[n0 + 4g + s][c + li]: the reduction runs over ROWS of W, so a lane's
-// four values are four 4-byte loads (16 lanes cover 64 contiguous bytes of a row; the neighbouring tile — the next wave's — takes the
-// other half of the cache line).
-__device__ __forceinline__ float tw_load1(const float* __restrict__ p, long long ld, int r, int c, int rows, int cols) {       // (clamped like tw_load4)
-    return p[(r < rows ? (long long)r * ld : 0) + (c < cols ? c : 0)];
-}
-__device__ __forceinline__ void tw_bwd_layer(const TowerArgs& a, int l, const float* cur, float* nxt, int m0, int lane, int wave) {
-    const int li = lane & 15, g = lane >> 4;
+// one layer backward: dA[16][K] = cur[16][N] (= dZ_l) . W[N, K]; then dZ_{l-1} = dA * act'_{l-1}(Y_{l-1}) -> nxt and dZ[l-1]   (l > 0)
+//                                                                 or dX = dA                                              (l == 0)
+// The reduction runs over ROWS of W: a chunk's panel is W[nc .. nc+31][0 .. K) as it lies in memory; MFMA s of a 16-wide step
+// multiplies the reduction indices nc + 16u + 4g + s, its B operand B[k = g][j = li] = panel[16u + 4g + s][c + li] is a 4-byte LDS read.
+template <bool VEC>
+__device__ __forceinline__ void tw_bwd_layer(const TowerArgs& a, int l, const float* cur, float* nxt, float* wst, int m0, int lane, int wave) {
+    const int li = lane & 15, g = lane >> 4, tid = threadIdx.x;
     const int K = a.width[l], N = a.width[l + 1];
-    const int Np = (N + 15) & ~15, ntiles = (K + 15) >> 4;
     const int LD = a.ld_lds;
     const float* __restrict__ W = a.W[l];
     const long long ldw = a.ldw[l];
-    for (int tb = 0; tb < ntiles; tb += TW_NW * TW_TPW) {
-        const int t0 = tb + wave;
-        if (t0 >= ntiles) break;
-        floatx4 acc[TW_TPW];
+    const int ntiles = (K + 15) >> 4;
+    const bool t0 = wave < ntiles, t1 = wave + TW_NW < ntiles;
+    const int c0 = wave * 16 + li, c1 = (wave + TW_NW) * 16 + li;
+    const int pq = (tid & 127) * 4;                           // panel element of this thread: rows (tid >> 7) + 8 i, column quad pq
+    const int pr = tid >> 7;
+    floatx4 acc[TW_TPW];
 #pragma unroll
-        for (int j = 0; j < TW_TPW; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
-        float4 a4[2][TW_KUB];
-        float b1[2][TW_KUB][TW_TPW][4];                   // (double buffered like the forward loop)
-        auto load = [&](int n0, float4 (&av)[TW_KUB], float (&bv)[TW_KUB][TW_TPW][4]) {
+    for (int j = 0; j < TW_TPW; ++j) acc[j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    float4 preA[4], preB[4];                                  // (two chunks ahead: see the forward loop)
+    auto fetch = [&](int nc, float4 (&pre)[4]) {
 #pragma unroll
-            for (int u = 0; u < TW_KUB; ++u) {
-                const int n = n0 + 16 * u;
-                av[u] = *(const float4*)(cur + li * LD + (n < Np ? n : 0) + 4 * g);          // (zeros for n in [N, Np): see the forward loop; past Np: a chunk that is dropped)
+        for (int i = 0; i < 4; ++i) pre[i] = tw_panel_quad<VEC>(W, ldw, nc + pr + 8 * i, pq, N, K);
+    };
+    auto park = [&](const float4 (&pre)[4]) {
 #pragma unroll
-                for (int j = 0; j < TW_TPW; ++j)
+        for (int i = 0; i < 4; ++i) *(float4*)(wst + (pr + 8 * i) * TW_WLD_B + pq) = pre[i];
+    };
+    auto products = [&](int nc) {
+        if (!t0) return;
 #pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_)
-                        bv[u][j][s_] = tw_load1(W, ldw, n + 4 * g + s_, (t0 + TW_NW * j) * 16 + li, N, K);
-            }
-        };
-        auto mma = [&](const float4 (&av)[TW_KUB], const float (&bv)[TW_KUB][TW_TPW][4]) {
+        for (int u = 0; u < TW_CK / 16; ++u) {
+            const float4 a4 = *(const float4*)(cur + li * LD + nc + 16 * u + 4 * g);
+            const float as[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float* prow = wst + (16 * u + 4 * g) * TW_WLD_B;
 #pragma unroll
-            for (int u = 0; u < TW_KUB; ++u) {
-                const float as[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
+            for (int s_ = 0; s_ < 4; ++s_) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s_], prow[s_ * TW_WLD_B + c0], acc[0], 0, 0, 0);
+            if (t1) {
 #pragma unroll
-                for (int j = 0; j < TW_TPW; ++j) {
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s_], bv[u][j][s_], acc[j], 0, 0, 0);
-                }
-            }
-        };
-        constexpr int CH = 16 * TW_KUB;                      // (TW_UNRB stages per body, drained at its end: see the forward loop)
-        for (int nb = 0; nb < Np; nb += TW_UNRB * CH) {
-            load(nb, a4[0], b1[0]);
-#pragma unroll
-            for (int u = 0; u < TW_UNRB; ++u) {
-                if (u + 1 < TW_UNRB) load(nb + (u + 1) * CH, a4[(u + 1) & 1], b1[(u + 1) & 1]);      // (unconditional: see the forward loop)
-                mma(a4[u & 1], b1[u & 1]);
-                TW_STAGE_ORDER(4 * TW_KUB * TW_TPW, TW_KUB, 4 * TW_KUB * TW_TPW);
-                if (nb + (u + 1) * CH >= Np) break;
+                for (int s_ = 0; s_ < 4; ++s_) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[s_], prow[s_ * TW_WLD_B + c1], acc[1], 0, 0, 0);
             }
         }
+    };
+    fetch(0, preA);
+    fetch(TW_CK, preB);
+    park(preA);
+    __syncthreads();
+    for (int nc = 0; nc < N; nc += 2 * TW_CK) {
+        fetch(nc + 2 * TW_CK, preA);
+        products(nc);
+        __syncthreads();
+        park(preB);
+        __syncthreads();
+        if (nc + TW_CK >= N) break;
+        fetch(nc + 3 * TW_CK, preB);
+        products(nc + TW_CK);
+        __syncthreads();
+        park(preA);
+        __syncthreads();
+    }
 #pragma unroll
-        for (int j = 0; j < TW_TPW; ++j) {
-            if (t0 + TW_NW * j >= ntiles) continue;
-            const int c = (t0 + TW_NW * j) * 16 + li;
+    for (int j = 0; j < TW_TPW; ++j) {
+        if (!(j ? t1 : t0)) continue;
+        const int c = j ? c1 : c0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * g + r;
-                float v = acc[j][r];
-                if (l > 0) {
-                    const bool in = c < K && m0 + row < a.M;
-                    v = in ? tw_act_grad(v, a.Y[l - 1][(long long)(m0 + row) * a.ldy[l - 1] + c], a.act[l - 1]) : 0.f;
-                    nxt[row * LD + c] = v;                        // (zeros beyond K: the k padding of the next product)
-                    if (in) a.dZ[l - 1][(long long)(m0 + row) * a.lddz[l - 1] + c] = v;
-                } else if (c < K && m0 + row < a.M) {
-                    a.dX[(long long)(m0 + row) * a.lddx + c] = v;
-                }
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            float v = acc[j][r];
+            if (l > 0) {
+                const bool in = c < K && m0 + row < a.M;
+                v = in ? tw_act_grad(v, a.Y[l - 1][(long long)(m0 + row) * a.ldy[l - 1] + c], a.act[l - 1]) : 0.f;
+                nxt[row * LD + c] = v;
+                if (in) a.dZ[l - 1][(long long)(m0 + row) * a.lddz[l - 1] + c] = v;
+            } else if (c < K && m0 + row < a.M) {
+                a.dX[(long long)(m0 + row) * a.lddx + c] = v;
             }
         }
     }
@@ -280,23 +297,26 @@ __global__ __launch_bounds__(TW_THREADS) void tower_bwd_kernel(TowerArgs a) {
     const int LD = a.ld_lds;
     float* cur = lds;
     float* nxt = lds + TW_ROWS * LD;
+    float* wst = lds + 2 * TW_ROWS * LD;
+    for (int e = threadIdx.x; e < 2 * TW_ROWS * LD; e += TW_THREADS) lds[e] = 0.f;
+    __syncthreads();
     {   // dZ of the last layer from the incoming gradient (a.X) and the layer's output
-        const int l = a.L - 1, N = a.width[a.L], Np = (N + 15) & ~15;
-        for (int e = threadIdx.x; e < TW_ROWS * Np; e += TW_THREADS) {
-            const int r = e / Np, c = e - r * Np;
-            float v = 0.f;
-            if (m0 + r < a.M && c < N) {
-                v = a.X[(long long)(m0 + r) * a.ldx + c];
+        const int l = a.L - 1, N = a.width[a.L];
+        for (int e = threadIdx.x; e < TW_ROWS * N; e += TW_THREADS) {
+            const int r = e / N, c = e - r * N;
+            if (m0 + r < a.M) {
+                float v = a.X[(long long)(m0 + r) * a.ldx + c];
                 if (!a.last_act_applied) v = tw_act_grad(v, a.Y[l][(long long)(m0 + r) * a.ldy[l] + c], a.act[l]);
                 a.dZ[l][(long long)(m0 + r) * a.lddz[l] + c] = v;
+                cur[r * LD + c] = v;
             }
-            cur[r * LD + c] = v;
         }
     }
     __syncthreads();
     const int stop = a.dX ? 0 : 1;
     for (int l = a.L - 1; l >= stop; --l) {
-        tw_bwd_layer(a, l, cur, nxt, m0, lane, wave);
+        if (tw_vec_ok(a.W[l], a.ldw[l], a.width[l])) tw_bwd_layer<true>(a, l, cur, nxt, wst, m0, lane, wave);
+        else tw_bwd_layer<false>(a, l, cur, nxt, wst, m0, lane, wave);
         __syncthreads();
         float* t = cur; cur = nxt; nxt = t;
     }
@@ -367,7 +387,7 @@ __device__ __forceinline__ void tw_wgrad_accumulate(const TowerWgradArgs& a, int
 // grid = tiles * S.  Workgroup (tile, s): partial of the 64 x 64 tile over batch slice s — the four waves' partials summed through LDS in
 // wave order — into its slab (S == 1: straight into dW / db).  tower_wgrad_finish_kernel then adds a tile's slabs in slice order.
 // (One launch with a "last workgroup of the tile reduces" ticket was measured first: the device-scope fences it needs write back and
-// invalidate the L2 of every XCD — 134 us for a launch whose products take 5, profiles/round5/step_trace_kaggle_graph_towers_v1.txt.)
+// invalidate the L2 of every XCD — 134 us for the launch, profiles/round5/step_trace_kaggle_graph_towers_v1.txt.)
 __device__ __forceinline__ void tw_store_tile_row(const TowerWgradArgs& a, int l, int n, int k, float4 v) {
     if (n >= a.N[l]) return;
     const int KS = a.kstore[l];
@@ -488,7 +508,7 @@ static int tw_check(int64_t M, int L, const int* widths) {
 static int tw_pitch(int L, const int* widths) {
     int w = 0;
     for (int l = 0; l <= L; ++l) if (widths[l] > w) w = widths[l];
-    return ((w + 63) & ~63) + 4;          // whole 64-column blocks (backward writes them) + 4: rows start 4 banks apart
+    return ((w + 31) & ~31) + 4;          // whole 32-element chunks + 4: rows start 4 banks apart
 }
 
 }  // namespace
@@ -507,7 +527,7 @@ extern "C" int dlrm_tower_fwd(int64_t M, int L, const int* widths, const int* ac
         a.W[l] = (const float*)W_host[l]; a.ldw[l] = ldw_host[l]; a.bias[l] = (const float*)bias_host[l];
         a.Y[l] = (float*)Y_host[l]; a.ldy[l] = ldy_host[l];
     }
-    const size_t lds = (size_t)2 * TW_ROWS * a.ld_lds * sizeof(float);
+    const size_t lds = ((size_t)2 * TW_ROWS * a.ld_lds + TW_WST_FLOATS) * sizeof(float);
     (void)hipFuncSetAttribute((const void*)tower_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(tower_fwd_kernel, dim3((unsigned)((M + TW_ROWS - 1) / TW_ROWS)), dim3(TW_THREADS), lds, (hipStream_t)stream, a);
     DLRM_LAUNCH_CHECK();
@@ -533,19 +553,19 @@ extern "C" int dlrm_tower_bwd(int64_t M, int L, const int* widths, const int* ac
         a.Y[l] = (float*)Y_host[l]; a.ldy[l] = ldy_host[l];
         a.dZ[l] = (float*)dZ_host[l]; a.lddz[l] = lddz_host[l];
     }
-    const size_t lds = (size_t)2 * TW_ROWS * a.ld_lds * sizeof(float);
+    const size_t lds = ((size_t)2 * TW_ROWS * a.ld_lds + TW_WST_FLOATS) * sizeof(float);
     (void)hipFuncSetAttribute((const void*)tower_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(tower_bwd_kernel, dim3((unsigned)((M + TW_ROWS - 1) / TW_ROWS)), dim3(TW_THREADS), lds, (hipStream_t)stream, a);
     DLRM_LAUNCH_CHECK();
     return 0;
 }
 
-// batch slices per tile: enough workgroups for four per CU, slices of at least 64 rows
+// batch slices per tile: enough workgroups for two per CU, slices of at least 256 rows
 static void tw_wgrad_plan(int64_t M, int L, const int* N, const int* K, int* tiles_out, int* S_out, int* rows_out) {
     int tiles = 0;
     for (int l = 0; l < L; ++l) tiles += ((N[l] + 63) / 64) * ((K[l] + 63) / 64);
-    int S = (1024 + tiles - 1) / tiles;
-    const int64_t maxS = (M + 63) / 64;
+    int S = (512 + tiles - 1) / tiles;
+    const int64_t maxS = (M + 255) / 256;                   // slices of >= 256 rows: every slice is a 16.6 KB slab per tile to write and re-read
     if (S > maxS) S = (int)maxS;
     if (S < 1) S = 1;
     int64_t rows = (M + S - 1) / S;

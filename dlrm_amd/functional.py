@@ -38,12 +38,12 @@ BF16_STORAGE = os.environ.get("DLRM_BF16_STORAGE", "1") == "1"
 BF16_LEAN = os.environ.get("DLRM_BF16_LEAN", "1") == "1"
 # DCN-v2 (bf16 storage): the elementwise half of a cross layer inside the epilogue of its second product (dlrm_gemm_bf16_cross); 0 = two kernels
 CROSS_FUSE = os.environ.get("DLRM_CROSS_FUSE", "1") == "1"
-# flag bit of MLPFunction's `arith` argument (see MLPFunction.forward); DLRM_FUSE_ACT_BWD=0 makes DLRM_Net never set it (A/B)
-# small batches: a whole fp32 tower per launch (csrc/tower.hip) for up to DLRM_TOWER_ROWS rows (0 = never, the default until the kernels
-# beat the per-layer GEMMs: profiles/round5/kaggle_towers.md) while the weight traffic of its 16-row workgroups stays under
-# DLRM_TOWER_L2_MB; see _tower_applies
-TOWER_ROWS = int(os.environ.get("DLRM_TOWER_ROWS", "0"))
+# small batches: a whole fp32 tower per launch (csrc/tower.hip) for up to DLRM_TOWER_ROWS rows (0 = never: the per-layer GEMMs) while the
+# weight traffic of its 16-row workgroups stays under DLRM_TOWER_L2_MB; see _tower_applies.  Criteo-Kaggle graph: 44 -> 19 kernels per step,
+# 0.367 -> 0.357 ms (profiles/round5/kaggle_towers.md)
+TOWER_ROWS = int(os.environ.get("DLRM_TOWER_ROWS", "4096"))
 TOWER_L2_BYTES = int(os.environ.get("DLRM_TOWER_L2_MB", "384")) << 20
+# flag bit of MLPFunction's `arith` argument (see MLPFunction.forward); DLRM_FUSE_ACT_BWD=0 makes DLRM_Net never set it (A/B)
 MLP_CONSUMER_APPLIES_LAST_ACT = 0x100
 FUSE_ACT_BWD = os.environ.get("DLRM_FUSE_ACT_BWD", "1") == "1"
 # bf16 towers: the bf16 copies of ALL weights of a tower (W16 for the forward GEMMs, W^T16 for the data gradients) in one launch at the start of

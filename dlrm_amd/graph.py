@@ -54,14 +54,15 @@ def _clone_struct(x: TensorOrList):
     return out
 
 
-def _copy_struct(dst: TensorOrList, src: TensorOrList, pairs: Optional[list] = None) -> None:
-    """static buffers <- the caller's tensors.  With `pairs` the (dst, src) tensor pairs are only COLLECTED (after the shape checks):
-    _flush_copies then moves all of them in one launch."""
-    def put(d, s_):
-        if pairs is not None:
-            pairs.append((d, s_))
-        else:
-            d.copy_(s_, non_blocking=True)
+def _copy_now(d: torch.Tensor, s_: torch.Tensor) -> None:
+    d.copy_(s_, non_blocking=True)
+
+
+def _copy_struct(dst: TensorOrList, src: TensorOrList, put=_copy_now) -> None:
+    """static buffers <- the caller's tensors: `put(dst_tensor, src_tensor)` for every distinct tensor whose storage differs, after the
+    shape / dtype checks (default: an ATen copy_ each; the raw replay path collects the pairs for dlrm_graph_replay instead).  (All copies
+    in ONE launch of the library's block copy was measured too: building its views costs the host more than the four copy_ calls it
+    replaces, and the host is what the GPU waits for between replays — Criteo-Kaggle graph 0.378 -> 0.406 ms, profiles/round5/kaggle_towers.md.)"""
     if isinstance(dst, torch.Tensor):
         if not isinstance(src, torch.Tensor) or src.shape != dst.shape or src.dtype != dst.dtype:
             raise RuntimeError("dlrm_amd.graph: input shape/dtype differs from the captured step")
@@ -82,29 +83,6 @@ def _copy_struct(dst: TensorOrList, src: TensorOrList, pairs: Optional[list] = N
         # torch 2.10 + ROCm 7 at B = 65536 — profiles/r02/graph_probe.md; pass stacked [T, B] index / offset tensors to
         # make this a single copy.)
         put(d, s_)
-
-
-def _flush_copies(pairs: list) -> None:
-    """All input copies of a replay in ONE launch of the library's strided block copy (dlrm_copy_blocks, every tensor seen as a row of
-    32-bit words) instead of one ATen copy kernel per tensor: at Criteo-Kaggle shapes the four copy_ calls (dense features, offsets,
-    indices, targets) were 45 us of a 390 us step, nearly all of it host time between four 2-us kernels
-    (profiles/round5/step_trace_kaggle_graph.txt).  Tensors the block copy cannot take (non-contiguous, other devices, element sizes
-    other than 4 / 8 bytes, more than 2^31 words) keep their copy_."""
-    words, rest = [], []
-    for d, s_ in pairs:
-        ok = (d.is_cuda and s_.is_cuda and d.device == s_.device and d.is_contiguous() and s_.is_contiguous() and d.element_size() in (4, 8)
-              and d.dtype == s_.dtype and 0 < d.numel() * d.element_size() // 4 < (1 << 31) and d.data_ptr() % 4 == 0 and s_.data_ptr() % 4 == 0)
-        (words if ok else rest).append((d, s_))
-    if len(words) > 1:
-        def w32(t):
-            t = t.detach().reshape(-1)
-            t = t.view(torch.int32) if t.element_size() == 8 else t
-            return (t if t.dtype == torch.float32 else t.view(torch.float32)).view(1, -1)
-        ops.copy_blocks([w32(s_) for _, s_ in words], [w32(d) for d, _ in words])
-    else:
-        rest = words + rest
-    for d, s_ in rest:
-        d.copy_(s_, non_blocking=True)
 
 
 class GraphedTrainStep:
@@ -146,6 +124,11 @@ class GraphedTrainStep:
         self._eager_calls = 0
         self._replayed = False
         self.serialize = _os.environ.get("DLRM_GTS_SERIALIZE", "1") == "1"
+        # raw replay: wait + input copies + hipGraphLaunch in ONE C call (dlrm_graph_replay) instead of stream.synchronize(), a copy_ per
+        # input and CUDAGraph.replay() from Python — the host path is what a launch-bound step waits for.  DLRM_GTS_RAW=0: the torch calls.
+        self.raw = _os.environ.get("DLRM_GTS_RAW", "1") == "1"
+        self._exec = None          # hipGraphExec_t of the captured step (None: not available -> torch's replay)
+        self._raw_arrays = None    # cached ctypes arrays of the raw call
 
     def _settle_sort_mode(self, lS_o, lS_i) -> None:
         """First batch: keep the sort-based embedding update only if every table segment goes through the library's own segmented
@@ -251,9 +234,45 @@ class GraphedTrainStep:
         self._pinned_ws = [w for (d_, _), w in list(ops._emb_ws.items()) + list(ops._wgrad_ws.items()) if d_ == dev]
         self._pinned_ws += [w for (d_, _), w in ops._tower_ws.items() if d_ == dev]
         self.captures += 1
+        self._exec, self._raw_arrays = None, None
+        if self.raw:
+            try:
+                self._exec = int(self.graph.raw_cuda_graph_exec())
+            except Exception:                               # noqa: BLE001 - a torch without the raw handle: keep its own replay
+                self._exec = None
         torch.cuda.current_stream(dev).wait_stream(self.stream)
 
+    def _raw_replay(self, X, lS_o, lS_i, T) -> bool:
+        """the steady state: inputs checked and collected, then ONE call that waits for the previous replay, copies and launches"""
+        import ctypes as C
+        from . import _lib
+        pairs = []
+        xs, os_, is_, ts = self.static
+        put = lambda d, s_: pairs.append((d, s_))           # noqa: E731
+        _copy_struct(xs, X, put); _copy_struct(os_, lS_o, put); _copy_struct(is_, lS_i, put); _copy_struct(ts, T, put)
+        n = len(pairs)
+        for d, s_ in pairs:
+            if not (d.is_cuda and s_.is_cuda and s_.device == d.device and d.is_contiguous() and s_.is_contiguous()):
+                return False                                # (host tensors, strided views: torch's copy_ handles them)
+        arr = self._raw_arrays
+        if arr is None or arr[0] != n:
+            arr = self._raw_arrays = (n, (C.c_void_p * max(n, 1))(), (C.c_void_p * max(n, 1))(), (C.c_int64 * max(n, 1))())
+        _, dst, src, nbytes = arr
+        for i, (d, s_) in enumerate(pairs):
+            dst[i], src[i], nbytes[i] = d.data_ptr(), s_.data_ptr(), d.numel() * d.element_size()
+        rc = _lib.load().dlrm_graph_replay(n, dst, src, nbytes, C.c_void_p(self._exec), int(self._replayed),
+                                           C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream))
+        _lib.check(rc, "dlrm_graph_replay")
+        self._keep = pairs                                  # the sources stay alive until the next call (their copies are asynchronous)
+        self._replayed = self.serialize
+        return True
+
     def __call__(self, X, lS_o, lS_i, T):
+        if (self._exec is not None and self.static is not None and self.graph is not None and self._eager_calls >= self.warmup
+                and self._lrs == self._current_lrs() and not _TRACE):
+            self._prove_one_lookup_per_bag(lS_o, lS_i)
+            if self.graph is not None and self._raw_replay(X, lS_o, lS_i, T):
+                return self.loss
         if _TRACE:
             print("[gts] call eager=%d captures=%d replay_in_flight=%s" % (self._eager_calls, self.captures, self._replayed),
                   flush=True)
@@ -273,12 +292,10 @@ class GraphedTrainStep:
             self.static = (X.clone(), _clone_struct(lS_o), _clone_struct(lS_i), T.clone())
         else:
             xs, os_, is_, ts = self.static
-            pairs = []
-            _copy_struct(xs, X, pairs)
-            _copy_struct(os_, lS_o, pairs)
-            _copy_struct(is_, lS_i, pairs)
-            _copy_struct(ts, T, pairs)
-            _flush_copies(pairs)
+            _copy_struct(xs, X)
+            _copy_struct(os_, lS_o)
+            _copy_struct(is_, lS_i)
+            _copy_struct(ts, T)
         dev = X.device
         if self._eager_calls < self.warmup:
             # the first calls are ordinary eager steps, issued on the stream the capture will use so that kernel

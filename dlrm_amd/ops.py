@@ -1045,7 +1045,7 @@ def pad_cols(src: torch.Tensor, Kp: int) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # small-batch towers (csrc/tower.hip): all layers of an MLP in one launch per direction
 # ------------------------------------------------------------------------------------------------
-TOWER_MAX_LAYERS, TOWER_MAX_WIDTH = 8, 1024          # DLRM_TOWER_MAX_LAYERS / DLRM_TOWER_MAX_WIDTH of include/dlrm_hip.h
+TOWER_MAX_LAYERS, TOWER_MAX_WIDTH = 8, 512          # DLRM_TOWER_MAX_LAYERS / DLRM_TOWER_MAX_WIDTH of include/dlrm_hip.h
 _tower_ws = {}     # (device, stream) -> slab workspace of tower_wgrad
 
 

@@ -354,7 +354,7 @@ int dlrm_pad_cols(int64_t M, int K, int Kp, const float* src, int64_t ld_src, fl
  *   every tile's slabs in slice order (deterministic).
  * Unaligned operands (13 dense features: rows of 52 bytes) take element loads; nothing needs padding. */
 #define DLRM_TOWER_MAX_LAYERS 8
-#define DLRM_TOWER_MAX_WIDTH 1024
+#define DLRM_TOWER_MAX_WIDTH 512
 int dlrm_tower_fwd(int64_t M, int L, const int* widths, const int* acts, const float* X, int64_t ldx, const void* const* W_host,
                    const int64_t* ldw_host, const void* const* bias_host, void* const* Y_host, const int64_t* ldy_host, void* stream);
 int dlrm_tower_bwd(int64_t M, int L, const int* widths, const int* acts, const float* dY, int64_t lddy, int last_act_applied,
@@ -461,6 +461,15 @@ int dlrm_multihot_gen_table(int table_id, int64_t rows, int hot, int dist, uint6
 int dlrm_multihot_expand(int T, int64_t B, const void* ids, int idx_bits, const void* const* tables_host,
                          const int64_t* rows_host, const int* hot_host, int32_t* values, int64_t* offsets_global,
                          int32_t* offsets_local, int64_t* err, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * One replay of a captured whole-step HIP graph from one host call (dlrm_amd.graph.GraphedTrainStep; the reference loop body
+ * dlrm_s_pytorch.py:1574-1621 captured once): optionally wait for the stream (the previous replay), copy n input tensors
+ * (device to device, bytes_host[i] each, skipped where source == destination) into the graph's static buffers, hipGraphLaunch.
+ * graph_exec is the hipGraphExec_t (torch.cuda.CUDAGraph.raw_cuda_graph_exec()).  The only entry point that synchronises, and
+ * only when asked to. */
+int dlrm_graph_replay(int n, void* const* dst_host, const void* const* src_host, const int64_t* bytes_host, void* graph_exec,
+                      int sync_first, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Strided block copy = torch.cat / torch.split along dim 1 without ATen:

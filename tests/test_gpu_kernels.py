@@ -377,7 +377,7 @@ def _linear_fwd_bwd(M, N, K, act, arith):
     (2048, [368, 512, 256, 1], [1, 1, 2], True),                  # ... top tower (the interaction's padded 367 columns), sigmoid head
     (128, [13, 512, 16], [1, 1], False), (128, [22, 512, 256, 1], [1, 1, 2], True),
     (1000, [7, 33, 130, 5], [1, 0, 2], True),                     # nothing aligned, ragged batch (1000 = 62 * 16 + 8), mixed activations
-    (17, [64, 1024, 1024, 64], [1, 1, 1], True), (1, [4, 4], [0], True), (4096, [16, 64, 48], [2, 1], True)])
+    (17, [64, 512, 512, 64], [1, 1, 1], True), (1, [4, 4], [0], True), (4096, [16, 64, 48], [2, 1], True)])
 def test_small_batch_tower_kernels_match_oracle(M, widths, acts, need_dx):
     """dlrm_tower_fwd / _bwd / _wgrad (csrc/tower.hip: a whole MLP per launch, activations of 16 rows in LDS, the weight gradients of all
     layers from one launch with an in-order slice sum) against the float64 oracle applied layer by layer (O.linear_fwd / O.linear_bwd,
