@@ -1061,7 +1061,8 @@ def main():
         "final_loss": final_loss,
         "launches": {"c_abi_calls_per_step": calls_per_step, "us_per_step": ms * 1e3,
                      "note": "categorised C-ABI calls of one eager step (one call = 1-4 kernel launches; rocprofv3 kernel counts per step: "
-                             "profiles/round4/kaggle_kernels.md); the whole-step HIP graph (--graph) replays them with one launch"},
+                             "profiles/round5/step_trace.txt — 52 at Criteo-Terabyte shapes —, step_trace_kaggle_graph_towers_v5.txt — 19 at "
+                             "Criteo-Kaggle shapes with the small-batch tower kernels); the whole-step HIP graph (--graph) replays them with one launch"},
         "box": box,
         "parity_check": parity,
         "kernel_timing": "HIP events on the launch stream, one per change of launch category (a run of consecutive launches of one category "
