@@ -1079,7 +1079,9 @@ def main():
                     "(dlrm_s_pytorch.py:129-145), and the one-lookup-per-bag proof (a device pass on its own stream + a host wait for its "
                     "event, the bottom tower enqueued in between) runs INSIDE the timed region.  host_wait_us_per_step is mostly the host "
                     "waiting for the GPU to finish the previous step (the wait ends the host's run-ahead), not GPU idle time; what the proof "
-                    "costs is iota_proof_us_per_step = headline ms_per_step - the same steps on producer-tagged offsets (no proof needed)"},
+                    "costs is AT MOST iota_proof_us_per_step = headline ms_per_step - the same steps re-run on producer-tagged offsets (no proof "
+                    "needed) — the second leg of a process runs warmer: as separate interleaved processes the difference is ~31 us per step "
+                    "(profiles/round5/offsets_mode_ab.txt)"},
         "kernels": kernels,
     }
     result.update(result_extra)
