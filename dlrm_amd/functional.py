@@ -43,6 +43,10 @@ CROSS_FUSE = os.environ.get("DLRM_CROSS_FUSE", "1") == "1"
 # 0.367 -> 0.357 ms (profiles/round5/kaggle_towers.md)
 TOWER_ROWS = int(os.environ.get("DLRM_TOWER_ROWS", "4096"))
 TOWER_L2_BYTES = int(os.environ.get("DLRM_TOWER_L2_MB", "384")) << 20
+# ... and which half of a tower they take: the BACKWARD launches always (data-gradient chain + grouped weight gradients: 2-3 launches instead
+# of 3 per layer), the forward launch only with DLRM_TOWER_FWD=1 — the per-layer forward GEMMs spread every layer over the whole chip and are
+# faster than one 128-workgroup tower launch (Criteo-Kaggle graph: 0.358 ms with the tower forward, 0.319 without, 0.362 with no tower kernels)
+TOWER_FWD = os.environ.get("DLRM_TOWER_FWD", "0") == "1"
 # flag bit of MLPFunction's `arith` argument (see MLPFunction.forward); DLRM_FUSE_ACT_BWD=0 makes DLRM_Net never set it (A/B)
 MLP_CONSUMER_APPLIES_LAST_ACT = 0x100
 FUSE_ACT_BWD = os.environ.get("DLRM_FUSE_ACT_BWD", "1") == "1"
@@ -333,18 +337,31 @@ class MLPFunction(Function):
 
     @staticmethod
     def _tower_forward(ctx, x, acts, out_slot, params):
-        """small batches, native fp32: the whole tower in ONE launch (csrc/tower.hip) — activations of 16 batch rows stay in LDS from layer
-        to layer; every layer's output is still written once, for the backward pass.  Nothing is padded: an input that arrives unpadded (13
-        dense features) is read with element loads; an input that arrives padded to a multiple of 4 (the interaction's 367 -> 368 columns)
-        meets a zero-padded copy of the first weight, as in the per-layer path."""
+        """small batches, native fp32: this tower's BACKWARD pass will run on the whole-tower kernels of csrc/tower.hip (one launch for the
+        data-gradient chain, one + one for all weight / bias gradients), so every layer's fp32 output is kept.  The forward pass is the
+        per-layer GEMMs by default, or (TOWER_FWD) one tower launch — activations of 16 batch rows stay in LDS from layer to layer, nothing
+        is padded: an input that arrives unpadded (13 dense features) is read with element loads; an input that arrives padded to a
+        multiple of 4 (the interaction's 367 -> 368 columns) meets a zero-padded copy of the first weight, as in the per-layer path."""
         L = len(acts)
         M = x.size(0)
         W0 = params[0]
         K0 = W0.size(1)
         W0p = ops.pad_cols(W0, x.size(1)) if x.size(1) != K0 else None
-        Ws = [W0p if (i == 0 and W0p is not None) else params[2 * i] for i in range(L)]
         outs = [(out_slot.get() if (i == L - 1 and out_slot is not None) else alloc2d(M, params[2 * i].size(0), x)) for i in range(L)]
-        ops.tower_fwd(x, Ws, [params[2 * i + 1] for i in range(L)], acts, outs)
+        if TOWER_FWD:
+            Ws = [W0p if (i == 0 and W0p is not None) else params[2 * i] for i in range(L)]
+            ops.tower_fwd(x, Ws, [params[2 * i + 1] for i in range(L)], acts, outs)
+        else:
+            # default: the forward pass on the per-layer GEMMs (which spread a layer over the whole chip), the backward pass on the tower
+            # kernels (which only need every layer's fp32 output); unaligned inputs are padded as the per-layer path does
+            if x.size(1) % 4 != 0:
+                Kp = _round4(x.size(1))
+                x, W0p = ops.pad_cols(x, Kp), ops.pad_cols(W0, Kp)
+            cur = x
+            for i in range(L):
+                ops.linear_fwd(cur, W0p if (i == 0 and W0p is not None) else params[2 * i], params[2 * i + 1], acts[i], outs[i],
+                               ops.arith_code("f32"), relu_bits=None)
+                cur = outs[i]
         ctx.tower, ctx.acts, ctx.padded = True, acts, W0p is not None
         ctx.save_for_backward(x, *params, *outs, *([W0p] if W0p is not None else []))
         return outs[-1]
@@ -368,6 +385,8 @@ class MLPFunction(Function):
         grads = []
         for i in range(L):
             grads += [dWs[i], dbs[i]]
+        if dX is not None and dX.size(1) != ctx.in_width:
+            dX = dX[:, :ctx.in_width]
         return (dX, None, None, None, *grads)
 
     @staticmethod

@@ -41,14 +41,17 @@ def build_model(meta, init, device, deterministic=True, mode=None):
 
 
 @pytest.mark.parametrize("name", FIXTURES)
-@pytest.mark.parametrize("mode,arith", [(1, "f32"), (2, "f32"), (0, "f32"), (2, "bf16x6"), (1, "f32-per-layer"), (1, "f32-towers")],
-                         ids=["deterministic", "sorted", "atomic", "sorted-bf16x6", "deterministic-per-layer-gemms", "deterministic-towers"])
+@pytest.mark.parametrize("mode,arith", [(1, "f32"), (2, "f32"), (0, "f32"), (2, "bf16x6"), (1, "f32-per-layer"), (1, "f32-towers"), (1, "f32-towers-fwd")],
+                         ids=["deterministic", "sorted", "atomic", "sorted-bf16x6", "deterministic-per-layer-gemms", "deterministic-towers",
+                              "deterministic-towers-forward-too"])
 def test_training_matches_reference_golden(name, mode, arith, monkeypatch):
-    # (the fixtures are small batches: "f32-towers" runs fp32 towers on the whole-tower kernels of csrc/tower.hip, "f32-per-layer" on the
-    # per-layer GEMMs whatever the default is — both paths are held to the same reference values)
-    if arith in ("f32-per-layer", "f32-towers"):
+    # (the fixtures are small batches: "f32-towers" runs the backward pass of fp32 towers on the whole-tower kernels of csrc/tower.hip,
+    # "f32-towers-fwd" the forward pass too, "f32-per-layer" everything on the per-layer GEMMs, whatever the defaults are — all held to the
+    # same reference values)
+    if arith in ("f32-per-layer", "f32-towers", "f32-towers-fwd"):
         from dlrm_amd import functional
         monkeypatch.setattr(functional, "TOWER_ROWS", 0 if arith == "f32-per-layer" else 4096)
+        monkeypatch.setattr(functional, "TOWER_FWD", arith == "f32-towers-fwd")
         arith = "f32"
     d, meta = load_golden(name)
     device = torch.device("cuda:0")
@@ -888,8 +891,8 @@ def test_kernel_timers_runs_partition_the_step(towers, monkeypatch):
     finally:
         ops.timers = None
     wall = a.elapsed_time(b)
-    if towers:
-        assert s["linear_fwd"]["calls"] == 2 and s["linear_bwd_weight"]["calls"] == 2 and s["linear_bwd_data"]["calls"] == 2
+    if towers:          # (the forward stays per layer by default: functional.TOWER_FWD)
+        assert s["linear_fwd"]["calls"] == 4 and s["linear_bwd_weight"]["calls"] == 2 and s["linear_bwd_data"]["calls"] == 2
     else:
         assert s["linear_fwd"]["calls"] == 4 and s["linear_bwd_weight"]["calls"] == 4 and s["linear_bwd_data"]["calls"] == 3
     assert s["emb_fwd"]["calls"] == 1 and s["emb_bwd_sgd"]["calls"] == 1 and s["interact_fwd"]["calls"] == 1
