@@ -8,11 +8,13 @@
 // Why: at Criteo-Kaggle shapes (BASELINE.json configs[1]: batch 2048, widths 13-512-256-64-16 / 367-512-256-1) a training step is
 // ~45 dependent kernels of 4-25 us: the per-layer GEMMs (64 x 64 tiles, split-k slabs + a reduction kernel per weight gradient) occupy
 // a fraction of the chip for a few microseconds each, and a replayed HIP graph pays per node (profiles/round5/step_trace_kaggle_graph.txt).
-// With these kernels the step is 19 kernels.  What they are NOT is fast per kernel: a batch of 2048 rows is 128 workgroups — half the
-// chip — and every workgroup streams ALL weights for its 16 rows (no reuse beyond one MFMA row block), so the forward / backward
-// launches run at about a third of the MFMA rate and the step gains 3 % rather than the 30 % the launch count suggests
-// (profiles/round5/kaggle_towers.md has the four versions that were measured).  Large batches keep the per-layer LDS-DMA GEMMs of
-// gemm.hip: (M / 16) x sum(N_l x K_l) x 4 bytes of weight traffic only pays while it is small (functional._tower_applies).
+// With all of these kernels the step is 19 kernels.  What they are NOT is fast per kernel: a batch of 2048 rows is 128 workgroups — half
+// the chip — and every workgroup streams ALL weights for its 16 rows (no reuse beyond one MFMA row block), so the forward / backward
+// launches run at about a third of the MFMA rate.  In the BACKWARD pass they replace three launches per layer and come out even in kernel
+// time, in the forward pass one launch per layer and lose to the per-layer GEMMs (which spread a layer over all 256 CUs): the default is
+// per-layer forward + tower backward, 0.388 -> 0.320 ms per graphed step (towers everywhere: 0.358; profiles/round5/kaggle_towers.md has
+// the five versions that were measured).  Large batches keep the per-layer LDS-DMA GEMMs of gemm.hip altogether: (M / 16) x
+// sum(N_l x K_l) x 4 bytes of weight traffic only pays while it is small (functional._tower_applies).
 //
 // MFMA use (v_mfma_f32_16x16x4_f32; lane l: li = l & 15, g = l >> 4; A[i = li][k = g], B[k = g][j = li], D[i = 4g + r][j = li]):
 // a lane loads FOUR consecutive floats of an operand row with one 16-byte load and feeds them to four MFMAs — the k index of a
