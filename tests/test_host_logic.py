@@ -258,6 +258,69 @@ def test_graph_input_helpers():
         _copy_struct(st, [off, off])
 
 
+def test_graph_input_pairs_for_the_raw_replay():
+    """The raw replay path (dlrm_graph_replay: wait + input copies + hipGraphLaunch in one C call) collects (static, caller) tensor pairs
+    through the same checks as the copy_ path: one pair per DISTINCT static tensor, none where the caller already passed the static
+    buffer, the shape / structure errors unchanged."""
+    from dlrm_amd.graph import _clone_struct, _copy_struct
+    off = torch.arange(5)
+    st = _clone_struct([off, off, torch.arange(5) * 2])
+    pairs = []
+    put = lambda d, s_: pairs.append((d, s_))           # noqa: E731
+    a, b = off + 1, off * 3
+    _copy_struct(st, [a, a, b], put)
+    assert len(pairs) == 2 and pairs[0][0] is st[0] and pairs[0][1] is a and pairs[1][0] is st[2] and pairs[1][1] is b
+    assert torch.equal(st[0], off)                      # nothing was copied: the pairs are for the C call
+    pairs.clear()
+    _copy_struct(st, [st[0], st[1], b], put)            # the caller handed the static buffers back: only the third tensor moves
+    assert len(pairs) == 1 and pairs[0][1] is b
+    with pytest.raises(RuntimeError, match="shape"):
+        _copy_struct(st, [a, a, torch.arange(6)], put)
+    t = _clone_struct(torch.ones(2, 3))
+    pairs.clear()
+    _copy_struct(t, t, put)
+    assert pairs == []
+
+
+def test_small_batch_tower_path_is_chosen_by_rows_widths_and_weight_traffic(monkeypatch):
+    """functional._tower_applies: the whole-tower kernels (csrc/tower.hip) take native-fp32 towers of small batches only — at most
+    TOWER_ROWS rows, widths the kernels hold in LDS (<= 512), at most 8 layers, and (M / 16) x parameters x 4 bytes of weight streaming
+    under TOWER_L2_BYTES: Criteo-Kaggle's towers at 2048 rows yes (bench/dlrm_s_criteo_kaggle.sh:24), the Criteo-Terabyte towers never
+    (1024-wide layers), any tower at the headline batch no."""
+    from dlrm_amd import functional, ops
+
+    class T:                                             # the attributes _tower_applies reads of a tensor
+        def __init__(self, *shape, cuda=True):
+            self.shape, self.is_cuda = shape, cuda
+
+        def size(self, i):
+            return self.shape[i]
+
+    def tower(widths):
+        ps = []
+        for k, n in zip(widths[:-1], widths[1:]):
+            ps += [T(n, k), T(n)]
+        return ps
+
+    f32, bf16 = ops.arith_code("f32"), ops.arith_code("bf16")
+    monkeypatch.setattr(functional, "TOWER_ROWS", 4096)
+    monkeypatch.setattr(functional, "TOWER_L2_BYTES", 384 << 20)
+    kag_bot, kag_top = [13, 512, 256, 64, 16], [367, 512, 256, 1]
+    tb_bot, tb_top = [13, 512, 256, 128], [479, 1024, 1024, 512, 256, 1]
+    ok = lambda M, w, xw=None, arith=f32, cuda=True: functional._tower_applies(T(M, xw or w[0], cuda=cuda), arith, tower(w), len(w) - 1)   # noqa: E731
+    assert ok(2048, kag_bot) and ok(2048, kag_top, xw=368) and ok(128, kag_bot) and ok(1, [4, 4])
+    assert not ok(2048, kag_top, xw=370)                 # an input that is neither the true nor the padded width
+    assert not ok(2048, tb_top, xw=480)                  # 1024-wide layers do not fit the kernels' LDS buffers
+    assert ok(2048, tb_bot) and not ok(8192, tb_bot)     # rows
+    assert not ok(65536, kag_bot) and not ok(0, kag_bot)
+    assert not ok(2048, kag_bot, arith=bf16) and not ok(2048, kag_bot, cuda=False)
+    assert not ok(64, [16] * 10)                         # more layers than a launch takes
+    wide = [512] * 9                                     # 8 layers of 512 x 512: 8 MB of weights per 16-row workgroup
+    assert ok(256, wide) and not ok(4096, wide)          # 16 x 8 MB = 128 MB of streaming yes, 256 x 8 MB = 2 GB no
+    monkeypatch.setattr(functional, "TOWER_ROWS", 0)
+    assert not ok(2048, kag_bot)
+
+
 def test_data_front_ends_refuse_cpu_and_malformed_input(tmp_path):
     from dlrm_amd.criteo_bin import CriteoBinBatches, batch_byte_range, num_batches
     from dlrm_amd.datagen import UniformBatchGenerator
