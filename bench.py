@@ -124,10 +124,10 @@ def parse():
                     help="per-kernel HIP events are recorded on every n-th step of the timed region (an event is a queue barrier, "
                          "~5 us: one per change of launch category, ~0.1 ms per instrumented step; dlrm_amd.ops.KernelTimers)")
     ap.add_argument("--cpu-row-cap", type=int, default=4000000, help="row cap of the baseline legs' tables (SURVEY 8d: 4 M)")
-    ap.add_argument("--cpu-steps", type=int, default=10, help="timed iterations of the CPU baseline (median reported)")
-    ap.add_argument("--cpu-warmup", type=int, default=3)
-    ap.add_argument("--cpu-budget", type=float, default=130.0, help="seconds of host time the CPU baseline leg may take (thread-count "
-                                                                     "probes + warm-up + as many of --cpu-steps as fit, at least 3)")
+    ap.add_argument("--cpu-steps", type=int, default=4, help="timed iterations of the CPU baseline (median reported; 10 in rounds 1-4)")
+    ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--cpu-budget", type=float, default=35.0, help="seconds of host time the CPU baseline leg may take (warm-up + as many of "
+                                                                    "--cpu-steps as fit, at least 3): ~30 s of CPU work at 6 s per iteration")
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
     ap.add_argument("--a2a-chunks", type=int, default=int(os.environ.get("DLRM_A2A_CHUNKS", "1")),
                     help="N > 1: schedule of the HEADLINE measurement. 1 (default) = the reference schedule: one all-to-all per "

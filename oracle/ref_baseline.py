@@ -93,15 +93,17 @@ def time_loop(ref, model, batch, lr, use_gpu, device, warmup, steps):
     return times, loss
 
 
-def run(state, lr, cpu_warmup=3, cpu_steps=10, gpu_warmup=3, gpu_steps=10, gpu_device=None, cpu_budget_s=130.0):
+def run(state, lr, cpu_warmup=2, cpu_steps=4, gpu_warmup=3, gpu_steps=10, gpu_device=None, cpu_budget_s=35.0):
     """state: m_spa, ln_bot, ln_top, tables (list of CPU fp32 [rows, D]), mlp (state_dict names -> CPU tensors), batch
     (X [B,13] f32, lS_o [T,B] i64, lS_i [T,B] i64, T [B,1] f32; CPU), row_cap.  Returns (cpu_baseline, stock_gpu_baseline) or None
     when oracle/_ref is absent.
 
-    The CPU leg is BOUNDED (`cpu_budget_s` of host time; bench.py must finish within minutes and the box's time is metered): the
-    thread count is chosen by one probe iteration each at torch's default (physical cores) and at os.cpu_count() — on the
-    2 x 64-core box of visit 1, 256 threads took 47 s per iteration against ~6 s at 128 — the faster one runs `cpu_warmup` warm-up
-    iterations (the probes count) and as many timed iterations (<= cpu_steps, >= 3) as the budget allows; median reported."""
+    The CPU leg is BOUNDED (`cpu_budget_s` of host time, ~30 s by default: bench.py must finish within minutes and the box's time is
+    metered): the first iteration runs at torch's default thread count (the physical cores) and counts as a warm-up; os.cpu_count()
+    threads are only tried where an iteration costs less than a twentieth of the budget — on the 2 x 64-core boxes of this
+    pool 256 threads took 47-49 s per iteration against ~6 s at 128 in every round that probed it (the `probe_ms_per_step` of
+    profiles/round2-5), which a 30 s leg cannot afford to re-establish — then `cpu_warmup` warm-up iterations in all (the probes count) and
+    as many timed iterations (<= cpu_steps, >= 3) as the budget allows; median reported."""
     ref = load_reference()
     if ref is None:
         return None
@@ -113,7 +115,7 @@ def run(state, lr, cpu_warmup=3, cpu_steps=10, gpu_warmup=3, gpu_steps=10, gpu_d
     (t1,), _ = time_loop(ref, model, state["batch"], lr, False, torch.device("cpu"), 0, 1)
     probes[default_threads] = t1
     best = default_threads
-    if os.cpu_count() != default_threads and t1 * 1e-3 < cpu_budget_s / 6:
+    if os.cpu_count() != default_threads and t1 * 1e-3 < cpu_budget_s / 20:       # (only where an iteration is cheap next to the budget)
         torch.set_num_threads(os.cpu_count())
         (t2,), _ = time_loop(ref, model, state["batch"], lr, False, torch.device("cpu"), 0, 1)
         probes[os.cpu_count()] = t2
@@ -141,9 +143,10 @@ def run(state, lr, cpu_warmup=3, cpu_steps=10, gpu_warmup=3, gpu_steps=10, gpu_d
                           % state["row_cap"],
                           "tables loaded into nn.EmbeddingBag(sum, sparse=True) modules after constructing the model small (the "
                           "constructor's float64 numpy draw of 4 M x 128 values takes ~30 s per table and would be overwritten)",
-                          "thread count = the faster of torch's default and os.cpu_count() by one probe iteration each (SURVEY 8d says "
-                          "os.cpu_count(); oversubscribing the physical cores was 7x slower on this host)"]
-                         + (["%d timed iterations instead of 10 (host-time budget)" % steps] if steps < 10 else [])}
+                          "thread count = torch's default (the physical cores); SURVEY 8d says os.cpu_count(), which is probed only where an "
+                          "iteration is cheap next to the budget: oversubscribing the physical cores was 7-8x slower on this pool's hosts in "
+                          "every earlier round (profiles/round5/visit_slow_gpu/bench.json: 6.2 s vs 49 s per iteration)"]
+                         + (["%d timed iterations instead of %d (host-time budget)" % (steps, cpu_steps)] if steps < cpu_steps else [])}
     stock = None
     if gpu_device is not None and torch.cuda.is_available():
         try:
