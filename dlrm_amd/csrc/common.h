@@ -29,7 +29,7 @@ static inline int dlrm_current_device() { int d = 0; (void)hipGetDevice(&d); ret
 static inline bool dlrm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // timing-only tuning switches (DLRM_GEMM_DEBUG, DLRM_INTERACT_DEBUG, DLRM_SEG_DEBUG) make kernels skip work: results are WRONG.
-// They exist ONLY in a tuning build (`make TUNING=1` -> -DDLRM_TUNING, tools/probes/): the product library never reads these
+// They — and since round 6 EVERY environment variable the library ever read — exist ONLY in a tuning build (`make TUNING=1` -> -DDLRM_TUNING, tools/probes/): the product library never reads these
 // environment variables — the function folds to the constant 0, so no environment can turn a kernel of the shipped library into
 // a no-op (tests/test_host_logic.py checks that the names are absent from the binary).
 #ifdef DLRM_TUNING
@@ -40,8 +40,17 @@ static inline int dlrm_debug_env(const char* name, int mask) {
     return v;
 }
 #define DLRM_DEBUG_ENV(name, mask) dlrm_debug_env(name, mask)
+// launch-plan / schedule knobs of the A/B visits (tools/gpu_visit.sh abx with DLRM_HIP_LIB = the tuning build): read once per process
+static inline int dlrm_tune_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline const char* dlrm_tune_env_str(const char* name) { return getenv(name); }
+#define DLRM_TUNE_ENV(name, dflt) dlrm_tune_env(name, dflt)
+#define DLRM_TUNE_ENV_STR(name) dlrm_tune_env_str(name)
 #else
 #define DLRM_DEBUG_ENV(name, mask) 0
+// the product library has NO environment switches: every knob folds to its default at compile time and the variable's name is not in the
+// binary (tests/test_host_logic.py); behaviour travels with the call's arguments only
+#define DLRM_TUNE_ENV(name, dflt) (dflt)
+#define DLRM_TUNE_ENV_STR(name) ((const char*)nullptr)
 #endif
 
 __device__ __forceinline__ float dlrm_wave_sum(float v) {

@@ -26,11 +26,25 @@
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
-#ifndef DLRM_GEMM_FRAG2
-#define DLRM_GEMM_FRAG2 1
+// fragment-read schedule (gemm3_kernel SCHED) of the forward / data-gradient / weight-gradient forms of the native fp32 GEMM
+#ifndef DLRM_SCHED_FWD
+#define DLRM_SCHED_FWD 0
 #endif
-#ifndef DLRM_GEMM_FRAG2_ALL
-#define DLRM_GEMM_FRAG2_ALL 0      /* tuning builds: the two fragment sets in every kernel form */
+#ifndef DLRM_SCHED_DGRAD
+#define DLRM_SCHED_DGRAD 0
+#endif
+#ifndef DLRM_SCHED_WGRAD
+#define DLRM_SCHED_WGRAD 1
+#endif
+// accumulators of the native fp32 loop in AGPRs (gemm3_kernel ACC_AGPR) per form
+#ifndef DLRM_AGPR_FWD
+#define DLRM_AGPR_FWD 0
+#endif
+#ifndef DLRM_AGPR_DGRAD
+#define DLRM_AGPR_DGRAD 0
+#endif
+#ifndef DLRM_AGPR_WGRAD
+#define DLRM_AGPR_WGRAD 0
 #endif
 
 namespace {
@@ -423,8 +437,22 @@ template <> struct FVec<4> { using T = floatx4; };
 
 // TN = 1 (with TM = 1: a 64 x 64 tile, four waves of 32 x 32): SMALL launches only (Criteo-Kaggle's batch of 2048, see launch_gemm) — no sign
 // bits in or out (the host takes the fp32 mask / the stand-alone bit kernel), the mask of the data gradient is read in the epilogue.
-template <bool A_KC, bool B_KC, int TM, int ARITH, bool ROWSUM, int FRAG = 0, int TN = 2>
+// One v_mfma_f32_32x32x2_f32, accumulator in place.  AGPR = true pins the accumulator tile to the ACCUMULATION half of the unified register file
+// (an "a" inline-asm operand; hipcc's own choice is architectural VGPRs whenever the kernel fits 256 of them).  Why it matters (round 6,
+// tools/probes/mfma_lds_probe.hip): with THREE waves per SIMD the same stream of MFMAs + fragment ds_reads sustains 0.89 of the fp32 MFMA peak with
+// VGPR accumulators and 0.95 with AGPR ones (two waves per SIMD: 0.96 either way).
+template <bool AGPR>
+__device__ __forceinline__ void mfma_f32(floatx16& c, float a, float b) {
+    if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    else c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// SCHED: fragment-read schedule of the native fp32 main loop (0 / 1 / 2, see the loop); NST: stages of the LDS ring
+// EPI: 0 = the general epilogue (any shape / alignment, atomics, fp32 masks, every activation); 1 / 2 = the STRAIGHT-LINE epilogue (no / ReLU activation)
+template <bool A_KC, bool B_KC, int TM, int ARITH, bool ROWSUM, int FRAG = 0, int TN = 2, int SCHED = 0, int NST = 3, bool ACC_AGPR = false, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
+    static_assert(SCHED == 0 || ARITH == 0, "fragment schedules exist for the native fp32 main loop");
+    static_assert(NST == 3, "three-stage ring");
     static_assert(TN == 2 || (TN == 1 && TM == 1 && ARITH == 0), "the 32-column wave tile exists for the small fp32 launches only");
     constexpr bool A_IL = FRAG && !A_KC, B_IL = FRAG && !B_KC;      // operand's sub-tiles interleaved (see above)
     static_assert(!FRAG || ARITH == 0, "vector fragments are implemented for the native fp32 main loop");
@@ -530,6 +558,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     const bool mask_pf = TN == 2 && MASKED && !use_bits && g.mask != nullptr && g.vecC && full_n;
     float4 mk[2][8];
     // bit form of the same mask: every lane holds ITS 32 sign bits of the band (one dword: 256 B per 32 x 64 band instead of 8 KB)
+    float4 bvf = make_float4(0.f, 0.f, 0.f, 0.f);      // EPI != 0: this lane's bias quad (prefetched in the k-loop)
     unsigned mkb[TM];       // ALL bands' words are loaded before the first store of the epilogue: a load issued between the store bursts makes
                             // the compiler drain vmcnt — i.e. wait for every store issued so far to complete — before the word is used
                             // (measured: the masked data-gradient GEMM 4-12 % slower than the unmasked one; with this, equal)
@@ -551,17 +580,89 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     };
 
     if (nk > 0) GEMM3_ISSUE(0);
-    if (nk > 1) GEMM3_ISSUE(STAGE);
-    unsigned cur = 0, nxt = 2 * STAGE;     // byte offsets of the stage being read / being refilled
+    if (nk > 1 && NST > 2) GEMM3_ISSUE(STAGE);
+    unsigned cur = 0, nxt = NST > 2 ? 2 * STAGE : STAGE;     // byte offsets of the stage being read / being refilled
     const char* ldsb = (const char*)lds;
+    // fragments of one 8-k half (j) of the tile in the stage at byte offset st_off -> fa[TM], fb[TN]
+    auto load_half = [&](unsigned st_off, int j, float4 (&fa)[TM], float4 (&fb)[TN]) {
+        if constexpr (A_IL) {           // one vector read per k row feeds all TM sub-tiles (rows TM*r + t)
+            using VA = typename FVec<TM>::T;
+            const char* pa = ldsb + st_off + fa_off[j];
+            const VA a0 = *(const VA*)(pa), a1 = *(const VA*)(pa + BMt * 4), a2 = *(const VA*)(pa + 2 * BMt * 4), a3 = *(const VA*)(pa + 3 * BMt * 4);
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fa[t] = make_float4(a0[t], a1[t], a2[t], a3[t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                if (A_KC) fa[t] = *(const float4*)(ldsb + st_off + fa_off[j] + t * 32 * 64);
+                else {
+                    const float* p = (const float*)(ldsb + st_off + fa_off[j]) + t * 32;
+                    fa[t] = make_float4(p[0], p[BMt], p[2 * BMt], p[3 * BMt]);
+                }
+            }
+        }
+        if constexpr (B_IL) {
+            using VB = typename FVec<TN>::T;
+            const char* pb = ldsb + st_off + fb_off[j];
+            const VB b0 = *(const VB*)(pb), b1 = *(const VB*)(pb + BNt * 4), b2 = *(const VB*)(pb + 2 * BNt * 4), b3 = *(const VB*)(pb + 3 * BNt * 4);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) fb[t] = make_float4(b0[t], b1[t], b2[t], b3[t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                if (B_KC) fb[t] = *(const float4*)(ldsb + st_off + fb_off[j] + t * 32 * 64);
+                else {
+                    const float* p = (const float*)(ldsb + st_off + fb_off[j]) + t * 32;
+                    fb[t] = make_float4(p[0], p[BNt], p[2 * BNt], p[3 * BNt]);
+                }
+            }
+        }
+    };
+    // the 4 x TM x TN products of one half (k-step major: every accumulator is touched once per k-step)
+    auto products = [&](const float4 (&fa)[TM], const float4 (&fb)[TN]) {
+        if (do_rowsum) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) rs[t] += (fa[t].x + fa[t].y) + (fa[t].z + fa[t].w);
+        }
+        if constexpr (!A_KC && !B_KC && !FRAG) __builtin_amdgcn_s_setprio(1);    // weight gradient with SCALAR fragments (32 ds_read_b32 per half tile): -1.5 %; nil elsewhere
+#define GEMM3_KSTEP(E)                                                                                              \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                           \
+            _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) mfma_f32<ACC_AGPR>(acc[tm][tn], fb[tn].E, fa[tm].E);
+        GEMM3_KSTEP(x) GEMM3_KSTEP(y) GEMM3_KSTEP(z) GEMM3_KSTEP(w)
+#undef GEMM3_KSTEP
+        if constexpr (!A_KC && !B_KC && !FRAG) __builtin_amdgcn_s_setprio(0);
+    };
+    float4 fa0[TM], fb0[TN], fa1[SCHED ? TM : 1], fb1[SCHED ? TN : 1];      // fragment register sets (native fp32 loop)
+    if constexpr (SCHED == 2) {
+        // rolling schedule: the first half of tile 0 is read here, every later half one half-tile of products ahead of its use
+        if (nk > 0) {
+            if (nk > 1 && NST > 2) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            load_half(0, 0, fa0, fb0);
+        }
+    }
     for (int kt = 0; kt < nk; ++kt) {
         if (!(g.debug & 2)) {
-            if (kt + 1 < nk) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();   // my share of tile kt has landed
-            __builtin_amdgcn_s_barrier();      // everyone's share has; everyone is done reading stage `nxt`
+            if constexpr (SCHED == 2) {
+                // tile kt + 1 (the only refill in flight here) must be visible to everyone before its first half is read below; the barrier
+                // also says everyone has consumed the fragments of tile kt - 1, whose stage the refill below overwrites
+                if constexpr (NST > 2) {
+                    if (kt + 1 < nk) wait_vmcnt<0>();
+                    __builtin_amdgcn_s_barrier();
+                }
+            } else {
+                if (kt + 1 < nk) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();   // my share of tile kt has landed
+                __builtin_amdgcn_s_barrier();      // everyone's share has; everyone is done reading stage `nxt`
+            }
         }
         // (issued BEFORE this tile's fragment reads: issuing it after them — the reads are on the first MFMA's critical path, the refill is not —
         // measured 1-2 % slower in every kernel form, profiles/round5/gemm_dma_late_ab.txt: the refill's head start matters more)
         if (kt + 2 < nk && !(g.debug & 1)) GEMM3_ISSUE(nxt);
+        if constexpr (EPI != 0) {
+            // (straight-line epilogue) the bias quad of this lane's columns, requested with the last two k-tiles still to multiply — as the mask words
+            // below: behind every DMA in the in-order vmcnt queue, retired by the loop's final vmcnt(0)
+            if (kt + 2 == nk && g.bias != nullptr && nb < g.N) bvf = *(const float4*)(g.bias + nb);
+        }
         if constexpr (MASKED) {
             // no DMA is issued after tile nk-1's (at kt == nk-3), so these loads sit behind every DMA in the in-order
             // vmcnt queue and the counted wait of kt == nk-2 (which leaves TM+TN newer operations in flight) and the
@@ -573,117 +674,33 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             }
         }
         if constexpr (ARITH == 0) {
-        // fragments of BOTH 8-k halves of the tile are requested before the first product (round 5; -DDLRM_GEMM_FRAG2=0 restores one set): with one
-        // register set the second half's ds_reads could only be issued when the first half's last MFMA had its operands, i.e. a second LDS
-        // round trip per k-tile sat in front of 16 (TM = 2) / 32 (TM = 4) MFMAs (disassembly: profiles/round5/gemm3_main_loop_isa.txt)
-        // Measured per kernel form (profiles/round5/gemm_frag2_ab.txt, A/B inside one visit): the WEIGHT GRADIENT (256-row tiles, two
-        // waves per SIMD: little else to hide an LDS round trip behind) gains 4 % (1024 x 1024: 1004 -> 965 us); the forward form (three
-        // waves per SIMD) does not move (+1 %), and the data gradient's 172 registers would cost it its third workgroup per CU (-4 to -7 %):
-        // only the weight gradient takes it.
-        constexpr bool F2 = DLRM_GEMM_FRAG2 && ((!A_KC && !B_KC) || DLRM_GEMM_FRAG2_ALL);
-        float4 fa2[F2 ? 2 : 1][TM], fb2[F2 ? 2 : 1][TN];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float4 (&fa)[TM] = fa2[F2 ? j : 0];
-            float4 (&fb)[TN] = fb2[F2 ? j : 0];
-            auto load_frags = [&]() {
-            if constexpr (A_IL) {           // one vector read per k row feeds all TM sub-tiles (rows TM*r + t)
-                using VA = typename FVec<TM>::T;
-                const char* pa = ldsb + cur + fa_off[j];
-                const VA a0 = *(const VA*)(pa), a1 = *(const VA*)(pa + BMt * 4), a2 = *(const VA*)(pa + 2 * BMt * 4), a3 = *(const VA*)(pa + 3 * BMt * 4);
-#pragma unroll
-                for (int t = 0; t < TM; ++t) fa[t] = make_float4(a0[t], a1[t], a2[t], a3[t]);
-            } else {
-#pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                if (A_KC) fa[t] = *(const float4*)(ldsb + cur + fa_off[j] + t * 32 * 64);
-                else {
-                    const float* p = (const float*)(ldsb + cur + fa_off[j]) + t * 32;
-                    fa[t] = make_float4(p[0], p[BMt], p[2 * BMt], p[3 * BMt]);
-                }
-            }
-            }
-            if constexpr (B_IL) {
-                using VB = typename FVec<TN>::T;
-                const char* pb = ldsb + cur + fb_off[j];
-                const VB b0 = *(const VB*)(pb), b1 = *(const VB*)(pb + BNt * 4), b2 = *(const VB*)(pb + 2 * BNt * 4), b3 = *(const VB*)(pb + 3 * BNt * 4);
-#pragma unroll
-                for (int t = 0; t < TN; ++t) fb[t] = make_float4(b0[t], b1[t], b2[t], b3[t]);
-            } else {
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                if (B_KC) fb[t] = *(const float4*)(ldsb + cur + fb_off[j] + t * 32 * 64);
-                else {
-                    const float* p = (const float*)(ldsb + cur + fb_off[j]) + t * 32;
-                    fb[t] = make_float4(p[0], p[BNt], p[2 * BNt], p[3 * BNt]);
-                }
-            }
-            }
-            };
-            if constexpr (F2) { load_frags(); }
-            else { (void)load_frags; }
-        }
-        if constexpr (F2) __builtin_amdgcn_sched_barrier(0);      // keep all fragment reads of the tile in front of its first MFMA
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float4 (&fa)[TM] = fa2[F2 ? j : 0];
-            float4 (&fb)[TN] = fb2[F2 ? j : 0];
-            if constexpr (!F2) {
-            if constexpr (A_IL) {
-                using VA = typename FVec<TM>::T;
-                const char* pa = ldsb + cur + fa_off[j];
-                const VA a0 = *(const VA*)(pa), a1 = *(const VA*)(pa + BMt * 4), a2 = *(const VA*)(pa + 2 * BMt * 4), a3 = *(const VA*)(pa + 3 * BMt * 4);
-#pragma unroll
-                for (int t = 0; t < TM; ++t) fa[t] = make_float4(a0[t], a1[t], a2[t], a3[t]);
-            } else {
-#pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                if (A_KC) fa[t] = *(const float4*)(ldsb + cur + fa_off[j] + t * 32 * 64);
-                else {
-                    const float* p = (const float*)(ldsb + cur + fa_off[j]) + t * 32;
-                    fa[t] = make_float4(p[0], p[BMt], p[2 * BMt], p[3 * BMt]);
-                }
-            }
-            }
-            if constexpr (B_IL) {
-                using VB = typename FVec<TN>::T;
-                const char* pb = ldsb + cur + fb_off[j];
-                const VB b0 = *(const VB*)(pb), b1 = *(const VB*)(pb + BNt * 4), b2 = *(const VB*)(pb + 2 * BNt * 4), b3 = *(const VB*)(pb + 3 * BNt * 4);
-#pragma unroll
-                for (int t = 0; t < TN; ++t) fb[t] = make_float4(b0[t], b1[t], b2[t], b3[t]);
-            } else {
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                if (B_KC) fb[t] = *(const float4*)(ldsb + cur + fb_off[j] + t * 32 * 64);
-                else {
-                    const float* p = (const float*)(ldsb + cur + fb_off[j]) + t * 32;
-                    fb[t] = make_float4(p[0], p[BNt], p[2 * BNt], p[3 * BNt]);
-                }
-            }
-            }
-            }
-            if (do_rowsum) {
-#pragma unroll
-                for (int t = 0; t < TM; ++t) rs[t] += (fa[t].x + fa[t].y) + (fa[t].z + fa[t].w);
-            }
-            if constexpr (!A_KC && !B_KC && !FRAG) __builtin_amdgcn_s_setprio(1);    // weight gradient with SCALAR fragments (32 ds_read_b32 per half tile): -1.5 %; nil elsewhere
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].x, fa[tm].x, acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].y, fa[tm].y, acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].z, fa[tm].z, acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].w, fa[tm].w, acc[tm][tn], 0, 0, 0);
-            if constexpr (!A_KC && !B_KC && !FRAG) __builtin_amdgcn_s_setprio(0);
+        // One 8-k half of a tile = TM + TN fragment reads feeding 4 x TM x TN MFMAs.  Three schedules of reads against products:
+        //   SCHED 0  one register set: the reads of half j sit right in front of its products (an LDS round trip per half, hidden only by
+        //            the other waves of the SIMD);
+        //   SCHED 1  (round 5, weight gradient) two sets, both halves' reads in front of the tile's first product: one round trip per tile;
+        //   SCHED 2  (round 6) two sets ROLLING ACROSS k-tiles: half 1 of tile kt is read under the products of its half 0, half 0 of tile
+        //            kt + 1 under the products of half 1 — no product of the loop ever waits for an LDS read that has not had 4 x TM x TN
+        //            MFMA slots to complete.  Needs tile kt + 1 visible at the barrier of iteration kt (its refill was issued one iteration
+        //            earlier: one k-tile of flight time instead of two) — same registers as SCHED 1.
+        if constexpr (SCHED == 2) {
+            load_half(cur, 1, fa1, fb1);                       // second half of this tile: lands under the first half's products
+            products(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned nst = (cur == (NST - 1) * STAGE) ? 0 : cur + STAGE;
+            if (kt + 1 < nk) load_half(nst, 0, fa0, fb0);      // first half of the NEXT tile (visible since this iteration's barrier)
+            products(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (SCHED == 1) {
+            load_half(cur, 0, fa0, fb0);
+            load_half(cur, 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);      // keep all fragment reads of the tile in front of its first MFMA
+            products(fa0, fb0);
+            products(fa1, fb1);
+        } else {
+            load_half(cur, 0, fa0, fb0);
+            products(fa0, fb0);
+            load_half(cur, 1, fa0, fb0);
+            products(fa0, fb0);
         }
         } else if constexpr (ARITH == 3) {
             // bf16 STORAGE: the operands already are bf16 in memory.  A k-contiguous bf16 row tile is, byte for byte, the fp32 tile
@@ -749,8 +766,8 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
 #undef GEMM3_PRODUCT
             }
         }
-        cur = (cur == 2 * STAGE) ? 0 : cur + STAGE;
-        nxt = (nxt == 2 * STAGE) ? 0 : nxt + STAGE;
+        cur = (cur == (NST - 1) * STAGE) ? 0 : cur + STAGE;
+        nxt = (nxt == (NST - 1) * STAGE) ? 0 : nxt + STAGE;
     }
 #undef GEMM3_ISSUE
     wait_vmcnt<0>();
@@ -783,7 +800,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     // (transposes back to [m][n]) -> 16-byte row segments.  Transposed C/D layout of the 32x32 MFMA:
     // lane owns m_local = lane & 31 and n_local = 8*q + 4*(lane>>5) + {0..3} for q = reg>>2.
     constexpr int ELD = TN == 2 ? EPI_LD : 32 + 4;                  // staged row pitch (floats)
-    static_assert(4 * 32 * ELD * 4 <= NSTAGE3 * STAGE, "epilogue staging does not fit the ring");
+    static_assert(4 * 32 * ELD * 4 <= NST * STAGE, "epilogue staging does not fit the ring");
     if constexpr (MASKED) {
         // the words were requested two k-tiles ago and the loop's final vmcnt(0) has retired them; the compiler cannot see that
         // through the hand-placed waits, and would drain vmcnt (= wait for the previous band's STORES) in front of every later use
@@ -803,6 +820,77 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
             for (int i = 0; i < TM; ++i) bits_fetch(i, mkb[i]);
         } }
     const bool write_bits = TN == 2 && A_KC && B_KC && g.bits_out != nullptr;
+    if constexpr (EPI != 0) {
+        // ---- STRAIGHT-LINE epilogue (round 6).  The general epilogue below carries every option of the entry points in one body (atomic
+        // accumulation, scalar edges, fp32 masks read in place, three activations behind run-time branches); the waitcnt pass then closes every
+        // join of those branches with s_waitcnt vmcnt(0) — IN FRONT OF EVERY ROW STORE AND EVERY STAGED READ — so a wave's 8 x TM row stores left one
+        // full memory round trip apart (disassembly: profiles/round6/gemm3_epilogue_isa.md; timing: the epilogue was 4.7 % of the 1024 x 1024
+        // layers and 11-16 % of the 512 -> 256 ones, of which the store traffic itself is a quarter).  This body is what the host selects when
+        // the call needs none of that (launch_gemm: 16-byte aligned C rows, N % 4 == 0, plain stores, no fp32 mask, no sigmoid): no loads, no
+        // divergent paths — the only VMEM operations are the row stores, and nothing waits for them.  Same arithmetic, same bits.
+        static_assert(TN == 2 && ARITH == 0, "the straight-line epilogue exists for the native fp32 128-column tiles");
+        const bool col_ok = nb < g.N;                       // (N % 4 == 0: a lane's four columns are all inside or all outside)
+        if (nk < 2 && g.bias != nullptr && col_ok) bvf = *(const float4*)(g.bias + nb);
+        asm volatile("" : "+v"(bvf.x), "+v"(bvf.y), "+v"(bvf.z), "+v"(bvf.w));      // (retired by the final vmcnt(0) / loaded just above: no wait at its uses)
+        float* cbase = g.C + (long long)zs * g.c_split_stride + nb;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            unsigned myword = 0u;
+            if constexpr (B_IL) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v0 = make_float4(acc[tm][0][4 * q], acc[tm][1][4 * q], acc[tm][0][4 * q + 1], acc[tm][1][4 * q + 1]);
+                    const float4 v1 = make_float4(acc[tm][0][4 * q + 2], acc[tm][1][4 * q + 2], acc[tm][0][4 * q + 3], acc[tm][1][4 * q + 3]);
+                    *(float4*)__builtin_assume_aligned(S + l31 * EPI_LD + 16 * q + 8 * h, 16) = v0;
+                    *(float4*)__builtin_assume_aligned(S + l31 * EPI_LD + 16 * q + 8 * h + 4, 16) = v1;
+                }
+            } else {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
+                        *(float4*)__builtin_assume_aligned(S + l31 * EPI_LD + tn * 32 + 8 * q + 4 * h, 16) = v;
+                    }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                const long long m = m0 + wm * 32 * TM + (A_IL ? TM * row + tm : tm * 32 + row);
+                float4 v = *(const float4*)__builtin_assume_aligned(S + row * EPI_LD + c4, 16);
+                v.x += bvf.x; v.y += bvf.y; v.z += bvf.z; v.w += bvf.w;
+                if constexpr (EPI == 2) {
+                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                }
+                if constexpr (A_KC && B_KC) {
+                    if (write_bits) {
+                        asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                     "v_cmp_lt_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                     "v_cmp_lt_f32 vcc, 0, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                     "v_cmp_lt_f32 vcc, 0, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                     : "+v"(myword) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "vcc");
+                    }
+                }
+                if constexpr (MASKED) {
+                    if (use_bits) {
+                        const unsigned wv = mkb[tm];
+                        if (!((wv >> (31 - (it * 4 + 0))) & 1u)) v.x = 0.f;
+                        if (!((wv >> (31 - (it * 4 + 1))) & 1u)) v.y = 0.f;
+                        if (!((wv >> (31 - (it * 4 + 2))) & 1u)) v.z = 0.f;
+                        if (!((wv >> (31 - (it * 4 + 3))) & 1u)) v.w = 0.f;
+                    }
+                }
+                if (m < g.M && col_ok) *(float4*)(cbase + m * g.ldc) = v;
+            }
+            if constexpr (A_KC && B_KC) {
+                if (write_bits) {
+                    const long long mb = (m0 + wm * 32 * TM + tm * 32) >> 5, nbk = (n0 + wn * 64) >> 6;
+                    if (mb <= ((g.M - 1) >> 5) && nbk < g.bits_nblk) g.bits_out[(mb * g.bits_nblk + nbk) * 64 + lane] = myword;
+                }
+            }
+        }
+        return;
+    }
     if constexpr (TN == 1) {
         // 32-column wave tile: a lane owns 4 columns of rows it*8 + (lane >> 3); the mask (data gradient) is read here — a small launch has no
         // synchronised epilogue burst to hide it from
@@ -1175,7 +1263,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_t_kernel(int R, int C, int R
 
 static int pow2ceil_i(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <bool A_KC, bool B_KC, int TM, int ARITH, int FRAG = 0, int TN = 2>
+template <bool A_KC, bool B_KC, int TM, int ARITH, int FRAG = 0, int TN = 2, int SCHED = 0, bool AGPR = false, int EPI = 0>
 static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     constexpr bool ROWSUM = !A_KC && !B_KC;          // only the weight-gradient GEMM carries the bias-gradient row sums
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
@@ -1189,25 +1277,23 @@ static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     }
     size_t lds = (size_t)NSTAGE3 * (BMt + BNt) * BK3 * 4;           // 72 KiB (TM=4) / 48 KiB (TM=2)
     {   // tuning aid (env DLRM_GEMM_LDS_PAD, bytes): extra dynamic LDS per workgroup = fewer resident workgroups per CU (occupancy probe)
-        static int pad = -1;
-        if (pad < 0) { const char* e = getenv("DLRM_GEMM_LDS_PAD"); pad = e ? atoi(e) : 0; }
+        static const int pad = DLRM_TUNE_ENV("DLRM_GEMM_LDS_PAD", 0);
         lds += (size_t)pad;
     }
     static bool attr_done[DLRM_MAX_DEVICES] = {};      // the attribute is per (function, device)
     const int dev = dlrm_current_device();
     if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN, SCHED, 3, AGPR, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[dev] = true;
     }
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), block(256);
-    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN>), grid, block, lds, st, g);
+    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN, SCHED, 3, AGPR, EPI>), grid, block, lds, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
 }
 
-static int gemm_path() {   // env DLRM_GEMM_PATH: 0 = auto (default), 2 = force the register-staged fallback kernel
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DLRM_GEMM_PATH"); v = e ? atoi(e) : 0; }
+static int gemm_path() {   // tuning builds, env DLRM_GEMM_PATH: 0 = auto (default), 2 = force the register-staged fallback kernel
+    static const int v = DLRM_TUNE_ENV("DLRM_GEMM_PATH", 0);
     return v;
 }
 
@@ -1224,8 +1310,7 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
         // 547 -> 521, out = 512 / K = 256: 162 -> 146; the one-round shapes (512 -> 256 forward, out = 256 data gradient) lose 1-4 %
         // with the small tiles and keep the large ones; the weight gradient loses 20 % with them.
         const long long wg256 = ((g.M + 255) / 256) * ((g.N + 127) / 128) * splits;
-        static int force_tm = -1;      // tuning aid: DLRM_GEMM_TM=2 forces the 128-row tiles, 4 the round-2 rule
-        if (force_tm < 0) { const char* e = getenv("DLRM_GEMM_TM"); force_tm = e ? atoi(e) : 0; }
+        static const int force_tm = DLRM_TUNE_ENV("DLRM_GEMM_TM", 0);      // tuning aid: 2 forces the 128-row tiles, 4 the round-2 rule
         bool big = g.M >= 256 && wg256 >= 512;
         // (fp32 MFMA only: the bf16x6 / bf16 main loops split or round every fragment they load, and the smaller tiles reuse a fragment
         // for half as many products — bf16x6 step 6.51 -> 6.93 ms with them)
@@ -1234,16 +1319,13 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
         // k-strided operands (data gradient: W; weight gradient: dY and X) are read with vector fragments over interleaved sub-tiles
         // (FRAG, see gemm3_kernel).  Tuning aids: DLRM_GEMM_FRAG=0 -> the scalar-fragment kernels of rounds 1-2;
         // DLRM_WGRAD_TM=2 -> 128-row weight-gradient tiles (three workgroups per CU; lost 20 % with scalar fragments).
-        static int frag = -1, wgrad_tm = -1;
-        if (frag < 0) { const char* e = getenv("DLRM_GEMM_FRAG"); frag = e ? atoi(e) : 1; }
-        if (wgrad_tm < 0) { const char* e = getenv("DLRM_WGRAD_TM"); wgrad_tm = e ? atoi(e) : 0; }
+        static const int frag = DLRM_TUNE_ENV("DLRM_GEMM_FRAG", 1), wgrad_tm = DLRM_TUNE_ENV("DLRM_WGRAD_TM", 0);
         if (splits > 1 && wgrad_tm == 2) big = false;
         if (fast) *fast = true;
         // SMALL launches (Criteo-Kaggle: batch 2048): a 128 x 128 tiling leaves most CUs idle and every wave walks its k-loop alone at one
         // SIMD's MFMA rate (29 / 25 / 44 us per forward / data- / weight-gradient GEMM of ~0.5 GFLOP, profiles/round4/kaggle_kernels.md).
         // 64-row tiles (TM = 1) double the workgroups and halve each wave's MFMA chain.  fp32 MFMA only.
-        static int small_tm = -1;       // tuning aid: DLRM_GEMM_SMALL=0 keeps the 128-row tiles
-        if (small_tm < 0) { const char* e = getenv("DLRM_GEMM_SMALL"); small_tm = e ? atoi(e) : 2; }      // 0 off, 1 64-row tiles only, 2 (default) also 64 x 64
+        static const int small_tm = DLRM_TUNE_ENV("DLRM_GEMM_SMALL", 2);       // 0 off (keeps the 128-row tiles), 1 64-row tiles only, 2 (default) also 64 x 64
         const long long wg128 = ((g.M + 127) / 128) * ((g.N + 127) / 128) * splits;
         const bool small = small_tm && !big && arith == DLRM_ARITH_F32 && wg128 < 128 && force_tm == 0;
         // ... and 64 x 64 tiles (TN = 1 too) while even the 64 x 128 tiling has fewer workgroups than 3/4 of the CUs; that kernel neither writes
@@ -1251,11 +1333,31 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
         const long long wg64 = ((g.M + 63) / 64) * ((g.N + 127) / 128) * splits;
         const bool tiny = small && small_tm >= 2 && wg64 < 192 && (g.bits_in == nullptr || g.mask != nullptr);
         if (tiny && fast) *fast = false;
+        // fragment-read schedule (gemm3_kernel SCHED) and accumulator register class (ACC_AGPR) of the native fp32 loop per kernel form.
+        // Both are compile-time per form (-DDLRM_SCHED_FWD=.. / -DDLRM_AGPR_FWD=.. etc., tools/build_variant_lib.sh).
+        constexpr int FORM = (A_KC && B_KC) ? 0 : (A_KC ? 1 : 2);
+        constexpr int SCHED_DEFAULT[3] = {DLRM_SCHED_FWD, DLRM_SCHED_DGRAD, DLRM_SCHED_WGRAD};
+        constexpr int AGPR_DEFAULT[3] = {DLRM_AGPR_FWD, DLRM_AGPR_DGRAD, DLRM_AGPR_WGRAD};
+        constexpr int SD = SCHED_DEFAULT[FORM];
+        // the straight-line epilogue (gemm3_kernel EPI) wherever the call needs nothing else: 16-byte aligned C rows, N % 4 == 0, plain stores, the
+        // ReLU derivative from sign bits (or none), bias 16-byte aligned, no sigmoid, fp32 results only.  Tuning builds: DLRM_GEMM_EPI=0 keeps the general one.
+        static const int epi_on = DLRM_TUNE_ENV("DLRM_GEMM_EPI", 1);
+        const bool fast_epi = epi_on && arith == DLRM_ARITH_F32 && g.vecC && g.N % 4 == 0 && g.ldc % 4 == 0 && !g.atomic_out && g.Cb == nullptr &&
+                              (g.mask == nullptr || g.bits_in != nullptr) && (g.bias == nullptr || dlrm_aligned16(g.bias)) &&
+                              (g.act == DLRM_ACT_NONE || (g.act == DLRM_ACT_RELU && FORM == 0)) && (g.c_split_stride % 4 == 0);
+        constexpr bool AG = AGPR_DEFAULT[FORM] != 0;
+#define GEMM3_LAUNCH(TM_, FR, EP) launch_gemm3<A_KC, B_KC, TM_, 0, FR, 2, SD, AG, EP>(g, splits, st)
+#define GEMM3_BIG_OR_NOT(FR)                                                                                   \
+        if (fast_epi) {                                                                                        \
+            if constexpr (FORM == 0) { if (g.act == DLRM_ACT_RELU) return big ? GEMM3_LAUNCH(4, FR, 2) : GEMM3_LAUNCH(2, FR, 2); } \
+            return big ? GEMM3_LAUNCH(4, FR, 1) : GEMM3_LAUNCH(2, FR, 1);                                      \
+        }                                                                                                      \
+        return big ? GEMM3_LAUNCH(4, FR, 0) : GEMM3_LAUNCH(2, FR, 0);
         if constexpr (!A_KC || !B_KC) {
             if (arith == DLRM_ARITH_F32 && frag) {
                 if (tiny) return launch_gemm3<A_KC, B_KC, 1, 0, 1, 1>(g, splits, st);
                 if (small) return launch_gemm3<A_KC, B_KC, 1, 0, 1>(g, splits, st);
-                return big ? launch_gemm3<A_KC, B_KC, 4, 0, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0, 1>(g, splits, st);
+                GEMM3_BIG_OR_NOT(1)
             }
         }
         if (tiny) return launch_gemm3<A_KC, B_KC, 1, 0, 0, 1>(g, splits, st);
@@ -1264,7 +1366,9 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
             return big ? launch_gemm3<A_KC, B_KC, 4, 1>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 1>(g, splits, st);
         if (arith == DLRM_ARITH_BF16)
             return big ? launch_gemm3<A_KC, B_KC, 4, 2>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 2>(g, splits, st);
-        return big ? launch_gemm3<A_KC, B_KC, 4, 0>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0>(g, splits, st);
+        GEMM3_BIG_OR_NOT(0)
+#undef GEMM3_BIG_OR_NOT
+#undef GEMM3_LAUNCH
     }
     g.bits_in = nullptr; g.bits_out = nullptr;       // the any-shape kernel neither reads nor writes sign bits
     g.tiles_m = (int)((g.M + BM - 1) / BM);
@@ -1515,9 +1619,9 @@ extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, in
 static void wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* kchunk_out) {
     // split the batch reduction so that >= ~4 workgroups per CU exist; slices of >= 512 rows
     const int tiles = (int)(((N + BM - 1) / BM) * ((K + BN - 1) / BN));
-    static int target_wgs = -1, min_rows = -1;   // tuning aids: DLRM_WGRAD_WGS (workgroups a launch aims at), DLRM_WGRAD_MINROWS (shortest batch slice)
-    if (target_wgs < 0) { const char* e = getenv("DLRM_WGRAD_WGS"); target_wgs = e && atoi(e) > 0 ? atoi(e) : 768; }
-    if (min_rows < 0) { const char* e = getenv("DLRM_WGRAD_MINROWS"); min_rows = e && atoi(e) >= 128 ? atoi(e) : 512; }
+    // tuning aids: DLRM_WGRAD_WGS (workgroups a launch aims at), DLRM_WGRAD_MINROWS (shortest batch slice)
+    static const int target_wgs_e = DLRM_TUNE_ENV("DLRM_WGRAD_WGS", 768), min_rows_e = DLRM_TUNE_ENV("DLRM_WGRAD_MINROWS", 512);
+    const int target_wgs = target_wgs_e > 0 ? target_wgs_e : 768, min_rows = min_rows_e >= 128 ? min_rows_e : 512;
     int splits = (target_wgs + tiles - 1) / tiles;
     const int64_t max_splits = (M + min_rows - 1) / min_rows;
     if (splits > max_splits) {
