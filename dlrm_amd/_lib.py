@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED = 0, 1, 2
 ARITH_F32, ARITH_BF16X6, ARITH_BF16 = 0, 1, 2
-EXPECTED_ABI = 14          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
+EXPECTED_ABI = 15          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
 
 _lock = threading.Lock()
 _lib = None
@@ -55,13 +55,13 @@ SIGNATURES = {
     "dlrm_linear_bwd_weight_bf16": (_i32, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp]),
     "dlrm_emb_sort_lookups": (_i32, [_i32, _i64, _pi64, _pp, _pp, _pi64, _i32, _vp, _i64, _vp, _vp, _vp, C.POINTER(_i32), _vp, _vp]),
     "dlrm_emb_bwd_sgd": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64,
-                                _f32, _i32, _vp, _i64, _vp, _vp]),
+                                _f32, _vp, _i32, _vp, _i64, _vp, _vp]),
     "dlrm_pool_weights_gather": (_i32, [_i32, _pi64, _pp, _pi64, _i32, _pp, _pp, _vp, _vp]),
     "dlrm_emb_psw_grad": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _i32, _vp, _i64, _pp, _vp]),
     "dlrm_emb_bwd_coo": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _i32, _vp, _i64, _pp, _vp]),
     "dlrm_emb_adagrad_workspace_bytes": (_i64, [_i32, _i32, _pi64, _pi64]),
     "dlrm_emb_bwd_rowwise_adagrad": (_i32, [_i32, _i64, _i32, _pp, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32,
-                                            _vp, _i64, _f32, _f32, _vp, _i64, _vp, _vp]),
+                                            _vp, _i64, _f32, _vp, _f32, _vp, _i64, _vp, _vp]),
     "dlrm_interact_fwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _vp]),
     "dlrm_interact_bwd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _i32, _vp, _i64, _pp, _pi64, _vp]),
     "dlrm_interact_gather_ok": (_i32, [_i32, _i32]),
@@ -81,9 +81,10 @@ SIGNATURES = {
     "dlrm_bce_logits_loss": (_i32, [_i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
     "dlrm_mse_loss": (_i32, [_i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp]),
     "dlrm_scale_by_device_scalar": (_i32, [_i64, _vp, _vp, _vp, _vp]),
-    "dlrm_sgd_dense": (_i32, [_i64, _vp, _vp, _f32, _vp]),
-    "dlrm_sgd_dense_multi": (_i32, [_i32, _pp, _pp, _pi64, _f32, _vp]),
-    "dlrm_adagrad_dense": (_i32, [_i64, _vp, _vp, _vp, _f32, _f32, _vp]),
+    "dlrm_sgd_dense": (_i32, [_i64, _vp, _vp, _f32, _vp, _vp]),
+    "dlrm_sgd_dense_multi": (_i32, [_i32, _pp, _pp, _pi64, _f32, _vp, _vp]),
+    "dlrm_adagrad_dense": (_i32, [_i64, _vp, _vp, _vp, _f32, _vp, _f32, _vp]),
+    "dlrm_set_f32": (_i32, [_i32, _pp, C.POINTER(_f32), _vp]),
     "dlrm_binary_metrics_workspace_bytes": (_i64, [_i64]),
     "dlrm_binary_metrics": (_i32, [_i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "dlrm_gen_workspace_bytes": (_i64, [_i32, _i64]),
@@ -99,7 +100,7 @@ SIGNATURES = {
     "dlrm_cross_bwd": (_i32, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "dlrm_gemm_bf16_cross": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_add": (_i32, [_i64, _vp, _vp, _vp, _vp]),
-    "dlrm_graph_replay": (_i32, [_i32, _pp, _pp, _pi64, _vp, _i32, _vp]),
+    "dlrm_graph_replay": (_i32, [_i32, _pp, _pp, _pi64, _i32, _pp, C.POINTER(_f32), _vp, _i32, _vp]),
     "dlrm_tower_fwd": (_i32, [_i64, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _i64, _pp, _pi64, _pp, _pp, _pi64, _vp]),
     "dlrm_tower_bwd": (_i32, [_i64, _i32, C.POINTER(_i32), C.POINTER(_i32), _vp, _i64, _i32, _pp, _pi64, _pp, _pi64, _pp, _pi64, _vp, _i64, _vp]),
     "dlrm_tower_wgrad_workspace_bytes": (_i64, [_i64, _i32, C.POINTER(_i32)]),

@@ -96,8 +96,9 @@ __global__ __launch_bounds__(256) void adagrad_groups_kernel(SortedArgs sa, Adag
                                                              const KT* __restrict__ keys, const unsigned* __restrict__ vals,
                                                              const unsigned* __restrict__ bag_of,
                                                              const float* __restrict__ dout, long long dout_ld,
-                                                             float clr, float eps, float* __restrict__ edge_first,
+                                                             DlrmStep clr_, float eps, float* __restrict__ edge_first,
                                                              float* __restrict__ edge_last) {
+    const float clr = clr_;              // (by value, or read from the device scalar: common.h DlrmStep)
     using VT = typename Vec<VEC>::T;
     constexpr int DP = NCH * LPB * VEC;                  // padded row length of the edge buffers
     constexpr int GPB = 256 / LPB;
@@ -223,9 +224,10 @@ __global__ __launch_bounds__(256) void adagrad_groups_kernel(SortedArgs sa, Adag
 // one lane group per group index: acts only where a run starts in this group and continues into the next one
 template <int VEC, int LPB, int NCH, typename KT>
 __global__ __launch_bounds__(256) void adagrad_fixup_kernel(SortedArgs sa, AdagradArgs aa, long long L, int D, int row_bits,
-                                                            const KT* __restrict__ keys, float clr, float eps,
+                                                            const KT* __restrict__ keys, DlrmStep clr_, float eps,
                                                             const float* __restrict__ edge_first,
                                                             const float* __restrict__ edge_last) {
+    const float clr = clr_;              // (by value, or read from the device scalar: common.h DlrmStep)
     using VT = typename Vec<VEC>::T;
     constexpr int DP = NCH * LPB * VEC;
     constexpr int GPB = 256 / LPB;
@@ -307,7 +309,7 @@ template <typename KT>
 static int run_adagrad(int n, const int* ids, int64_t B, int D, void* const* weight_host, void* const* state_host,
                        const int64_t* rows_host, const void* const* indices_host, const void* const* offsets_host,
                        const int64_t* nnz_host, const void* const* psw_host, int idx_bits, const float* dout, int64_t dout_ld,
-                       float clr, float eps, char* ws, const AdaLayout& lo, size_t L, int row_bits, int key_bits, bool vec_ok,
+                       DlrmStep clr, float eps, char* ws, const AdaLayout& lo, size_t L, int row_bits, int key_bits, bool vec_ok,
                        hipStream_t st, int64_t* err) {
     SortedArgs sa;
     int rc = expand_and_sort<KT>(n, ids, B, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host, idx_bits, ws,
@@ -359,7 +361,8 @@ static int run_adagrad(int n, const int* ids, int64_t B, int D, void* const* wei
 }
 
 __global__ __launch_bounds__(256) void adagrad_dense_kernel(long long n, float* __restrict__ w, float* __restrict__ sum,
-                                                            const float* __restrict__ g, float clr, float eps) {
+                                                            const float* __restrict__ g, DlrmStep clr_, float eps) {
+    const float clr = clr_;              // (by value, or read from the device scalar: common.h DlrmStep)
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float gi = g[i];
@@ -391,7 +394,7 @@ extern "C" int dlrm_emb_bwd_rowwise_adagrad(int T, int64_t B, int D, void* const
                                             void* const* state_host, const int64_t* rows_host,
                                             const void* const* indices_host, const void* const* offsets_host,
                                             const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
-                                            const float* dout, int64_t dout_ld, float lr, float eps,
+                                            const float* dout, int64_t dout_ld, float lr, const float* lr_dev, float eps,
                                             void* workspace, int64_t workspace_bytes, int64_t* err, void* stream) {
     if (T <= 0 || B <= 0 || D <= 0 || !weight_host || !state_host || !rows_host || !indices_host || !offsets_host || !nnz_host ||
         !dout || dout_ld < (int64_t)T * D)
@@ -424,20 +427,20 @@ extern "C" int dlrm_emb_bwd_rowwise_adagrad(int T, int64_t B, int D, void* const
             return DLRM_E_ARG;
         }
         rc = wide ? run_adagrad<unsigned long long>(n, ids, B, D, weight_host, state_host, rows_host, indices_host, offsets_host,
-                                                    nnz_host, psw_host, idx_bits, dout, dout_ld, lr, eps, (char*)workspace, lo, L,
+                                                    nnz_host, psw_host, idx_bits, dout, dout_ld, dlrm_step_pos(lr, lr_dev), eps, (char*)workspace, lo, L,
                                                     row_bits, key_bits, vec_ok, st, err)
                   : run_adagrad<unsigned>(n, ids, B, D, weight_host, state_host, rows_host, indices_host, offsets_host, nnz_host,
-                                          psw_host, idx_bits, dout, dout_ld, lr, eps, (char*)workspace, lo, L, row_bits, key_bits,
+                                          psw_host, idx_bits, dout, dout_ld, dlrm_step_pos(lr, lr_dev), eps, (char*)workspace, lo, L, row_bits, key_bits,
                                           vec_ok, st, err);
         if (rc) return rc;
     }
     return 0;
 }
 
-extern "C" int dlrm_adagrad_dense(int64_t n, float* w, float* sum, const float* g, float lr, float eps, void* stream) {
+extern "C" int dlrm_adagrad_dense(int64_t n, float* w, float* sum, const float* g, float lr, const float* lr_dev, float eps, void* stream) {
     if (n <= 0 || !w || !sum || !g) return DLRM_E_ARG;
     long long nblk = (n + 255) / 256; if (nblk > 4096) nblk = 4096;
-    hipLaunchKernelGGL(adagrad_dense_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (long long)n, w, sum, g, lr, eps);
+    hipLaunchKernelGGL(adagrad_dense_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (long long)n, w, sum, g, dlrm_step_pos(lr, lr_dev), eps);
     DLRM_LAUNCH_CHECK();
     return 0;
 }

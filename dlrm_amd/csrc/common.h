@@ -53,6 +53,18 @@ static inline const char* dlrm_tune_env_str(const char* name) { return getenv(na
 #define DLRM_TUNE_ENV_STR(name) ((const char*)nullptr)
 #endif
 
+// A step size (learning rate) that travels BY VALUE in the kernarg or is READ FROM DEVICE MEMORY when the kernel runs (dev != nullptr:
+// value = sign * *dev).  The second form is what a captured HIP graph needs: the reference's LRPolicyScheduler changes lr every
+// iteration during warm-up and decay (dlrm_s_pytorch.py:169-203, stepped at :1621); a graph whose update kernels read lr from a device
+// scalar is replayed unchanged, the new value written in front of the replay (dlrm_graph_replay) — no re-capture.  sign = -1 gives the
+// exact negation the kernels multiply with (fma(-lr, g, w)), bit-identical to passing -lr by value.
+struct DlrmStep {
+    float v; const float* dev; float sign;
+    __device__ __forceinline__ operator float() const { return dev ? sign * *dev : v; }
+};
+static inline DlrmStep dlrm_step_neg(float lr, const float* lr_dev) { DlrmStep s; s.v = -lr; s.dev = lr_dev; s.sign = -1.f; return s; }
+static inline DlrmStep dlrm_step_pos(float lr, const float* lr_dev) { DlrmStep s; s.v = lr; s.dev = lr_dev; s.sign = 1.f; return s; }
+
 __device__ __forceinline__ float dlrm_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -107,7 +119,7 @@ __device__ __forceinline__ bool dlrm_index_ok(long long idx, long long rows) {
 int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_host, const int64_t* rows_host,
                                  const void* const* indices_host, const void* const* offsets_host,
                                  const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
-                                 const float* dout, int64_t dout_ld, float lr, void* workspace,
+                                 const float* dout, int64_t dout_ld, float lr, const float* lr_dev, void* workspace,
                                  int64_t workspace_bytes, int64_t* err, void* stream);
 
 // gemv.hip: the N == 1 MLP layer as HBM-streaming kernels; each returns 0 when it handled the call and

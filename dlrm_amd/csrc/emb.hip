@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs a, long long B, in
 template <int VEC, int LPB, int NCH, typename IT, int U>
 __global__ __launch_bounds__(256) void emb_bwd_sgd_atomic_kernel(EmbArgs a, long long B, int D,
                                                                  const float* __restrict__ dout,
-                                                                 long long dout_ld, float neg_lr) {
+                                                                 long long dout_ld, DlrmStep neg_lr_) {
+    const float neg_lr = neg_lr_;        // (by value, or read from the device scalar: common.h DlrmStep)
     using VT = typename Vec<VEC>::T;
     const int t = blockIdx.y;
     float* __restrict__ W = a.w[t];
@@ -244,8 +245,9 @@ __global__ __launch_bounds__(256) void emb_bwd_sgd_atomic_kernel(EmbArgs a, long
 template <typename IT>
 __global__ __launch_bounds__(256) void emb_bwd_sgd_lds_kernel(EmbArgs a, long long B, int D,
                                                               const float* __restrict__ dout,
-                                                              long long dout_ld, float neg_lr,
+                                                              long long dout_ld, DlrmStep neg_lr_,
                                                               int bags_per_block) {
+    const float neg_lr = neg_lr_;        // (by value, or read from the device scalar: common.h DlrmStep)
     extern __shared__ __attribute__((aligned(16))) float lds_acc[];
     const int t = blockIdx.y;
     float* __restrict__ W = a.w[t];
@@ -294,7 +296,8 @@ __global__ __launch_bounds__(256) void emb_bwd_sgd_lds_kernel(EmbArgs a, long lo
 template <typename IT>
 __global__ __launch_bounds__(256) void emb_bwd_sgd_det_kernel(EmbArgs a, long long B, int D,
                                                               const float* __restrict__ dout,
-                                                              long long dout_ld, float neg_lr) {
+                                                              long long dout_ld, DlrmStep neg_lr_) {
+    const float neg_lr = neg_lr_;        // (by value, or read from the device scalar: common.h DlrmStep)
     const int t = blockIdx.y;
     float* __restrict__ W = a.w[t];
     const IT* __restrict__ idx = (const IT*)a.idx[t];
@@ -528,7 +531,7 @@ extern "C" int dlrm_emb_bwd_sgd(int T, int64_t B, int D, void* const* weight_hos
                                 const int64_t* rows_host, const void* const* indices_host,
                                 const void* const* offsets_host, const int64_t* nnz_host,
                                 const void* const* psw_host, int idx_bits, const float* dout,
-                                int64_t dout_ld, float lr, int mode, void* workspace,
+                                int64_t dout_ld, float lr, const float* lr_dev, int mode, void* workspace,
                                 int64_t workspace_bytes, int64_t* err, void* stream) {
     int rc = check_common(T, B, D, (const void* const*)weight_host, rows_host, indices_host, offsets_host,
                           nnz_host, idx_bits);
@@ -537,9 +540,9 @@ extern "C" int dlrm_emb_bwd_sgd(int T, int64_t B, int D, void* const* weight_hos
     if (mode != DLRM_UPD_ATOMIC && mode != DLRM_UPD_DETERMINISTIC && mode != DLRM_UPD_SORTED) return DLRM_E_MODE;
     if (mode == DLRM_UPD_SORTED)
         return dlrm_emb_bwd_sgd_sorted_impl(T, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host,
-                                            psw_host, idx_bits, dout, dout_ld, lr, workspace, workspace_bytes, err, stream);
+                                            psw_host, idx_bits, dout, dout_ld, lr, lr_dev, workspace, workspace_bytes, err, stream);
     hipStream_t st = (hipStream_t)stream;
-    const float neg_lr = -lr;
+    const DlrmStep neg_lr = dlrm_step_neg(lr, lr_dev);
     dim3 block(256, 1, 1);
 
     if (mode == DLRM_UPD_DETERMINISTIC) {

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(256) void sorted_update_kernel(SortedArgs sa, long 
                                                             const unsigned* __restrict__ vals,
                                                             const unsigned* __restrict__ bag_of,
                                                             const float* __restrict__ dout, long long dout_ld,
-                                                            float neg_lr) {
+                                                            DlrmStep neg_lr_) {
+    const float neg_lr = neg_lr_;        // (by value, or read from the device scalar: common.h DlrmStep)
     using VT = typename Vec<VEC>::T;
     __shared__ long long s_w[DLRM_MAX_TABLES_PER_LAUNCH];
     __shared__ long long s_psw[DLRM_MAX_TABLES_PER_LAUNCH];
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void sorted_update_kernel(SortedArgs sa, long 
 template <typename KT>
 static int run_sorted(int n, const int* ids, int64_t B, int D, void* const* weight_host, const int64_t* rows_host,
                       const void* const* indices_host, const void* const* offsets_host, const int64_t* nnz_host,
-                      const void* const* psw_host, int idx_bits, const float* dout, int64_t dout_ld, float neg_lr,
+                      const void* const* psw_host, int idx_bits, const float* dout, int64_t dout_ld, DlrmStep neg_lr,
                       char* ws, const Layout& lo, size_t L, int row_bits, int key_bits, bool vec_ok, hipStream_t st,
                       int64_t* err) {
     SortedArgs sa;
@@ -270,7 +271,7 @@ extern "C" int dlrm_emb_sort_lookups(int T, int64_t B, const int64_t* rows_host,
 int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_host, const int64_t* rows_host,
                                  const void* const* indices_host, const void* const* offsets_host,
                                  const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
-                                 const float* dout, int64_t dout_ld, float lr, void* workspace,
+                                 const float* dout, int64_t dout_ld, float lr, const float* lr_dev, void* workspace,
                                  int64_t workspace_bytes, int64_t* err, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     bool vec_ok = dlrm_aligned16(dout) && (dout_ld % 4 == 0);
@@ -299,10 +300,10 @@ int dlrm_emb_bwd_sgd_sorted_impl(int T, int64_t B, int D, void* const* weight_ho
             return DLRM_E_ARG;
         }
         rc = wide ? run_sorted<unsigned long long>(n, ids, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host,
-                                                   psw_host, idx_bits, dout, dout_ld, -lr, (char*)workspace, lo, L, row_bits,
+                                                   psw_host, idx_bits, dout, dout_ld, dlrm_step_neg(lr, lr_dev), (char*)workspace, lo, L, row_bits,
                                                    key_bits, vec_ok, st, err)
                   : run_sorted<unsigned>(n, ids, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host,
-                                         idx_bits, dout, dout_ld, -lr, (char*)workspace, lo, L, row_bits, key_bits, vec_ok, st, err);
+                                         idx_bits, dout, dout_ld, dlrm_step_neg(lr, lr_dev), (char*)workspace, lo, L, row_bits, key_bits, vec_ok, st, err);
         if (rc) return rc;
     }
     return 0;

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void loss_finish_kernel(int n, const float* __
 
 __global__ __launch_bounds__(256) void sgd_dense_kernel(long long n4, long long n, float4* __restrict__ w4,
                                                         const float4* __restrict__ g4, float* __restrict__ w,
-                                                        const float* __restrict__ g, float neg_lr) {
+                                                        const float* __restrict__ g, DlrmStep neg_lr_) {
+    const float neg_lr = neg_lr_;        // (by value, or read from the device scalar: common.h DlrmStep)
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         float4 a = w4[i];
@@ -157,7 +158,8 @@ struct MultiSgdArgs {
     int          count;
 };
 
-__global__ __launch_bounds__(256) void sgd_dense_multi_kernel(MultiSgdArgs a, float neg_lr) {
+__global__ __launch_bounds__(256) void sgd_dense_multi_kernel(MultiSgdArgs a, DlrmStep neg_lr_) {
+    const float neg_lr = neg_lr_;        // (by value, or read from the device scalar: common.h DlrmStep)
     int k = 0;
     while (k + 1 < a.count && (int)blockIdx.x >= a.blk0[k + 1]) ++k;     // wave-uniform scan over <= 48 entries
     float* __restrict__ w = a.w[k];
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void clamp_bwd_kernel(long long n, const float
 
 }  // namespace
 
-extern "C" int dlrm_hip_abi_version(void) { return 14; }
+extern "C" int dlrm_hip_abi_version(void) { return 15; }
 
 extern "C" const char* dlrm_hip_build_info(void) {
     return "libdlrm_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " clang " __clang_version__;
@@ -309,7 +311,27 @@ extern "C" int dlrm_hip_device_info(int device, int* cu_count, int* lds_bytes, i
 // One replay of a captured training step (dlrm_amd.graph.GraphedTrainStep) from ONE host call: wait for the previous replay, copy the
 // step's inputs into the graph's static buffers, launch.  At Criteo-Kaggle shapes the GPU finishes a replay in ~0.3 ms and then waits for
 // the host; the same sequence issued from Python (stream.synchronize(), one copy_ per input, CUDAGraph.replay()) was ~60 us of that wait.
-extern "C" int dlrm_graph_replay(int n, void* const* dst_host, const void* const* src_host, const int64_t* bytes_host, void* graph_exec,
+namespace {
+#define DLRM_MAX_SCALARS 16
+struct SetF32Args { float* dst[DLRM_MAX_SCALARS]; float v[DLRM_MAX_SCALARS]; int n; };
+__global__ void set_f32_kernel(SetF32Args a) { if ((int)threadIdx.x < a.n) *a.dst[threadIdx.x] = a.v[threadIdx.x]; }
+}  // namespace
+
+// dst_host[i][0] = values_host[i] for i < n (n <= 16), values BY VALUE in the kernarg: no host buffer has to outlive the call, nothing is
+// copied from pageable memory.  The device scalars the update kernels read their learning rate from (DlrmStep, common.h).
+extern "C" int dlrm_set_f32(int n, float* const* dst_host, const float* values_host, void* stream) {
+    if (n < 0 || n > DLRM_MAX_SCALARS || (n > 0 && (!dst_host || !values_host))) return DLRM_E_ARG;
+    if (n == 0) return 0;
+    SetF32Args a = {};
+    a.n = n;
+    for (int i = 0; i < n; ++i) { if (!dst_host[i]) return DLRM_E_ARG; a.dst[i] = dst_host[i]; a.v[i] = values_host[i]; }
+    hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dlrm_graph_replay(int n, void* const* dst_host, const void* const* src_host, const int64_t* bytes_host,
+                                 int n_scalars, float* const* scalar_dst_host, const float* scalar_values_host, void* graph_exec,
                                  int sync_first, void* stream) {
     if (n < 0 || !graph_exec || (n > 0 && (!dst_host || !src_host || !bytes_host))) return DLRM_E_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -322,6 +344,10 @@ extern "C" int dlrm_graph_replay(int n, void* const* dst_host, const void* const
         if (dst_host[i] == src_host[i] || bytes_host[i] == 0) continue;
         hipError_t e = hipMemcpyAsync(dst_host[i], src_host[i], (size_t)bytes_host[i], hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return (int)e;
+    }
+    if (n_scalars > 0) {          // the step sizes of this replay (a schedule changed them): written behind the previous replay, in front of this one
+        const int rc = dlrm_set_f32(n_scalars, scalar_dst_host, scalar_values_host, stream);
+        if (rc) return rc;
     }
     hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, st);
     return e == hipSuccess ? 0 : (int)e;
@@ -374,13 +400,13 @@ extern "C" int dlrm_mse_loss(int64_t B, const float* p, const float* target, flo
     return 0;
 }
 
-extern "C" int dlrm_sgd_dense(int64_t n, float* w, const float* g, float lr, void* stream) {
+extern "C" int dlrm_sgd_dense(int64_t n, float* w, const float* g, float lr, const float* lr_dev, void* stream) {
     if (n <= 0 || !w || !g) return DLRM_E_ARG;
     const bool vec = dlrm_aligned16(w) && dlrm_aligned16(g);
     const long long n4 = vec ? n / 4 : 0;
     long long nblk = (n / 4 + 255) / 256; if (nblk < 1) nblk = 1; if (nblk > 2048) nblk = 2048;
     hipLaunchKernelGGL(sgd_dense_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, n4, (long long)n,
-                       (float4*)w, (const float4*)g, w, g, -lr);
+                       (float4*)w, (const float4*)g, w, g, dlrm_step_neg(lr, lr_dev));
     DLRM_LAUNCH_CHECK();
     return 0;
 }
@@ -403,7 +429,7 @@ extern "C" int dlrm_pad_cols(int64_t M, int K, int Kp, const float* src, int64_t
 }
 
 extern "C" int dlrm_sgd_dense_multi(int count, float* const* w_host, const float* const* g_host, const int64_t* n_host,
-                                    float lr, void* stream) {
+                                    float lr, const float* lr_dev, void* stream) {
     if (count <= 0 || !w_host || !g_host || !n_host) return DLRM_E_ARG;
     for (int c0 = 0; c0 < count; c0 += DLRM_MAX_DENSE_TENSORS) {
         MultiSgdArgs a = {};
@@ -417,7 +443,7 @@ extern "C" int dlrm_sgd_dense_multi(int count, float* const* w_host, const float
             if (blocks > 0x7fffffffLL) return DLRM_E_RANGE;
         }
         a.blk0[m] = (int)blocks; a.count = m;
-        hipLaunchKernelGGL(sgd_dense_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, -lr);
+        hipLaunchKernelGGL(sgd_dense_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, dlrm_step_neg(lr, lr_dev));
         DLRM_LAUNCH_CHECK();
     }
     return 0;

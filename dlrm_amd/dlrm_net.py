@@ -619,7 +619,10 @@ def _embedding_update_plan(optimizer, weights, count=1):
             states.append(st["momentum"])
         if len(set(clrs)) != 1 or len({float(g["eps"]) for g in groups}) != 1:
             sys.exit("ERROR: embedding tables in param groups with different learning rates are not supported")
-        return ("rwsadagrad", clrs[0], float(groups[0]["eps"]), states)
+        clr = clrs[0]
+        if float(groups[0]["lr_decay"]) == 0.0:
+            clr = ops.device_lr(groups[0], clr)          # clr == lr: the group's device scalar while a whole-step graph captures (graph.py)
+        return ("rwsadagrad", clr, float(groups[0]["eps"]), states)
     if not isinstance(optimizer, torch.optim.SGD):
         return ("coo",)
     for g in groups:
@@ -628,4 +631,4 @@ def _embedding_update_plan(optimizer, weights, count=1):
     lrs = [float(g["lr"]) for g in groups]
     if len(set(lrs)) != 1:
         sys.exit("ERROR: embedding tables in param groups with different learning rates are not supported")
-    return ("sgd", lrs[0])
+    return ("sgd", ops.device_lr(groups[0], lrs[0]))     # (the group's device scalar while a whole-step graph captures: graph.py)

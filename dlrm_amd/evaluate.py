@@ -25,7 +25,7 @@ def inference(model, test_batches: Iterable, device: Optional[torch.device] = No
     for i, (X, lS_o, lS_i, T) in enumerate(test_batches):
         if 0 < nbatches <= i:
             break
-        if ext_dist.my_size > 1 and X.size(0) % ext_dist.my_size != 0:
+        if ext_dist.is_distributed() and X.size(0) % ext_dist.my_size != 0:
             print("Warning: Skiping the batch %d with size %d" % (i, X.size(0)))       # reference :784-787
             continue
         if device is not None:
@@ -34,7 +34,7 @@ def inference(model, test_batches: Iterable, device: Optional[torch.device] = No
             lS_i = [x.to(device) for x in lS_i] if isinstance(lS_i, (list, tuple)) else lS_i.to(device)
             T = T.to(device)
         Z = model(X, lS_o, lS_i)
-        if ext_dist.my_size > 1:
+        if ext_dist.is_distributed():
             _, batch_split_lengths = ext_dist.get_split_lengths(X.size(0))
             Z = ext_dist.all_gather(Z, batch_split_lengths)
         scores.append(Z.detach().reshape(-1))

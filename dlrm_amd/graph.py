@@ -23,8 +23,12 @@ Constraints (checked, never silently worked around):
     (csrc/seg_sort.h) whenever every table segment holds <= 262144 lookups — then the graph keeps the sorted update and the fused
     row-wise Adagrad; otherwise it switches SGD to the atomic update and refuses the Adagrad update (GraphedTrainStep.
     _settle_sort_mode).  tests/test_gpu_model.py replays 36 full-batch steps with host syncs in between, bit-identical to eager;
-  * learning rates are baked into kernel arguments at capture time: when a scheduler changes a param group's lr the
-    step is re-captured (correct, but a schedule that changes lr every step gains nothing from replay).
+  * learning rates (round 6): with this package's optimizers (FusedSGD, FusedRWSAdagrad with lr_decay == 0) every captured update kernel
+    reads its step size from a DEVICE scalar (one per param group; include/dlrm_hip.h "LEARNING RATES"), and a replay whose param groups
+    carry new lr values writes them in front of the launch (dlrm_graph_replay / dlrm_set_f32: values in the kernarg, no host buffer, no
+    synchronisation) — the reference's LRPolicyScheduler, which moves lr EVERY iteration during warm-up and decay
+    (dlrm_s_pytorch.py:169-203, :1621), is followed with ONE capture.  Any other optimizer (torch.optim.SGD: its foreach step takes lr as a
+    host number) keeps the old rule: lr is baked in at capture time and a change re-captures the step.
 """
 from __future__ import annotations
 
@@ -93,7 +97,7 @@ class GraphedTrainStep:
     `self.out` holds the predictions of the last step (static buffer)."""
 
     def __init__(self, model, optimizer, warmup: int = 2):
-        if ext_dist.my_size > 1:
+        if ext_dist.is_distributed():       # (a forced one-rank group routes through distributed_forward as well: its RCCL calls must not be captured)
             raise RuntimeError("dlrm_amd.graph: the whole-step HIP graph is single-process only "
                                "(RCCL all-to-all / DDP all-reduce are not captured)")
         self.model, self.optimizer = model, optimizer
@@ -120,6 +124,10 @@ class GraphedTrainStep:
         self.loss: Optional[torch.Tensor] = None
         self.out: Optional[torch.Tensor] = None
         self._lrs: List[float] = []
+        # step sizes on the device: one fp32 scalar per param group, read by the captured update kernels (module docstring)
+        self._lr_on_device = type(optimizer).__name__ in ("FusedSGD", "FusedRWSAdagrad") and _os.environ.get("DLRM_GTS_DEVICE_LR", "1") == "1"
+        self._lr_dev: Optional[torch.Tensor] = None
+        self.lr_writes = 0          # replays that carried new step sizes (observability: tests, bench)
         self.captures = 0
         self._eager_calls = 0
         self._replayed = False
@@ -188,9 +196,18 @@ class GraphedTrainStep:
             return
         if ops.offsets_are_iota(lS_o) is False:
             model.fuse_emb_interact = False
-            if self.graph is not None:
-                self.graph.reset()
-                self.graph = None
+            self._drop_graph(lS_o)
+
+    def _drop_graph(self, like) -> None:
+        """forget the captured step (the next call re-captures): the replay in flight is waited for first, and the raw handle and its
+        cached argument arrays go with the graph — a dangling hipGraphExec_t must never reach dlrm_graph_replay"""
+        if self.graph is None:
+            return
+        dev = like.device if isinstance(like, torch.Tensor) else like[0].device
+        torch.cuda.current_stream(dev).synchronize()
+        self._replayed = False
+        self.graph.reset()
+        self.graph, self._exec, self._raw_arrays = None, None, None
 
     # one eager training step on the static buffers (the reference loop body)
     def _eager(self):
@@ -224,9 +241,21 @@ class GraphedTrainStep:
         if self.graph is not None:
             self.graph.reset()
         self.graph = torch.cuda.CUDAGraph()
-        # backward runs on the autograd engine's thread: "relaxed" lets that thread enqueue into the capturing stream
-        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
-            Z, E = self._eager()
+        groups = self.optimizer.param_groups
+        if self._lr_on_device:
+            # one device scalar per param group, holding the CURRENT lr; registered for the duration of the capture only, so that an eager
+            # step of the same optimizer outside the graph keeps passing its host value
+            self._lr_dev = torch.tensor(self._current_lrs(), dtype=torch.float32, device=dev)
+            self.stream.wait_stream(torch.cuda.current_stream(dev))
+            for i, g in enumerate(groups):
+                ops._graph_lr[id(g)] = self._lr_dev[i:i + 1]
+        try:
+            # backward runs on the autograd engine's thread: "relaxed" lets that thread enqueue into the capturing stream
+            with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode="relaxed"):
+                Z, E = self._eager()
+        finally:
+            for g in groups:
+                ops._graph_lr.pop(id(g), None)
         self.out, self.loss = Z.detach(), E.detach()
         self._lrs = self._current_lrs()
         # the graph holds raw pointers into the cached scratch workspaces: pin those tensors so that a later, larger
@@ -241,6 +270,28 @@ class GraphedTrainStep:
             except Exception:                               # noqa: BLE001 - a torch without the raw handle: keep its own replay
                 self._exec = None
         torch.cuda.current_stream(dev).wait_stream(self.stream)
+
+    def _changed_lrs(self):
+        """(count, device pointers, values) of the step sizes this replay must write first: every group's value whenever any changed (a
+        schedule moves all groups together; at most 16 go with dlrm_graph_replay, more are written by dlrm_set_f32 right here)"""
+        import ctypes as C
+        if not self._lr_on_device or self._lr_dev is None:
+            return 0, None, None
+        lrs = self._current_lrs()
+        if lrs == self._lrs:
+            return 0, None, None
+        self._lrs = lrs
+        self.lr_writes += 1
+        n = len(lrs)
+        if n > 16:
+            ops.set_f32([self._lr_dev[i:i + 1] for i in range(n)], lrs)
+            return 0, None, None
+        base = self._lr_dev.data_ptr()
+        return n, (C.c_void_p * n)(*[base + 4 * i for i in range(n)]), (C.c_float * n)(*lrs)
+
+    def _lr_current_or_on_device(self) -> bool:
+        """True when the captured graph is valid for the optimizer's present learning rates"""
+        return self._lr_on_device or self._lrs == self._current_lrs()
 
     def _raw_replay(self, X, lS_o, lS_i, T) -> bool:
         """the steady state: inputs checked and collected, then ONE call that waits for the previous replay, copies and launches"""
@@ -260,7 +311,8 @@ class GraphedTrainStep:
         _, dst, src, nbytes = arr
         for i, (d, s_) in enumerate(pairs):
             dst[i], src[i], nbytes[i] = d.data_ptr(), s_.data_ptr(), d.numel() * d.element_size()
-        rc = _lib.load().dlrm_graph_replay(n, dst, src, nbytes, C.c_void_p(self._exec), int(self._replayed),
+        ns, sdst, sval = self._changed_lrs()
+        rc = _lib.load().dlrm_graph_replay(n, dst, src, nbytes, ns, sdst, sval, C.c_void_p(self._exec), int(self._replayed),
                                            C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream))
         _lib.check(rc, "dlrm_graph_replay")
         self._keep = pairs                                  # the sources stay alive until the next call (their copies are asynchronous)
@@ -269,7 +321,7 @@ class GraphedTrainStep:
 
     def __call__(self, X, lS_o, lS_i, T):
         if (self._exec is not None and self.static is not None and self.graph is not None and self._eager_calls >= self.warmup
-                and self._lrs == self._current_lrs() and not _TRACE):
+                and self._lr_current_or_on_device() and not _TRACE):
             self._prove_one_lookup_per_bag(lS_o, lS_i)
             if self.graph is not None and self._raw_replay(X, lS_o, lS_i, T):
                 return self.loss
@@ -309,8 +361,12 @@ class GraphedTrainStep:
             self._eager_calls += 1
             self.out, self.loss = Z.detach(), E.detach()
             return self.loss
-        if self.graph is None or self._lrs != self._current_lrs():
+        if self.graph is None or not self._lr_current_or_on_device():
             self._capture()          # capture only records; the replay below executes this step
+        ns, sdst, sval = self._changed_lrs()
+        if ns:                       # torch's replay path: the new step sizes go in front of the launch on the same stream
+            from . import _lib
+            _lib.check(_lib.load().dlrm_set_f32(ns, sdst, sval, torch.cuda.current_stream(dev).cuda_stream), "dlrm_set_f32")
         self.graph.replay()
         self._replayed = self.serialize
         return self.loss

@@ -10,7 +10,7 @@ from __future__ import annotations
 import os
 
 import ctypes as C
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Union
 
 import torch
 
@@ -373,7 +373,29 @@ def sort_lookups(rows: Sequence[int], bags: BagBatch):
     return pos.long() & 0xFFFFFFFF, keys, bag_of.long(), rb.value
 
 
-def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Tensor, lr: float,
+# ---- learning rates: a Python float (by value in the launch) or a 1-element fp32 GPU tensor the kernel reads WHEN IT RUNS (include/dlrm_hip.h,
+# "LEARNING RATES").  The second form is what a captured whole-step HIP graph takes, so that the reference's per-iteration LRPolicyScheduler
+# (dlrm_s_pytorch.py:169-203, stepped at :1621) is followed without re-capture: GraphedTrainStep registers one device scalar per param group for
+# the duration of the capture, the optimizer-side callers ask device_lr(group, value) for it.
+LrLike = Union[float, torch.Tensor]
+_graph_lr = {}          # id(param_group dict) -> 1-element fp32 GPU tensor; populated only while a GraphedTrainStep captures
+
+
+def device_lr(group, value):
+    """the device scalar registered for this param group (inside a graph capture), else `value` unchanged"""
+    t = _graph_lr.get(id(group))
+    return t if t is not None else value
+
+
+def _lr_args(lr: LrLike):
+    if isinstance(lr, torch.Tensor):
+        if lr.dtype != torch.float32 or not lr.is_cuda or lr.numel() != 1:
+            raise RuntimeError("dlrm_amd: a device-side learning rate must be a 1-element float32 GPU tensor")
+        return 0.0, C.c_void_p(lr.data_ptr())
+    return float(lr), None
+
+
+def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Tensor, lr: LrLike,
                 mode: int = UPD_SORTED) -> None:
     """Fused EmbeddingBag backward + sparse SGD: W_t[idx] -= lr * dout[bag, t*D:(t+1)*D] (in place)."""
     lib = _lib.load()
@@ -388,15 +410,16 @@ def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Ten
             raise RuntimeError("dlrm_amd: dlrm_emb_bwd_workspace_bytes failed")
         ws = _emb_workspace(need, dout.device)
         ws_ptr, ws_bytes = C.c_void_p(ws.data_ptr()), ws.numel()
+    lr_v, lr_p = _lr_args(lr)
     with _timed("emb_bwd_sgd"):
         rc = lib.dlrm_emb_bwd_sgd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
-                                  bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout), float(lr), int(mode),
+                                  bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout), lr_v, lr_p, int(mode),
                                   ws_ptr, ws_bytes, None if bags.ignore_oob else C.c_void_p(_err_block(dout.device).data_ptr()), _stream(dout))
     _lib.check(rc, "dlrm_emb_bwd_sgd")
 
 
 def emb_bwd_rowwise_adagrad(weights: Sequence[torch.Tensor], states: Sequence[torch.Tensor], bags: BagBatch,
-                            dout: torch.Tensor, lr: float, eps: float) -> None:
+                            dout: torch.Tensor, lr: LrLike, eps: float) -> None:
     """Fused EmbeddingBag backward + row-wise sparse Adagrad (optim/rwsadagrad.py:117-143), in place:
     per touched row r:  g_r = sum of its lookups' gradients;  states[t][r] += mean(g_r^2);
     W_t[r] -= lr * g_r / (sqrt(states[t][r]) + eps).  `lr` is the decayed clr of rwsadagrad.py:115."""
@@ -414,10 +437,11 @@ def emb_bwd_rowwise_adagrad(weights: Sequence[torch.Tensor], states: Sequence[to
     if need < 0:
         raise RuntimeError("dlrm_amd: dlrm_emb_adagrad_workspace_bytes failed")
     ws = _emb_workspace(need, dout.device)
+    lr_v, lr_p = _lr_args(lr)
     with _timed("emb_bwd_adagrad"):
         rc = lib.dlrm_emb_bwd_rowwise_adagrad(bags.T, bags.B, D, wp, sp, rows, bags._idx, bags._off, bags._nnz,
                                               bags._psw, bags.idx_bits, C.c_void_p(dout.data_ptr()), _ld(dout),
-                                              float(lr), float(eps), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                              lr_v, lr_p, float(eps), C.c_void_p(ws.data_ptr()), ws.numel(),
                                               None if bags.ignore_oob else C.c_void_p(_err_block(dout.device).data_ptr()), _stream(dout))
     _lib.check(rc, "dlrm_emb_bwd_rowwise_adagrad")
 
@@ -1231,17 +1255,17 @@ def scale_by_scalar(x: torch.Tensor, scalar: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def sgd_dense(w: torch.Tensor, g: torch.Tensor, lr: float) -> None:
+def sgd_dense(w: torch.Tensor, g: torch.Tensor, lr: LrLike) -> None:
     lib = _lib.load()
     _req(w, "w"); _req(g, "g")
     if not w.is_contiguous() or not g.is_contiguous() or w.numel() != g.numel():
         raise RuntimeError("dlrm_amd: sgd_dense needs contiguous tensors of equal size")
     with _timed("sgd_dense"):
-        rc = lib.dlrm_sgd_dense(w.numel(), C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), float(lr), _stream())
+        rc = lib.dlrm_sgd_dense(w.numel(), C.c_void_p(w.data_ptr()), C.c_void_p(g.data_ptr()), *_lr_args(lr), _stream())
     _lib.check(rc, "dlrm_sgd_dense")
 
 
-def sgd_dense_multi(ws: Sequence[torch.Tensor], gs: Sequence[torch.Tensor], lr: float) -> None:
+def sgd_dense_multi(ws: Sequence[torch.Tensor], gs: Sequence[torch.Tensor], lr: LrLike) -> None:
     """w -= lr * g for a whole list of dense parameters, one kernel launch."""
     if not ws:
         return
@@ -1253,11 +1277,11 @@ def sgd_dense_multi(ws: Sequence[torch.Tensor], gs: Sequence[torch.Tensor], lr: 
     with _timed("sgd_dense"):
         rc = lib.dlrm_sgd_dense_multi(len(ws), _lib.ptr_array([w.data_ptr() for w in ws]),
                                       _lib.ptr_array([g.data_ptr() for g in gs]), _lib.i64_array([w.numel() for w in ws]),
-                                      float(lr), _stream())
+                                      *_lr_args(lr), _stream())
     _lib.check(rc, "dlrm_sgd_dense_multi")
 
 
-def adagrad_dense(w: torch.Tensor, state_sum: torch.Tensor, g: torch.Tensor, lr: float, eps: float) -> None:
+def adagrad_dense(w: torch.Tensor, state_sum: torch.Tensor, g: torch.Tensor, lr: LrLike, eps: float) -> None:
     """state_sum += g*g; w -= lr * g / (sqrt(state_sum) + eps)   (optim/rwsadagrad.py:145-148)"""
     lib = _lib.load()
     _req(w, "w"); _req(g, "g"); _req(state_sum, "state_sum")
@@ -1265,8 +1289,20 @@ def adagrad_dense(w: torch.Tensor, state_sum: torch.Tensor, g: torch.Tensor, lr:
             w.numel() != g.numel() or w.numel() != state_sum.numel():
         raise RuntimeError("dlrm_amd: adagrad_dense needs contiguous tensors of equal size")
     rc = lib.dlrm_adagrad_dense(w.numel(), C.c_void_p(w.data_ptr()), C.c_void_p(state_sum.data_ptr()),
-                                C.c_void_p(g.data_ptr()), float(lr), float(eps), _stream())
+                                C.c_void_p(g.data_ptr()), *_lr_args(lr), float(eps), _stream())
     _lib.check(rc, "dlrm_adagrad_dense")
+
+
+def set_f32(dsts: Sequence[torch.Tensor], values: Sequence[float]) -> None:
+    """dsts[i][0] = values[i] on the current stream, the values travelling in the kernarg (dlrm_set_f32: at most 16 per call)"""
+    if len(dsts) != len(values):
+        raise RuntimeError("dlrm_amd: set_f32 needs one value per destination")
+    for i in range(0, len(dsts), 16):
+        d, v = dsts[i:i + 16], values[i:i + 16]
+        for t in d:
+            _req(t, "scalar")
+        rc = _lib.load().dlrm_set_f32(len(d), _lib.ptr_array([t.data_ptr() for t in d]), (C.c_float * len(d))(*[float(x) for x in v]), _stream(d[0]))
+        _lib.check(rc, "dlrm_set_f32")
 
 
 _METRIC_NAMES = ("n", "positives", "tp", "fp", "fn", "tn", "roc_auc", "ap", "round_matches")

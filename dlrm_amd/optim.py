@@ -22,7 +22,7 @@ class FusedSGD(torch.optim.SGD):
             with torch.enable_grad():
                 loss = closure()
         for group in self.param_groups:
-            lr = float(group["lr"])
+            lr = ops.device_lr(group, float(group["lr"]))      # (a device scalar while a whole-step graph captures: graph.py)
             ws, gs = [], []
             for p in group["params"]:
                 g = p.grad
@@ -81,5 +81,7 @@ class FusedRWSAdagrad(torch.optim.Optimizer):
                     state["sum"] = torch.full_like(p.data, self.defaults["initial_accumulator_value"], dtype=torch.float32)
                 state["step"] += 1
                 clr = group["lr"] / (1.0 + (state["step"] - 1.0) * group["lr_decay"])
+                if group["lr_decay"] == 0:
+                    clr = ops.device_lr(group, clr)          # (clr == lr: a device scalar while a whole-step graph captures)
                 ops.adagrad_dense(p.data, state["sum"], g if g.is_contiguous() else g.contiguous(), clr, group["eps"])
         return loss

@@ -119,7 +119,7 @@ int dlrm_emb_bwd_sgd(int T, int64_t B, int D,
                      void* const* weight_host, const int64_t* rows_host,
                      const void* const* indices_host, const void* const* offsets_host,
                      const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
-                     const float* dout, int64_t dout_ld, float lr, int mode,
+                     const float* dout, int64_t dout_ld, float lr, const float* lr_dev, int mode,
                      void* workspace, int64_t workspace_bytes, int64_t* err, void* stream);
 
 /* Pooling weights (--weighted-pooling fixed | learned; dlrm_s_pytorch.py:289-293, 370-375, 425-428).
@@ -156,7 +156,7 @@ int dlrm_emb_bwd_rowwise_adagrad(int T, int64_t B, int D,
                      void* const* weight_host, void* const* state_host, const int64_t* rows_host,
                      const void* const* indices_host, const void* const* offsets_host,
                      const int64_t* nnz_host, const void* const* psw_host, int idx_bits,
-                     const float* dout, int64_t dout_ld, float lr, float eps,
+                     const float* dout, int64_t dout_ld, float lr, const float* lr_dev, float eps,
                      void* workspace, int64_t workspace_bytes, int64_t* err, void* stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -396,15 +396,22 @@ int dlrm_mse_loss(int64_t B, const float* p, const float* target,
  * autograd hands over as a device scalar — read on the device, no host synchronisation) */
 int dlrm_scale_by_device_scalar(int64_t n, const float* x, const float* scalar_dev, float* y, void* stream);
 
+/* LEARNING RATES (ABI 15).  Every update entry point takes `float lr` AND `const float* lr_dev`: lr_dev == NULL -> the step size is the by-value
+ * lr, baked into the launch; lr_dev != NULL -> the kernel reads it from that device float WHEN IT RUNS and `lr` is ignored.  The second form is
+ * for captured HIP graphs: the reference steps its LRPolicyScheduler every iteration (dlrm_s_pytorch.py:169-203, :1621), and a graph whose
+ * update kernels read a device scalar follows the schedule without re-capture (dlrm_set_f32 / dlrm_graph_replay write the scalar).  Both forms
+ * multiply with the same fp32 value: bit-identical results. */
 /* dense SGD step over a flat parameter buffer: w -= lr * g   (torch.optim.SGD, no momentum) */
-int dlrm_sgd_dense(int64_t n, float* w, const float* g, float lr, void* stream);
+int dlrm_sgd_dense(int64_t n, float* w, const float* g, float lr, const float* lr_dev, void* stream);
+/* dst_host[i][0] = values_host[i], i < n <= 16: the values travel in the kernarg (no host buffer outlives the call) */
+int dlrm_set_f32(int n, float* const* dst_host, const float* values_host, void* stream);
 /* the same step for `count` parameter tensors in ONE launch (w_host/g_host: host arrays of device pointers,
  * n_host: element counts) — the 16 weight/bias tensors of the two MLP towers (dlrm_s_pytorch.py:1620). */
 int dlrm_sgd_dense_multi(int count, float* const* w_host, const float* const* g_host, const int64_t* n_host,
-                         float lr, void* stream);
+                         float lr, const float* lr_dev, void* stream);
 /* dense Adagrad step, RWSAdagrad's dense branch (optim/rwsadagrad.py:145-148):
  *   sum += g*g;  w -= lr * g / (sqrt(sum) + eps)        (lr = the decayed clr of :115) */
-int dlrm_adagrad_dense(int64_t n, float* w, float* sum, const float* g, float lr, float eps, void* stream);
+int dlrm_adagrad_dense(int64_t n, float* w, float* sum, const float* g, float lr, const float* lr_dev, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Evaluation metrics of the inference pass, on the device (dlrm_s_pytorch.py:759-899: numpy accuracy :819-821,
@@ -465,10 +472,12 @@ int dlrm_multihot_expand(int T, int64_t B, const void* ids, int idx_bits, const 
 /* ---------------------------------------------------------------------------------------
  * One replay of a captured whole-step HIP graph from one host call (dlrm_amd.graph.GraphedTrainStep; the reference loop body
  * dlrm_s_pytorch.py:1574-1621 captured once): optionally wait for the stream (the previous replay), copy n input tensors
- * (device to device, bytes_host[i] each, skipped where source == destination) into the graph's static buffers, hipGraphLaunch.
+ * (device to device, bytes_host[i] each, skipped where source == destination) into the graph's static buffers, write n_scalars
+ * device floats (dlrm_set_f32: the learning rates the captured update kernels read through lr_dev; 0 = none changed), hipGraphLaunch.
  * graph_exec is the hipGraphExec_t (torch.cuda.CUDAGraph.raw_cuda_graph_exec()).  The only entry point that synchronises, and
  * only when asked to. */
-int dlrm_graph_replay(int n, void* const* dst_host, const void* const* src_host, const int64_t* bytes_host, void* graph_exec,
+int dlrm_graph_replay(int n, void* const* dst_host, const void* const* src_host, const int64_t* bytes_host,
+                      int n_scalars, float* const* scalar_dst_host, const float* scalar_values_host, void* graph_exec,
                       int sync_first, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -75,7 +75,10 @@ def sd_np(model, prefix):
 
 def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, lr, loss, itself=False,
                      num_idx=10, fixed=False, seed=123, round_targets=True, compact=False, interaction="dot",
-                     loss_threshold=0.0, loss_weights=None, weighted_pooling=None):
+                     loss_threshold=0.0, loss_weights=None, weighted_pooling=None, lr_schedule=None):
+    """lr_schedule = (num_warmup_steps, decay_start_step, num_decay_steps): the reference's LRPolicyScheduler (dlrm_s_pytorch.py:169-203)
+    built on the optimizer as run() does (:1370) and stepped after every optimizer step (:1621); the lr each step was applied with is
+    recorded as `lrs`."""
     ln_emb = np.asarray(ln_emb)
     ln_bot = np.asarray(ln_bot)
     F = ln_emb.size + 1
@@ -101,8 +104,10 @@ def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, l
     batches = [gen_batch(dp, int(ln_bot[0]), ln_emb, B, num_idx, fixed, round_targets) for _ in range(steps)]
     out.update(pack_batches(batches))
     opt = torch.optim.SGD(model.parameters(), lr=lr)
-    losses = []
+    sched = ref.LRPolicyScheduler(opt, *lr_schedule) if lr_schedule is not None else None
+    losses, lrs = [], []
     for s, (X, lS_o, lS_i, T) in enumerate(batches):
+        lrs.append(float(opt.param_groups[0]["lr"]))
         Z = model(X, lS_o, lS_i)
         E = ref.loss_fn_wrap(Z, T, False, "cpu") if loss == "wbce" else model.loss_fn(Z, T)
         out[f"s{s}.Z"] = Z.detach().numpy().copy()
@@ -116,14 +121,19 @@ def capture_training(ref, dp, name, m_spa, ln_emb, ln_bot, top_tail, B, steps, l
             out["s0.top0_weight_grad"] = model.top_l[0].weight.grad.numpy().copy()
             out["s0.bot0_bias_grad"] = model.bot_l[0].bias.grad.numpy().copy()
         opt.step()
+        if sched is not None:
+            sched.step()
         if s == 0 and not compact:
             out.update(sd_np(model, "after1"))
     out.update(sd_np(model, "final"))
     out["losses"] = np.asarray(losses, dtype=np.float64)
+    if sched is not None:
+        out["lrs"] = np.asarray(lrs, dtype=np.float64)
     meta = dict(name=name, m_spa=int(m_spa), ln_emb=ln_emb.tolist(), ln_bot=ln_bot.tolist(), ln_top=ln_top.tolist(),
                 B=B, steps=steps, lr=lr, loss=loss, itself=bool(itself), sigmoid_top=int(ln_top.size - 2),
                 interaction=interaction, loss_threshold=float(loss_threshold), weighted_pooling=weighted_pooling,
                 loss_ws=None if loss_weights is None else [float(x) for x in loss_weights.split("-")],
+                lr_schedule=None if lr_schedule is None else [int(x) for x in lr_schedule],
                 torch=torch.__version__, reference="facebookresearch/dlrm @ /root/reference (2025-10-03)")
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
@@ -697,6 +707,15 @@ def main(which):
         # --weighted-pooling=learned: per-row pooling weights as parameters (dlrm_s_pytorch.py:289-293, 370-375, 425-428), multi-hot bags
         capture_training(ref, dp, "learned_pooling", 8, [20, 3, 150], [6, 12, 8], [10, 1], B=48, steps=3, lr=0.3, loss="bce",
                          num_idx=5, weighted_pooling="learned")
+    if which in ("all", "train", "lr_schedule"):
+        # the reference's learning-rate schedule (LRPolicyScheduler, :169-203; --lr-num-warmup-steps=3 --lr-decay-start-step=5
+        # --lr-num-decay-steps=4): warm-up 0, 1/3, 2/3 of lr, two steps at lr, quadratic decay, then frozen — a different lr on almost every
+        # one of the 11 steps; multi-hot bags with hot rows (every update mode sees duplicates)
+        capture_training(ref, dp, "lr_schedule_tiny", 8, [40, 6, 300], [7, 16, 8], [12, 1], B=64, steps=11, lr=0.8, loss="bce",
+                         num_idx=4, lr_schedule=(3, 5, 4), compact=True)
+        # ... and on the fused lookup + interaction path of the Criteo data sets (one lookup per bag, D = 128)
+        capture_training(ref, dp, "lr_schedule_onehot_d128", 128, [50, 9, 700, 3], [13, 32, 128], [64, 1], B=96, steps=8, lr=0.5, loss="bce",
+                         num_idx=1, fixed=True, lr_schedule=(2, 3, 3), compact=True)
     if which in ("all", "kaggle"):
         # BASELINE.json configs[1]: Criteo-Kaggle shapes — 26 tables, D = 16, bot 13-512-256-64-16, top 512-256-1
         # (bench/dlrm_s_criteo_kaggle.sh:24), batch 2048, one lookup per bag; table rows capped at 600 to keep the fixture small

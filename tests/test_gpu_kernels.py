@@ -1429,6 +1429,65 @@ def test_dense_optimizer_kernels():
     np.testing.assert_allclose(dw.cpu().numpy(), w - 0.05 * g / (np.sqrt(s2) + 1e-10), rtol=1e-5, atol=1e-6)
 
 
+def test_learning_rate_from_a_device_scalar_is_bit_identical_to_by_value():
+    """include/dlrm_hip.h "LEARNING RATES" (ABI 15): every update entry point takes its step size by value OR reads it from a device float when
+    the kernel runs (what a captured HIP graph needs to follow the reference's per-iteration LRPolicyScheduler, dlrm_s_pytorch.py:169-203).
+    Both forms multiply with the same fp32 value: deterministic / row-wise-Adagrad / dense kernels must agree BIT FOR BIT, the sorted and
+    atomic embedding updates up to the order of their atomic adds; a later write to the scalar (dlrm_set_f32) is what the next launch sees."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(17)
+    D, rows, B = 32, [7, 3000, 90], 2500
+    bags = [ragged(rng, B, n, 3) for n in rows]
+    dV = to_dev((rng.standard_normal((B, len(rows) * D)) * 0.1).astype(np.float32))
+    W0 = [rng.standard_normal((n, D)).astype(np.float32) for n in rows]
+    bb = ops.BagBatch([to_dev(o) for o, _ in bags], [to_dev(i) for _, i in bags])
+    lr = 0.3125 + 1e-3                                           # not exactly representable: float(lr) is what both forms must use
+    lr_t = torch.zeros(1, device=dev())
+    ops.set_f32([lr_t], [lr])
+    assert float(lr_t) == float(np.float32(lr))
+    for mode, exact in ((ops.UPD_DETERMINISTIC, True), (ops.UPD_SORTED, False), (ops.UPD_ATOMIC, False)):
+        got = []
+        for step in (lr, lr_t):
+            dW = [to_dev(W) for W in W0]
+            ops.emb_bwd_sgd(dW, bb, dV, step, mode)
+            torch.cuda.synchronize()
+            got.append([w.cpu().numpy() for w in dW])
+        for a, b in zip(*got):
+            if exact:
+                assert np.array_equal(a, b)
+            else:
+                np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+    got = []
+    for step in (lr, lr_t):
+        dW = [to_dev(W) for W in W0]
+        dM = [torch.zeros(n, device=dev()) for n in rows]
+        ops.emb_bwd_rowwise_adagrad(dW, dM, bb, dV, step, 1e-8)
+        torch.cuda.synchronize()
+        got.append([w.cpu().numpy() for w in dW] + [m.cpu().numpy() for m in dM])
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)
+    n = 4097
+    w0, g0, s0 = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32), np.abs(rng.standard_normal(n)).astype(np.float32)
+    res = []
+    for step in (lr, lr_t):
+        w1, w2, w3, sm = to_dev(w0), to_dev(w0), to_dev(w0), to_dev(s0)
+        ops.sgd_dense(w1, to_dev(g0), step)
+        ops.sgd_dense_multi([w2], [to_dev(g0)], step)
+        ops.adagrad_dense(w3, sm, to_dev(g0), step, 1e-10)
+        torch.cuda.synchronize()
+        res.append([t.cpu().numpy() for t in (w1, w2, w3, sm)])
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    # the scalar is read when the kernel RUNS: rewrite it, launch again with the same tensor
+    ops.set_f32([lr_t], [0.0])
+    w = to_dev(w0)
+    ops.sgd_dense(w, to_dev(g0), lr_t)
+    torch.cuda.synchronize()
+    assert np.array_equal(w.cpu().numpy(), w0)
+    with pytest.raises(RuntimeError):
+        ops.sgd_dense(w, to_dev(g0), torch.zeros(1, dtype=torch.float64, device=dev()))
+
+
 # ------------------------------------------------------------------------------------------ evaluation metrics
 def test_binary_metrics_match_scikit_learn_golden():
     from conftest import load_golden

@@ -178,6 +178,96 @@ def test_graphed_step_equals_eager_step(update, monkeypatch):
             np.testing.assert_allclose(results[0][1][k].cpu().numpy(), results[1][1][k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
 
 
+def _run_schedule(name, device, mode, graphed, monkeypatch=None, raw="1", ragged_at=None):
+    """the fixture's steps with the lr of every step set as the reference's scheduler set it (d["lrs"]); returns (losses, state_dict, step)"""
+    import dlrm_amd
+    from dlrm_amd.graph import GraphedTrainStep
+    from dlrm_amd.optim import FusedSGD
+    d, meta = load_golden(name)
+    model = build_model(meta, params_with_prefix(d, "init"), device, mode=mode)
+    opt = FusedSGD(model.parameters(), lr=meta["lr"])
+    if monkeypatch is not None:
+        monkeypatch.setenv("DLRM_GTS_RAW", raw)
+        monkeypatch.setenv("DLRM_GRAPH_SORTED", "1")
+    step = GraphedTrainStep(model, opt, warmup=2) if graphed else None
+    losses = []
+    for s, (X, lS_o, lS_i, T) in enumerate(golden_batches(d, meta)):
+        for g in opt.param_groups:
+            g["lr"] = float(d["lrs"][s])
+        Xd, Td = torch.from_numpy(X).to(device), torch.from_numpy(T).to(device)
+        lS_od = [torch.from_numpy(o).to(device) for o in lS_o]
+        lS_id = [torch.from_numpy(i).to(device) for i in lS_i]
+        if ragged_at is not None and s == ragged_at:
+            # still B lookups per table, but bag 0 is empty and bag 1 holds two of them: NOT one lookup per bag
+            for o in lS_od:
+                o[1] = 0
+        if graphed:
+            losses.append(float(step(Xd, lS_od, lS_id, Td)))
+        else:
+            E = model.loss_fn(model(Xd, lS_od, lS_id), Td)
+            opt.zero_grad()
+            E.backward()
+            opt.step()
+            losses.append(float(E.detach()))
+            del E
+    torch.cuda.synchronize()
+    return d, losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, step
+
+
+@pytest.mark.parametrize("name,mode,graphed,raw", [
+    ("lr_schedule_tiny", 1, False, "1"), ("lr_schedule_tiny", 2, False, "1"), ("lr_schedule_tiny", 0, False, "1"),
+    ("lr_schedule_onehot_d128", 1, False, "1"), ("lr_schedule_onehot_d128", 2, False, "1"),
+    ("lr_schedule_onehot_d128", 1, True, "1"), ("lr_schedule_onehot_d128", 2, True, "1"), ("lr_schedule_onehot_d128", 0, True, "1"),
+    ("lr_schedule_onehot_d128", 1, True, "0")],
+    ids=["multihot-deterministic", "multihot-sorted", "multihot-atomic", "onehot-deterministic", "onehot-sorted",
+         "onehot-graph-deterministic", "onehot-graph-sorted", "onehot-graph-atomic", "onehot-graph-torch-replay"])
+def test_lr_schedule_matches_reference_golden(name, mode, graphed, raw, monkeypatch):
+    """SURVEY a-17 / VERDICT r5 #2: a learning rate that CHANGES between steps, against the live reference run with its own
+    LRPolicyScheduler (oracle/make_golden.py `lr_schedule`: warm-up, plateau, quadratic decay, frozen tail; dlrm_s_pytorch.py:169-203,
+    :1621).  Every step's loss within the 1e-5 bar and the final parameters — for the eager step in all three update modes (multi-hot bags
+    with hot rows; one lookup per bag on the fused lookup + interaction path) and for the whole-step HIP GRAPH, where the captured update
+    kernels read their step size from a device scalar: ONE capture for the whole schedule, one scalar write per change."""
+    device = torch.device("cuda:0")
+    d, losses, sd, step = _run_schedule(name, device, mode, graphed, monkeypatch, raw)
+    assert len(set(np.round(d["lrs"], 9))) >= 4                                   # the schedule really moves
+    for s_, (a, b) in enumerate(zip(losses, d["losses"])):
+        assert abs(a - b) <= 1e-5 * abs(b), (s_, a, b, float(d["lrs"][s_]))
+    for k, v in params_with_prefix(d, "final").items():
+        np.testing.assert_allclose(sd[k].cpu().numpy(), v, rtol=1e-4, atol=5e-6, err_msg=k)
+    if graphed:
+        assert step.captures == 1, "a changing learning rate re-captured the step"
+        lrs = [float(x) for x in d["lrs"]]
+        # replays start at call 2 (two warm-up calls); the capture bakes nothing in, every later change is one scalar write
+        changes = sum(1 for i in range(3, len(lrs)) if lrs[i] != lrs[i - 1])
+        assert step.lr_writes == changes, (step.lr_writes, changes, lrs)
+        assert (step._exec is not None) == (raw == "1")
+
+
+def test_graphed_lr_schedule_is_bit_identical_to_eager(monkeypatch):
+    """the same schedule, graph against eager, deterministic update: not one bit apart (the device scalar holds the very fp32 value the
+    eager launch passes by value)"""
+    device = torch.device("cuda:0")
+    _, le, sde, _ = _run_schedule("lr_schedule_onehot_d128", device, 1, False)
+    _, lg, sdg, step = _run_schedule("lr_schedule_onehot_d128", device, 1, True, monkeypatch)
+    assert le == lg, (le, lg)
+    for k in sde:
+        assert torch.equal(sde[k], sdg[k]), k
+
+
+@pytest.mark.parametrize("raw", ["1", "0"])
+def test_ragged_batch_during_replay_recaptures_and_equals_eager(raw, monkeypatch):
+    """a batch that is NOT one lookup per bag (bag 0 empty, bag 1 double) arrives while the graph of the fused lookup +
+    interaction path is being replayed.  The proof in front of the replay must catch it, the captured step (and its raw executable handle)
+    must be dropped only after the replay in flight has finished, and the re-captured two-kernel step must give what the eager step gives."""
+    device = torch.device("cuda:0")
+    _, le, sde, _ = _run_schedule("lr_schedule_onehot_d128", device, 1, False, ragged_at=5)
+    _, lg, sdg, step = _run_schedule("lr_schedule_onehot_d128", device, 1, True, monkeypatch, raw=raw, ragged_at=5)
+    assert step.captures == 2 and step.model.fuse_emb_interact is False
+    np.testing.assert_allclose(le, lg, rtol=1e-6)          # (fused and two-kernel forward differ in the last bits before the switch)
+    for k in sde:
+        np.testing.assert_allclose(sde[k].cpu().numpy(), sdg[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
 def test_inference_metrics_on_device():
     """dlrm_amd.evaluate.inference (forward + device-side metrics) against the oracle forward + numpy metrics."""
     from dlrm_amd.evaluate import inference
@@ -592,7 +682,8 @@ def test_launcher_trains_under_the_unmodified_reference_run(tmp_path):
     """`python -m dlrm_amd.launch` — the reference's own run() (CLI, data generation, training loop, timing,
     printing, LR scheduler) with OUR DLRM_Net / ext_dist swapped in — trains on the GPU end to end: losses are printed by the
     reference loop, finite, and equal to the reference's own CPU run of the same command line within the 1e-5 bar at the
-    first iteration (identical seeds => identical initial parameters and data)."""
+    first iteration (identical seeds => identical initial parameters and data) and at every later one — under a learning-rate
+    SCHEDULE (round 6, SURVEY a-17): a step that used the wrong lr shows up in the next printed loss."""
     import re
     import subprocess
     import sys
@@ -600,7 +691,10 @@ def test_launcher_trains_under_the_unmodified_reference_run(tmp_path):
     env = dict(os.environ, PYTHONPATH=root, PYTHONDONTWRITEBYTECODE="1")
     cli = ["--arch-sparse-feature-size=16", "--arch-embedding-size=1000-1000-1000", "--arch-mlp-bot=13-512-16",
            "--arch-mlp-top=22-256-1", "--mini-batch-size=128", "--data-generation=random", "--num-batches=6", "--nepochs=1",
-           "--print-freq=1", "--print-time", "--numpy-rand-seed=123", "--learning-rate=0.1"]
+           "--print-freq=1", "--print-time", "--numpy-rand-seed=123", "--learning-rate=0.1",
+           # the reference's LRPolicyScheduler (:169-203, stepped every iteration at :1621): warm-up over 2 steps, quadratic decay from step 3
+           # over 3 steps — lr differs on almost every one of the 6 iterations, for the dense step AND the fused embedding update
+           "--lr-num-warmup-steps=2", "--lr-decay-start-step=3", "--lr-num-decay-steps=3"]
     ours = subprocess.run([sys.executable, "-m", "dlrm_amd.launch", "--reference", _REF, "--"] + cli + ["--use-gpu"],
                           cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     assert ours.returncode == 0, ours.stderr[-3000:]
