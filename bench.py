@@ -123,11 +123,17 @@ def parse():
     ap.add_argument("--timer-every", type=int, default=4,
                     help="per-kernel HIP events are recorded on every n-th step of the timed region (an event is a queue barrier, "
                          "~5 us: one per change of launch category, ~0.1 ms per instrumented step; dlrm_amd.ops.KernelTimers)")
+    ap.add_argument("--no-reference-region", action="store_true", help="skip the reference_timed_region leg (the same steps with the reference "
+                                                                        "loop's per-step H2D input copies and loss read-back inside the timing)")
     ap.add_argument("--cpu-row-cap", type=int, default=4000000, help="row cap of the baseline legs' tables (SURVEY 8d: 4 M)")
-    ap.add_argument("--cpu-steps", type=int, default=4, help="timed iterations of the CPU baseline (median reported; 10 in rounds 1-4)")
-    ap.add_argument("--cpu-warmup", type=int, default=2)
-    ap.add_argument("--cpu-budget", type=float, default=35.0, help="seconds of host time the CPU baseline leg may take (warm-up + as many of "
-                                                                    "--cpu-steps as fit, at least 3): ~30 s of CPU work at 6 s per iteration")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed iterations of the CPU baseline (median reported; SURVEY 8d: >= 10)")
+    ap.add_argument("--cpu-warmup", type=int, default=3, help="warm-up iterations of the CPU baseline (SURVEY 8d: >= 3)")
+    ap.add_argument("--cpu-batch", type=int, default=16384,
+                    help="rows of the global batch the CPU baseline leg iterates over (a BOUNDED sample of the same workload: the first rows of the GPU "
+                         "run's first batch, same tables / weights; 0 = the whole global batch, ~6 s per iteration on this pool's hosts).  samples/s is "
+                         "what is compared; 3 + 10 iterations of 16384 samples are ~20-25 s of host time")
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of host time the CPU baseline leg may take: a safety net only (the timed "
+                                                                    "iterations are cut short, never below 3, when a host is slower than expected)")
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
     ap.add_argument("--a2a-chunks", type=int, default=int(os.environ.get("DLRM_A2A_CHUNKS", "1")),
                     help="N > 1: schedule of the HEADLINE measurement. 1 (default) = the reference schedule: one all-to-all per "
@@ -340,8 +346,12 @@ def baseline_state(model, batch, wl, ln_top, args):
     tables = [e.weight.detach()[:cap].cpu().contiguous() for e in model.emb_l]
     rows = torch.tensor([t.shape[0] for t in tables], dtype=idx.dtype, device=idx.device).view(-1, 1)
     mlp = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if not k.startswith("emb_l.")}
+    full = (X.cpu(), off.cpu(), (idx % rows).cpu(), T.cpu())
+    nb = int(args.cpu_batch) if 0 < int(args.cpu_batch) < X.shape[0] else X.shape[0]
+    # the CPU leg's sample: the first nb samples of that batch (one lookup per bag: bag b of every table is lookup b, so the slice is a batch)
+    sample = (full[0][:nb].contiguous(), full[1][:, :nb].contiguous(), full[2][:, :nb].contiguous(), full[3][:nb].contiguous())
     return {"m_spa": wl["D"], "ln_bot": list(wl["bot"]), "ln_top": [int(v) for v in ln_top], "tables": tables, "mlp": mlp,
-            "batch": (X.cpu(), off.cpu(), (idx % rows).cpu(), T.cpu()), "row_cap": cap}
+            "batch": full, "cpu_batch": sample, "row_cap": cap}
 
 
 def baseline_legs(state, args, device):
@@ -363,7 +373,7 @@ def baseline_legs(state, args, device):
     params = {f"emb_l.{k}.weight": t for k, t in enumerate(state["tables"])}
     params.update(state["mlp"])
     m = TorchPortDLRM(params, sigmoid_top=len(state["ln_top"]) - 2, loss="bce", lr=args.lr)
-    X, off, idx, T = state["batch"]
+    X, off, idx, T = state.get("cpu_batch", state["batch"])
     off, idx = list(off), list(idx)
     times, t_begin = [], time.time()
     for it in range(args.cpu_warmup + args.cpu_steps):
@@ -596,6 +606,89 @@ def resolve_world(args, argv=None, environ=None):
               f"that was not asked for", file=sys.stderr)
         sys.exit(2)
     return "run", world
+
+
+KERNELS_OF_CATEGORY = [      # launch category of dlrm_amd.ops -> substrings of the kernels one of its C-ABI calls launches (headline workload)
+    ("emb_bwd_sgd", ["expand_kernel", "seg_hist_kernel", "seg_colscan_kernel", "seg_groupscan_kernel", "seg_binscan_kernel", "seg_scatter_kernel",
+                     "sorted_update_kernel", "emb_bwd_sgd_"]),
+    ("linear_bwd_weight", ["gemm3_kernel<false, false", "splitk_reduce_kernel", "smallk_wgrad", "gemv_bwd_weight"]),
+    ("linear_bwd_data", ["gemm3_kernel<true, false", "gemv_bwd_data"]),
+    ("linear_fwd", ["gemm3_kernel<true, true", "gemv_fwd", "pad_cols_kernel"]),
+    ("emb_interact_fwd", ["interact_fwd_dma_kernel"]), ("emb_interact_bwd", ["interact_bwd_dma_kernel"]),
+    ("sgd_dense", ["sgd_dense"]), ("bce_loss", ["bce_kernel", "loss_finish_kernel", "scale_kernel"]), ("act_bwd", ["act_bwd_kernel"]),
+    ("iota_proof", ["offsets_iota_kernel"])]
+
+
+def kernel_launches_per_step():
+    """KERNEL launches per training step by launch category, counted from the committed rocprofv3 --kernel-trace --stats summary of this
+    command (profiles/round*/rocprof_kernel_stats.csv; steps = launches of the dense-SGD kernel) — a C-ABI call is 1-11 kernels (the sorted
+    embedding update: expand + two radix rounds of four kernels + the update), which `c_abi_calls_per_step` alone hides."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "rocprof_kernel_stats.csv")))
+    if not files:
+        return None
+    rows = list(csv.DictReader(open(files[-1])))
+    steps = sum(int(r["Calls"]) for r in rows if "sgd_dense_multi_kernel" in r["Name"])
+    if steps <= 0:
+        return None
+    out, total = {}, 0
+    for r in rows:
+        for cat, subs in KERNELS_OF_CATEGORY:
+            if any(s_ in r["Name"] for s_ in subs):
+                out[cat] = out.get(cat, 0) + int(r["Calls"])
+                total += int(r["Calls"])
+                break
+    return {"by_category": {c: round(v / steps, 2) for c, v in out.items()}, "total": round(total / steps, 1),
+            "source": os.path.relpath(files[-1], ROOT), "steps_in_profile": steps}
+
+
+def scaling_model(kernels, ms_step, B, T, D, emb_standalone, link_gbs=153.0, link_eff=0.7, allreduce_bytes=9.48e6):
+    """PREDICTED step time at 1 / 2 / 4 / 8 GPUs of one node, made from THIS run's measured single-GPU kernel times and the guide's xGMI link
+    rate, BEFORE any multi-GPU measurement exists (no multi-GPU node was reachable in rounds 1-6: SCALE_rNN is `skipped`) — so that the first
+    measured curve lands beside a prediction (tools/scaling_model.py is the same arithmetic as a script).
+    Strong scaling of the global batch B, the reference's partition (extend_distributed.py:47-62, dlrm_s_pytorch.py:528-585):
+      * MLP towers, interaction, loss, dense step: batch-split -> measured time / N (the efficiency loss of N-times shorter GEMMs is NOT modelled:
+        optimistic by a few % at N = 8, where M = 8192 rows still fill the chip twice);
+      * lookups and the fused sparse update: table-split, the WHOLE batch for ceil(T / N) of T tables (the fused lookup + interaction kernels are
+        single-process only: the distributed forward runs dlrm_emb_fwd -> measured stand-alone here);
+      * all-to-all of pooled embeddings, each direction: a rank sends (B / N) * T_loc * D * 4 bytes to every peer over its own xGMI link
+        (7 links x 153 GB/s per GPU, point to point): time = bytes per peer / (link rate x efficiency); the forward one overlaps the bottom
+        MLP (dlrm_s_pytorch.py:563-568), the backward one the bottom tower's backward: only what exceeds them is exposed;
+      * DDP all-reduce of the 9.48 MB of MLP gradients: ring over the slowest link, 2 (N - 1) / N x bytes / link rate, overlapped with the backward
+        GEMMs -> exposed only beyond them (never at these sizes)."""
+    k = {n: v["ms_per_step"] for n, v in kernels.items() if "ms_per_step" in v}
+    gemm = k.get("linear_fwd", 0) + k.get("linear_bwd_data", 0) + k.get("linear_bwd_weight", 0)
+    other_dense = k.get("act_bwd", 0) + k.get("bce_loss", 0) + k.get("sgd_dense", 0)
+    inter = k.get("interact_fwd", 0) + k.get("interact_bwd", 0)
+    emb_f = k.get("emb_fwd", 0)
+    if "emb_interact_fwd" in k:                       # fused on one GPU: split into a lookup share (what table-sharding scales) and an interaction share
+        emb_f = (emb_standalone or {}).get("ms", 0.33)
+        inter = max(k["emb_interact_fwd"] + k.get("emb_interact_bwd", 0), 0.0) + 0.25      # + the pooled-buffer round trip of the two-kernel forward (DESIGN: 0.25 ms at B = 65536)
+    emb_b = k.get("emb_bwd_sgd", k.get("emb_bwd_adagrad", 0))
+    bot_share = 0.0722                                  # bottom tower's share of the tower FLOPs (340 992 of 4 730 368 per sample)
+    out = {}
+    for N in (1, 2, 4, 8):
+        if N == 1:
+            out["1"] = {"ms_per_step": ms_step, "samples_per_s": B / ms_step * 1e3, "measured": True}
+            continue
+        t_loc = -(-T // N)
+        dense = (gemm + other_dense + inter) / N
+        emb = (emb_f + emb_b) * t_loc / T
+        a2a = (B / N) * t_loc * D * 4 / (link_gbs * link_eff * 1e9) * 1e3
+        exposed_f = max(a2a - bot_share * k.get("linear_fwd", 0) / N, 0.0)
+        exposed_b = max(a2a - bot_share * (k.get("linear_bwd_data", 0) + k.get("linear_bwd_weight", 0)) / N, 0.0)
+        allred = 2.0 * (N - 1) / N * allreduce_bytes / (link_gbs * link_eff * 1e9) * 1e3
+        exposed_ar = max(allred - (1 - bot_share) * (k.get("linear_bwd_data", 0) + k.get("linear_bwd_weight", 0)) / N, 0.0)
+        step = dense + emb + exposed_f + exposed_b + exposed_ar
+        out[str(N)] = {"ms_per_step": step, "samples_per_s": B / step * 1e3, "efficiency_vs_linear": ms_step / step / N,
+                       "dense_ms": dense, "embedding_ms": emb, "all_to_all_ms_each_way": a2a, "all_to_all_exposed_ms": exposed_f + exposed_b,
+                       "allreduce_ms": allred, "tables_per_rank_max": t_loc}
+    out["assumptions"] = {"link_gbs": link_gbs, "link_efficiency": link_eff, "scaling": "strong (global batch fixed)",
+                          "status": "PREDICTION from single-GPU measurements of this run; no multi-GPU measurement exists yet",
+                          "not_modelled": ["shorter GEMMs' efficiency", "table-size imbalance between ranks (the 4-table ranks hold two 40 M-row tables)",
+                                           "host launch path (~1 ms per step bounds the step from below at N = 8)"]}
+    return out
 
 
 def main():
@@ -1019,6 +1112,11 @@ def main():
                                         "traffic_gbps (PMC HBM bytes / time)", "frac_traffic (traffic_gbps / 8000)"],
                 "embedding_hbm_gbps": emb_gbps, "box": box}
 
+    klaunch = kernel_launches_per_step() if (N == 1 and args.workload == "criteo_terabyte" and graphed is None) else None
+    for name, k in kernels.items():
+        k["c_abi_calls_per_step"] = k.get("launches_per_step")          # ("launches_per_step" stays as the older name of the same number: C-ABI calls)
+        k["kernel_launches_per_step"] = (klaunch or {}).get("by_category", {}).get(name)
+    cat_sum = sum(k["ms_per_step"] for k in kernels.values() if "ms_per_step" in k)
     emb_gbps = {"fwd": kernels.get("emb_fwd", {}).get("achieved"), "bwd_sgd": kernels.get("emb_bwd_sgd", {}).get("achieved"),
                 "fwd_fused_with_interaction": kernels.get("emb_interact_fwd", {}).get("achieved"),
                 "fwd_traffic": kernels.get("emb_interact_fwd", kernels.get("emb_fwd", {})).get("traffic_gbps"),
@@ -1059,14 +1157,16 @@ def main():
                                          "v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulate, fp32 master weights (reduced precision: NOT the headline "
                                          "configuration)"}[args.mlp_arith]},
         "final_loss": final_loss,
-        "launches": {"c_abi_calls_per_step": calls_per_step, "us_per_step": ms * 1e3,
+        "launches": {"c_abi_calls_per_step": calls_per_step, "kernel_launches_per_step": klaunch, "us_per_step": ms * 1e3,
                      "note": "categorised C-ABI calls of one eager step (one call = 1-4 kernel launches; rocprofv3 kernel counts per step: "
                              "profiles/round5/step_trace.txt — 52 at Criteo-Terabyte shapes —, step_trace_kaggle_graph_towers_v5.txt — 19 at "
                              "Criteo-Kaggle shapes with the small-batch tower kernels); the whole-step HIP graph (--graph) replays them with one launch"},
         "box": box,
         "parity_check": parity,
         "kernel_timing": "HIP events on the launch stream, one per change of launch category (a run of consecutive launches of one category "
-                         "is one event pair; dlrm_amd.ops.KernelTimers), on %d of the %d timed steps" % (timed_steps, args.steps),
+                         "is one event pair; dlrm_amd.ops.KernelTimers), on %d of the %d timed steps.  An event is a queue barrier (~5 us) charged to "
+                         "the category it closes: the categories sum to %.3f ms against the %.3f ms step (+%.1f %%) — every frac of this line is "
+                         "that much pessimistic, none optimistic" % (timed_steps, args.steps, cat_sum, ms, (cat_sum / ms - 1) * 100 if ms else 0),
         "roofline": roof(dom) if dom else None,
         "roofline_embedding": roof("emb_fwd") if "emb_fwd" in kernels else None,
         "embedding_hbm_gbps": emb_gbps,
@@ -1121,6 +1221,55 @@ def main():
             result["high_row_check"] = high_row_check(model, D, device)
         except Exception as e:                              # noqa: BLE001 - a report beside the headline
             result["high_row_check"] = {"ok": False, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        partial["json"] = json.dumps(result)
+    if N == 1 and graphed is None and not hot and not args.no_reference_region:
+        # ---- the reference's FULL timed region ("stock_gpu_baseline pays both, ours excludes both").  Between its time_wrap
+        # calls (dlrm_s_pytorch.py:1558,1626) the reference loop also moves the batch to the device (dlrm_wrap :129-145: X / lS_o / lS_i .to(device)
+        # from the loader's host tensors; T in loss_fn_wrap :150-156) and reads the loss back (`L = E.detach().cpu().numpy()`, :1592, before
+        # backward).  The headline keeps inputs resident (the contract of this bench; f-2 moved the producer to the device) and never reads
+        # the loss; THIS leg runs the same steps with both inside the timing, from pageable host tensors as a DataLoader hands them over:
+        # what the headline omits is a number in the line, and stock_gpu_baseline has a like-for-like partner.
+        try:
+            keep_timers, ops.timers = ops.timers, None
+            host = [tuple(t.cpu() for t in b) for b in batches]
+            nref = max(min(args.steps, 10), 3)
+
+            def ref_region_step(i):
+                Xh, oh, ih, Th = host[i % len(host)]
+                X, off, idx = Xh.to(device), oh.to(device), ih.to(device)          # dlrm_wrap
+                Z = model(X, off, idx)
+                E = model.loss_fn(Z, Th.to(device))                                  # loss_fn_wrap
+                L = E.detach().cpu().numpy()                                         # :1592
+                opt.zero_grad()
+                E.backward(one)
+                opt.step()
+                return float(L)
+            for i in range(2):
+                ref_region_step(i)
+            torch.cuda.synchronize()
+            t0r = time.perf_counter()
+            for i in range(nref):
+                lr_ = ref_region_step(2 + i)
+            torch.cuda.synchronize()
+            dtr = (time.perf_counter() - t0r) / nref
+            h2d = sum(t.numel() * t.element_size() for t in host[0])
+            result["reference_timed_region"] = {
+                "ms_per_step": dtr * 1e3, "value": B / dtr, "unit": "samples/s", "steps": nref, "final_loss": lr_,
+                "h2d_bytes_per_step": h2d, "headline_ms_per_step": ms, "cost_of_what_the_headline_omits_ms": dtr * 1e3 - ms,
+                "what": "the headline's steps with the reference loop's per-step host work INSIDE the timing: four .to(device) copies of a "
+                        "pageable host batch (dlrm_wrap / loss_fn_wrap, dlrm_s_pytorch.py:129-156) and the loss read-back before backward "
+                        "(:1592, a host synchronisation); every step therefore also gets a new untagged offsets tensor (proof inside).  "
+                        "stock_gpu_baseline times the unmodified reference the same way: value / stock_gpu_baseline.value is like for like"}
+            ops.timers = keep_timers
+            del host
+        except Exception as e:                              # noqa: BLE001 - a report beside the headline
+            result["reference_timed_region"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        partial["json"] = json.dumps(result)
+    if N == 1 and not hot:
+        try:
+            result["scaling_model"] = scaling_model(kernels, ms, B, len(rows), D, result.get("embedding_kernel_standalone"))
+        except Exception as e:                              # noqa: BLE001
+            result["scaling_model"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         partial["json"] = json.dumps(result)
     if N == 1 and not args.no_rccl_selfcheck:
         result["rccl_selfcheck"] = rccl_selfcheck()

@@ -93,48 +93,47 @@ def time_loop(ref, model, batch, lr, use_gpu, device, warmup, steps):
     return times, loss
 
 
-def run(state, lr, cpu_warmup=2, cpu_steps=4, gpu_warmup=3, gpu_steps=10, gpu_device=None, cpu_budget_s=35.0):
+def run(state, lr, cpu_warmup=3, cpu_steps=10, gpu_warmup=3, gpu_steps=10, gpu_device=None, cpu_budget_s=60.0):
     """state: m_spa, ln_bot, ln_top, tables (list of CPU fp32 [rows, D]), mlp (state_dict names -> CPU tensors), batch
-    (X [B,13] f32, lS_o [T,B] i64, lS_i [T,B] i64, T [B,1] f32; CPU), row_cap.  Returns (cpu_baseline, stock_gpu_baseline) or None
-    when oracle/_ref is absent.
+    (X [B,13] f32, lS_o [T,B] i64, lS_i [T,B] i64, T [B,1] f32; CPU), cpu_batch (the CPU leg's sample: the first rows of `batch`),
+    row_cap.  Returns (cpu_baseline, stock_gpu_baseline) or None when oracle/_ref is absent.
 
-    The CPU leg is BOUNDED (`cpu_budget_s` of host time, ~30 s by default: bench.py must finish within minutes and the box's time is
-    metered): the first iteration runs at torch's default thread count (the physical cores) and counts as a warm-up; os.cpu_count()
-    threads are only tried where an iteration costs less than a twentieth of the budget — on the 2 x 64-core boxes of this
-    pool 256 threads took 47-49 s per iteration against ~6 s at 128 in every round that probed it (the `probe_ms_per_step` of
-    profiles/round2-5), which a 30 s leg cannot afford to re-establish — then `cpu_warmup` warm-up iterations in all (the probes count) and
-    as many timed iterations (<= cpu_steps, >= 3) as the budget allows; median reported."""
+    The CPU leg follows SURVEY 8(d)'s protocol — >= 3 warm-up + >= 10 timed iterations, median — on a BOUNDED SAMPLE of the workload (the
+    first `cpu_batch` rows of the GPU run's batch; the metric is samples/s) so that the whole leg is ~20-30 s of host time.  Thread count:
+    torch's default (the physical cores) — os.cpu_count() threads (SURVEY 8d's wording) are probed with ONE iteration and used only if
+    faster: on the 2 x 64-core hosts of this pool oversubscribing the physical cores was 7-8 x slower in every round that probed it."""
     ref = load_reference()
     if ref is None:
         return None
-    B = state["batch"][0].shape[0]
+    batch = state.get("cpu_batch", state["batch"])
+    Bc = batch[0].shape[0]
     default_threads = torch.get_num_threads()
     model = build_model(ref, state["m_spa"], state["ln_bot"], state["ln_top"], state["tables"], state["mlp"])
     t_start = time.time()
     probes = {}
-    (t1,), _ = time_loop(ref, model, state["batch"], lr, False, torch.device("cpu"), 0, 1)
+    (t1,), _ = time_loop(ref, model, batch, lr, False, torch.device("cpu"), 0, 1)           # (counts as the first warm-up iteration)
     probes[default_threads] = t1
     best = default_threads
-    if os.cpu_count() != default_threads and t1 * 1e-3 < cpu_budget_s / 20:       # (only where an iteration is cheap next to the budget)
+    if os.cpu_count() != default_threads and t1 * 1e-3 < cpu_budget_s / 15:
         torch.set_num_threads(os.cpu_count())
-        (t2,), _ = time_loop(ref, model, state["batch"], lr, False, torch.device("cpu"), 0, 1)
+        (t2,), _ = time_loop(ref, model, batch, lr, False, torch.device("cpu"), 0, 1)
         probes[os.cpu_count()] = t2
         if t2 < t1:
             best = os.cpu_count()
     torch.set_num_threads(best)
     t_it = probes[best] * 1e-3
-    warm = max(cpu_warmup - len(probes), 0)
+    warm = max(cpu_warmup - 1, 0)                                 # warm-up iterations AT the chosen thread count (+ the first probe)
     left = cpu_budget_s - (time.time() - t_start)
     steps = int(max(3, min(cpu_steps, (left - warm * t_it) / max(t_it, 1e-9))))
-    times, loss = time_loop(ref, model, state["batch"], lr, False, torch.device("cpu"), warm, steps)
+    times, loss = time_loop(ref, model, batch, lr, False, torch.device("cpu"), warm, steps)
     med = float(np.median(times))
-    cpu = {"value": B / (med * 1e-3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "reference",
+    cpu = {"value": Bc / (med * 1e-3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "reference",
            "ms_per_step": med, "ms_per_step_min_max": [float(min(times)), float(max(times))], "final_loss": loss,
-           "iterations_run": len(probes) + warm + steps,
-           "sample": "%d warm-up (incl. %d thread-count probes) + %d timed iterations (median) of the reference's own DLRM_Net + loop "
-                     "body (oracle/_ref: dlrm_s_pytorch compiled where it lay) at global batch %d, tables capped at %d rows, the GPU run's "
-                     "own MLP weights / first %d table rows / first batch; bounded to %.0f s of host time"
-                     % (warm + len(probes), len(probes), steps, B, state["row_cap"], state["row_cap"], cpu_budget_s),
+           "batch": Bc, "iterations_run": len(probes) + warm + steps, "host_seconds": time.time() - t_start,
+           "sample": "%d warm-up + %d timed iterations (median) of the reference's own DLRM_Net + loop body (oracle/_ref: dlrm_s_pytorch "
+                     "compiled where it lay) over the first %d samples of the GPU run's first global batch (a bounded sample of the same "
+                     "workload: samples/s is the metric), tables capped at %d rows, the GPU run's own MLP weights / first %d table rows"
+                     % (warm + 1, steps, Bc, state["row_cap"], state["row_cap"]),
            "threads": {"used": torch.get_num_threads(), "os_cpu_count": os.cpu_count(), "torch_default": default_threads,
                        "probe_ms_per_step": {str(k): float(v) for k, v in probes.items()}},
            "parallel_info": torch.__config__.parallel_info().strip().splitlines()[:8],
@@ -143,13 +142,15 @@ def run(state, lr, cpu_warmup=2, cpu_steps=4, gpu_warmup=3, gpu_steps=10, gpu_de
                           % state["row_cap"],
                           "tables loaded into nn.EmbeddingBag(sum, sparse=True) modules after constructing the model small (the "
                           "constructor's float64 numpy draw of 4 M x 128 values takes ~30 s per table and would be overwritten)",
-                          "thread count = torch's default (the physical cores); SURVEY 8d says os.cpu_count(), which is probed only where an "
-                          "iteration is cheap next to the budget: oversubscribing the physical cores was 7-8x slower on this pool's hosts in "
-                          "every earlier round (profiles/round5/visit_slow_gpu/bench.json: 6.2 s vs 49 s per iteration)"]
+                          "iterations of %d samples instead of the global batch of %d (bounded host time; the stock-GPU leg below runs the "
+                          "whole batch)" % (Bc, state["batch"][0].shape[0]),
+                          "thread count = the faster of torch's default (the physical cores) and os.cpu_count() (one probe iteration each; "
+                          "the probe at os.cpu_count() is skipped where the first iteration already takes more than a fifteenth of the budget)"]
                          + (["%d timed iterations instead of %d (host-time budget)" % (steps, cpu_steps)] if steps < cpu_steps else [])}
     stock = None
     if gpu_device is not None and torch.cuda.is_available():
         try:
+            B = state["batch"][0].shape[0]               # (the stock-GPU leg runs the WHOLE global batch)
             torch.set_num_threads(default_threads)
             model.ndevices = 1                            # what --use-gpu computes for one GPU (:1079)
             model = model.to(gpu_device)                  # :1314-1316
