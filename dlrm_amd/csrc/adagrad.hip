@@ -325,9 +325,9 @@ static int run_adagrad(int n, const int* ids, int64_t B, int D, void* const* wei
     Shape s;
     rc = pick(D, vec_ok, &s);
     if (rc) return rc;
-    static int kc = -1;        // gradient rows in flight per lane group (env DLRM_ADAGRAD_KC = 1 | 2 | 4 | 8, default 2: measured 3.62 / 3.68 / 3.98 ms for 2 / 4 / 8 on the MLPerf-v2 batch): with the group-level resolve the
+    // gradient rows in flight per lane group (tuning builds: env DLRM_ADAGRAD_KC = 1 | 2 | 4 | 8, default 2: measured 3.62 / 3.68 / 3.98 ms for 2 / 4 / 8 on the MLPerf-v2 batch): with the group-level resolve the
                                // rows depend on registers only, so more in flight is more bandwidth (before it, 1 was best: see the kernel's comment)
-    if (kc < 0) { const char* e = getenv("DLRM_ADAGRAD_KC"); kc = e ? atoi(e) : 2; }
+    static const int kc = DLRM_TUNE_ENV("DLRM_ADAGRAD_KC", 2);
     const size_t groups = (L + kG - 1) / kG;
     const int gpb = 256 / s.lpb;
     dim3 grid((unsigned)((groups + gpb - 1) / gpb), 1, 1), block(256);

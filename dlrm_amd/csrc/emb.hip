@@ -508,8 +508,7 @@ extern "C" int dlrm_emb_fwd(int T, int64_t B, int D, const void* const* weight_h
         // bags per lane group for the D = 128 shape: 2 (default; env DLRM_EMB_FWD_U = 1 | 2 | 4 | 8).  Measured on one box at
         // Criteo-Terabyte shapes: U = 1 0.356 ms, 2 0.282, 4 0.315, 8 0.312 — two independent row loads per half-wave and twice
         // the waves beat four loads per half-wave
-        static int u_alt = -1;
-        if (u_alt < 0) { const char* e = getenv("DLRM_EMB_FWD_U"); u_alt = e ? atoi(e) : 2; }
+        static const int u_alt = DLRM_TUNE_ENV("DLRM_EMB_FWD_U", 2);      // (the variable exists in tuning builds only)
         if (u_alt && sh.vec == 4 && sh.lpb == 32 && sh.nch == 1 && (u_alt == 1 || u_alt == 2 || u_alt == 8)) {
             const int bpb = (256 / 32) * u_alt;
             dim3 g2((unsigned)((B + bpb - 1) / bpb), (unsigned)n, 1);

@@ -161,10 +161,10 @@ static int run_sorted(int n, const int* ids, int64_t B, int D, void* const* weig
     constexpr int kQ = 8;                            // chunks per group: 64 / nch consecutive entries per group
     const size_t per_wg = (size_t)gpb * cc * kQ;
     dim3 ugrid((unsigned)((L + per_wg - 1) / per_wg), 1, 1);
-    static int cdiv = -1;       // entries per chunk (x NCH registers), 64 entries per group either way; env DLRM_SORTED_C = 8 | 4 (default) | 2.  Measured on
+    // entries per chunk (x NCH registers), 64 entries per group either way; tuning builds: env DLRM_SORTED_C = 8 | 4 (default) | 2.  Measured on
                                 // one box (profiles/r03/ceilings.md): 0.626 / 0.524 / 0.538 ms for the whole update at Criteo-Terabyte shapes — occupancy beats
                                 // per-wave loads in flight
-    if (cdiv < 0) { const char* e = getenv("DLRM_SORTED_C"); cdiv = e ? atoi(e) : 4; }
+    static const int cdiv = DLRM_TUNE_ENV("DLRM_SORTED_C", 4);
 #define SU_ARGS ugrid, block, 0, st, sa, (long long)L, D, row_bits, (const KT*)keys_out, (const unsigned*)vals_out, (const unsigned*)bag_of, dout, (long long)dout_ld, neg_lr
 #define SU(V, LP, NC)                                                                                              \
     do {                                                                                                           \

@@ -583,9 +583,8 @@ static void phased_attr(const void* fn, bool& done, int bytes = LDS_PL1) {
     }
 }
 
-static int phased_enabled() {           // DLRM_BF16_PHASED=0: keep the fp32-shaped kernels everywhere (A/B runs)
-    static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("DLRM_BF16_PHASED"); enabled = e ? atoi(e) : 1; }
+static int phased_enabled() {           // tuning builds, DLRM_BF16_PHASED=0: keep the fp32-shaped kernels everywhere (A/B runs)
+    static const int enabled = DLRM_TUNE_ENV("DLRM_BF16_PHASED", 1);
     return enabled;
 }
 
@@ -603,8 +602,7 @@ int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t ld
     g.mul = mul; g.ldmul = ldmul; g.Ub = Ub; g.ldub = ldub;
     g.bits_out = (unsigned*)relu_bits_out; g.bits_in = (const unsigned*)relu_bits_in; g.bits_nblk = ((long long)N + 63) / 64;
     g.tiles_m = (int)((M + PBM - 1) / PBM); g.tiles_n = (int)((N + PBN - 1) / PBN);
-    static int wide = -1;               // tuning aid: DLRM_BF16_WIDE_STORE=0 keeps the 8-byte bf16 stores
-    if (wide < 0) { const char* e = getenv("DLRM_BF16_WIDE_STORE"); wide = e ? atoi(e) : 1; }
+    static const int wide = DLRM_TUNE_ENV("DLRM_BF16_WIDE_STORE", 1);      // tuning builds: 0 keeps the 8-byte bf16 stores
 #ifdef DLRM_TUNING
     { static int dbg = -1; if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_BF16_DEBUG", 31); g.debug = dbg; }
 #endif

@@ -735,8 +735,7 @@ static int log2_exact(int x) {
 }
 
 static bool interact_dma_ok(int F, int D, int vec) {
-    static int off = -1;      // env DLRM_INTERACT_PATH=1 forces the register-staged kernels
-    if (off < 0) { const char* e = getenv("DLRM_INTERACT_PATH"); off = (e && atoi(e) == 1) ? 1 : 0; }
+    static const int off = DLRM_TUNE_ENV("DLRM_INTERACT_PATH", 0) == 1;      // tuning builds: 1 forces the register-staged kernels
     return !off && D == IDMA_D && F >= 1 && F <= IDMA_ROWS && vec;
 }
 
@@ -759,8 +758,7 @@ static size_t fwd_dma_lds(int ni, int W) {
     return 5 * DLRM_MAX_FEATURES * sizeof(long long) + (size_t)W * (2 * (size_t)(2 * ni * IDMA_D * 4) + GSEL_WAVE_BYTES) + slack;
 }
 static int fwd_dma_waves(int ni) {
-    static int forced = -1;      // env DLRM_INTERACT_WAVES (tuning aid)
-    if (forced < 0) { const char* e = getenv("DLRM_INTERACT_WAVES"); forced = e ? atoi(e) : 0; }
+    static const int forced = DLRM_TUNE_ENV("DLRM_INTERACT_WAVES", 0);      // (tuning builds)
     int W = (forced >= 1 && forced <= 5) ? forced : 4;      // five waves fit F <= 28 but two of them then share a SIMD: 245 vs 211 us measured
     while (W > 1 && fwd_dma_lds(ni, W) > 160 * 1024) --W;
     return W;

@@ -116,11 +116,16 @@ struct Layout {
     SegPlan plan;
 };
 
-// env DLRM_SORT: "rocprim" forces the general (vendor) sorter everywhere (A/B), "own" lets the segmented sorter take long segments too
-// (> 262144 lookups per table: measured slower than the general sorter there, see seg_plan); default: segmented sorter for short segments
+// Which sorter takes a launch group.  DESIGN DECISION (round 6): the library's own segmented sorter (seg_sort.h) for table
+// segments of up to 262144 lookups — every one-lookup-per-bag batch, i.e. the headline — and the vendor's general radix sort (rocPRIM
+// onesweep) for longer segments (the multi-hot MLPerf-v2 batch: measured 773 vs 1146 us per 14 M-lookup sort, profiles/round4/
+// sort_long_segments.md).  Tuning builds only: env DLRM_SORT = "rocprim" (the general sorter everywhere) | "own" (the segmented sorter for
+// long segments too: correct, tested through tools/, slower).
 static int seg_sort_mode() {            // 0 rocprim, 1 default, 2 own everywhere
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("DLRM_SORT"); v = (e && strcmp(e, "rocprim") == 0) ? 0 : (e && strcmp(e, "own") == 0) ? 2 : 1; }
+    static const int v = [] {
+        const char* e = DLRM_TUNE_ENV_STR("DLRM_SORT");
+        return (e && strcmp(e, "rocprim") == 0) ? 0 : (e && strcmp(e, "own") == 0) ? 2 : 1;
+    }();
     return v;
 }
 static bool seg_sort_enabled() { return seg_sort_mode() != 0; }

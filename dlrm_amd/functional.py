@@ -37,7 +37,7 @@ BF16_STORAGE = os.environ.get("DLRM_BF16_STORAGE", "1") == "1"
 # bf16 storage, LEAN: hidden activations / gradients exist only as bf16 (+ ReLU sign bits) wherever every consumer reads bf16 (MLPFunction)
 BF16_LEAN = os.environ.get("DLRM_BF16_LEAN", "1") == "1"
 # DCN-v2 (bf16 storage): the elementwise half of a cross layer inside the epilogue of its second product (dlrm_gemm_bf16_cross); 0 = two kernels
-CROSS_FUSE = os.environ.get("DLRM_CROSS_FUSE", "1") == "1"
+CROSS_FUSE = os.environ.get("DLRM_CROSS_FUSE", "1") == "1"      # (1: the forward x_{l+1} is bit-identical to the two kernels, but the backward reads bf16(u) instead of the fp32 u: gradients differ at that rounding — INTEGRATION.md)
 # small batches: a whole fp32 tower per launch (csrc/tower.hip) for up to DLRM_TOWER_ROWS rows (0 = never: the per-layer GEMMs) while the
 # weight traffic of its 16-row workgroups stays under DLRM_TOWER_L2_MB; see _tower_applies.  Criteo-Kaggle graph: 44 -> 19 kernels per step,
 # 0.367 -> 0.357 ms (profiles/round5/kaggle_towers.md)
@@ -256,7 +256,7 @@ class MLPFunction(Function):
         st = _Bf16Store
         store16 = BF16_STORAGE and arith == ops.arith_code("bf16")
         lean = store16 and BF16_LEAN
-        if BF16X6_PLANES and arith == ops.arith_code("bf16x6") and M >= 256 and RELU_BITS and os.environ.get("DLRM_BF16_PHASED", "1") != "0":
+        if BF16X6_PLANES and arith == ops.arith_code("bf16x6") and M >= 256 and RELU_BITS and ops.BF16_PHASED:
             st, store16, lean = _PlaneStore, True, True
         ctx.st = st
         widths = [params[2 * i].size(0) for i in range(L)]                                   # N_i
@@ -268,7 +268,7 @@ class MLPFunction(Function):
             use16[L - 1] = False
         # weight gradient of layer i from bf16 operands as stored (X16_i = the bf16 input of its forward GEMM, dZ16_i)
         wg16 = [lean and need_grad and use16[i] and M >= 256 and M % 64 == 0 and widths[i] % 8 == 0 and widths[i] >= 64 and kin[i] >= 64
-                and os.environ.get("DLRM_BF16_PHASED", "1") != "0" for i in range(L)]
+                and ops.BF16_PHASED for i in range(L)]
         # data gradient of layer i (dX = dZ . W) on bf16 operands: reduction over widths[i]
         # (its epilogue applies the derivative of the activation BELOW it: none, or ReLU through that layer's sign bits)
         dg16 = [store16 and use16[i] and widths[i] % 32 == 0 and kin[i] % 4 == 0 and st.fwd_ok(M, kin[i], widths[i]) and
@@ -634,7 +634,7 @@ class LowRankCrossNetFunction(Function):
         operands (dlrm_linear_bwd_weight_bf16); the gradient sum g + dv.V inside the GEMM epilogue (addend).  Needs the shapes of the
         bf16-shaped kernels."""
         return (BF16_STORAGE and BF16_LEAN and arith == ops.arith_code("bf16") and M >= 256 and M % 64 == 0 and n_in % 64 == 0 and r % 64 == 0
-                and n_in >= 192 and r >= 192 and os.environ.get("DLRM_BF16_PHASED", "1") != "0")
+                and n_in >= 192 and r >= 192 and ops.BF16_PHASED)
 
     @staticmethod
     def forward(ctx, arith, x0, *params):

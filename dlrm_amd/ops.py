@@ -377,6 +377,11 @@ def sort_lookups(rows: Sequence[int], bags: BagBatch):
 # "LEARNING RATES").  The second form is what a captured whole-step HIP graph takes, so that the reference's per-iteration LRPolicyScheduler
 # (dlrm_s_pytorch.py:169-203, stepped at :1621) is followed without re-capture: GraphedTrainStep registers one device scalar per param group for
 # the duration of the capture, the optimizer-side callers ask device_lr(group, value) for it.
+# the bf16-shaped GEMM kernels (csrc/gemm_bf16.hip) are what the product library runs wherever their preconditions hold; the fp32-shaped
+# ones can only be forced in a TUNING build of the library (DLRM_HIP_LIB=... DLRM_BF16_PHASED=0: tools/bf16_gemm_bench.py), and only then does
+# the host plan follow the switch
+BF16_PHASED = not (os.environ.get("DLRM_HIP_LIB") and os.environ.get("DLRM_BF16_PHASED", "1") == "0")
+
 LrLike = Union[float, torch.Tensor]
 _graph_lr = {}          # id(param_group dict) -> 1-element fp32 GPU tensor; populated only while a GraphedTrainStep captures
 
@@ -525,13 +530,17 @@ def mark_one_lookup_per_bag(t: torch.Tensor) -> torch.Tensor:
     """Producer-side proof: whoever WROTE the bag starts as 0, 1, ..., B-1 (dlrm_amd.datagen with one fixed lookup per bag,
     CriteoBinBatches, Multihot over all-ones hot sizes — by construction of their kernels) tags the tensor object, and
     `offsets_are_iota` then needs neither a device pass nor a synchronisation for it.  The tag holds the tensor's in-place version
-    counter, so a later versioned write voids it; views and copies are new objects and carry no tag (they take the device proof)."""
-    setattr(t, _IOTA_TAG, t._version)
+    counter, so a later versioned write voids it; views and copies are new objects and carry no tag (they take the device proof) — and
+    because Python attributes DO travel with copy.deepcopy / pickle, the tag also names the object and the storage address it was given
+    for: a deep copy or an unpickled tensor is a different object at a different address and is therefore untagged.  What no tag
+    can see is a write that bypasses the version counter (`.data` writes, a foreign kernel): producers tag tensors their own kernel has just
+    written and hand them over; the fused kernels still verify every bag start they use and report a violation through the error block."""
+    setattr(t, _IOTA_TAG, (t._version, id(t), t.data_ptr()))
     return t
 
 
 def _iota_tagged(t: torch.Tensor) -> bool:
-    return getattr(t, _IOTA_TAG, None) == t._version
+    return getattr(t, _IOTA_TAG, None) == (t._version, id(t), t.data_ptr())
 
 
 def _iota_cached(t: torch.Tensor):
@@ -979,7 +988,7 @@ _wgrad_ws = {}   # (device, stream) -> cached split-K workspace (kernels of one 
 def _wgrad_workspace(need: int, device) -> Optional[torch.Tensor]:
     if need <= 0:
         return None
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)        # (the stream of the TENSORS' device: what the launch uses)
     ws = _wgrad_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(int(need), dtype=torch.uint8, device=device)
@@ -1023,7 +1032,7 @@ def linear_bwd_weight_bf16_ok(M: int, N: int, K: int, dZ16: torch.Tensor, X16: t
     """preconditions of dlrm_linear_bwd_weight_bf16 (csrc/gemm_bf16.hip, weight-gradient form)"""
     K = (K + 7) & ~7
     return (M >= 256 and M % 64 == 0 and N % 8 == 0 and N >= 64 and K >= 64 and X16.size(1) >= K and dZ16.stride(0) % 8 == 0 and X16.stride(0) % 8 == 0
-            and dZ16.data_ptr() % 16 == 0 and X16.data_ptr() % 16 == 0 and os.environ.get("DLRM_BF16_PHASED", "1") != "0")
+            and dZ16.data_ptr() % 16 == 0 and X16.data_ptr() % 16 == 0 and BF16_PHASED)
 
 
 def linear_bwd_weight_bf16(dZ16: torch.Tensor, X16: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor] = None,
@@ -1150,7 +1159,7 @@ def tower_wgrad(dZs: Sequence[torch.Tensor], ins: Sequence[torch.Tensor], dWs: S
     wa = _int_array(widths)
     need = int(lib.dlrm_tower_wgrad_workspace_bytes(M, L, wa))
     dev = dZs[0].device
-    key = (dev, torch.cuda.current_stream().cuda_stream)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)              # (the stream of the tensors' device: what _stream(dZs[0]) launches on)
     ws = _tower_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = _tower_ws[key] = torch.empty(need, dtype=torch.uint8, device=dev)

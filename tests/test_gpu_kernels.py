@@ -172,20 +172,9 @@ def test_lookup_sort_is_stable_and_exact(case, monkeypatch):
     from dlrm_amd import ops
     rng = np.random.default_rng(len(case))
     idx_dtype = torch.int64
-    if case == "mlperf_v2_100hot_segment":
-        # the segmented sorter's long-segment path is opt-in (DLRM_SORT=own; measured slower than the general sorter there): the library
-        # reads the switch once per process, so this case runs the sort in a child process with the switch set
-        import subprocess
-        import sys as _sys
-        code = ("import os, sys; sys.path.insert(0, os.path.join(%r, 'tests')); os.environ['DLRM_SORT'] = 'own'\n"
-                "import test_gpu_kernels as t\n"
-                "class MP:\n    def setenv(self, *a): pass\n"
-                "os.environ['_DLRM_SORT_CHILD'] = '1'\n"
-                "t.test_lookup_sort_is_stable_and_exact('mlperf_v2_100hot_segment', MP())\nprint('CHILD_OK')" % ROOT)
-        if os.environ.get("_DLRM_SORT_CHILD") != "1":
-            r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
-            assert r.returncode == 0 and "CHILD_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
-            return
+    # ("mlperf_v2_100hot_segment" and "long_segment_general_sorter" hold table segments of more than 262144 lookups: the product library hands those
+    # to the general sorter — DESIGN.md section 6, round 6: the segmented sorter's long-segment path exists in tuning builds only
+    # (DLRM_HIP_LIB=... DLRM_SORT=own tools/sort_bench.py v2) — and the contract checked here is the same: stable, exact.)
     if case == "criteo_onehot":
         rows, B = CRITEO_TB_ROWS, 5000
         bags = [(np.arange(B, dtype=np.int64), rng.integers(0, n, size=B).astype(np.int64)) for n in rows]

@@ -519,6 +519,9 @@ def test_producer_tags_and_the_proof_stream():
     assert so.shape == (len(rows), B) and si.shape == (len(rows), B) and ops.offsets_are_iota(so) is True
     assert ops.IOTA_STATS["tagged"] == s0["tagged"] + 2 and ops.IOTA_STATS["checked"] == s0["checked"]      # no device pass so far
     assert torch.equal(so, torch.arange(B, device=device).repeat(len(rows), 1))                               # ... and the tag tells the truth
+    import copy
+    dc = copy.deepcopy(lS_o[0])                      # Python attributes travel with a deep copy: the tag must NOT (it names object + address)
+    assert getattr(dc, ops._IOTA_TAG, None) is not None and not ops._iota_tagged(dc) and ops._iota_tagged(lS_o[0])
     c = so.clone()                                   # a copy is a new object: it takes the device proof
     assert ops.offsets_are_iota(c) is True and ops.IOTA_STATS["checked"] == s0["checked"] + 1
     so[2, 7] = 9                                     # a versioned write voids the tag; the device pass then sees the ragged bags
