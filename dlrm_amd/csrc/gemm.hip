@@ -46,6 +46,22 @@
 #ifndef DLRM_AGPR_WGRAD
 #define DLRM_AGPR_WGRAD 0
 #endif
+#ifndef DLRM_WGRAD_MAXSPLITS_DEFAULT
+#define DLRM_WGRAD_MAXSPLITS_DEFAULT 64
+#endif
+#ifndef DLRM_WGRAD_WGS_DEFAULT
+#define DLRM_WGRAD_WGS_DEFAULT 1024
+#endif
+// stages of the LDS ring of the 128-row fp32 tiles (gemm3_kernel NST) per form
+#ifndef DLRM_NST_FWD
+#define DLRM_NST_FWD 2
+#endif
+#ifndef DLRM_NST_DGRAD
+#define DLRM_NST_DGRAD 2
+#endif
+#ifndef DLRM_NST_WGRAD
+#define DLRM_NST_WGRAD 2
+#endif
 
 namespace {
 
@@ -450,9 +466,13 @@ __device__ __forceinline__ void mfma_f32(floatx16& c, float a, float b) {
 // SCHED: fragment-read schedule of the native fp32 main loop (0 / 1 / 2, see the loop); NST: stages of the LDS ring
 // EPI: 0 = the general epilogue (any shape / alignment, atomics, fp32 masks, every activation); 1 / 2 = the STRAIGHT-LINE epilogue (no / ReLU activation)
 template <bool A_KC, bool B_KC, int TM, int ARITH, bool ROWSUM, int FRAG = 0, int TN = 2, int SCHED = 0, int NST = 3, bool ACC_AGPR = false, int EPI = 0>
-__global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (NST == 2 && TM <= 2) ? 4 : 2) void gemm3_kernel(GemmArgs g) {
     static_assert(SCHED == 0 || ARITH == 0, "fragment schedules exist for the native fp32 main loop");
-    static_assert(NST == 3, "three-stage ring");
+    // NST = 3: tile kt + 2 is in flight while tile kt is multiplied (two k-tiles of flight time).  NST = 2 (round 6, 128-row fp32 tiles): one tile of
+    // lookahead, 32 KB of ring (34 KB with the epilogue staging) -> FOUR workgroups per CU instead of three (tools/probes/mfma_lds_probe.hip:
+    // the MFMA + ds_read stream of this loop sustains 0.958 of the peak at four waves per SIMD, 0.941 at three)
+    static_assert(NST == 2 || NST == 3, "two- or three-stage ring");
+    static_assert(NST == 3 || SCHED != 2, "the rolling fragment schedule reads tile kt + 1 during tile kt: it needs the three-stage ring");
     static_assert(TN == 2 || (TN == 1 && TM == 1 && ARITH == 0), "the 32-column wave tile exists for the small fp32 launches only");
     constexpr bool A_IL = FRAG && !A_KC, B_IL = FRAG && !B_KC;      // operand's sub-tiles interleaved (see above)
     static_assert(!FRAG || ARITH == 0, "vector fragments are implemented for the native fp32 main loop");
@@ -651,13 +671,13 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
                     __builtin_amdgcn_s_barrier();
                 }
             } else {
-                if (kt + 1 < nk) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();   // my share of tile kt has landed
+                if (NST > 2 && kt + 1 < nk) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();   // my share of tile kt has landed (NST = 2: it is the only refill in flight)
                 __builtin_amdgcn_s_barrier();      // everyone's share has; everyone is done reading stage `nxt`
             }
         }
         // (issued BEFORE this tile's fragment reads: issuing it after them — the reads are on the first MFMA's critical path, the refill is not —
         // measured 1-2 % slower in every kernel form, profiles/round5/gemm_dma_late_ab.txt: the refill's head start matters more)
-        if (kt + 2 < nk && !(g.debug & 1)) GEMM3_ISSUE(nxt);
+        if (kt + (NST - 1) < nk && !(g.debug & 1)) GEMM3_ISSUE(nxt);
         if constexpr (EPI != 0) {
             // (straight-line epilogue) the bias quad of this lane's columns, requested with the last two k-tiles still to multiply — as the mask words
             // below: behind every DMA in the in-order vmcnt queue, retired by the loop's final vmcnt(0)
@@ -800,7 +820,7 @@ __global__ __launch_bounds__(256, 2) void gemm3_kernel(GemmArgs g) {
     // (transposes back to [m][n]) -> 16-byte row segments.  Transposed C/D layout of the 32x32 MFMA:
     // lane owns m_local = lane & 31 and n_local = 8*q + 4*(lane>>5) + {0..3} for q = reg>>2.
     constexpr int ELD = TN == 2 ? EPI_LD : 32 + 4;                  // staged row pitch (floats)
-    static_assert(4 * 32 * ELD * 4 <= NST * STAGE, "epilogue staging does not fit the ring");
+    // (the staging area of the four waves may be larger than a two-stage ring: launch_gemm3 sizes the dynamic LDS as the maximum of the two)
     if constexpr (MASKED) {
         // the words were requested two k-tiles ago and the loop's final vmcnt(0) has retired them; the compiler cannot see that
         // through the hand-placed waits, and would drain vmcnt (= wait for the previous band's STORES) in front of every later use
@@ -1263,7 +1283,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_t_kernel(int R, int C, int R
 
 static int pow2ceil_i(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <bool A_KC, bool B_KC, int TM, int ARITH, int FRAG = 0, int TN = 2, int SCHED = 0, bool AGPR = false, int EPI = 0>
+template <bool A_KC, bool B_KC, int TM, int ARITH, int FRAG = 0, int TN = 2, int SCHED = 0, bool AGPR = false, int EPI = 0, int NST = 3>
 static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     constexpr bool ROWSUM = !A_KC && !B_KC;          // only the weight-gradient GEMM carries the bias-gradient row sums
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
@@ -1275,7 +1295,9 @@ static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
         if (dbg < 0) dbg = DLRM_DEBUG_ENV("DLRM_GEMM_DEBUG", 0x7fffffff);
         g.debug = dbg;
     }
-    size_t lds = (size_t)NSTAGE3 * (BMt + BNt) * BK3 * 4;           // 72 KiB (TM=4) / 48 KiB (TM=2)
+    size_t lds = (size_t)NST * (BMt + BNt) * BK3 * 4;           // 72 KiB (TM=4) / 48 KiB (TM=2) with three stages
+    const size_t staging = (size_t)4 * 32 * (TN == 2 ? EPI_LD : 32 + 4) * 4;      // the epilogue's four wave-private staging areas reuse the ring
+    if (lds < staging) lds = staging;
     {   // tuning aid (env DLRM_GEMM_LDS_PAD, bytes): extra dynamic LDS per workgroup = fewer resident workgroups per CU (occupancy probe)
         static const int pad = DLRM_TUNE_ENV("DLRM_GEMM_LDS_PAD", 0);
         lds += (size_t)pad;
@@ -1283,11 +1305,11 @@ static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     static bool attr_done[DLRM_MAX_DEVICES] = {};      // the attribute is per (function, device)
     const int dev = dlrm_current_device();
     if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN, SCHED, 3, AGPR, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN, SCHED, NST, AGPR, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[dev] = true;
     }
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), block(256);
-    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN, SCHED, 3, AGPR, EPI>), grid, block, lds, st, g);
+    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN, SCHED, NST, AGPR, EPI>), grid, block, lds, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
 }
@@ -1352,13 +1374,23 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
                               (g.mask == nullptr || g.bits_in != nullptr) && (g.bias == nullptr || dlrm_aligned16(g.bias)) &&
                               (g.act == DLRM_ACT_NONE || (g.act == DLRM_ACT_RELU && FORM == 0)) && (g.c_split_stride % 4 == 0);
         constexpr bool AG = AGPR_DEFAULT[FORM] != 0;
-#define GEMM3_LAUNCH(TM_, FR, EP) launch_gemm3<A_KC, B_KC, TM_, 0, FR, 2, SD, AG, EP>(g, splits, st)
+        // ring depth of the 128-row tiles (gemm3_kernel NST): 2 = four workgroups per CU.  Compile-time per form (-DDLRM_NST_FWD=.. etc.);
+        // tuning builds: DLRM_GEMM_NST = three digits (forward, data gradient, weight gradient), each 2 / 3
+        constexpr int NST_DEFAULT[3] = {DLRM_NST_FWD, DLRM_NST_DGRAD, DLRM_NST_WGRAD};
+#ifdef DLRM_TUNING
+        static const int nst_all = DLRM_TUNE_ENV("DLRM_GEMM_NST", -1);
+        const int nst = nst_all < 0 ? NST_DEFAULT[FORM] : (FORM == 0 ? nst_all / 100 : FORM == 1 ? (nst_all / 10) % 10 : nst_all % 10);
+#define GEMM3_LAUNCH2(FR, EP) (nst == 2 ? launch_gemm3<A_KC, B_KC, 2, 0, FR, 2, SD, AG, EP, 2>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0, FR, 2, SD, AG, EP, 3>(g, splits, st))
+#else
+#define GEMM3_LAUNCH2(FR, EP) launch_gemm3<A_KC, B_KC, 2, 0, FR, 2, SD, AG, EP, NST_DEFAULT[FORM]>(g, splits, st)
+#endif
+#define GEMM3_LAUNCH4(FR, EP) launch_gemm3<A_KC, B_KC, 4, 0, FR, 2, SD, AG, EP>(g, splits, st)
 #define GEMM3_BIG_OR_NOT(FR)                                                                                   \
         if (fast_epi) {                                                                                        \
-            if constexpr (FORM == 0) { if (g.act == DLRM_ACT_RELU) return big ? GEMM3_LAUNCH(4, FR, 2) : GEMM3_LAUNCH(2, FR, 2); } \
-            return big ? GEMM3_LAUNCH(4, FR, 1) : GEMM3_LAUNCH(2, FR, 1);                                      \
+            if constexpr (FORM == 0) { if (g.act == DLRM_ACT_RELU) return big ? GEMM3_LAUNCH4(FR, 2) : GEMM3_LAUNCH2(FR, 2); } \
+            return big ? GEMM3_LAUNCH4(FR, 1) : GEMM3_LAUNCH2(FR, 1);                                          \
         }                                                                                                      \
-        return big ? GEMM3_LAUNCH(4, FR, 0) : GEMM3_LAUNCH(2, FR, 0);
+        return big ? GEMM3_LAUNCH4(FR, 0) : GEMM3_LAUNCH2(FR, 0);
         if constexpr (!A_KC || !B_KC) {
             if (arith == DLRM_ARITH_F32 && frag) {
                 if (tiny) return launch_gemm3<A_KC, B_KC, 1, 0, 1, 1>(g, splits, st);
@@ -1374,7 +1406,8 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
             return big ? launch_gemm3<A_KC, B_KC, 4, 2>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 2>(g, splits, st);
         GEMM3_BIG_OR_NOT(0)
 #undef GEMM3_BIG_OR_NOT
-#undef GEMM3_LAUNCH
+#undef GEMM3_LAUNCH2
+#undef GEMM3_LAUNCH4
     }
     g.bits_in = nullptr; g.bits_out = nullptr;       // the any-shape kernel neither reads nor writes sign bits
     g.tiles_m = (int)((g.M + BM - 1) / BM);
@@ -1623,12 +1656,19 @@ extern "C" int dlrm_linear_bwd_data(int64_t M, int N, int K, const float* dY, in
 }
 
 static void wgrad_plan(int64_t M, int N, int K, int* splits_out, int64_t* kchunk_out) {
-    // split the batch reduction so that >= ~4 workgroups per CU exist; slices of >= 512 rows
+    // split the batch reduction so that ~4 workgroups per CU exist (1024: with the two-stage ring four 128-row workgroups fit a CU, and the wide
+    // layers then take the 256-row tiles at exactly one round of 512 — round 6, in-step A/B profiles/round6/gemm_nst_wgrad_plan_ab.md: 768 -> 1024 =
+    // linear_bwd_weight 2.44 -> 2.37 ms per step; round 5 had gone 1024 -> 768 with the three-stage ring); slices of >= 512 rows.
+    // NOTE: the plan fixes the split-K summation order: weight gradients differ in the last bits between plans (deterministic for one plan)
     const int tiles = (int)(((N + BM - 1) / BM) * ((K + BN - 1) / BN));
     // tuning aids: DLRM_WGRAD_WGS (workgroups a launch aims at), DLRM_WGRAD_MINROWS (shortest batch slice)
-    static const int target_wgs_e = DLRM_TUNE_ENV("DLRM_WGRAD_WGS", 768), min_rows_e = DLRM_TUNE_ENV("DLRM_WGRAD_MINROWS", 512);
-    const int target_wgs = target_wgs_e > 0 ? target_wgs_e : 768, min_rows = min_rows_e >= 128 ? min_rows_e : 512;
+    static const int target_wgs_e = DLRM_TUNE_ENV("DLRM_WGRAD_WGS", DLRM_WGRAD_WGS_DEFAULT), min_rows_e = DLRM_TUNE_ENV("DLRM_WGRAD_MINROWS", 512);
+    const int target_wgs = target_wgs_e > 0 ? target_wgs_e : DLRM_WGRAD_WGS_DEFAULT, min_rows = min_rows_e >= 128 ? min_rows_e : 512;
     int splits = (target_wgs + tiles - 1) / tiles;
+    // few output tiles (512 -> 256: 8): every slice costs a whole slab of N x K floats written and read back, so no more slices than
+    // keep >= 2 workgroups per CU (round 6: 64 x 8 instead of 96 x 8 = 146 -> 139 us per call; tuning builds: DLRM_WGRAD_MAXSPLITS, 0 = no cap)
+    static const int cap_e = DLRM_TUNE_ENV("DLRM_WGRAD_MAXSPLITS", DLRM_WGRAD_MAXSPLITS_DEFAULT);
+    if (cap_e > 0 && splits > cap_e && (long long)tiles * cap_e >= 512) splits = cap_e;
     const int64_t max_splits = (M + min_rows - 1) / min_rows;
     if (splits > max_splits) {
         // small batches (Criteo-Kaggle: 2048 rows): slices down to 128 rows while the launch still has fewer workgroups than the chip has CUs

@@ -17,7 +17,7 @@ __device__ __forceinline__ void mfma(floatx16& c, float a, float b) {
 }
 
 template <int TM, bool AGPR, int READS>
-__global__ __launch_bounds__(256, 2) void loop_kernel(float* out, const float* in, int iters, int lds_pad) {
+__global__ __launch_bounds__(256, TM == 2 ? 4 : 2) void loop_kernel(float* out, const float* in, int iters, int lds_pad) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 3 * 6144; i += 256) lds[i] = in[i];          // three stages of a 256 x 16 + 128 x 16 tile of random data
@@ -115,7 +115,7 @@ int main() {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
     printf("%s, %d CUs\n", p.name, cus);
-    for (int w = 1; w <= 3; ++w) {
+    for (int w = 1; w <= 4; ++w) {
         run<2, false, 0>("TM2 acc=VGPR mfma only", out, in, cus, w);
         run<2, true, 0>("TM2 acc=AGPR mfma only", out, in, cus, w);
         run<2, false, 1>("TM2 acc=VGPR + ds_read", out, in, cus, w);
