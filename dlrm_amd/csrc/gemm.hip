@@ -1336,13 +1336,10 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
         bool big = g.M >= 256 && wg256 >= 512;
         // (fp32 MFMA only: the bf16x6 / bf16 main loops split or round every fragment they load, and the smaller tiles reuse a fragment
         // for half as many products — bf16x6 step 6.51 -> 6.93 ms with them)
-        if (splits == 1 && force_tm != 4 && arith == DLRM_ARITH_F32) {
-            big = g.M >= 256 && wg256 > 384 && wg256 <= 512;
-            // ... and the data gradient over a LONG reduction (the layers that are 1024 wide on the output side: 1024 -> 1024, 480 -> 1024): with
-            // the straight-line epilogue (round 6) the 256-row tiles win there, 1024 x 1024: 1011 -> 960 us, 480 -> 1024: 489 -> 485 us, and lose
-            // on the 256- / 512-long reductions (profiles/round6/gemm_tile_rule_ab.md, A/B inside one visit)
-            if (A_KC && !B_KC && g.K >= 1024 && g.M >= 256 && wg256 >= 512) big = true;
-        }
+        // Round 6: with the two-stage ring four 128-row workgroups fit a CU, and the 128-row tiles then win or tie on EVERY one-slice shape — also the
+        // one-round ones (512 -> 256 forward 130.8 -> 127.7 us, 256 -> 128 data gradient 44.2 -> 40.6) and the long reductions that took the
+        // 256-row tiles for a while this round (profiles/round6/gemm_tile_rule_ab.md).  The weight gradient keeps the 256-row tiles.
+        if (splits == 1 && force_tm != 4 && arith == DLRM_ARITH_F32) big = false;
         if (force_tm == 2) big = false;
         // k-strided operands (data gradient: W; weight gradient: dY and X) are read with vector fragments over interleaved sub-tiles
         // (FRAG, see gemm3_kernel).  Tuning aids: DLRM_GEMM_FRAG=0 -> the scalar-fragment kernels of rounds 1-2;
