@@ -134,8 +134,13 @@ __device__ __forceinline__ uintx4 p_tr_read8(unsigned lds_addr) {
 // swapped for rows 16-31 of every 32 (ds_read_b128 serves lanes {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} together: each group then
 // covers the 256-byte bank row once); k-strided (WG): [sub-run][plane][16 k-rows][64 B].  A piece = 12 chunks of 1 KiB (4 row groups x 3
 // planes): every wave issues one, waves 0-3 a second one — the counted waits differ by wave accordingly.
-template <bool WG, int PL>
+// EP: 0 = the general epilogue; 1 / 2 = STRAIGHT-LINE bf16-only output (the lean towers' 16-byte stores), no / ReLU activation, no addends;
+// 3 = straight-line fp32 store (the weight gradient's slabs).  Round 6, as in gemm3_kernel: the general body's run-time branches and in-loop
+// addend loads make the compiler close every join with s_waitcnt vmcnt(0) — 108 of them for 116 stores in the forward instance — so the
+// stores of a band left one memory round trip apart; the straight-line bodies contain no load and no divergent path.
+template <bool WG, int PL, int EP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
+    static_assert(EP == 0 || (EP == 3) == WG, "EP 1 / 2: forward / data gradient; EP 3: weight gradient");
     constexpr int BK_ = PL == 1 ? PBK : 16;                       // k per tile
     constexpr int OPB = PL == 1 ? OP_BYTES : 3 * 256 * 32;        // one operand of one k-tile (PL 3: 24 KiB)
     constexpr int STG = 2 * OPB;
@@ -438,6 +443,103 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_phased_kernel(BfArgs g) {
     float* S = lds + wave * (32 * P_EPI_LD);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias && nb < g.N) bv = *(const float4*)(g.bias + nb);      // N % 4 == 0 and nb % 4 == 0: the quad is inside the bias vector
+    if constexpr (EP == 3) {
+        // weight gradient: the fp32 slab of this k-slice, plain 16-byte row segments
+        auto band_wg = [&](auto TMC) {
+            constexpr int tm = decltype(TMC)::value;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
+                    *(float4*)__builtin_assume_aligned(S + l31 * P_EPI_LD + tn * 32 + 8 * q + 4 * h, 16) = v;
+                }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                const long long m = m0 + wr * 128 + tm * 32 + row;
+                const float4 v = *(const float4*)__builtin_assume_aligned(S + row * P_EPI_LD + c4, 16);
+                if (m < g.M && nb < g.N) *(float4*)(Cz + m * g.ldc + nb) = v;
+            }
+        };
+        band_wg(IC<0>{}); band_wg(IC<1>{}); band_wg(IC<2>{}); band_wg(IC<3>{});
+        return;
+    }
+    if constexpr (EP == 1 || EP == 2) {
+        // bf16-only output (host: wide16 preconditions hold, no addend / mul / Ub / fp32 output, act none | ReLU)
+        const int c8 = (lane & 7) * 8;
+        const long long nb8 = n0 + wc * 64 + c8;
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (g.bias && nb8 < g.N) { b0 = *(const float4*)(g.bias + nb8); b1 = *(const float4*)(g.bias + nb8 + 4); }
+        asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w), "+v"(bv.x), "+v"(bv.y), "+v"(bv.z), "+v"(bv.w),
+                     "+v"(mkb[0]), "+v"(mkb[1]), "+v"(mkb[2]), "+v"(mkb[3]));      // every load of the epilogue is waited for HERE, before the first store
+        auto relu = [](float x) { return EP == 2 ? (x > 0.f ? x : 0.f) : x; };
+        auto band_fast = [&](auto TMC) {
+            constexpr int tm = decltype(TMC)::value;
+            unsigned myword = 0u;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = make_float4(acc[tm][tn][4 * q], acc[tm][tn][4 * q + 1], acc[tm][tn][4 * q + 2], acc[tm][tn][4 * q + 3]);
+                    *(float4*)__builtin_assume_aligned(S + l31 * P_EPI_LD + tn * 32 + 8 * q + 4 * h, 16) = v;
+                }
+            if (g.bits_out) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const float4 v = *(const float4*)__builtin_assume_aligned(S + (it * 4 + (lane >> 4)) * P_EPI_LD + c4, 16);
+                    const float x0 = v.x + bv.x, x1 = v.y + bv.y, x2 = v.z + bv.z, x3 = v.w + bv.w;          // (ReLU(x) > 0 <=> x > 0)
+                    asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                 "v_cmp_lt_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                 "v_cmp_lt_f32 vcc, 0, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+                                 "v_cmp_lt_f32 vcc, 0, %4\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                 : "+v"(myword) : "v"(x0), "v"(x1), "v"(x2), "v"(x3) : "vcc");
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + (lane >> 3);
+                const long long m = m0 + wr * 128 + tm * 32 + row;
+                float4 v0 = *(const float4*)__builtin_assume_aligned(S + row * P_EPI_LD + c8, 16);
+                float4 v1 = *(const float4*)__builtin_assume_aligned(S + row * P_EPI_LD + c8 + 4, 16);
+                v0.x = relu(v0.x + b0.x); v0.y = relu(v0.y + b0.y); v0.z = relu(v0.z + b0.z); v0.w = relu(v0.w + b0.w);
+                v1.x = relu(v1.x + b1.x); v1.y = relu(v1.y + b1.y); v1.z = relu(v1.z + b1.z); v1.w = relu(v1.w + b1.w);
+                if (g.bits_in) {
+                    const int src = (row & 3) * 16 + (lane & 7) * 2;
+                    const unsigned w0 = (unsigned)__shfl((int)mkb[tm], src, 64), w1 = (unsigned)__shfl((int)mkb[tm], src + 1, 64);
+                    const int sh = 31 - 4 * (row >> 2);
+                    if (!((w0 >> (sh - 0)) & 1u)) v0.x = 0.f;
+                    if (!((w0 >> (sh - 1)) & 1u)) v0.y = 0.f;
+                    if (!((w0 >> (sh - 2)) & 1u)) v0.z = 0.f;
+                    if (!((w0 >> (sh - 3)) & 1u)) v0.w = 0.f;
+                    if (!((w1 >> (sh - 0)) & 1u)) v1.x = 0.f;
+                    if (!((w1 >> (sh - 1)) & 1u)) v1.y = 0.f;
+                    if (!((w1 >> (sh - 2)) & 1u)) v1.z = 0.f;
+                    if (!((w1 >> (sh - 3)) & 1u)) v1.w = 0.f;
+                }
+                if (m < g.M && nb8 < g.N) {
+                    if constexpr (PL == 1) {
+                        uintx4 pk;
+                        pk[0] = p_cvt_pk_bf16(v0.x, v0.y); pk[1] = p_cvt_pk_bf16(v0.z, v0.w);
+                        pk[2] = p_cvt_pk_bf16(v1.x, v1.y); pk[3] = p_cvt_pk_bf16(v1.z, v1.w);
+                        *(uintx4*)(g.Cb + m * g.ldcb + nb8) = pk;
+                    } else {
+                        uintx4 ph, pm, pl;
+                        { unsigned h_, m_, l_; p_split2(v0.x, v0.y, h_, m_, l_); ph[0] = h_; pm[0] = m_; pl[0] = l_; } { unsigned h_, m_, l_; p_split2(v0.z, v0.w, h_, m_, l_); ph[1] = h_; pm[1] = m_; pl[1] = l_; }
+                        { unsigned h_, m_, l_; p_split2(v1.x, v1.y, h_, m_, l_); ph[2] = h_; pm[2] = m_; pl[2] = l_; } { unsigned h_, m_, l_; p_split2(v1.z, v1.w, h_, m_, l_); ph[3] = h_; pm[3] = m_; pl[3] = l_; }
+                        unsigned short* cb = g.Cb + m * g.ldcb + nb8;
+                        *(uintx4*)cb = ph; *(uintx4*)(cb + g.planeC) = pm; *(uintx4*)(cb + 2 * g.planeC) = pl;
+                    }
+                }
+            }
+            if (g.bits_out) {
+                const long long mb = (m0 + wr * 128 + tm * 32) >> 5, nbk = (n0 + wc * 64) >> 6;
+                if (mb <= ((g.M - 1) >> 5) && nbk < g.bits_nblk) g.bits_out[(mb * g.bits_nblk + nbk) * 64 + lane] = myword;
+            }
+        };
+        band_fast(IC<0>{}); band_fast(IC<1>{}); band_fast(IC<2>{}); band_fast(IC<3>{});
+        return;
+    }
     // (one instantiation per band through a generic lambda: with the second output form the unroller refused the pragma on a plain loop —
     // "unrolled size is too large" — and a rolled loop indexes acc[tm] dynamically, i.e. puts the accumulators into scratch memory)
     auto band = [&](auto TMC) {
@@ -609,9 +711,24 @@ int dlrm_gemm_bf16_phased(int64_t M, int N, int K, const uint16_t* A, int64_t ld
     g.wide16 = (wide && Cb && !C && !addend && !mul && !Ub && N % 8 == 0 && ldcb % 8 == 0 && dlrm_aligned16(Cb) && (!bias || dlrm_aligned16(bias))) ? 1 : 0;
     // (a DIRECT epilogue — bias / activation / rounding in registers, v_permlane32_swap to 16 contiguous bytes per lane, no LDS round trip — was
     // built and measured in round 5: correct, 4-6 % slower than this staged one; profiles/round5/bf16_epilogue_ablation.txt)
+    // the straight-line epilogue where the call is bf16-only with no / ReLU activation (the lean towers' hidden layers); tuning builds: DLRM_BF16_EPI=0
+    static const int epi_on = DLRM_TUNE_ENV("DLRM_BF16_EPI", 1);
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+    if (epi_on && g.wide16 && (act == DLRM_ACT_NONE || act == DLRM_ACT_RELU)) {
+        static bool attr1_done[DLRM_MAX_DEVICES] = {}, attr2_done[DLRM_MAX_DEVICES] = {};
+        if (act == DLRM_ACT_RELU) {
+            phased_attr((const void*)gemm_bf16_phased_kernel<false, 1, 2>, attr2_done[dlrm_current_device()]);
+            hipLaunchKernelGGL((gemm_bf16_phased_kernel<false, 1, 2>), grid, dim3(512), LDS_PL1, st, g);
+        } else {
+            phased_attr((const void*)gemm_bf16_phased_kernel<false, 1, 1>, attr1_done[dlrm_current_device()]);
+            hipLaunchKernelGGL((gemm_bf16_phased_kernel<false, 1, 1>), grid, dim3(512), LDS_PL1, st, g);
+        }
+        DLRM_LAUNCH_CHECK();
+        return 0;
+    }
     static bool attr_done[DLRM_MAX_DEVICES] = {};
     phased_attr((const void*)gemm_bf16_phased_kernel<false, 1>, attr_done[dlrm_current_device()]);
-    hipLaunchKernelGGL((gemm_bf16_phased_kernel<false, 1>), dim3((unsigned)(g.tiles_m * g.tiles_n)), dim3(512), LDS_PL1, st, g);
+    hipLaunchKernelGGL((gemm_bf16_phased_kernel<false, 1>), grid, dim3(512), LDS_PL1, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
 }
@@ -692,14 +809,14 @@ int dlrm_gemm_bf16_wgrad_phased(int64_t Mb, int N_out, int K_in, const uint16_t*
         if (!planes_reachable(planeZ, lddz, 16) || !planes_reachable(planeX, ldx, 16)) return DLRM_E_ALIGN;
         g.planeA = planeZ * 2; g.planeB = planeX * 2;
         static bool attr3_done[DLRM_MAX_DEVICES] = {};
-        phased_attr((const void*)gemm_bf16_phased_kernel<true, 3>, attr3_done[dlrm_current_device()], LDS_PL3);
-        hipLaunchKernelGGL((gemm_bf16_phased_kernel<true, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), dim3(512), LDS_PL3, st, g);
+        phased_attr((const void*)gemm_bf16_phased_kernel<true, 3, 3>, attr3_done[dlrm_current_device()], LDS_PL3);
+        hipLaunchKernelGGL((gemm_bf16_phased_kernel<true, 3, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), dim3(512), LDS_PL3, st, g);
         DLRM_LAUNCH_CHECK();
         return 0;
     }
-    static bool attr_done[DLRM_MAX_DEVICES] = {};
-    phased_attr((const void*)gemm_bf16_phased_kernel<true, 1>, attr_done[dlrm_current_device()]);
-    hipLaunchKernelGGL((gemm_bf16_phased_kernel<true, 1>), dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), dim3(512), LDS_PL1, st, g);
+    static bool attr_done[DLRM_MAX_DEVICES] = {};       // (the weight gradient's slabs always leave through the straight-line fp32 epilogue, EP = 3)
+    phased_attr((const void*)gemm_bf16_phased_kernel<true, 1, 3>, attr_done[dlrm_current_device()]);
+    hipLaunchKernelGGL((gemm_bf16_phased_kernel<true, 1, 3>), dim3((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), dim3(512), LDS_PL1, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
 }
