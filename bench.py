@@ -1046,9 +1046,9 @@ def main():
             k["frac_traffic_of_measured_peak"] = k["traffic_gbps"] / hbm_measured
     heavy = [n for n in kernels if "achieved" in kernels[n]]
     dom = max(heavy, key=lambda n: kernels[n]["ms_per_step"]) if heavy else None
-    kname = {"linear_fwd": "gemm3_kernel<KC,KC> (Y = X*W^T + bias, act; LDS-DMA ring, 256x128x16 tiles)",
-             "linear_bwd_data": "gemm3_kernel<KC,KS> (dX = dY*W, previous layer's act' fused in the epilogue)",
-             "linear_bwd_weight": "gemm3_kernel<KS,KS> (dW = dY^T*X split over the batch + bias-grad row sums) + splitk_reduce_kernel",
+    kname = {"linear_fwd": "gemm3_kernel<KC,KC> (Y = X*W^T + bias, ReLU, sign bits; 128x128x16 tiles, two-stage LDS-DMA ring = 4 workgroups per CU, straight-line epilogue)",
+             "linear_bwd_data": "gemm3_kernel<KC,KS> (dX = dY*W, previous layer's ReLU derivative from sign bits in the straight-line epilogue; 128x128x16 tiles, 4 workgroups per CU)",
+             "linear_bwd_weight": "gemm3_kernel<KS,KS> (dW = dY^T*X split over the batch into slabs + bias-grad row sums; 256x128x16 tiles at one round of 512 workgroups for the wide layers) + splitk_reduce_kernel",
              "emb_bwd_adagrad": "expand + lookup sort (seg_sort.h, or rocPRIM for segments > 262144 lookups) + adagrad_groups_kernel + adagrad_fixup_kernel",
              "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "expand + segmented radix sort (seg_hist / seg_colscan / seg_binscan / seg_scatter, csrc/seg_sort.h) + sorted_update_kernel" if args.emb_update == "sorted" else "emb_bwd_sgd_{atomic,lds}_kernel",
              "interact_fwd": "interact_fwd_dma_kernel", "interact_bwd": "interact_bwd_dma_kernel",
@@ -1159,7 +1159,7 @@ def main():
         "final_loss": final_loss,
         "launches": {"c_abi_calls_per_step": calls_per_step, "kernel_launches_per_step": klaunch, "us_per_step": ms * 1e3,
                      "note": "categorised C-ABI calls of one eager step (one call = 1-4 kernel launches; rocprofv3 kernel counts per step: "
-                             "profiles/round5/step_trace.txt — 52 at Criteo-Terabyte shapes —, step_trace_kaggle_graph_towers_v5.txt — 19 at "
+                             "profiles/round6/step_trace.txt — 52 at Criteo-Terabyte shapes —, profiles/round5/step_trace_kaggle_graph_towers_v5.txt — 19 at "
                              "Criteo-Kaggle shapes with the small-batch tower kernels); the whole-step HIP graph (--graph) replays them with one launch"},
         "box": box,
         "parity_check": parity,

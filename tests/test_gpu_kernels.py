@@ -472,6 +472,47 @@ def test_relu_sign_bits_replace_the_fp32_mask(M, N, K, Nn):
     assert bool(torch.all(d_bits[~(Y > 0)] == 0))
 
 
+@pytest.mark.parametrize("M,N,K,act", [(4096, 512, 256, 1), (1000, 320, 192, 1), (65536, 128, 256, 0), (300, 1024, 480, 1), (8192, 256, 512, 1)])
+def test_straight_line_epilogue_equals_general_epilogue(M, N, K, act):
+    """Round 6: `gemm3_kernel`'s straight-line epilogue (EPI 1 / 2: what the host selects for aligned plain-store calls — every layer of the
+    headline) against the general epilogue of the same kernel, on the same operands: a bias vector that starts 4 bytes off a 16-byte
+    boundary is all it takes to send the call down the general path (csrc/gemm.hip launch_gemm `fast_epi`).  Outputs AND ReLU sign bits must
+    be identical bit for bit — same products, same order, same bias add.  (The data gradient's pair — fp32 mask = general, sign bits =
+    straight-line — is `test_relu_sign_bits_replace_the_fp32_mask`.)"""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    X = to_dev(rng.standard_normal((M, K)).astype(np.float32))
+    W = to_dev((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    b = rng.standard_normal(N).astype(np.float32)
+    b_al = to_dev(b)
+    holder = torch.empty(N + 1, device=dev())
+    b_un = holder[1:]
+    b_un.copy_(b_al)
+    assert b_al.data_ptr() % 16 == 0 and b_un.data_ptr() % 16 == 4
+    outs = []
+    for bias in (b_al, b_un):
+        Y = torch.full((M, N), 7.0, device=dev())
+        bits = ops.relu_bits_alloc(M, N, dev()) if act == 1 else None
+        if bits is not None:
+            bits.fill_(0)
+        ops.linear_fwd(X, W, bias, act, Y, relu_bits=bits)
+        torch.cuda.synchronize()
+        outs.append((Y, bits))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if act == 1:
+        # (bits of elements outside the matrix are unspecified: compare through the consumer — the next layer's data gradient)
+        dZ = to_dev(rng.standard_normal((M, 64)).astype(np.float32))
+        W2 = to_dev(rng.standard_normal((64, N)).astype(np.float32))
+        d = [torch.empty((M, N), device=dev()) for _ in range(2)]
+        for i in range(2):
+            ops.linear_bwd_data(dZ, W2, outs[i][0], 1, d[i], relu_bits=outs[i][1])
+        assert torch.equal(d[0], d[1])
+    want = X.double().cpu().numpy() @ W.double().cpu().numpy().T + b.astype(np.float64)
+    if act == 1:
+        want = np.maximum(want, 0)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+
+
 def test_linear_bwd_data_fused_mask():
     """dgrad epilogue: previous layer's ReLU mask fused in (aligned and unaligned leading dimensions)"""
     from dlrm_amd import ops
