@@ -132,7 +132,7 @@ def parse():
                     help="rows of the global batch the CPU baseline leg iterates over (a BOUNDED sample of the same workload: the first rows of the GPU "
                          "run's first batch, same tables / weights; 0 = the whole global batch, ~6 s per iteration on this pool's hosts).  samples/s is "
                          "what is compared; 3 + 10 iterations of 16384 samples are ~20-25 s of host time")
-    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of host time the CPU baseline leg may take: a safety net only (the timed "
+    ap.add_argument("--cpu-budget", type=float, default=90.0, help="seconds of host time the CPU baseline leg may take: a safety net only (the timed "
                                                                     "iterations are cut short, never below 3, when a host is slower than expected)")
     ap.add_argument("--emb-update", default="sorted", choices=["sorted", "atomic", "deterministic"])
     ap.add_argument("--a2a-chunks", type=int, default=int(os.environ.get("DLRM_A2A_CHUNKS", "1")),
