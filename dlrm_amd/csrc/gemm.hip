@@ -26,7 +26,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
-// fragment-read schedule (gemm3_kernel SCHED) of the forward / data-gradient / weight-gradient forms of the native fp32 GEMM
+// fragment-read schedule (gemm3_kernel SCHED: 0 one register set, 1 both halves of a k-tile before its first product) of the forward /
+// data-gradient / weight-gradient forms of the native fp32 GEMM
 #ifndef DLRM_SCHED_FWD
 #define DLRM_SCHED_FWD 0
 #endif
@@ -35,16 +36,6 @@
 #endif
 #ifndef DLRM_SCHED_WGRAD
 #define DLRM_SCHED_WGRAD 1
-#endif
-// accumulators of the native fp32 loop in AGPRs (gemm3_kernel ACC_AGPR) per form
-#ifndef DLRM_AGPR_FWD
-#define DLRM_AGPR_FWD 0
-#endif
-#ifndef DLRM_AGPR_DGRAD
-#define DLRM_AGPR_DGRAD 0
-#endif
-#ifndef DLRM_AGPR_WGRAD
-#define DLRM_AGPR_WGRAD 0
 #endif
 #ifndef DLRM_WGRAD_MAXSPLITS_DEFAULT
 #define DLRM_WGRAD_MAXSPLITS_DEFAULT 64
@@ -360,7 +351,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 // stored), so M and N are unrestricted.
 // =============================================================================================
 constexpr int BK3 = 16;
-constexpr int NSTAGE3 = 3;
 
 // ---- fp32 through the bf16 matrix pipe (ARITH = 1, "bf16x6") --------------------------------------
 // An fp32 value has a 24-bit significand; truncating to bf16 three times,
@@ -453,26 +443,18 @@ template <> struct FVec<4> { using T = floatx4; };
 
 // TN = 1 (with TM = 1: a 64 x 64 tile, four waves of 32 x 32): SMALL launches only (Criteo-Kaggle's batch of 2048, see launch_gemm) — no sign
 // bits in or out (the host takes the fp32 mask / the stand-alone bit kernel), the mask of the data gradient is read in the epilogue.
-// One v_mfma_f32_32x32x2_f32, accumulator in place.  AGPR = true pins the accumulator tile to the ACCUMULATION half of the unified register file
-// (an "a" inline-asm operand; hipcc's own choice is architectural VGPRs whenever the kernel fits 256 of them).  Why it matters (round 6,
-// tools/probes/mfma_lds_probe.hip): with THREE waves per SIMD the same stream of MFMAs + fragment ds_reads sustains 0.89 of the fp32 MFMA peak with
-// VGPR accumulators and 0.95 with AGPR ones (two waves per SIMD: 0.96 either way).
-template <bool AGPR>
-__device__ __forceinline__ void mfma_f32(floatx16& c, float a, float b) {
-    if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    else c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// SCHED: fragment-read schedule of the native fp32 main loop (0 / 1 / 2, see the loop); NST: stages of the LDS ring
+// SCHED: fragment-read schedule of the native fp32 main loop (0 / 1, see the loop); NST: stages of the LDS ring.
+// (Round 6 also built and measured, inside one visit each: fragment reads ROLLING across k-tiles — no product ever waits for an LDS read — and the
+// accumulators pinned to AGPRs: no gain / +0.5 % forward, -8 % data gradient.  Both were removed again; commit a2c519a has them.)
 // EPI: 0 = the general epilogue (any shape / alignment, atomics, fp32 masks, every activation); 1 / 2 = the STRAIGHT-LINE epilogue (no / ReLU activation)
-template <bool A_KC, bool B_KC, int TM, int ARITH, bool ROWSUM, int FRAG = 0, int TN = 2, int SCHED = 0, int NST = 3, bool ACC_AGPR = false, int EPI = 0>
+template <bool A_KC, bool B_KC, int TM, int ARITH, bool ROWSUM, int FRAG = 0, int TN = 2, int SCHED = 0, int NST = 3, int EPI = 0>
 __global__ __launch_bounds__(256, (NST == 2 && TM <= 2) ? 4 : 2) void gemm3_kernel(GemmArgs g) {
     static_assert(SCHED == 0 || ARITH == 0, "fragment schedules exist for the native fp32 main loop");
     // NST = 3: tile kt + 2 is in flight while tile kt is multiplied (two k-tiles of flight time).  NST = 2 (round 6, 128-row fp32 tiles): one tile of
     // lookahead, 32 KB of ring (34 KB with the epilogue staging) -> FOUR workgroups per CU instead of three (tools/probes/mfma_lds_probe.hip:
     // the MFMA + ds_read stream of this loop sustains 0.958 of the peak at four waves per SIMD, 0.941 at three)
     static_assert(NST == 2 || NST == 3, "two- or three-stage ring");
-    static_assert(NST == 3 || SCHED != 2, "the rolling fragment schedule reads tile kt + 1 during tile kt: it needs the three-stage ring");
+    static_assert(SCHED == 0 || SCHED == 1, "fragment schedules 0 / 1");
     static_assert(TN == 2 || (TN == 1 && TM == 1 && ARITH == 0), "the 32-column wave tile exists for the small fp32 launches only");
     constexpr bool A_IL = FRAG && !A_KC, B_IL = FRAG && !B_KC;      // operand's sub-tiles interleaved (see above)
     static_assert(!FRAG || ARITH == 0, "vector fragments are implemented for the native fp32 main loop");
@@ -647,33 +629,16 @@ __global__ __launch_bounds__(256, (NST == 2 && TM <= 2) ? 4 : 2) void gemm3_kern
         if constexpr (!A_KC && !B_KC && !FRAG) __builtin_amdgcn_s_setprio(1);    // weight gradient with SCALAR fragments (32 ds_read_b32 per half tile): -1.5 %; nil elsewhere
 #define GEMM3_KSTEP(E)                                                                                              \
         _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)                                                           \
-            _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) mfma_f32<ACC_AGPR>(acc[tm][tn], fb[tn].E, fa[tm].E);
+            _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[tn].E, fa[tm].E, acc[tm][tn], 0, 0, 0);
         GEMM3_KSTEP(x) GEMM3_KSTEP(y) GEMM3_KSTEP(z) GEMM3_KSTEP(w)
 #undef GEMM3_KSTEP
         if constexpr (!A_KC && !B_KC && !FRAG) __builtin_amdgcn_s_setprio(0);
     };
     float4 fa0[TM], fb0[TN], fa1[SCHED ? TM : 1], fb1[SCHED ? TN : 1];      // fragment register sets (native fp32 loop)
-    if constexpr (SCHED == 2) {
-        // rolling schedule: the first half of tile 0 is read here, every later half one half-tile of products ahead of its use
-        if (nk > 0) {
-            if (nk > 1 && NST > 2) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            load_half(0, 0, fa0, fb0);
-        }
-    }
     for (int kt = 0; kt < nk; ++kt) {
         if (!(g.debug & 2)) {
-            if constexpr (SCHED == 2) {
-                // tile kt + 1 (the only refill in flight here) must be visible to everyone before its first half is read below; the barrier
-                // also says everyone has consumed the fragments of tile kt - 1, whose stage the refill below overwrites
-                if constexpr (NST > 2) {
-                    if (kt + 1 < nk) wait_vmcnt<0>();
-                    __builtin_amdgcn_s_barrier();
-                }
-            } else {
-                if (NST > 2 && kt + 1 < nk) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();   // my share of tile kt has landed (NST = 2: it is the only refill in flight)
-                __builtin_amdgcn_s_barrier();      // everyone's share has; everyone is done reading stage `nxt`
-            }
+            if (NST > 2 && kt + 1 < nk) wait_vmcnt<TM + TN>(); else wait_vmcnt<0>();   // my share of tile kt has landed (NST = 2: it is the only refill in flight)
+            __builtin_amdgcn_s_barrier();      // everyone's share has; everyone is done reading stage `nxt`
         }
         // (issued BEFORE this tile's fragment reads: issuing it after them — the reads are on the first MFMA's critical path, the refill is not —
         // measured 1-2 % slower in every kernel form, profiles/round5/gemm_dma_late_ab.txt: the refill's head start matters more)
@@ -694,23 +659,11 @@ __global__ __launch_bounds__(256, (NST == 2 && TM <= 2) ? 4 : 2) void gemm3_kern
             }
         }
         if constexpr (ARITH == 0) {
-        // One 8-k half of a tile = TM + TN fragment reads feeding 4 x TM x TN MFMAs.  Three schedules of reads against products:
+        // One 8-k half of a tile = TM + TN fragment reads feeding 4 x TM x TN MFMAs.  Two schedules of reads against products:
         //   SCHED 0  one register set: the reads of half j sit right in front of its products (an LDS round trip per half, hidden only by
         //            the other waves of the SIMD);
         //   SCHED 1  (round 5, weight gradient) two sets, both halves' reads in front of the tile's first product: one round trip per tile;
-        //   SCHED 2  (round 6) two sets ROLLING ACROSS k-tiles: half 1 of tile kt is read under the products of its half 0, half 0 of tile
-        //            kt + 1 under the products of half 1 — no product of the loop ever waits for an LDS read that has not had 4 x TM x TN
-        //            MFMA slots to complete.  Needs tile kt + 1 visible at the barrier of iteration kt (its refill was issued one iteration
-        //            earlier: one k-tile of flight time instead of two) — same registers as SCHED 1.
-        if constexpr (SCHED == 2) {
-            load_half(cur, 1, fa1, fb1);                       // second half of this tile: lands under the first half's products
-            products(fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned nst = (cur == (NST - 1) * STAGE) ? 0 : cur + STAGE;
-            if (kt + 1 < nk) load_half(nst, 0, fa0, fb0);      // first half of the NEXT tile (visible since this iteration's barrier)
-            products(fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-        } else if constexpr (SCHED == 1) {
+        if constexpr (SCHED == 1) {
             load_half(cur, 0, fa0, fb0);
             load_half(cur, 1, fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);      // keep all fragment reads of the tile in front of its first MFMA
@@ -1283,7 +1236,7 @@ __global__ __launch_bounds__(256) void split_bf16x3_t_kernel(int R, int C, int R
 
 static int pow2ceil_i(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <bool A_KC, bool B_KC, int TM, int ARITH, int FRAG = 0, int TN = 2, int SCHED = 0, bool AGPR = false, int EPI = 0, int NST = 3>
+template <bool A_KC, bool B_KC, int TM, int ARITH, int FRAG = 0, int TN = 2, int SCHED = 0, int EPI = 0, int NST = 3>
 static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     constexpr bool ROWSUM = !A_KC && !B_KC;          // only the weight-gradient GEMM carries the bias-gradient row sums
     constexpr int BMt = 64 * TM, BNt = 64 * TN;
@@ -1305,11 +1258,11 @@ static int launch_gemm3(GemmArgs& g, int splits, hipStream_t st) {
     static bool attr_done[DLRM_MAX_DEVICES] = {};      // the attribute is per (function, device)
     const int dev = dlrm_current_device();
     if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN, SCHED, NST, AGPR, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN, SCHED, NST, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done[dev] = true;
     }
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits), block(256);
-    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN, SCHED, NST, AGPR, EPI>), grid, block, lds, st, g);
+    hipLaunchKernelGGL((gemm3_kernel<A_KC, B_KC, TM, ARITH, ROWSUM, FRAG, TN, SCHED, NST, EPI>), grid, block, lds, st, g);
     DLRM_LAUNCH_CHECK();
     return 0;
 }
@@ -1358,11 +1311,9 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
         const long long wg64 = ((g.M + 63) / 64) * ((g.N + 127) / 128) * splits;
         const bool tiny = small && small_tm >= 2 && wg64 < 192 && (g.bits_in == nullptr || g.mask != nullptr);
         if (tiny && fast) *fast = false;
-        // fragment-read schedule (gemm3_kernel SCHED) and accumulator register class (ACC_AGPR) of the native fp32 loop per kernel form.
-        // Both are compile-time per form (-DDLRM_SCHED_FWD=.. / -DDLRM_AGPR_FWD=.. etc., tools/build_variant_lib.sh).
+        // fragment-read schedule (gemm3_kernel SCHED) of the native fp32 loop per kernel form: compile-time (-DDLRM_SCHED_FWD=.. etc., tools/build_variant_lib.sh)
         constexpr int FORM = (A_KC && B_KC) ? 0 : (A_KC ? 1 : 2);
         constexpr int SCHED_DEFAULT[3] = {DLRM_SCHED_FWD, DLRM_SCHED_DGRAD, DLRM_SCHED_WGRAD};
-        constexpr int AGPR_DEFAULT[3] = {DLRM_AGPR_FWD, DLRM_AGPR_DGRAD, DLRM_AGPR_WGRAD};
         constexpr int SD = SCHED_DEFAULT[FORM];
         // the straight-line epilogue (gemm3_kernel EPI) wherever the call needs nothing else: 16-byte aligned C rows, N % 4 == 0, plain stores, the
         // ReLU derivative from sign bits (or none), bias 16-byte aligned, no sigmoid, fp32 results only.  Tuning builds: DLRM_GEMM_EPI=0 keeps the general one.
@@ -1370,18 +1321,17 @@ static int launch_gemm(GemmArgs& g, int splits, hipStream_t st, int arith, bool*
         const bool fast_epi = epi_on && arith == DLRM_ARITH_F32 && g.vecC && g.N % 4 == 0 && g.ldc % 4 == 0 && !g.atomic_out && g.Cb == nullptr &&
                               (g.mask == nullptr || g.bits_in != nullptr) && (g.bias == nullptr || dlrm_aligned16(g.bias)) &&
                               (g.act == DLRM_ACT_NONE || (g.act == DLRM_ACT_RELU && FORM == 0)) && (g.c_split_stride % 4 == 0);
-        constexpr bool AG = AGPR_DEFAULT[FORM] != 0;
         // ring depth of the 128-row tiles (gemm3_kernel NST): 2 = four workgroups per CU.  Compile-time per form (-DDLRM_NST_FWD=.. etc.);
         // tuning builds: DLRM_GEMM_NST = three digits (forward, data gradient, weight gradient), each 2 / 3
         constexpr int NST_DEFAULT[3] = {DLRM_NST_FWD, DLRM_NST_DGRAD, DLRM_NST_WGRAD};
 #ifdef DLRM_TUNING
         static const int nst_all = DLRM_TUNE_ENV("DLRM_GEMM_NST", -1);
         const int nst = nst_all < 0 ? NST_DEFAULT[FORM] : (FORM == 0 ? nst_all / 100 : FORM == 1 ? (nst_all / 10) % 10 : nst_all % 10);
-#define GEMM3_LAUNCH2(FR, EP) (nst == 2 ? launch_gemm3<A_KC, B_KC, 2, 0, FR, 2, SD, AG, EP, 2>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0, FR, 2, SD, AG, EP, 3>(g, splits, st))
+#define GEMM3_LAUNCH2(FR, EP) (nst == 2 ? launch_gemm3<A_KC, B_KC, 2, 0, FR, 2, SD, EP, 2>(g, splits, st) : launch_gemm3<A_KC, B_KC, 2, 0, FR, 2, SD, EP, 3>(g, splits, st))
 #else
-#define GEMM3_LAUNCH2(FR, EP) launch_gemm3<A_KC, B_KC, 2, 0, FR, 2, SD, AG, EP, NST_DEFAULT[FORM]>(g, splits, st)
+#define GEMM3_LAUNCH2(FR, EP) launch_gemm3<A_KC, B_KC, 2, 0, FR, 2, SD, EP, NST_DEFAULT[FORM]>(g, splits, st)
 #endif
-#define GEMM3_LAUNCH4(FR, EP) launch_gemm3<A_KC, B_KC, 4, 0, FR, 2, SD, AG, EP>(g, splits, st)
+#define GEMM3_LAUNCH4(FR, EP) launch_gemm3<A_KC, B_KC, 4, 0, FR, 2, SD, EP>(g, splits, st)
 #define GEMM3_BIG_OR_NOT(FR)                                                                                   \
         if (fast_epi) {                                                                                        \
             if constexpr (FORM == 0) { if (g.act == DLRM_ACT_RELU) return big ? GEMM3_LAUNCH4(FR, 2) : GEMM3_LAUNCH2(FR, 2); } \
