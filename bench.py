@@ -89,6 +89,8 @@ def parse():
                          "proves one-lookup-per-bag on the device with a stream synchronisation INSIDE the timed region, every step; tagged: "
                          "new tensor objects carrying the producer's proof (dlrm_amd.datagen / CriteoBinBatches tag what their kernels "
                          "wrote: no device pass, no synchronisation); resident: four batches reused (their proof is cached after warm-up)")
+    ap.add_argument("--no-full-size-parity", action="store_true", help="skip the 3-step comparison with the unmodified reference module at the FULL table sizes "
+                                                                        "(both models resident on the GPU: 2 x 96 GB)")
     ap.add_argument("--no-high-row-check", action="store_true", help="skip the top-eighth-of-every-table check of the embedding kernels after the timed region")
     ap.add_argument("--no-standalone-emb", action="store_true", help="skip the stand-alone dlrm_emb_fwd measurement (profiling runs)")
     ap.add_argument("--no-rccl-selfcheck", action="store_true", help="skip the one-rank RCCL self-check child process (N = 1)")
@@ -474,6 +476,67 @@ KERNEL_SOURCES = {
     "linear_fwd": ["gemm.hip", "gemv.hip", "common.h"], "linear_bwd_data": ["gemm.hip", "gemv.hip", "common.h"],
     "linear_bwd_weight": ["gemm.hip", "gemv.hip", "smallk.hip", "common.h"],
 }
+
+
+def full_size_parity(model, opt, wl, ln_top, batches, lr, device, steps=3):
+    """"the 1e-5 loss bar has never been checked on the 96 GB model" — every golden fixture caps the tables (2000 / 4 M rows)
+    because the reference's CPU path does not fit a host with the full tables.  288 GB of HBM hold BOTH models: the unmodified reference
+    `DLRM_Net` (oracle/_ref; stock PyTorch-ROCm kernels, `--use-gpu` semantics) is given a copy of THIS model's present parameters — all 26 tables at
+    full size — and both then train `steps` steps on the same batches; the losses must agree to 1e-5 relative (north_star's bar) and the rows the
+    first samples looked up must agree afterwards.  The checker is the reference's own code; what it is NOT is the reference's CPU arithmetic
+    (ATen's GPU kernels re-associate sums too: the fixtures cover the CPU path at capped sizes)."""
+    from oracle import ref_baseline
+    ref = ref_baseline.load_reference()
+    if ref is None:
+        return {"skipped": "oracle/_ref (the compiled reference) is absent"}
+    free, _total = torch.cuda.mem_get_info(device)
+    need = sum(e.weight.numel() * 4 for e in model.emb_l)
+    if free < need + (8 << 30):
+        return {"skipped": "not enough free HBM for a second copy of the tables (%.0f GB free, %.0f GB needed)" % (free / 1e9, need / 1e9)}
+    D = wl["D"]
+    tables = [e.weight.detach().clone() for e in model.emb_l]                       # device-to-device: the reference model's own storage
+    mlp = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("emb_l.")}
+    refm = ref_baseline.build_model(ref, D, list(wl["bot"]), [int(v) for v in ln_top], tables, mlp, ndevices=1).to(device)
+    ref.dlrm = refm
+    optr = torch.optim.SGD(refm.parameters(), lr=lr)
+    one = torch.ones((), dtype=torch.float32, device=device)
+    ours, theirs = [], []
+    for s_ in range(steps):
+        X, off, idx, T = batches[s_ % len(batches)]
+        Zr = refm(X, off, idx)
+        Er = refm.loss_fn(Zr, T)
+        optr.zero_grad()
+        Er.backward()
+        optr.step()
+        Z = model(X, off, idx)
+        E = model.loss_fn(Z, T)
+        opt.zero_grad()
+        E.backward(one)
+        opt.step()
+        ours.append(float(E.detach())); theirs.append(float(Er.detach()))
+        pred_err = float((Z.detach() - Zr.detach()).abs().max())
+        del E, Er, Z, Zr
+    torch.cuda.synchronize()
+    rel = [abs(a - b) / abs(b) for a, b in zip(ours, theirs)]
+    # rows that WERE updated: what the first 256 samples of the first batch looked up, every table
+    row_err = 0.0
+    X, off, idx, T = batches[0]
+    for t, (e, r) in enumerate(zip(model.emb_l, refm.emb_l)):
+        rows_t = idx[t, :256] if idx.dim() == 2 else idx[t][:256]
+        a, b = e.weight.detach()[rows_t], r.weight.detach()[rows_t]
+        row_err = max(row_err, float(((a - b).abs() / (b.abs() + 1e-6)).max()))
+    mlp_err = 0.0
+    sd_o, sd_r = model.state_dict(), refm.state_dict()
+    for k in mlp:
+        mlp_err = max(mlp_err, float(((sd_o[k] - sd_r[k]).abs().max() / (sd_r[k].abs().max() + 1e-12))))
+    out = {"table_rows_total": int(sum(e.weight.size(0) for e in model.emb_l)), "table_bytes": int(need), "steps": steps,
+           "loss": ours, "reference_loss": theirs, "rel_err_per_step": rel, "bar": 1e-5, "pass": bool(max(rel) <= 1e-5),
+           "max_prediction_abs_err_last_step": pred_err, "max_rel_err_updated_table_rows": row_err, "max_rel_err_mlp_parameters": mlp_err,
+           "what": "the unmodified reference DLRM_Net (oracle/_ref) on the same MI355X holding a copy of this model's parameters at the FULL "
+                   "table sizes, both trained on the same batches with SGD: loss within 1e-5 relative per step"}
+    del refm, optr, tables
+    torch.cuda.empty_cache()
+    return out
 
 
 def high_row_check(model, D, device, B=4096, seed=99):
@@ -1264,6 +1327,15 @@ def main():
             del host
         except Exception as e:                              # noqa: BLE001 - a report beside the headline
             result["reference_timed_region"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        partial["json"] = json.dumps(result)
+    if N == 1 and graphed is None and not hot and args.optimizer == "sgd" and args.mlp_arith == "f32" and not args.no_full_size_parity and not args.row_cap:
+        try:
+            keep_timers, ops.timers = ops.timers, None
+            result["full_size_parity"] = full_size_parity(model, opt, wl, ln_top, batches, args.lr, device)
+            ops.timers = keep_timers
+        except Exception as e:                              # noqa: BLE001 - a report beside the headline
+            result["full_size_parity"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            torch.cuda.empty_cache()
         partial["json"] = json.dumps(result)
     if N == 1 and not hot:
         try:

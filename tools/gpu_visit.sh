@@ -16,7 +16,7 @@ OUT=gpurun_out/${1:?out tag}; shift
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-QUICK="--no-cpu-baseline --no-parity-check --no-box-calibration --no-rccl-selfcheck --no-high-row-check"
+QUICK="--no-cpu-baseline --no-parity-check --no-box-calibration --no-rccl-selfcheck --no-high-row-check --no-full-size-parity --no-reference-region"
 n=0
 summ() { python - "$1" <<'PY'
 import json, sys
@@ -25,7 +25,7 @@ try:
     r = d.get("roofline") or {}
     print("  ms %.3f  value %.0f  loss %.5f  roofline %s frac %s" % (d["ms_per_step"], d["value"], d.get("final_loss", float("nan")), (r.get("kernel") or "")[:24], r.get("frac")))
     print("  " + "  ".join("%s %.3f" % (k[:16], v[0]) for k, v in (r.get("by_category") or {}).items() if v[0] > 0.03))
-    for k in ("parity_check", "high_row_check", "rccl_selfcheck", "iota_proof"):
+    for k in ("parity_check", "full_size_parity", "high_row_check", "rccl_selfcheck", "iota_proof"):
         if d.get(k) is not None:
             v = d[k]; print("  %s: %s" % (k, {a: v[a] for a in list(v)[:8]} if isinstance(v, dict) else v))
     c = d.get("cpu_baseline") or {}
