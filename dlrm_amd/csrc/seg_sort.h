@@ -40,6 +40,7 @@ constexpr int SEG_MAX_DBITS = 13;        // 8192 bins: 32 KB of LDS per wave
 constexpr int SEG_GROUP_TILES = 128;     // tiles whose counts ONE thread of seg_colscan_kernel prefixes (262144 lookups); longer segments: several groups
 constexpr int SEG_MAX_GROUPS = 256;      // per table segment (67 M lookups)
 constexpr int SEG_MAX_ROUNDS = 4;
+constexpr int SEG_BLOCKS = (1 << SEG_MAX_DBITS) / 256;   // 256-bin blocks of the widest digit: per-tile block sums [tile][SEG_BLOCKS] (seg_scan_kernel)
 constexpr long long SEG_HIST_BUDGET = 8ll << 20;   // words of per-tile histogram per table and round (32 MB): bounds the digit width of long segments
 
 struct SegRound {
@@ -63,7 +64,7 @@ struct SegRound {
 struct SegPlan {
     int rounds;
     SegRound round[SEG_MAX_ROUNDS];
-    size_t hist_words, bin_words, gtot_words;                // buffer sizes (u32 words), the maximum over rounds
+    size_t hist_words, bin_words, gtot_words, bsum_words;    // buffer sizes (u32 words), the maximum over rounds
 };
 
 static int seg_bits_for(long long n) { int b = 0; while (((long long)1 << b) < n) ++b; return b < 1 ? 1 : b; }
@@ -87,7 +88,7 @@ static bool seg_plan(int n, const long long* nnz, const long long* rows, SegPlan
         if (passes[k] > R) R = passes[k];
     }
     p->rounds = R;
-    p->hist_words = 0; p->bin_words = 0; p->gtot_words = 0;
+    p->hist_words = 0; p->bin_words = 0; p->gtot_words = 0; p->bsum_words = 0;
     long long base[DLRM_MAX_TABLES_PER_LAUNCH];
     long long acc = 0;
     for (int k = 0; k < n; ++k) { base[k] = acc; acc += nnz[k]; }
@@ -118,6 +119,7 @@ static bool seg_plan(int n, const long long* nnz, const long long* rows, SegPlan
             q.base[i] = base[k]; q.nnz[i] = nnz[k];
             hw += (size_t)tiles << d; bw += (size_t)1 << d;
             if (groups > 1) gw += (size_t)groups << d;
+            hw = (hw + 3) & ~(size_t)3; bw = (bw + 3) & ~(size_t)3; gw = (gw + 3) & ~(size_t)3;   // rows of the next table start 16-byte aligned (seg_scatter_tile)
         }
         for (int i = q.ntab; i < DLRM_MAX_TABLES_PER_LAUNCH; ++i) {
             q.tab[i] = 0; q.tile_start[i + 1] = q.tile_start[q.ntab]; q.scan_start[i + 1] = q.scan_start[q.ntab]; q.gscan_start[i + 1] = q.gscan_start[q.ntab];
@@ -127,6 +129,7 @@ static bool seg_plan(int n, const long long* nnz, const long long* rows, SegPlan
         if (hw > p->hist_words) p->hist_words = hw;
         if (bw > p->bin_words) p->bin_words = bw;
         if (gw > p->gtot_words) p->gtot_words = gw;
+        if ((size_t)q.tile_start[q.ntab] * SEG_BLOCKS > p->bsum_words) p->bsum_words = (size_t)q.tile_start[q.ntab] * SEG_BLOCKS;
         if (hw > 0xFFFFFFFFull || gw > 0xFFFFFFFFull) return false;      // (offsets are 32-bit words)
     }
     return true;
@@ -146,8 +149,9 @@ constexpr int SEG_CHUNKS = SEG_TILE / 64;     // 64-entry steps per tile: a lane
 // (profiles/round3: the first version of this sorter was slower than rocPRIM for exactly that reason).
 template <typename KT>
 __global__ __launch_bounds__(64) void seg_hist_kernel(SegRound q, const KT* __restrict__ in, const KT* __restrict__ tmp,
-                                                      const KT* __restrict__ out, unsigned* __restrict__ hist) {
-    __shared__ unsigned h[1 << SEG_MAX_DBITS];
+                                                      const KT* __restrict__ out, unsigned* __restrict__ hist, unsigned* __restrict__ bsum) {
+    __shared__ __attribute__((aligned(16))) unsigned h[1 << SEG_MAX_DBITS];
+    __shared__ unsigned bs[SEG_BLOCKS];                       // the tile's entries per block of 256 bins (what seg_scan_kernel needs of the OTHER blocks)
     const int lane = threadIdx.x;
     const int i = seg_find(q, blockIdx.x);
     const unsigned tile = blockIdx.x - q.tile_start[i];
@@ -161,14 +165,28 @@ __global__ __launch_bounds__(64) void seg_hist_kernel(SegRound q, const KT* __re
     // (indices past the tile's end are clamped to its last entry, not predicated: 64 unconditional loads in straight-line code)
 #pragma unroll
     for (int j = 0; j < SEG_CHUNKS; ++j) { const int e = j * 64 + lane; k[j] = src[s + (e < n ? e : n - 1)]; }
-    for (unsigned b = lane; b < bins; b += 64) h[b] = 0u;
-    // (one wave: its LDS operations complete in order, no barrier needed between the fill, the adds and the read-out)
+    // (one wave: its LDS operations complete in order, no barrier needed between the fill, the adds and the read-out; rows of >= 256 bins
+    // move 16 bytes per lane — the table's rows are 16-byte aligned, seg_plan)
+    if (d >= 8) { for (unsigned b = lane * 4; b < bins; b += 256) *(uint4*)(h + b) = make_uint4(0u, 0u, 0u, 0u); }
+    else        { for (unsigned b = lane; b < bins; b += 64) h[b] = 0u; }
+    if (lane < SEG_BLOCKS) bs[lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < SEG_CHUNKS; ++j)
-        if (j * 64 + lane < n) atomicAdd(&h[(unsigned)(k[j] >> shift) & mask], 1u);
+        if (j * 64 + lane < n) {
+            const unsigned dg = (unsigned)(k[j] >> shift) & mask;
+            atomicAdd(&h[dg], 1u);
+            atomicAdd(&bs[dg >> 8], 1u);
+        }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < SEG_BLOCKS) bsum[(size_t)blockIdx.x * SEG_BLOCKS + lane] = bs[lane];
     unsigned* __restrict__ dst = hist + q.hist_off[i] + ((size_t)tile << d);
+    if (d >= 8) {
 #pragma unroll 8
-    for (unsigned b = lane; b < bins; b += 64) dst[b] = h[b];
+        for (unsigned b = lane * 4; b < bins; b += 256) *(uint4*)(dst + b) = *(const uint4*)(h + b);
+    } else {
+        for (unsigned b = lane; b < bins; b += 64) dst[b] = h[b];
+    }
 }
 
 // one thread per (table, tile group, bin): hist[tile][bin] -> exclusive prefix over the GROUP's tiles (in place); the group's total goes to
@@ -199,6 +217,54 @@ __global__ __launch_bounds__(256) void seg_colscan_kernel(SegRound q, unsigned* 
     }
     if (q.ngroups[i] > 1) gtot[q.gtot_off[i] + ((size_t)grp << d) + b] = run;
     else tot[q.bin_off[i] + b] = run;
+}
+
+// Rounds without long segments (every one-lookup-per-bag batch): seg_colscan_kernel AND seg_binscan_kernel in one launch (round 6; two
+// launches of ~9.5 us each for a few hundred KB of counters).  One workgroup per (table, block of 256 bins), one thread per bin:
+//   hist[tile][bin] -> exclusive prefix over the table's tiles (in place, as seg_colscan_kernel), the bin's total stays in a register;
+//   first position of the bin = entries of the table in EARLIER blocks (summed from the per-tile block sums seg_hist_kernel wrote:
+//   at most 128 tiles x 31 blocks words) + exclusive prefix of the totals inside the block (wave scans + the four waves' sums)
+// -> tot[bin], final: what seg_binscan_kernel produced.  Integer sums: any order gives the same words.
+__global__ __launch_bounds__(256) void seg_scan_kernel(SegRound q, unsigned* __restrict__ hist, unsigned* __restrict__ tot,
+                                                       const unsigned* __restrict__ bsum) {
+    __shared__ unsigned wtot[4], wbase[4];
+    int i = 0;
+    while (i + 1 < q.ntab && blockIdx.x >= q.scan_start[i + 1]) ++i;
+    const int d = q.dbits[i], tid = threadIdx.x;
+    const unsigned bins = 1u << d;
+    const unsigned bb = blockIdx.x - q.scan_start[i];         // (one tile group: scan_start counts 256-bin blocks)
+    const unsigned b = bb * 256 + tid;
+    const unsigned tiles = q.tile_start[i + 1] - q.tile_start[i];
+    // entries of the table in the blocks before mine: thread -> (tile = tid / 32 + 8 r, block = tid % 32), rows of 32 words read whole
+    unsigned before = 0;
+    if ((unsigned)(tid & 31) < bb) {
+        const unsigned* __restrict__ bp = bsum + (size_t)q.tile_start[i] * SEG_BLOCKS + (tid & 31);
+        for (unsigned t = tid >> 5; t < tiles; t += 8) before += bp[(size_t)t * SEG_BLOCKS];
+    }
+    unsigned run = 0;
+    if (b < bins) {
+        unsigned* __restrict__ h = hist + q.hist_off[i] + b;
+        for (unsigned t0 = 0; t0 < tiles; t0 += 16) {
+            unsigned c[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) c[u] = (t0 + u < tiles) ? h[(size_t)(t0 + u) << d] : 0u;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (t0 + u < tiles) { h[(size_t)(t0 + u) << d] = run; run += c[u]; }
+        }
+    }
+    unsigned inc = run, bsumw = before;                       // inclusive scan of the totals / plain sum of `before` over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += v;
+        bsumw += __shfl_xor(bsumw, o, 64);
+    }
+    if ((tid & 63) == 63) { wtot[tid >> 6] = inc; wbase[tid >> 6] = bsumw; }
+    __syncthreads();
+    unsigned first = inc - run + wbase[0] + wbase[1] + wbase[2] + wbase[3];
+    for (int w = 0; w < (tid >> 6); ++w) first += wtot[w];
+    if (b < bins) tot[q.bin_off[i] + b] = first;
 }
 
 // long segments only — one thread per (table, bin): gtot[group][bin] -> exclusive prefix over the table's groups (in place), tot[bin] = total
@@ -277,64 +343,105 @@ __device__ __forceinline__ void seg_scatter_tile(const SegRound& q, int i, unsig
 #pragma unroll
         for (int j = 0; j < SEG_CHUNKS; ++j) { const int e = j * 64 + lane; v[j] = vsrc[s + (e < n ? e : n - 1)]; }
     }
-    // ---- where the tile's entries of digit g start:  first[g] (seg_binscan_kernel) + entries of g in the earlier tiles (seg_colscan_kernel),
-    // GATHERED for the digits this lane actually holds (SEG_CHUNKS independent 4-byte reads from each array) — a tile of 2048 entries
-    // touches at most 2048 of up to 8192 bins, and loading + prefix-scanning all of them per tile cost more than the scatter itself
-    // (35 of 49 us, profiles/round3).  LDS keeps only the running COUNT of every digit inside this tile.
+    // ---- where the tile's entries of digit g start:  first[g] (seg_binscan_kernel) + entries of g in the earlier tiles (seg_colscan_kernel)
+    // [+ in the earlier tile groups of a long segment] = the INITIAL VALUE of the digit's cursor in LDS: all bins of the table are filled, by
+    // coalesced 16-byte loads of the two (three) rows.  (Rounds 3-5 gathered the two words for the digits a lane holds — 2 x SEG_CHUNKS
+    // divergent 4-byte loads per lane — and added them to a cursor that counted from zero; measured equal, 26.4 vs 27.0 us per launch,
+    // profiles/round6/sort_kernels.md: the fill needs no per-entry registers and no add after the hand-over.)
     const unsigned* __restrict__ tt = tot + q.bin_off[i];
     const unsigned* __restrict__ h = hist + q.hist_off[i] + ((size_t)tile << d);
-    unsigned off[SEG_CHUNKS];
+    const unsigned* __restrict__ gg = q.ngroups[i] > 1 ? gtot + q.gtot_off[i] + ((size_t)(tile / SEG_GROUP_TILES) << d) : nullptr;
+    if (d >= 8) {                                             // whole rows of 256 bins: a lane owns 4 consecutive bins per sweep (rows are 16-byte aligned: seg_plan)
+        for (unsigned b0 = 0; b0 < bins; b0 += 256 * 8) {
+            uint4 a[8], c[8];
 #pragma unroll
-    for (int j = 0; j < SEG_CHUNKS; ++j) { const unsigned dg = (unsigned)(k[j] >> shift) & mask; off[j] = tt[dg]; }
+            for (int u = 0; u < 8; ++u) {
+                const unsigned b = b0 + u * 256 + lane * 4;
+                if (b < bins) { a[u] = *(const uint4*)(tt + b); c[u] = *(const uint4*)(h + b); }
+            }
+            if (gg) {
 #pragma unroll
-    for (int j = 0; j < SEG_CHUNKS; ++j) { const unsigned dg = (unsigned)(k[j] >> shift) & mask; off[j] += h[dg]; }
-    if (q.ngroups[i] > 1) {                                   // long segment: + the entries of the digit in the earlier tile groups
-        const unsigned* __restrict__ gg = gtot + q.gtot_off[i] + ((size_t)(tile / SEG_GROUP_TILES) << d);
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned b = b0 + u * 256 + lane * 4;
+                    if (b < bins) { const uint4 g = *(const uint4*)(gg + b); a[u].x += g.x; a[u].y += g.y; a[u].z += g.z; a[u].w += g.w; }
+                }
+            }
 #pragma unroll
-        for (int j = 0; j < SEG_CHUNKS; ++j) { const unsigned dg = (unsigned)(k[j] >> shift) & mask; off[j] += gg[dg]; }
-    }
-#pragma unroll 16
-    for (unsigned b = lane; b < bins; b += 64) cur[b] = 0u;
-    __builtin_amdgcn_wave_barrier();
-    // ---- 64 entries at a time, in order
-    const unsigned long long below = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int j = 0; j < SEG_CHUNKS; ++j) {
-        if (j * 64 >= n) break;
-        const bool valid = j * 64 + lane < n;
-        const unsigned dg = (unsigned)(k[j] >> shift) & mask;
-        // match-any: the set of valid lanes holding my digit.  Bitwise over the d <= 13 digit bits it took 13 ballots per step (62 of
-        // the first version's 172 us per sort); instead every lane writes its number into the digit's CLAIM byte — lanes of one digit
-        // hit one address and exactly one write survives — reads it back, and the lanes are matched on that 6-bit winner number.
-        unsigned long long same = __ballot(valid);
-        if (!(dbg & 2)) {
-            if (valid) claim[dg] = (unsigned char)lane;
-            __builtin_amdgcn_wave_barrier();
-            const unsigned w = valid ? (unsigned)claim[dg] : 64u;
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const bool bit = (w >> b) & 1u;
-                const unsigned long long bal = __ballot(bit);
-                same &= bit ? bal : ~bal;
+            for (int u = 0; u < 8; ++u) {
+                const unsigned b = b0 + u * 256 + lane * 4;
+                if (b < bins) *(uint4*)(cur + b) = make_uint4(a[u].x + c[u].x, a[u].y + c[u].y, a[u].z + c[u].z, a[u].w + c[u].w);
             }
         }
-        const int rank = __popcll(same & below);
-        const int leader = __ffsll((long long)same) - 1;                 // lowest lane of my group (valid lanes only use it)
-        unsigned start = 0u;
-        if (valid && rank == 0 && !(dbg & 4)) {                          // one lane per distinct digit: no two leaders share an address
-            start = cur[dg];
-            cur[dg] = start + (unsigned)__popcll(same);
+    } else {
+        for (unsigned b = lane; b < bins; b += 64) cur[b] = tt[b] + h[b] + (gg ? gg[b] : 0u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // ---- 64 entries at a time IN ORDER — but no step waits for another (round 6).  The first version ran the steps one after the other,
+    // each paying its own LDS round trips (claim byte back, cursor read, cursor write, shuffle) with one wave per SIMD and nothing to hide
+    // them behind: 36-39 us per launch, now 26-27 (profiles/round6/sort_kernels.md).  A wave's LDS instructions execute in program order, so the ORDER between steps needs
+    // no waiting at all: four passes over the tile's steps, each a run of independent LDS instructions issued back to back.
+    // (dbg, tuning builds: 1 = no scattered stores)
+    // pass A: match-any labels.  Every lane writes its number into its digit's CLAIM byte (lanes of one digit hit one address, one write
+    // survives) and reads the winner back; the next step's writes are queued behind this step's reads.
+    // pass B (registers only): the lanes holding my digit = the lanes that read my winner: 6 ballots over the winner's bits.
+    // pass C: the WINNER of every group takes the digit's cursor and advances it by the group's size: ONE returning LDS add per step
+    // (no two winners of a step share an address; the adds of consecutive steps on one digit execute in step order).
+    // pass D: the group's start from its winner, then the entry goes to start + its rank in the group (lanes of the group below it):
+    // stable by construction.
+    // The passes run over SEG_PIPE steps at a time (the LDS queue holds 16 instructions; more steps per pass only cost registers).
+    constexpr int SEG_PIPE = 8;
+    static_assert(SEG_CHUNKS % SEG_PIPE == 0, "tile = whole pipeline groups");
+#pragma unroll
+    for (int j0 = 0; j0 < SEG_CHUNKS; j0 += SEG_PIPE) {
+        if (j0 * 64 >= n) break;
+        unsigned w[SEG_PIPE];                                 // the lane whose claim survived = the group's leader (any agreed member will do)
+        unsigned pk[SEG_PIPE];                                // my rank in the group | group size << 8
+        unsigned st[SEG_PIPE];
+#pragma unroll
+        for (int u = 0; u < SEG_PIPE; ++u) {                  // ---- pass A
+            const int j = j0 + u;
+            const bool valid = j * 64 + lane < n;
+            const unsigned dg = (unsigned)(k[j] >> shift) & mask;
+            if (valid) claim[dg] = (unsigned char)lane;
+            __builtin_amdgcn_wave_barrier();
+            w[u] = valid ? (unsigned)claim[dg] : 64u;
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int u = 0; u < SEG_PIPE; ++u) {                  // ---- pass B: same = lanes whose winner equals mine, as two 32-bit halves
+            const unsigned long long bv = __ballot(w[u] < 64u);
+            unsigned slo = (unsigned)bv, shi = (unsigned)(bv >> 32);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const int bm = (int)(w[u] << (31 - b)) >> 31;            // bit b of my winner, spread over the word (0 / -1)
+                const unsigned long long bal = __ballot(bm != 0);
+                slo &= ~((unsigned)bal ^ (unsigned)bm);                  // lanes whose bit b equals mine
+                shi &= ~((unsigned)(bal >> 32) ^ (unsigned)bm);
+            }
+            const unsigned rank = __builtin_amdgcn_mbcnt_hi(shi, __builtin_amdgcn_mbcnt_lo(slo, 0u));   // lanes of my group below me
+            pk[u] = rank | ((unsigned)(__popc(slo) + __popc(shi)) << 8);
+        }
+#pragma unroll
+        for (int u = 0; u < SEG_PIPE; ++u) {                  // ---- pass C
+            const unsigned dg = (unsigned)(k[j0 + u] >> shift) & mask;
+            st[u] = 0u;
+            if (w[u] == (unsigned)lane) st[u] = atomicAdd(&cur[dg], pk[u] >> 8);
         }
         __builtin_amdgcn_wave_barrier();
-        start = off[j] + __shfl(start, leader < 0 ? 0 : leader, 64);    // (off[j] is the same for every lane of the group)
-        const unsigned val = FIRST ? (unsigned)(s + j * 64 + lane) : v[FIRST ? 0 : j];
-        if (valid && !(dbg & 1)) {
-            const long long dst = seg + (long long)start + rank;
-            kdst[dst] = k[j];
-            vdst[dst] = val;
+#pragma unroll
+        for (int u = 0; u < SEG_PIPE; ++u)                    // ---- pass D: starts from the winners ...
+            st[u] = __shfl(st[u], (int)(w[u] & 63u), 64);
+#pragma unroll
+        for (int u = 0; u < SEG_PIPE; ++u) {                  // ... and the stores
+            const int j = j0 + u;
+            const unsigned val = FIRST ? (unsigned)(s + j * 64 + lane) : v[FIRST ? 0 : j];
+            if (w[u] < 64u && !(dbg & 1)) {
+                const long long dst = seg + (long long)(st[u] + (pk[u] & 63u));
+                kdst[dst] = k[j];
+                vdst[dst] = val;
+            }
         }
-        if ((dbg & 1) && start + rank + k[j] + val == 0x7fffffffu) kdst[0] = 0;   // keeps the values live
     }
 }
 
@@ -345,10 +452,10 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
                                                          unsigned* __restrict__ vtmp, unsigned* __restrict__ vout,
                                                          const unsigned* __restrict__ hist, const unsigned* __restrict__ tot,
                                                          const unsigned* __restrict__ gtot, int dbg) {
-    // dbg (env DLRM_SEG_DEBUG, timing only — WRONG results): 1 no scattered stores, 2 no match-any, 4 no LDS cursor hand-over.
+    // dbg (env DLRM_SEG_DEBUG, tuning builds, timing only — WRONG results): 1 no scattered stores.
     // Lanes hand cursors to each other through `cur`.  One wave: its LDS instructions execute in program order; the
     // __builtin_amdgcn_wave_barrier() calls keep the COMPILER from moving LDS accesses across the hand-over points.
-    __shared__ unsigned cur[1 << SEG_MAX_DBITS];            // per digit: entries of it placed so far in this tile
+    __shared__ __attribute__((aligned(16))) unsigned cur[1 << SEG_MAX_DBITS];   // per digit: where its next entry of this tile goes (position inside the table's segment)
     __shared__ unsigned char claim[1 << SEG_MAX_DBITS];     // per digit: the lane that claimed it in the current step (match-any label)
     const int i = seg_find(q, blockIdx.x);
     const unsigned tile = blockIdx.x - q.tile_start[i];
@@ -369,21 +476,24 @@ static int seg_debug() {
 
 template <typename KT>
 static int seg_sort_run(const SegPlan& p, const KT* keys_in, KT* keys_tmp, KT* keys_out, unsigned* vals_tmp, unsigned* vals_out,
-                        unsigned* hist, unsigned* binbase, unsigned* gtot, hipStream_t st) {
+                        unsigned* hist, unsigned* binbase, unsigned* gtot, unsigned* bsum, hipStream_t st) {
     for (int r = 0; r < p.rounds; ++r) {
         const SegRound& q = p.round[r];
         const unsigned tiles = q.tile_start[q.ntab];
         if (q.ntab == 0 || tiles == 0) continue;
-        hipLaunchKernelGGL((seg_hist_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out, hist);
+        hipLaunchKernelGGL((seg_hist_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out, hist, bsum);
         DLRM_LAUNCH_CHECK();
-        hipLaunchKernelGGL(seg_colscan_kernel, dim3(q.scan_start[q.ntab]), dim3(256), 0, st, q, hist, binbase, gtot);
-        DLRM_LAUNCH_CHECK();
-        if (q.gscan_start[q.ntab] > 0) {
+        if (q.gscan_start[q.ntab] == 0) {                     // no long segment in this round: tile prefixes and digit starts from ONE launch
+            hipLaunchKernelGGL(seg_scan_kernel, dim3(q.scan_start[q.ntab]), dim3(256), 0, st, q, hist, binbase, (const unsigned*)bsum);
+            DLRM_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(seg_colscan_kernel, dim3(q.scan_start[q.ntab]), dim3(256), 0, st, q, hist, binbase, gtot);
+            DLRM_LAUNCH_CHECK();
             hipLaunchKernelGGL(seg_groupscan_kernel, dim3(q.gscan_start[q.ntab]), dim3(256), 0, st, q, gtot, binbase);
             DLRM_LAUNCH_CHECK();
+            hipLaunchKernelGGL(seg_binscan_kernel, dim3((unsigned)q.ntab), dim3(1024), 0, st, q, binbase);
+            DLRM_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(seg_binscan_kernel, dim3((unsigned)q.ntab), dim3(1024), 0, st, q, binbase);
-        DLRM_LAUNCH_CHECK();
         hipLaunchKernelGGL((seg_scatter_kernel<KT>), dim3(tiles), dim3(64), 0, st, q, keys_in, (const KT*)keys_tmp, (const KT*)keys_out,
                            keys_tmp, keys_out, (const unsigned*)vals_tmp, (const unsigned*)vals_out, vals_tmp, vals_out,
                            (const unsigned*)hist, (const unsigned*)binbase, (const unsigned*)gtot, seg_debug());

@@ -111,7 +111,7 @@ static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct Layout {
     size_t keys_in, keys_out, vals_in, vals_out, bag_of, temp, temp_bytes, total;
     // the segmented sorter of seg_sort.h (own = true: it handles this group; the rocPRIM temp then stays unused)
-    size_t keys_tmp, vals_tmp, hist, binbase, gtot;
+    size_t keys_tmp, vals_tmp, hist, binbase, gtot, bsum;
     bool own;
     SegPlan plan;
 };
@@ -153,7 +153,7 @@ static int make_layout(size_t L, bool wide, int bits, Layout* lo, int n = 0, con
     lo->vals_out = o; o += align256(L * 4);
     lo->bag_of = o;   o += align256(L * 4);
     lo->temp = o; lo->temp_bytes = 0;
-    lo->keys_tmp = lo->vals_tmp = lo->hist = lo->binbase = lo->gtot = 0;
+    lo->keys_tmp = lo->vals_tmp = lo->hist = lo->binbase = lo->gtot = lo->bsum = 0;
     if (lo->own) {
         // (the general sorter's temporary storage is neither sized nor reserved when the segmented sorter takes the group)
         lo->keys_tmp = o; o += align256(L * ksz);
@@ -161,6 +161,7 @@ static int make_layout(size_t L, bool wide, int bits, Layout* lo, int n = 0, con
         lo->hist = o;     o += align256(lo->plan.hist_words * 4);
         lo->binbase = o;  o += align256(lo->plan.bin_words * 4);
         lo->gtot = o;     o += align256(lo->plan.gtot_words * 4);
+        lo->bsum = o;     o += align256(lo->plan.bsum_words * 4);
     } else {
         hipError_t e = wide ? sort_temp_bytes<unsigned long long>(L, bits, &lo->temp_bytes)
                             : sort_temp_bytes<unsigned>(L, bits, &lo->temp_bytes);
@@ -219,7 +220,7 @@ static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight
     DLRM_LAUNCH_CHECK();
     if (lo.own)         // table-major segments, per-table digit counts: seg_sort.h (graph-replayable: plain kernels, no memsets)
         return seg_sort_run<KT>(lo.plan, (const KT*)keys_in, (KT*)(ws + lo.keys_tmp), keys_out, (unsigned*)(ws + lo.vals_tmp), vals_out,
-                                (unsigned*)(ws + lo.hist), (unsigned*)(ws + lo.binbase), (unsigned*)(ws + lo.gtot), st);
+                                (unsigned*)(ws + lo.hist), (unsigned*)(ws + lo.binbase), (unsigned*)(ws + lo.gtot), (unsigned*)(ws + lo.bsum), st);
     size_t tb = lo.temp_bytes;
     hipError_t e = rocprim::radix_sort_pairs(ws + lo.temp, tb, (const KT*)keys_in, keys_out, (const unsigned*)vals_in,
                                              vals_out, L, 0, key_bits, st, false);
