@@ -142,6 +142,16 @@ __device__ __forceinline__ int seg_find(const SegRound& q, unsigned w) {
     return i;
 }
 
+// tools/probes/seg_scatter_probe.hip only: cycle stamps of a scatter tile's phases (each stamp waits for everything issued before it,
+// so the stamped build serialises what the product build overlaps: it prices the phases, it is not the product's timeline)
+#ifdef DLRM_SEG_STAMPS
+__device__ unsigned long long seg_stamps[8192 * 8];
+#define SEG_STAMP(n) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+                          if (threadIdx.x == 0) seg_stamps[(size_t)blockIdx.x * 8 + (n)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SEG_STAMP(n) do { } while (0)
+#endif
+
 constexpr int SEG_CHUNKS = SEG_TILE / 64;     // 64-entry steps per tile: a lane keeps its SEG_CHUNKS keys of the tile in registers
 
 // All loads of a tile are issued up front (SEG_CHUNKS independent, coalesced loads per lane): a wave that fetched one 64-entry step
@@ -333,6 +343,7 @@ __device__ __forceinline__ void seg_scatter_tile(const SegRound& q, int i, unsig
     const long long s = seg + (long long)tile * SEG_TILE;
     long long nn = q.nnz[i] - (long long)tile * SEG_TILE; if (nn > SEG_TILE) nn = SEG_TILE;
     const int n = (int)nn;
+    SEG_STAMP(1);
     // ---- the whole tile into registers: SEG_CHUNKS independent loads per lane (and as many for the values after the first round);
     // indices past the tile's end are clamped to its last entry, not predicated: unconditional loads in straight-line code
     KT k[SEG_CHUNKS];
@@ -343,6 +354,7 @@ __device__ __forceinline__ void seg_scatter_tile(const SegRound& q, int i, unsig
 #pragma unroll
         for (int j = 0; j < SEG_CHUNKS; ++j) { const int e = j * 64 + lane; v[j] = vsrc[s + (e < n ? e : n - 1)]; }
     }
+    SEG_STAMP(2);
     // ---- where the tile's entries of digit g start:  first[g] (seg_binscan_kernel) + entries of g in the earlier tiles (seg_colscan_kernel)
     // [+ in the earlier tile groups of a long segment] = the INITIAL VALUE of the digit's cursor in LDS: all bins of the table are filled, by
     // coalesced 16-byte loads of the two (three) rows.  (Rounds 3-5 gathered the two words for the digits a lane holds — 2 x SEG_CHUNKS
@@ -376,6 +388,7 @@ __device__ __forceinline__ void seg_scatter_tile(const SegRound& q, int i, unsig
         for (unsigned b = lane; b < bins; b += 64) cur[b] = tt[b] + h[b] + (gg ? gg[b] : 0u);
     }
     __builtin_amdgcn_wave_barrier();
+    SEG_STAMP(3);
     const unsigned long long below = (1ull << lane) - 1ull;
     // ---- 64 entries at a time IN ORDER — but no step waits for another (round 6).  The first version ran the steps one after the other,
     // each paying its own LDS round trips (claim byte back, cursor read, cursor write, shuffle) with one wave per SIMD and nothing to hide
@@ -442,7 +455,11 @@ __device__ __forceinline__ void seg_scatter_tile(const SegRound& q, int i, unsig
                 vdst[dst] = val;
             }
         }
+#ifdef DLRM_SEG_STAMPS
+        if (j0 == SEG_CHUNKS - SEG_PIPE) { if (threadIdx.x == 0) seg_stamps[(size_t)blockIdx.x * 8 + 4] = __builtin_readcyclecounter(); }
+#endif
     }
+    SEG_STAMP(5);
 }
 
 template <typename KT>
@@ -457,6 +474,7 @@ __global__ __launch_bounds__(64) void seg_scatter_kernel(SegRound q, const KT* _
     // __builtin_amdgcn_wave_barrier() calls keep the COMPILER from moving LDS accesses across the hand-over points.
     __shared__ __attribute__((aligned(16))) unsigned cur[1 << SEG_MAX_DBITS];   // per digit: where its next entry of this tile goes (position inside the table's segment)
     __shared__ unsigned char claim[1 << SEG_MAX_DBITS];     // per digit: the lane that claimed it in the current step (match-any label)
+    SEG_STAMP(0);
     const int i = seg_find(q, blockIdx.x);
     const unsigned tile = blockIdx.x - q.tile_start[i];
     const bool to_out = q.dst_out[i] != 0;
