@@ -17,6 +17,7 @@ all-to-all per direction, MLP gradients one DDP all-reduce (extend_distributed.p
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -91,6 +92,9 @@ def parse():
                          "wrote: no device pass, no synchronisation); resident: four batches reused (their proof is cached after warm-up)")
     ap.add_argument("--no-full-size-parity", action="store_true", help="skip the 3-step comparison with the unmodified reference module at the FULL table sizes "
                                                                         "(both models resident on the GPU: 2 x 96 GB)")
+    ap.add_argument("--gc", choices=["default", "freeze", "off"], default="default",
+                    help="Python garbage collector around the timed region: default = untouched; freeze = gc.collect() + gc.freeze() before the "
+                         "warm-up (objects alive then are never scanned again); off = gc.disable() inside the timed region (A/B of host stalls)")
     ap.add_argument("--no-high-row-check", action="store_true", help="skip the top-eighth-of-every-table check of the embedding kernels after the timed region")
     ap.add_argument("--no-standalone-emb", action="store_true", help="skip the stand-alone dlrm_emb_fwd measurement (profiling runs)")
     ap.add_argument("--no-rccl-selfcheck", action="store_true", help="skip the one-rank RCCL self-check child process (N = 1)")
@@ -539,6 +543,21 @@ def full_size_parity(model, opt, wl, ln_top, batches, lr, device, steps=3):
     return out
 
 
+def host_step_intervals(t0, returns, gc_before):
+    """Host time between the returns of consecutive timed step() calls (ms).  With --offsets fresh every step ends the host's run-ahead once
+    (the proof's verdict), so these intervals ARE the steps as the GPU ran them and a single long one is a host stall the GPU sat out
+    (garbage collection, a descheduled thread, a slow wake-up): the headline is their mean, this says how it is distributed."""
+    if len(returns) < 2:
+        return None
+    iv = sorted((b - a) * 1e3 for a, b in zip([t0] + returns[:-1], returns))
+    n = len(iv)
+    gc_now = [g["collections"] for g in gc.get_stats()]
+    return {"min_ms": iv[0], "median_ms": iv[n // 2], "max_ms": iv[-1], "second_max_ms": iv[-2], "first_ms": (returns[0] - t0) * 1e3,
+            "python_gc_collections_in_timed_region": [b - a for a, b in zip(gc_before, gc_now)], "gc_enabled": gc.isenabled(),
+            "note": "intervals between the returns of step(); with the default --offsets fresh the host waits for the GPU once per step, so "
+                    "median_ms is the undisturbed step and (ms_per_step - median_ms) * steps the sum of the host stalls of the region"}
+
+
 def high_row_check(model, D, device, B=4096, seed=99):
     """The headline's embedding kernels on the benchmark's OWN tables at their full size, lookups drawn from the TOP EIGHTH of every table
     (byte offsets of up to 20 GB from a table base; tools/visualize.py:1195-1223 sizes): dlrm_emb_fwd and the fused lookup + interaction
@@ -672,8 +691,8 @@ def resolve_world(args, argv=None, environ=None):
 
 
 KERNELS_OF_CATEGORY = [      # launch category of dlrm_amd.ops -> substrings of the kernels one of its C-ABI calls launches (headline workload)
-    ("emb_bwd_sgd", ["expand_kernel", "seg_hist_kernel", "seg_colscan_kernel", "seg_groupscan_kernel", "seg_binscan_kernel", "seg_scatter_kernel",
-                     "sorted_update_kernel", "emb_bwd_sgd_"]),
+    ("emb_bwd_sgd", ["expand_kernel", "seg_hist_kernel", "seg_scan_kernel", "seg_colscan_kernel", "seg_groupscan_kernel", "seg_binscan_kernel",
+                     "seg_scatter_kernel", "sorted_update_kernel", "emb_bwd_sgd_"]),
     ("linear_bwd_weight", ["gemm3_kernel<false, false", "splitk_reduce_kernel", "smallk_wgrad", "gemv_bwd_weight"]),
     ("linear_bwd_data", ["gemm3_kernel<true, false", "gemv_bwd_data"]),
     ("linear_fwd", ["gemm3_kernel<true, true", "gemv_fwd", "pad_cols_kernel"]),
@@ -684,8 +703,8 @@ KERNELS_OF_CATEGORY = [      # launch category of dlrm_amd.ops -> substrings of 
 
 def kernel_launches_per_step():
     """KERNEL launches per training step by launch category, counted from the committed rocprofv3 --kernel-trace --stats summary of this
-    command (profiles/round*/rocprof_kernel_stats.csv; steps = launches of the dense-SGD kernel) — a C-ABI call is 1-11 kernels (the sorted
-    embedding update: expand + two radix rounds of four kernels + the update), which `c_abi_calls_per_step` alone hides."""
+    command (profiles/round*/rocprof_kernel_stats.csv; steps = launches of the dense-SGD kernel) — a C-ABI call is 1-8 kernels (the sorted
+    embedding update: expand + two radix rounds of three kernels + the update), which `c_abi_calls_per_step` alone hides."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "rocprof_kernel_stats.csv")))
@@ -991,6 +1010,12 @@ def main():
     torch.cuda.synchronize()
     ops.timers = None if args.no_kernel_timers else ops.KernelTimers()
     iota0 = dict(ops.IOTA_STATS)
+    if args.gc == "freeze":
+        gc.collect(); gc.freeze()
+    elif args.gc == "off":
+        gc.collect(); gc.disable()
+    step_returns = []                     # host time at which every timed step() call returned (diagnostics: host_step_intervals)
+    gc_before = [g["collections"] for g in gc.get_stats()]
     t0 = time.perf_counter()
     timed_steps = 0
     for i in range(args.steps):
@@ -998,10 +1023,13 @@ def main():
             ops.timers.enabled = (i % max(args.timer_every, 1) == 0)
             timed_steps += int(ops.timers.enabled)
         loss = step(args.warmup + 1 + i)          # (index args.warmup was the extra untimed step above: every timed step sees a NEW offsets object)
+        step_returns.append(time.perf_counter())
     torch.cuda.synchronize()
     if N > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    if args.gc == "off":
+        gc.enable()
     iota = {k: ops.IOTA_STATS[k] - iota0[k] for k in iota0}
     tagged_ms = None
     if fresh_off is not None and args.offsets == "fresh" and graphed is None:
@@ -1113,7 +1141,7 @@ def main():
              "linear_bwd_data": "gemm3_kernel<KC,KS> (dX = dY*W, previous layer's ReLU derivative from sign bits in the straight-line epilogue; 128x128x16 tiles, 4 workgroups per CU)",
              "linear_bwd_weight": "gemm3_kernel<KS,KS> (dW = dY^T*X split over the batch into slabs + bias-grad row sums; 256x128x16 tiles at one round of 512 workgroups for the wide layers) + splitk_reduce_kernel",
              "emb_bwd_adagrad": "expand + lookup sort (seg_sort.h, or rocPRIM for segments > 262144 lookups) + adagrad_groups_kernel + adagrad_fixup_kernel",
-             "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "expand + segmented radix sort (seg_hist / seg_colscan / seg_binscan / seg_scatter, csrc/seg_sort.h) + sorted_update_kernel" if args.emb_update == "sorted" else "emb_bwd_sgd_{atomic,lds}_kernel",
+             "emb_fwd": "emb_fwd_kernel", "emb_bwd_sgd": "expand + segmented radix sort (seg_hist / seg_scan / seg_scatter per round, csrc/seg_sort.h) + sorted_update_kernel" if args.emb_update == "sorted" else "emb_bwd_sgd_{atomic,lds}_kernel",
              "interact_fwd": "interact_fwd_dma_kernel", "interact_bwd": "interact_bwd_dma_kernel",
              "emb_interact_fwd": "interact_fwd_dma_kernel<gather>: one-hot embedding lookups fetched by the interaction kernel (K1 + K6 fused)",
              "emb_interact_bwd": "interact_bwd_dma_kernel<gather>"}
@@ -1234,17 +1262,21 @@ def main():
         "roofline_embedding": roof("emb_fwd") if "emb_fwd" in kernels else None,
         "embedding_hbm_gbps": emb_gbps,
         "iota_proof": None if (N > 1 or hot) else {
-            "offsets": args.offsets, "device_proofs_in_timed_region": iota["checked"], "tagged": iota["tagged"], "cached": iota["cached"],
+            "offsets": args.offsets, "verdict": "device predicate (ABI 16)" if dlrm_amd.dlrm_net.DEVICE_PREDICATE else "host proof (DLRM_DEVICE_PREDICATE=0)",
+            "device_predicates_in_timed_region": iota.get("device_predicates", 0), "host_proofs_in_timed_region": iota["checked"],
+            "tagged": iota["tagged"], "cached": iota["cached"],
             "launch_us_per_step": iota["host_us"] / max(args.steps, 1), "host_wait_us_per_step": iota["wait_us"] / max(args.steps, 1),
             "ms_per_step_with_producer_tagged_offsets": tagged_ms,
             "iota_proof_us_per_step": None if tagged_ms is None else (ms - tagged_ms) * 1e3,
             "note": "with --offsets fresh (default) every timed step hands the module a NEW untagged offsets tensor, as the reference loop does "
-                    "(dlrm_s_pytorch.py:129-145), and the one-lookup-per-bag proof (a device pass on its own stream + a host wait for its "
-                    "event, the bottom tower enqueued in between) runs INSIDE the timed region.  host_wait_us_per_step is mostly the host "
-                    "waiting for the GPU to finish the previous step (the wait ends the host's run-ahead), not GPU idle time; what the proof "
-                    "costs is AT MOST iota_proof_us_per_step = headline ms_per_step - the same steps re-run on producer-tagged offsets (no proof "
-                    "needed) — the second leg of a process runs warmer: as separate interleaved processes the difference is ~31 us per step "
-                    "(profiles/round5/offsets_mode_ab.txt)"},
+                    "(dlrm_s_pytorch.py:129-145): whether it holds one lookup per bag is counted by a device pass INSIDE the timed region "
+                    "(dlrm_offsets_iota_flags, on the step's stream) and the verdict stays on the device — the fused lookup + interaction "
+                    "kernels and the two-kernel form are both enqueued behind that launch predicate (three launches per step return at once) "
+                    "and the host never waits (rounds 4-6 had the host wait for the verdict once per step: 30-110 us on a quiet box, "
+                    "1.25 ms per step on a bad day — profiles/round6/proof_wait.md).  iota_proof_us_per_step = headline ms_per_step - the same "
+                    "steps re-run on producer-tagged offsets (no pass, no predicate); the second leg of a process runs warmer, so it is an "
+                    "upper bound of what the proof and the three empty launches cost"},
+        "host_step_intervals": host_step_intervals(t0, step_returns, gc_before),
         "kernels": kernels,
     }
     result.update(result_extra)
@@ -1451,7 +1483,6 @@ def main():
         # ---- the OTHER dense-gradient synchronisation, same process, same parameters -------------------------------------------
         if args.alts and not hot:
             try:
-                import gc
                 other = "flat" if args.dense_sync == "ddp" else "ddp"
                 watchdog(args.hang_timeout + 20 * args.steps, "alternative dense-gradient all-reduce (%s)" % other)
                 if os.environ.get("DLRM_BENCH_SELFTEST_HANG") == "alt":        # development: proves the watchdog still prints the headline

@@ -91,6 +91,15 @@ static inline int dlrm_zero2d(float* p, long long ld, long long cols, long long 
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// A launch PREDICATE read on the device (ABI 16): a kernel given one runs only if (*flag != 0) == (nonzero != 0), else every workgroup
+// returns at once.  It lets a caller enqueue BOTH implementations of a step whose choice depends on a device-side fact — the fused lookup +
+// interaction kernels if the batch has one lookup per bag (dlrm_offsets_iota_flags counted no violation), dlrm_emb_fwd + dlrm_interact_*
+// otherwise — without the host waiting for that fact (the host wait ended the host's run-ahead once per step: profiles/round6/proof_wait.md).
+struct DlrmPred {
+    const int* flag; int nonzero;
+    __device__ __forceinline__ bool skip() const { return flag != nullptr && ((*flag != 0) != (nonzero != 0)); }
+};
+
 // Tables are passed to the embedding kernels BY VALUE in the kernarg segment (no H2D copy of a
 // pointer table, HIP-graph friendly).  32 tables x 6 x 8 B = 1.5 KiB.
 #define DLRM_MAX_TABLES_PER_LAUNCH 32
@@ -103,6 +112,7 @@ struct EmbArgs {
     long long   rows[DLRM_MAX_TABLES_PER_LAUNCH];
     int         slot[DLRM_MAX_TABLES_PER_LAUNCH];  // feature slot (column block) of the table in out/dout
     long long*  err;                               // device-visible int64[4] out-of-range report (nullable), see dlrm_hip.h
+    DlrmPred    pred;                              // launch predicate (dlrm_emb_fwd_pred); flag == nullptr: always run
 };
 
 // Out-of-range index: the lookup is SKIPPED (never read or written out of bounds) and, when the caller passed an error

@@ -48,10 +48,14 @@ __device__ __forceinline__ void v_atomic_add(float* p, const float& v) { atomicA
 // -------------------------------------------------------------------------------------------
 // forward
 // -------------------------------------------------------------------------------------------
-template <int VEC, int LPB, int NCH, typename IT, int U>
+// LOOP (dlrm_emb_fwd_pred only): a capped grid walks the bags with a grid stride.  A predicated launch that does NOT run still has its
+// workgroups dispatched, and the plain launch has one workgroup per 16 bags (106 k workgroups at Criteo-Terabyte shapes: ~20 us of dispatch
+// for a launch that returns at once); LOOP = false is the straight-line kernel of every other call, unchanged.
+template <int VEC, int LPB, int NCH, typename IT, int U, bool LOOP = false>
 __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs a, long long B, int D,
                                                       float* __restrict__ out, long long out_ld) {
     using VT = typename Vec<VEC>::T;
+    if (a.pred.skip()) return;      // (dlrm_emb_fwd_pred: the other implementation of this step runs instead)
     const int t = blockIdx.y;
     const float* __restrict__ W = a.w[t];
     const IT* __restrict__ idx = (const IT*)a.idx[t];
@@ -63,9 +67,9 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs a, long long B, in
     constexpr int GPB = 256 / LPB;  // groups (bags in flight) per workgroup
     const int g = threadIdx.x / LPB;
     const int lig = threadIdx.x % LPB;
-    const long long b0 = ((long long)blockIdx.x * GPB + g) * U;
+    long long b0 = ((long long)blockIdx.x * GPB + g) * U;
     if (b0 >= B) return;
-
+  for (;;) {
     long long s[U], e[U];
     {
         long long o[U + 1];
@@ -170,6 +174,10 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(EmbArgs a, long long B, in
             }
         }
     }
+    if constexpr (!LOOP) break;
+    b0 += (long long)gridDim.x * GPB * U;
+    if (b0 >= B) break;
+  }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -466,6 +474,7 @@ static void fill_args(EmbArgs& a, const int* ids, int n, void* const* weight_hos
                       const void* const* indices_host, const void* const* offsets_host,
                       const int64_t* nnz_host, const void* const* psw_host, int64_t* err) {
     a.err = (long long*)err;
+    a.pred.flag = nullptr; a.pred.nonzero = 0;
     for (int k = 0; k < DLRM_MAX_TABLES_PER_LAUNCH; ++k) {
         const int t = ids[k < n ? k : 0];
         a.w[k] = (float*)weight_host[t];
@@ -480,11 +489,35 @@ static void fill_args(EmbArgs& a, const int* ids, int n, void* const* weight_hos
 
 }  // namespace
 
+static int emb_fwd_impl(int T, int64_t B, int D, const void* const* weight_host,
+                        const int64_t* rows_host, const void* const* indices_host,
+                        const void* const* offsets_host, const int64_t* nnz_host,
+                        const void* const* psw_host, int idx_bits, float* out, int64_t out_ld,
+                        int64_t* err, DlrmPred pred, void* stream);
+
 extern "C" int dlrm_emb_fwd(int T, int64_t B, int D, const void* const* weight_host,
                             const int64_t* rows_host, const void* const* indices_host,
                             const void* const* offsets_host, const int64_t* nnz_host,
                             const void* const* psw_host, int idx_bits, float* out, int64_t out_ld,
                             int64_t* err, void* stream) {
+    return emb_fwd_impl(T, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host, idx_bits, out, out_ld, err,
+                        DlrmPred{nullptr, 0}, stream);
+}
+
+extern "C" int dlrm_emb_fwd_pred(int T, int64_t B, int D, const void* const* weight_host,
+                                 const int64_t* rows_host, const void* const* indices_host,
+                                 const void* const* offsets_host, const int64_t* nnz_host,
+                                 const void* const* psw_host, int idx_bits, float* out, int64_t out_ld,
+                                 int64_t* err, const int32_t* pred_flag, int pred_nonzero, void* stream) {
+    return emb_fwd_impl(T, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host, idx_bits, out, out_ld, err,
+                        DlrmPred{(const int*)pred_flag, pred_nonzero}, stream);
+}
+
+static int emb_fwd_impl(int T, int64_t B, int D, const void* const* weight_host,
+                        const int64_t* rows_host, const void* const* indices_host,
+                        const void* const* offsets_host, const int64_t* nnz_host,
+                        const void* const* psw_host, int idx_bits, float* out, int64_t out_ld,
+                        int64_t* err, DlrmPred pred, void* stream) {
     int rc = check_common(T, B, D, weight_host, rows_host, indices_host, offsets_host, nnz_host, idx_bits);
     if (rc) return rc;
     if (!out || out_ld < (int64_t)T * D) return DLRM_E_ARG;
@@ -504,7 +537,16 @@ extern "C" int dlrm_emb_fwd(int T, int64_t B, int D, const void* const* weight_h
         for (int k = 0; k < n; ++k) ids[k] = t0 + k;
         EmbArgs a;
         fill_args(a, ids, n, (void* const*)weight_host, rows_host, indices_host, offsets_host, nnz_host, psw_host, err);
+        a.pred = pred;
         dim3 grid((unsigned)((B + bags_per_block - 1) / bags_per_block), (unsigned)n, 1), block(256, 1, 1);
+        if (pred.flag) {           // predicated: the D = 128 shape only (what the fused path's fallback needs), capped grid + grid stride
+            if (!(sh.vec == 4 && sh.lpb == 32 && sh.nch == 1)) return DLRM_E_MODE;
+            dim3 gl(grid.x < 512u ? grid.x : 512u, (unsigned)n, 1);
+            if (idx_bits == 64) hipLaunchKernelGGL((emb_fwd_kernel<4, 32, 1, long long, 2, true>), gl, block, 0, st, a, (long long)B, D, out, (long long)out_ld);
+            else                hipLaunchKernelGGL((emb_fwd_kernel<4, 32, 1, int, 2, true>), gl, block, 0, st, a, (long long)B, D, out, (long long)out_ld);
+            DLRM_LAUNCH_CHECK();
+            continue;
+        }
         // bags per lane group for the D = 128 shape: 2 (default; env DLRM_EMB_FWD_U = 1 | 2 | 4 | 8).  Measured on one box at
         // Criteo-Terabyte shapes: U = 1 0.356 ms, 2 0.282, 4 0.315, 8 0.312 — two independent row loads per half-wave and twice
         // the waves beat four loads per half-wave
@@ -697,16 +739,30 @@ extern "C" int dlrm_emb_psw_grad(int T, int64_t B, int D, const void* const* wei
 namespace {
 struct IotaArgs { const void* off[DLRM_MAX_TABLES_PER_LAUNCH]; };
 template <typename IdxT>
-__global__ __launch_bounds__(256) void offsets_iota_kernel(IotaArgs a, long long B, int* __restrict__ violations) {
+__global__ __launch_bounds__(256) void offsets_iota_kernel(IotaArgs a, long long B, int* __restrict__ violations, int* __restrict__ mirror) {
     const IdxT* off = (const IdxT*)a.off[blockIdx.y];
     int bad = 0;
     for (long long b = (long long)blockIdx.x * 256 + threadIdx.x; b < B; b += (long long)gridDim.x * 256)
         bad += ((long long)off[b] != b);
-    if (__any(bad != 0)) atomicAdd(violations, bad);
+    if (__any(bad != 0)) {
+        atomicAdd(violations, bad);
+        if (mirror && bad) *(volatile int*)mirror = 1;       // (a host-visible copy of "not zero": plain stores, any one of them wins)
+    }
 }
 }  // namespace
 
+static int offsets_iota_impl(int T, int64_t B, const void* const* offsets_host, int idx_bits, int32_t* violations, int32_t* mirror, void* stream);
+
 extern "C" int dlrm_offsets_are_iota(int T, int64_t B, const void* const* offsets_host, int idx_bits, int32_t* violations, void* stream) {
+    return offsets_iota_impl(T, B, offsets_host, idx_bits, violations, nullptr, stream);
+}
+
+extern "C" int dlrm_offsets_iota_flags(int T, int64_t B, const void* const* offsets_host, int idx_bits, int32_t* flag_dev, int32_t* flag_host,
+                                       void* stream) {
+    return offsets_iota_impl(T, B, offsets_host, idx_bits, flag_dev, flag_host, stream);
+}
+
+static int offsets_iota_impl(int T, int64_t B, const void* const* offsets_host, int idx_bits, int32_t* violations, int32_t* mirror, void* stream) {
     if (T <= 0 || B <= 0 || !offsets_host || !violations) return DLRM_E_ARG;
     if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
     hipStream_t st = (hipStream_t)stream;
@@ -716,8 +772,8 @@ extern "C" int dlrm_offsets_are_iota(int T, int64_t B, const void* const* offset
         for (int k = 0; k < n; ++k) { if (!offsets_host[t0 + k]) return DLRM_E_ARG; a.off[k] = offsets_host[t0 + k]; }
         long long nb = (B + 255) / 256; if (nb > 256) nb = 256;
         dim3 grid((unsigned)nb, (unsigned)n, 1), block(256);
-        if (idx_bits == 64) hipLaunchKernelGGL(offsets_iota_kernel<long long>, grid, block, 0, st, a, (long long)B, violations);
-        else                hipLaunchKernelGGL(offsets_iota_kernel<int>, grid, block, 0, st, a, (long long)B, violations);
+        if (idx_bits == 64) hipLaunchKernelGGL(offsets_iota_kernel<long long>, grid, block, 0, st, a, (long long)B, (int*)violations, (int*)mirror);
+        else                hipLaunchKernelGGL(offsets_iota_kernel<int>, grid, block, 0, st, a, (long long)B, (int*)violations, (int*)mirror);
         DLRM_LAUNCH_CHECK();
     }
     return 0;

@@ -53,6 +53,7 @@ struct GatherArgs {
     long long   rows[DLRM_MAX_FEATURES];
     long long*  err;
     int         idx_bits;
+    DlrmPred    pred;                       // launch predicate of the *_pred entry points (both D = 128 kernels, gather or not, take this struct)
 };
 
 __device__ __forceinline__ void gather_to_lds(const GatherArgs& ga, long long* tq, long long* to, long long* tr, int F) {
@@ -415,6 +416,7 @@ __device__ __forceinline__ void gather_rows_issue(const GatherCtx<NI>& gc, const
 template <int NI, bool GATHER>       // NI = ceil(F / 2)
 __global__ __launch_bounds__(320) void interact_fwd_dma_kernel(FeatArgs fa, GatherArgs ga, long long B, int F, int self,
                                                                float* __restrict__ R, long long ldr) {
+    if (ga.pred.skip()) return;                              // (*_pred entry points: the other implementation of this step runs instead)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -556,6 +558,7 @@ constexpr int IDMA_DR_BYTES = 3072;      // dR row image (<= 656 floats for F = 
 template <int NI, bool GATHER>
 __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, FeatArgs da, GatherArgs ga, long long B, int F, int self,
                                                                const float* __restrict__ dR, long long ldr) {
+    if (ga.pred.skip()) return;
     constexpr int NB = (2 * NI + 15) / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -776,6 +779,7 @@ static int pick_grid(int64_t B) {
 static int fill_gather(GatherArgs& ga, int F, const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
                        int64_t* err) {
     ga.err = (long long*)err; ga.idx_bits = idx_bits;
+    ga.pred.flag = nullptr; ga.pred.nonzero = 0;
     const void* any_idx = nullptr; const void* any_off = nullptr;
     for (int f = 0; gidx && f < F; ++f) if (gidx[f]) { any_idx = gidx[f]; any_off = goff ? goff[f] : nullptr; break; }
     for (int f = 0; f < DLRM_MAX_FEATURES; ++f) {
@@ -795,7 +799,7 @@ extern "C" int dlrm_interact_gather_ok(int F, int D) {
 
 static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
                              const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
-                             int self_interaction, float* R, int64_t ldr, int64_t* err, void* stream);
+                             int self_interaction, float* R, int64_t ldr, int64_t* err, void* stream, DlrmPred pred = DlrmPred{nullptr, 0});
 
 extern "C" int dlrm_interact_fwd(int64_t B, int F, int D, const void* const* feat_host,
                                  const int64_t* feat_ld_host, int self_interaction, float* R,
@@ -813,9 +817,22 @@ extern "C" int dlrm_interact_fwd_gather(int64_t B, int F, int D, const void* con
                              ldr, err, stream);
 }
 
+// One call, two implementations, chosen ON THE DEVICE (ABI 16): the same arguments as dlrm_interact_fwd / _fwd_gather / _bwd / _bwd_gather plus a
+// predicate — the launch's workgroups return at once unless (*pred_flag != 0) == (pred_nonzero != 0).  Only the D = 128 LDS-DMA kernels take
+// one (the shapes of the fused path); other shapes: DLRM_E_MODE.
+extern "C" int dlrm_interact_fwd_pred(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                                      const void* const* index_host, const void* const* offsets_host, const int64_t* rows_host,
+                                      int idx_bits, int self_interaction, float* R, int64_t ldr, int64_t* err,
+                                      const int32_t* pred_flag, int pred_nonzero, void* stream) {
+    if (index_host && (!offsets_host || !rows_host)) return DLRM_E_ARG;
+    if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
+    return interact_fwd_impl(B, F, D, feat_host, feat_ld_host, index_host, offsets_host, rows_host, idx_bits, self_interaction, R,
+                             ldr, err, stream, DlrmPred{(const int*)pred_flag, pred_nonzero});
+}
+
 static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
                              const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
-                             int self_interaction, float* R, int64_t ldr, int64_t* err, void* stream) {
+                             int self_interaction, float* R, int64_t ldr, int64_t* err, void* stream, DlrmPred pred) {
     if (B <= 0 || F <= 0 || D <= 0 || !feat_host || !feat_ld_host || !R) return DLRM_E_ARG;
     if (F > DLRM_MAX_FEATURES) {
         fprintf(stderr, "libdlrm_hip: dlrm_interact_fwd: F=%d exceeds %d features\n", F, DLRM_MAX_FEATURES);
@@ -832,6 +849,7 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
     GatherArgs ga;
     rc = fill_gather(ga, F, gidx, goff, grows, idx_bits, err);
     if (rc) return rc;
+    ga.pred = pred;
     if (gidx) {          // gathered features exist only in the D = 128 LDS-DMA kernel
         if (!(dlrm_interact_gather_ok(F, D) && vec && dlrm_aligned16(R) && ldr % 4 == 0)) return DLRM_E_MODE;
         const int ni = (F + 1) / 2;
@@ -875,6 +893,7 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
         DLRM_LAUNCH_CHECK();
         return 0;
     }
+    if (pred.flag) return DLRM_E_MODE;                         // (predicated launches exist for the LDS-DMA kernels only)
     const int Dp = (D + 15) & ~15;
     const size_t lds = 2 * DLRM_MAX_FEATURES * sizeof(long long) + 4 * (size_t)(((F + 15) >> 4) * 16) * (Dp + 4) * sizeof(float);
     if (lds > 160 * 1024) {
@@ -892,7 +911,7 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
 static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
                              const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
                              int self_interaction, const float* dR, int64_t ldr, void* const* dfeat_host,
-                             const int64_t* dfeat_ld_host, int64_t* err, void* stream);
+                             const int64_t* dfeat_ld_host, int64_t* err, void* stream, DlrmPred pred = DlrmPred{nullptr, 0});
 
 extern "C" int dlrm_interact_bwd(int64_t B, int F, int D, const void* const* feat_host,
                                  const int64_t* feat_ld_host, int self_interaction, const float* dR,
@@ -913,10 +932,20 @@ extern "C" int dlrm_interact_bwd_gather(int64_t B, int F, int D, const void* con
                              ldr, dfeat_host, dfeat_ld_host, err, stream);
 }
 
+extern "C" int dlrm_interact_bwd_pred(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                                      const void* const* index_host, const void* const* offsets_host, const int64_t* rows_host,
+                                      int idx_bits, int self_interaction, const float* dR, int64_t ldr, void* const* dfeat_host,
+                                      const int64_t* dfeat_ld_host, int64_t* err, const int32_t* pred_flag, int pred_nonzero, void* stream) {
+    if (index_host && (!offsets_host || !rows_host)) return DLRM_E_ARG;
+    if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
+    return interact_bwd_impl(B, F, D, feat_host, feat_ld_host, index_host, offsets_host, rows_host, idx_bits, self_interaction, dR,
+                             ldr, dfeat_host, dfeat_ld_host, err, stream, DlrmPred{(const int*)pred_flag, pred_nonzero});
+}
+
 static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
                              const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
                              int self_interaction, const float* dR, int64_t ldr, void* const* dfeat_host,
-                             const int64_t* dfeat_ld_host, int64_t* err, void* stream) {
+                             const int64_t* dfeat_ld_host, int64_t* err, void* stream, DlrmPred pred) {
     if (B <= 0 || F <= 0 || D <= 0 || !feat_host || !feat_ld_host || !dR || !dfeat_host || !dfeat_ld_host)
         return DLRM_E_ARG;
     if (F > DLRM_MAX_FEATURES) return DLRM_E_RANGE;
@@ -938,6 +967,7 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
         GatherArgs ga;
         rc = fill_gather(ga, F, gidx, goff, grows, idx_bits, err);
         if (rc) return rc;
+        ga.pred = pred;
         const bool dma_path = (gidx ? (dlrm_interact_gather_ok(F, D) && vec) : interact_dma_ok(F, D, vec)) && dvec && dlrm_aligned16(dR) &&
                               ldr % 4 == 0 && ldr * 4 <= (gidx ? GDR_BYTES : IDMA_DR_BYTES);
         if (gidx && !dma_path) return DLRM_E_MODE;
@@ -970,6 +1000,7 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
             return 0;
         }
     }
+    if (pred.flag) return DLRM_E_MODE;                         // (predicated launches exist for the LDS-DMA kernels only)
     const int Dp = (D + 15) & ~15, NB = (F + 15) >> 4, rows = NB * 16;
     const size_t lds = 4 * DLRM_MAX_FEATURES * sizeof(long long) +
                        4 * ((size_t)F * (Dp + 16) + (size_t)F * (rows + 1)) * sizeof(float);

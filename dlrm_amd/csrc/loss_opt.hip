@@ -4,6 +4,7 @@
 //   torch.nn.BCELoss(reduction="mean") / MSELoss via loss_fn_wrap   dlrm_s_pytorch.py:386-393,148-156
 //   torch.optim.SGD.step on dense MLP parameters                      dlrm_s_pytorch.py:1343-1369,1620
 //   All2All_Wait.forward's split + view of the receive buffer          extend_distributed.py:446-465
+#include <chrono>
 #include "common.h"
 
 namespace {
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void clamp_bwd_kernel(long long n, const float
 
 }  // namespace
 
-extern "C" int dlrm_hip_abi_version(void) { return 15; }
+extern "C" int dlrm_hip_abi_version(void) { return 16; }
 
 extern "C" const char* dlrm_hip_build_info(void) {
     return "libdlrm_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " clang " __clang_version__;
@@ -336,7 +337,15 @@ extern "C" int dlrm_graph_replay(int n, void* const* dst_host, const void* const
     if (n < 0 || !graph_exec || (n > 0 && (!dst_host || !src_host || !bytes_host))) return DLRM_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (sync_first) {
-        hipError_t e = hipStreamSynchronize(st);
+        // the previous replay is POLLED for (hipStreamQuery), not slept on: how long a thread blocked in hipStreamSynchronize takes to wake up
+        // after the GPU signalled is the box's business (30 us ... 1.2 ms measured on this pool, profiles/round6/proof_wait.md) and a
+        // launch-bound step (Criteo-Kaggle: 0.32 ms per replay) pays it every step.  The wait is one step long; after 50 ms the thread sleeps.
+        hipError_t e = hipStreamQuery(st);
+        if (e == hipErrorNotReady) {
+            const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(50);
+            while ((e = hipStreamQuery(st)) == hipErrorNotReady)
+                if (std::chrono::steady_clock::now() > t_end) { e = hipStreamSynchronize(st); break; }
+        }
         if (e != hipSuccess) return (int)e;
     }
     for (int i = 0; i < n; ++i) {

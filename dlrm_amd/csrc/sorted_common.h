@@ -182,7 +182,7 @@ static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight
                            const void* const* psw_host, int idx_bits, char* ws, const Layout& lo, size_t L, int row_bits,
                            int key_bits, hipStream_t st, SortedArgs* sa_out, int64_t* err) {
     EmbArgs a;
-    a.err = (long long*)err;
+    a.err = (long long*)err; a.pred.flag = nullptr; a.pred.nonzero = 0;
     SortedArgs& sa = *sa_out;
     long long base = 0;
     for (int k = 0; k < DLRM_MAX_TABLES_PER_LAUNCH; ++k) {

@@ -32,6 +32,9 @@ from .functional import (BCEElementwiseFunction, BCELossFunction, CatFunction, C
                          OutSlot)
 from . import functional as _functional
 from .functional import MLP_CONSUMER_APPLIES_LAST_ACT, _side_stream
+
+# one-lookup-per-bag verdict of untagged offsets: left on the device as a launch predicate (default) or waited for by the host (0)
+DEVICE_PREDICATE = os.environ.get("DLRM_DEVICE_PREDICATE", "1") != "0"
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, BagBatch
 
 
@@ -485,13 +488,24 @@ class DLRM_Net(nn.Module):
             # reference computes it): ops.offsets_are_iota proves offsets == arange(B) on the device, once per offsets tensor
             # object (None = undecided, only while a HIP graph is being captured: GraphedTrainStep proves every incoming batch).
             if all(n == B for n in bags.nnz) and all(e.weight.data_ptr() % 16 == 0 for e in self.emb_l):
-                # the proof of a tensor nobody vouched for is a device pass the HOST waits for: it is started first (on its own stream,
-                # behind what this stream holds now), the bottom tower is enqueued, and only then the host waits for the verdict — the
-                # GPU has the tower's GEMMs to run while the host catches up, so the wait does not drain the stream
-                proof = ops.offsets_are_iota_start(lS_o)
-                if proof is not False:
+                # True / None (capturing): the fused kernels alone.  A tensor nobody vouched for: its proof is a device pass whose verdict
+                # STAYS on the device (round 6; until then the host waited for it, which ended the host's run-ahead once per step) —
+                # GatherInteractFunction enqueues the fused kernels and the two-kernel form, each behind the launch predicate, and the
+                # host goes on.  False (this tensor object was proven ragged before): the two kernels below.
+                # (DLRM_DEVICE_PREDICATE=0: the host-side proof of rounds 4-6 — started on its own stream, the bottom tower enqueued, then the
+                # host waits for the verdict — kept for A/B and for the tests of that path)
+                proof = None
+                if DEVICE_PREDICATE:
+                    state = ops.offsets_iota_state(lS_o)
+                else:
+                    proof = ops.offsets_are_iota_start(lS_o)
+                    state = proof if (proof is None or isinstance(proof, bool)) else "pending"
+                if state is not False:
                     x = self.apply_mlp(dense_x, self.bot_l, consumer_applies_last_act=bool(rx))
-                    if ops.offsets_are_iota_finish(proof) is not False:
+                    if proof is not None and state == "pending":
+                        state = ops.offsets_are_iota_finish(proof)
+                    if state is not False:
+                        bags.iota_flag = state if isinstance(state, torch.Tensor) else None
                         z = GatherInteractFunction.apply(self._stash_embedding_grad, D, self._interaction_mode() | rx, bags, x,
                                                          *self._emb_weights(self.emb_l))
                         return self._clamp(self.apply_mlp(z, self.top_l))

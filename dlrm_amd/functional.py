@@ -594,25 +594,45 @@ class GatherInteractFunction(Function):
 
     @staticmethod
     def forward(ctx, sink, D, self_interaction, bags, x, *weights):
+        # `bags.iota_flag` (a device int32, ops.offsets_iota_state): whether the batch really has ONE lookup per bag is known on the device
+        # only — nnz == B does not prove it.  Both implementations are enqueued with that launch predicate (ABI 16): the fused kernel runs if
+        # the flag is zero; dlrm_emb_fwd + the plain interaction (the reference's apply_emb + interact_features as two kernels, through a pooled
+        # buffer that then has to live until backward) run if it is not.  The launches that do not run return at once; the host never waits.
         x = _rowmajor(x)
         F = 1 + len(weights)
         mode = int(self_interaction) & 3                      # (| ops.INTERACT_RELU_X: see InteractFunction.forward)
         Wd = ops.interact_out_width(F, D, mode)
         R = torch.empty((x.size(0), _round4(Wd)), dtype=torch.float32, device=x.device)
-        ops.interact_fwd_gather(x, weights, bags, D, mode, R)
+        flag = getattr(bags, "iota_flag", None)
+        ly = None
+        if flag is None:
+            ops.interact_fwd_gather(x, weights, bags, D, mode, R)
+        else:
+            ops.interact_fwd_gather(x, weights, bags, D, mode, R, pred=(flag, 0))
+            ly = alloc2d(x.size(0), len(weights) * D, x)
+            ops.emb_fwd(weights, bags, ly, pred=(flag, 1))
+            ops.interact_fwd((x, ly), D, mode, R, pred=(flag, 1))
         ctx.sink, ctx.bags, ctx.weights = sink, bags, weights
         ctx.D, ctx.self_interaction = D, int(self_interaction) & (3 | ops.INTERACT_RELU_X)
-        ctx.save_for_backward(x)
+        ctx.flag = flag
+        if ly is None:
+            ctx.save_for_backward(x)
+        else:
+            ctx.save_for_backward(x, ly)
         return R                                   # [B, round4(width)], zero padding columns (what MLPFunction takes as is)
 
     @staticmethod
     def backward(ctx, dR):
-        (x,) = ctx.saved_tensors
+        x = ctx.saved_tensors[0]
         dR = _rowmajor(dR)
         B, D, T = x.size(0), ctx.D, len(ctx.weights)
         flat = torch.empty(B * (1 + T) * D, dtype=torch.float32, device=dR.device)
         dx, dE = flat[:B * D].view(B, D), flat[B * D:].view(B, T * D)
-        ops.interact_bwd_gather(x, ctx.weights, ctx.bags, D, ctx.self_interaction, dR, dx, dE)
+        if ctx.flag is None:
+            ops.interact_bwd_gather(x, ctx.weights, ctx.bags, D, ctx.self_interaction, dR, dx, dE)
+        else:
+            ops.interact_bwd_gather(x, ctx.weights, ctx.bags, D, ctx.self_interaction, dR, dx, dE, pred=(ctx.flag, 0))
+            ops.interact_bwd((x, ctx.saved_tensors[1]), D, ctx.self_interaction, dR, (dx, dE), pred=(ctx.flag, 1))
         if ctx.sink is None:
             raise RuntimeError("dlrm_amd: embedding backward needs a gradient sink (fused update)")
         ctx.sink(ctx.weights, ctx.bags, dE)

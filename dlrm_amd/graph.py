@@ -336,7 +336,7 @@ class GraphedTrainStep:
             # after every replay", so that is what happens here before the static inputs are touched again.  At
             # Criteo-Terabyte sizes the GPU is the bottleneck (the wait costs one launch latency per step); at launch-bound
             # sizes the replay has finished long before the host gets here.
-            torch.cuda.current_stream(X.device).synchronize()
+            ops.wait_spinning(torch.cuda.current_stream(X.device))      # (polled, not slept on: ops._wait_event_spinning)
             self._replayed = False
         self._prove_one_lookup_per_bag(lS_o, lS_i)
         if self.static is None:

@@ -313,17 +313,30 @@ def _weights_desc(weights: Sequence[torch.Tensor]):
     return int(D), _lib.ptr_array([w.data_ptr() for w in weights]), _lib.i64_array([w.size(0) for w in weights])
 
 
-def emb_fwd(weights: Sequence[torch.Tensor], bags: BagBatch, out: torch.Tensor) -> torch.Tensor:
-    """out[b, t*D:(t+1)*D] = sum-pooled bag (t, b).  `out` is a [B, >= T*D] view (row stride free)."""
+def _pred_args(pred):
+    """pred = None | (flag, nonzero): flag a device int32 tensor; the launch runs iff (flag != 0) == bool(nonzero) (include/dlrm_hip.h, ABI 16)"""
+    flag, nonzero = pred
+    if flag.dtype != torch.int32 or not flag.is_cuda or flag.numel() < 1:
+        raise RuntimeError("dlrm_amd: a launch predicate is a device int32 tensor")
+    return C.c_void_p(flag.data_ptr()), int(bool(nonzero))
+
+
+def emb_fwd(weights: Sequence[torch.Tensor], bags: BagBatch, out: torch.Tensor, pred=None) -> torch.Tensor:
+    """out[b, t*D:(t+1)*D] = sum-pooled bag (t, b).  `out` is a [B, >= T*D] view (row stride free).  pred: see _pred_args."""
     lib = _lib.load()
     D, wp, rows = _weights_desc(weights)
     _req(out, "out", ndim=2)
     if out.size(0) != bags.B or out.size(1) < bags.T * D or len(weights) != bags.T:
         raise RuntimeError("dlrm_amd: emb_fwd shape mismatch")
-    with _timed("emb_fwd"):
-        rc = lib.dlrm_emb_fwd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
-                              bags.idx_bits, C.c_void_p(out.data_ptr()), _ld(out),
-                              None if bags.ignore_oob else C.c_void_p(_err_block(out.device).data_ptr()), _stream(out))
+    err = None if bags.ignore_oob else C.c_void_p(_err_block(out.device).data_ptr())
+    # (a predicated launch belongs to the step's fused lookup + interaction: same timing category, so the three launches are ONE run)
+    with _timed("emb_fwd" if pred is None else "emb_interact_fwd"):
+        if pred is None:
+            rc = lib.dlrm_emb_fwd(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
+                                  bags.idx_bits, C.c_void_p(out.data_ptr()), _ld(out), err, _stream(out))
+        else:
+            rc = lib.dlrm_emb_fwd_pred(bags.T, bags.B, D, wp, rows, bags._idx, bags._off, bags._nnz, bags._psw,
+                                       bags.idx_bits, C.c_void_p(out.data_ptr()), _ld(out), err, *_pred_args(pred), _stream(out))
     _lib.check(rc, "dlrm_emb_fwd")
     return out
 
@@ -494,7 +507,7 @@ def _permute(order, *lists):
     return lists if order is None else tuple([l[i] for i in order] for l in lists)
 
 
-def interact_fwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool, R: torch.Tensor, order=None) -> torch.Tensor:
+def interact_fwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool, R: torch.Tensor, order=None, pred=None) -> torch.Tensor:
     """order: optional permutation — canonical feature f is the order[f]-th feature of the block list (lets the interaction read
     features that live in several buffers, e.g. all-to-all blocks of table-wise shards + the reduce-scatter block of row-wise
     ones, in global table order without copying them together)"""
@@ -505,9 +518,13 @@ def interact_fwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool,
     F = len(ptrs)
     if R.size(0) != B or R.size(1) < interact_out_width(F, D, self_interaction):
         raise RuntimeError("dlrm_amd: interact_fwd output shape mismatch")
-    with _timed("interact_fwd"):
-        rc = lib.dlrm_interact_fwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(self_interaction),
-                                   C.c_void_p(R.data_ptr()), _ld(R), _stream(R))
+    with _timed("interact_fwd" if pred is None else "emb_interact_fwd"):
+        if pred is None:
+            rc = lib.dlrm_interact_fwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(self_interaction),
+                                       C.c_void_p(R.data_ptr()), _ld(R), _stream(R))
+        else:
+            rc = lib.dlrm_interact_fwd_pred(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), None, None, None, 64, int(self_interaction),
+                                            C.c_void_p(R.data_ptr()), _ld(R), None, *_pred_args(pred), _stream(R))
     _lib.check(rc, "dlrm_interact_fwd")
     return R
 
@@ -522,7 +539,7 @@ def gather_ok(F: int, D: int) -> bool:
 # synchronisation, paid once per distinct offsets tensor: the verdict is cached on the tensor OBJECT (weak reference, so a recycled
 # address can never alias) together with its in-place version counter.
 _iota_cache: dict = {}          # id(tensor) -> (weakref, _version, verdict)
-IOTA_STATS = {"checked": 0, "cached": 0, "tagged": 0, "host_us": 0.0, "wait_us": 0.0}
+IOTA_STATS = {"checked": 0, "cached": 0, "tagged": 0, "device_predicates": 0, "host_us": 0.0, "wait_us": 0.0}
 _IOTA_TAG = "_dlrm_one_lookup_per_bag"      # attribute a PRODUCER sets on an offsets tensor it wrote as 0, 1, ..., B-1 (value: t._version)
 
 
@@ -620,6 +637,99 @@ def offsets_are_iota_start(lS_o):
     return h
 
 
+# Host wait for an event that ends the host's run-ahead once per step: POLL it (hipEventQuery) instead of sleeping on it.
+# hipEventSynchronize blocks the thread in the driver, and how long the wake-up takes after the GPU signalled is the BOX's business
+# (interrupt routing, CPU idle states, a runtime that polls with sleeps): measured 30-110 us per step on most MI355X boxes of the pool and
+# 1.25 ms on one (profiles/round6/proof_wait.md: the same step 9.14 ms instead of 7.89, the GPU idle while the host slept — the verdict of the
+# proof was there, the bottom tower long finished).  The wait is at most one training step long; after SPIN_WAIT_S the thread sleeps after all.
+SPIN_WAIT_S = 0.0 if os.environ.get("DLRM_SPIN_WAIT", "1") == "0" else 0.05        # DLRM_SPIN_WAIT=0: sleep on the event (A/B)
+
+
+def _wait_event_spinning(ev) -> None:
+    """ev: a torch.cuda.Event or a torch.cuda.Stream (both have query() / synchronize())"""
+    import time as _time
+    if ev.query():
+        return
+    end = _time.perf_counter() + SPIN_WAIT_S
+    while not ev.query():
+        if _time.perf_counter() > end:
+            ev.synchronize()
+            return
+
+
+wait_spinning = _wait_event_spinning
+
+
+# ---- the verdict left on the DEVICE (ABI 16): no host wait at all ---------------------------------------------------------------------------
+_FLAG_POOL = 1024
+_iota_flag_slots: dict = {}     # device index -> [device int32 pool, pinned int32 pool, next slot]: a slot is used ONCE (zeroed at allocation, never re-armed)
+_iota_unresolved: list = []     # (event, pinned slot, [tensor objects]): proofs whose host-visible verdict has not been looked at yet
+
+
+def _iota_drain() -> None:
+    """remember the verdicts of finished device proofs (event.query(): no wait) — a tensor object that comes back is then known"""
+    keep = []
+    for ev, host, srcs in _iota_unresolved:
+        if ev.query():
+            ok = int(host[0]) == 0
+            for t in srcs:
+                _iota_remember(t, ok)
+        else:
+            keep.append((ev, host, srcs))
+    _iota_unresolved[:] = keep[-64:]           # (bounded: a verdict nobody came back for within 64 steps is dropped — the next encounter proves again)
+
+
+def offsets_iota_state(lS_o):
+    """What the caller of the fused lookup + interaction path needs to know about `lS_o`, WITHOUT waiting for the device:
+      True / False    the verdict is known (producer tag, or this tensor object was proven earlier);
+      None            a HIP graph is being captured (undecided: GraphedTrainStep proves every incoming batch before the replay);
+      a device int32  the proof was enqueued on the CURRENT stream (dlrm_offsets_iota_flags: number of bags whose start differs from their
+                      number) — the caller enqueues both implementations with that launch predicate (GatherInteractFunction) and never
+                      waits; the host-visible copy of the verdict is looked at whenever a later call finds its event complete."""
+    srcs = [lS_o] if isinstance(lS_o, torch.Tensor) else list(lS_o)
+    _iota_drain()
+    if all(_iota_tagged(t) for t in srcs):
+        IOTA_STATS["tagged"] += 1
+        return True
+    verdicts = [True if _iota_tagged(t) else _iota_cached(t) for t in srcs]
+    if all(v is not None for v in verdicts):
+        IOTA_STATS["cached"] += 1
+        return all(verdicts)
+    dev = srcs[0].device
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    import time as _time
+    t0 = _time.perf_counter()
+    ptrs, keep = [], []
+    for t in srcs:
+        if not t.is_cuda or t.dtype not in (torch.int64, torch.int32) or t.dtype != srcs[0].dtype:
+            raise RuntimeError("dlrm_amd: offsets must be int32/int64 GPU tensors of one dtype")
+        if t.dim() == 2:
+            if t.stride(1) != 1 and t.size(1) > 1:
+                t = t.contiguous()
+            ptrs += [t.data_ptr() + k * t.stride(0) * t.element_size() for k in range(t.size(0))]
+        else:
+            t = t.contiguous()
+            ptrs.append(t.data_ptr())
+        keep.append(t)
+    slots = _iota_flag_slots.get(dev.index)
+    if slots is None or slots[2] >= _FLAG_POOL:
+        slots = _iota_flag_slots[dev.index] = [torch.zeros(_FLAG_POOL, dtype=torch.int32, device=dev),
+                                               torch.zeros(_FLAG_POOL, dtype=torch.int32).pin_memory(), 0]
+    k = slots[2]
+    slots[2] = k + 1
+    flag, host = slots[0][k:k + 1], slots[1][k:k + 1]
+    with _timed("iota_proof"):
+        rc = _lib.load().dlrm_offsets_iota_flags(len(ptrs), srcs[0].size(-1), _lib.ptr_array(ptrs), 64 if srcs[0].dtype == torch.int64 else 32,
+                                                 C.c_void_p(flag.data_ptr()), C.c_void_p(host.data_ptr()), _stream(srcs[0]))
+    _lib.check(rc, "dlrm_offsets_iota_flags")
+    _iota_unresolved.append((torch.cuda.current_stream(dev).record_event(), host, srcs))
+    IOTA_STATS["device_predicates"] = IOTA_STATS.get("device_predicates", 0) + 1
+    IOTA_STATS["host_us"] += (_time.perf_counter() - t0) * 1e6
+    del keep
+    return flag
+
+
 def offsets_are_iota_finish(h) -> bool:
     """Second half: wait for the check kernel alone (an event of the proof stream, not a stream synchronisation of the caller's) and
     read the verdict.  The offsets tensors stayed alive in the handle until here."""
@@ -627,7 +737,7 @@ def offsets_are_iota_finish(h) -> bool:
         return h
     import time as _time
     t0 = _time.perf_counter()
-    h.done.synchronize()
+    _wait_event_spinning(h.done)
     ok = int(h.flag[0]) == 0
     _iota_flag_pool[h.srcs[0].device.index].append(h.flag)
     IOTA_STATS["checked"] += 1
@@ -669,7 +779,7 @@ def _gather_desc(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: BagBatc
 
 
 def interact_fwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: BagBatch, D: int, self_interaction: bool,
-                        R: torch.Tensor) -> torch.Tensor:
+                        R: torch.Tensor, pred=None) -> torch.Tensor:
     """R = interaction of [x | one-hot embedding rows], the rows fetched by the kernel itself (no pooled-embedding buffer)."""
     lib = _lib.load()
     F, p, ld, gidx, goff, rows = _gather_desc(x, weights, bags, D)
@@ -677,8 +787,13 @@ def interact_fwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: 
     if R.size(0) != bags.B or x.size(0) != bags.B or R.size(1) < interact_out_width(F, D, self_interaction):
         raise RuntimeError("dlrm_amd: interact_fwd_gather shape mismatch")
     with _timed("emb_interact_fwd"):
-        rc = lib.dlrm_interact_fwd_gather(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(self_interaction),
-                                          C.c_void_p(R.data_ptr()), _ld(R), C.c_void_p(_err_block(R.device).data_ptr()), _stream(R))
+        if pred is None:
+            rc = lib.dlrm_interact_fwd_gather(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(self_interaction),
+                                              C.c_void_p(R.data_ptr()), _ld(R), C.c_void_p(_err_block(R.device).data_ptr()), _stream(R))
+        else:
+            rc = lib.dlrm_interact_fwd_pred(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(self_interaction),
+                                            C.c_void_p(R.data_ptr()), _ld(R), C.c_void_p(_err_block(R.device).data_ptr()),
+                                            *_pred_args(pred), _stream(R))
     _lib.check(rc, "dlrm_interact_fwd_gather")
     return R
 
@@ -687,7 +802,7 @@ INTERACT_RELU_X = 4         # DLRM_INTERACT_RELU_X of include/dlrm_hip.h: OR-ed 
 
 
 def interact_bwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: BagBatch, D: int, self_interaction: bool,
-                        dR: torch.Tensor, dx: torch.Tensor, dE: torch.Tensor) -> None:
+                        dR: torch.Tensor, dx: torch.Tensor, dE: torch.Tensor, pred=None) -> None:
     """dx [B, D] = gradient of x; dE [B, T*D] = gradients of the T gathered rows (the dout of the fused embedding update).
     `self_interaction | INTERACT_RELU_X`: x is a ReLU output and dx comes back multiplied by [x > 0] (see interact_bwd)."""
     lib = _lib.load()
@@ -696,14 +811,19 @@ def interact_bwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: 
     dptrs = [dx.data_ptr()] + [dE.data_ptr() + 4 * k * D for k in range(bags.T)]
     dlds = [_ld(dx)] + [_ld(dE)] * bags.T
     with _timed("emb_interact_bwd"):
-        rc = lib.dlrm_interact_bwd_gather(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(self_interaction),
-                                          C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
-                                          C.c_void_p(_err_block(dR.device).data_ptr()), _stream(dR))
+        if pred is None:
+            rc = lib.dlrm_interact_bwd_gather(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(self_interaction),
+                                              C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
+                                              C.c_void_p(_err_block(dR.device).data_ptr()), _stream(dR))
+        else:
+            rc = lib.dlrm_interact_bwd_pred(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(self_interaction),
+                                            C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
+                                            C.c_void_p(_err_block(dR.device).data_ptr()), *_pred_args(pred), _stream(dR))
     _lib.check(rc, "dlrm_interact_bwd_gather")
 
 
 def interact_bwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool, dR: torch.Tensor,
-                 dblocks: Sequence[torch.Tensor], order=None) -> None:
+                 dblocks: Sequence[torch.Tensor], order=None, pred=None) -> None:
     """`self_interaction` is the forward's mode, optionally OR-ed with INTERACT_RELU_X: feature 0 (the first D columns of blocks[0],
     the bottom tower's output) is then taken as a ReLU output and its gradient is multiplied by the derivative [feature 0 > 0] inside
     the kernel, which has the feature staged anyway — the tower's backward then starts without its act_bwd pass over [B, D]."""
@@ -715,10 +835,15 @@ def interact_bwd(blocks: Sequence[torch.Tensor], D: int, self_interaction: bool,
     if B != B2 or len(ptrs) != len(dptrs) or dR.size(0) != B:
         raise RuntimeError("dlrm_amd: interact_bwd shape mismatch")
     F = len(ptrs)
-    with _timed("interact_bwd"):
-        rc = lib.dlrm_interact_bwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(self_interaction),
-                                   C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
-                                   _stream(dR))
+    with _timed("interact_bwd" if pred is None else "emb_interact_bwd"):
+        if pred is None:
+            rc = lib.dlrm_interact_bwd(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), int(self_interaction),
+                                       C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
+                                       _stream(dR))
+        else:
+            rc = lib.dlrm_interact_bwd_pred(B, F, D, _lib.ptr_array(ptrs), _lib.i64_array(lds), None, None, None, 64, int(self_interaction),
+                                            C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds), None,
+                                            *_pred_args(pred), _stream(dR))
     _lib.check(rc, "dlrm_interact_bwd")
 
 

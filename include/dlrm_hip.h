@@ -214,6 +214,33 @@ int dlrm_interact_bwd_gather(int64_t B, int F, int D, const void* const* feat_ho
                              int idx_bits, int self_interaction, const float* dR, int64_t ldr,
                              void* const* dfeat_host, const int64_t* dfeat_ld_host, int64_t* err, void* stream);
 
+/* ABI 16 — the choice between the fused path and the two kernels taken ON THE DEVICE.  Until round 6 the caller proved "one lookup per bag"
+ * for every offsets tensor nobody vouched for by a device pass the HOST waited for (dlrm_offsets_are_iota into pinned memory), which ended the
+ * host's run-ahead once per training step: 30-110 us per step on most boxes of the pool, 1.25 ms on a bad day (profiles/round6/proof_wait.md).
+ * Now the caller enqueues BOTH implementations with a launch predicate and never waits:
+ *   dlrm_offsets_iota_flags   as dlrm_offsets_are_iota, into *flag_dev (device int32, zeroed by the caller) and, when the count is not zero,
+ *                             1 into *flag_host (pinned, zeroed by the caller; nullable) — the host may read that LATER, to remember the verdict
+ *                             of a tensor object it will see again;
+ *   dlrm_*_pred               the call without the suffix, whose workgroups return at once unless (*pred_flag != 0) == (pred_nonzero != 0)
+ *                             (pred_flag == NULL: always run).  dlrm_interact_fwd_pred / _bwd_pred are the gather form when index_host != NULL
+ *                             and the plain form otherwise; only the D = 128 LDS-DMA kernels take a predicate (else DLRM_E_MODE).
+ * A step therefore runs  fused(pred_nonzero = 0)  +  dlrm_emb_fwd_pred + dlrm_interact_fwd_pred(plain)(pred_nonzero = 1)  — three launches that
+ * return at once for a one-lookup-per-bag batch, the fused one for a ragged batch — and its results are those of the implementation that ran. */
+int dlrm_offsets_iota_flags(int T, int64_t B, const void* const* offsets_host, int idx_bits, int32_t* flag_dev, int32_t* flag_host, void* stream);
+int dlrm_emb_fwd_pred(int T, int64_t B, int D, const void* const* weight_host, const int64_t* rows_host,
+                      const void* const* indices_host, const void* const* offsets_host, const int64_t* nnz_host,
+                      const void* const* psw_host, int idx_bits, float* out, int64_t out_ld, int64_t* err,
+                      const int32_t* pred_flag, int pred_nonzero, void* stream);
+int dlrm_interact_fwd_pred(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                           const void* const* index_host, const void* const* offsets_host, const int64_t* rows_host,
+                           int idx_bits, int self_interaction, float* R, int64_t ldr, int64_t* err,
+                           const int32_t* pred_flag, int pred_nonzero, void* stream);
+int dlrm_interact_bwd_pred(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                           const void* const* index_host, const void* const* offsets_host, const int64_t* rows_host,
+                           int idx_bits, int self_interaction, const float* dR, int64_t ldr,
+                           void* const* dfeat_host, const int64_t* dfeat_ld_host, int64_t* err,
+                           const int32_t* pred_flag, int pred_nonzero, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * K5  MLP layer = nn.Linear + activation  (dlrm_s_pytorch.py:216,238-241,405), fp32 MFMA.
  *   Y[M,N] = act(X[M,K] · W[N,K]^T + bias[N])

@@ -1641,3 +1641,62 @@ def test_criteo_bin_batches_match_reference(tmp_path, idx_dtype, mir):
     out = torch.empty(X.size(0), 26 * 8, device=dev())
     ops.emb_fwd(Ws, ops.BagBatch(lS_o, torch.remainder(lS_i, rows)), out)
     assert bool(torch.isfinite(out).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,B", [(26, 1000), (3, 67)])
+def test_launch_predicates_choose_the_implementation_on_the_device(T, B):
+    """ABI 16 (include/dlrm_hip.h: dlrm_*_pred, dlrm_offsets_iota_flags): a launch given a predicate runs iff (flag != 0) == nonzero, and
+    what it then writes are the bits of the call without one; a launch whose predicate fails leaves its outputs untouched.  The proof leaves
+    its verdict in a device word (0 = one lookup per bag) and in a pinned host word the host looks at later — never waiting — so a tensor
+    object that comes back is known (ops.offsets_iota_state)."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(T + B)
+    D = 128
+    rows = [int(r) for r in rng.integers(1, 5000, size=T)]
+    Ws = [to_dev(rng.standard_normal((n, D)).astype(np.float32)) for n in rows]
+    idx = torch.stack([to_dev(rng.integers(0, n, size=B)) for n in rows])
+    off = torch.arange(B, device=dev()).repeat(T, 1)
+    x = to_dev(rng.standard_normal((B, D)).astype(np.float32))
+    bags = ops.BagBatch(off, idx)
+    F = T + 1
+    ldr = (ops.interact_out_width(F, D, False) + 3) & ~3
+    zero, one = torch.zeros(1, dtype=torch.int32, device=dev()), torch.ones(1, dtype=torch.int32, device=dev())
+    # references without predicates
+    ly0 = torch.empty((B, T * D), device=dev()); ops.emb_fwd(Ws, bags, ly0)
+    R0 = torch.empty((B, ldr), device=dev()); ops.interact_fwd_gather(x, Ws, bags, D, False, R0)
+    dR = to_dev(rng.standard_normal((B, ldr)).astype(np.float32))
+    dx0, dE0 = torch.empty((B, D), device=dev()), torch.empty((B, T * D), device=dev())
+    ops.interact_bwd_gather(x, Ws, bags, D, ops.INTERACT_RELU_X, dR, dx0, dE0)
+    for flag, nz, runs in ((zero, 0, True), (one, 0, False), (one, 1, True), (zero, 1, False)):
+        ly = torch.full((B, T * D), -7.0, device=dev()); ops.emb_fwd(Ws, bags, ly, pred=(flag, nz))
+        Rg = torch.full((B, ldr), -7.0, device=dev()); ops.interact_fwd_gather(x, Ws, bags, D, False, Rg, pred=(flag, nz))
+        Rp = torch.full((B, ldr), -7.0, device=dev()); ops.interact_fwd((x, ly0), D, False, Rp, pred=(flag, nz))
+        dxg, dEg = torch.full((B, D), -7.0, device=dev()), torch.full((B, T * D), -7.0, device=dev())
+        ops.interact_bwd_gather(x, Ws, bags, D, ops.INTERACT_RELU_X, dR, dxg, dEg, pred=(flag, nz))
+        dxp, dEp = torch.full((B, D), -7.0, device=dev()), torch.full((B, T * D), -7.0, device=dev())
+        ops.interact_bwd((x, ly0), D, ops.INTERACT_RELU_X, dR, (dxp, dEp), pred=(flag, nz))
+        torch.cuda.synchronize()
+        if runs:
+            assert torch.equal(ly, ly0) and torch.equal(Rg, R0) and torch.equal(Rp, R0)
+            assert torch.equal(dxg, dx0) and torch.equal(dEg, dE0) and torch.equal(dxp, dx0) and torch.equal(dEp, dE0)
+        else:
+            for t_ in (ly, Rg, Rp, dxg, dEg, dxp, dEp):
+                assert bool((t_ == -7.0).all())
+    ops.check_index_errors(sync=True)
+    # the proof that stays on the device
+    s0 = dict(ops.IOTA_STATS)
+    fresh = torch.arange(B, device=dev()).repeat(T, 1)
+    f1 = ops.offsets_iota_state(fresh)
+    assert isinstance(f1, torch.Tensor) and f1.dtype == torch.int32 and f1.numel() == 1
+    bad = fresh.clone(); bad[T - 1, 3] = 2; bad[0, 5] = 4
+    f2 = ops.offsets_iota_state(bad)
+    torch.cuda.synchronize()
+    assert int(f1.item()) == 0 and int(f2.item()) == 2
+    assert ops.IOTA_STATS["device_predicates"] == s0["device_predicates"] + 2 and ops.IOTA_STATS["checked"] == s0["checked"]
+    assert ops.offsets_iota_state(fresh) is True and ops.offsets_iota_state(bad) is False          # known by now: no second pass
+    assert ops.IOTA_STATS["device_predicates"] == s0["device_predicates"] + 2 and ops.IOTA_STATS["cached"] == s0["cached"] + 2
+    lst = [torch.arange(B, device=dev(), dtype=torch.int32) for _ in range(T)]                      # list form, int32
+    f3 = ops.offsets_iota_state(lst)
+    torch.cuda.synchronize()
+    assert int(f3.item()) == 0

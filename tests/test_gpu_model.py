@@ -442,12 +442,18 @@ def test_coo_escape_hatch_runs_any_torch_optimizer(route):
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=2e-4, atol=5e-6, err_msg=k)
 
 
-def test_ragged_batch_with_one_lookup_per_bag_on_average_takes_the_two_kernels():
+@pytest.mark.parametrize("verdict", ["device_predicate", "host_proof"])
+def test_ragged_batch_with_one_lookup_per_bag_on_average_takes_the_two_kernels(verdict, monkeypatch):
     """every table has nnz == B, but table 1 has an EMPTY bag next to a TWO-lookup bag — legal EmbeddingBag
     input the reference computes correctly (dlrm_s_pytorch.py:453-457).  The fused lookup + interaction path (on by default, D = 128)
-    must not be taken: ops.offsets_are_iota proves offsets == arange(B) per offsets tensor, and the step matches the oracle."""
+    must not RUN for it, and the step matches the oracle.  host_proof (rounds 4-6, DLRM_DEVICE_PREDICATE=0): ops.offsets_are_iota proves
+    offsets == arange(B) per offsets tensor before anything is launched.  device_predicate (default since ABI 16): the verdict stays on the
+    device — the fused launch and the two kernels are BOTH enqueued behind the launch predicate, the one that must not run returns at
+    once (nothing reaches the error block), and a tensor object that comes back is known by then (no second device pass)."""
     import dlrm_amd
-    from dlrm_amd import ops
+    from dlrm_amd import dlrm_net as _net, ops
+    monkeypatch.setattr(_net, "DEVICE_PREDICATE", verdict == "device_predicate")
+    dp = verdict == "device_predicate"
     device = torch.device("cuda:0")
     rng = np.random.default_rng(5)
     D, rows, B = 128, [50, 300, 7], 96
@@ -475,6 +481,7 @@ def test_ragged_batch_with_one_lookup_per_bag_on_average_takes_the_two_kernels()
         for ragged in (True, False):
             off = lS_o if ragged else [np.arange(B, dtype=np.int64) for _ in rows]
             od = [torch.from_numpy(o).to(device) for o in off]
+            g0 = calls["gather"]
             Z = model(torch.from_numpy(X).to(device), od, [torch.from_numpy(i).to(device) for i in lS_i])
             E = model.loss_fn(Z, torch.from_numpy(T).to(device))
             opt.zero_grad(); E.backward(); opt.step()
@@ -482,15 +489,21 @@ def test_ragged_batch_with_one_lookup_per_bag_on_average_takes_the_two_kernels()
             loss, Zr = ref.train_step(X, off, lS_i, T, 0.1)
             assert abs(float(E) - loss) <= 1e-5 * abs(loss), (ragged, float(E), loss)
             np.testing.assert_allclose(Z.detach().cpu().numpy(), Zr, rtol=2e-5, atol=1e-6)
-            assert calls["gather"] == (0 if ragged else 1)
+            # (device predicate: the fused launch is ENQUEUED for the ragged batch too — and returns at once on the device)
+            assert calls["gather"] - g0 == ((1 if dp else 0) if ragged else 1)
             # the same tensor objects again: the verdict is cached (no second device pass), and still right
             Z2 = model(torch.from_numpy(X).to(device), od, [torch.from_numpy(i).to(device) for i in lS_i])
-            assert calls["gather"] == (0 if ragged else 2)
+            assert calls["gather"] - g0 == ((1 if dp else 0) if ragged else 2)
+            np.testing.assert_allclose(Z2.detach().cpu().numpy(), ref.forward(X, off, lS_i), rtol=2e-5, atol=1e-6)   # (after the update)
             del Z2
             model._pending_emb.clear()
     finally:
         ops.interact_fwd_gather = orig
-    assert ops.IOTA_STATS["checked"] == seen["checked"] + 2 and ops.IOTA_STATS["cached"] == seen["cached"] + 2
+    if dp:
+        assert ops.IOTA_STATS["device_predicates"] == seen["device_predicates"] + 2 and ops.IOTA_STATS["checked"] == seen["checked"]
+        assert ops.IOTA_STATS["cached"] == seen["cached"] + 2
+    else:
+        assert ops.IOTA_STATS["checked"] == seen["checked"] + 2 and ops.IOTA_STATS["cached"] == seen["cached"] + 2
     for k, v in ref.p.items():
         np.testing.assert_allclose(model.state_dict()[k].cpu().numpy(), v, rtol=1e-4, atol=2e-6, err_msg=k)
     # an in-place edit of a proven tensor invalidates its verdict (version counter)

@@ -11,7 +11,7 @@ import sys
 
 CATS = {
     "emb_fwd": ["emb_fwd_kernel"],
-    "emb_bwd_sgd": ["expand_kernel", "rocprim::", "seg_hist_kernel", "seg_colscan_kernel", "seg_binscan_kernel", "seg_scatter_kernel",
+    "emb_bwd_sgd": ["expand_kernel", "rocprim::", "seg_hist_kernel", "seg_scan_kernel", "seg_colscan_kernel", "seg_binscan_kernel", "seg_scatter_kernel",
                     "sorted_update_kernel"],
     "interact_fwd": ["interact_fwd"],                                  # (the gather instantiations <NI, true> are split off below)
     "interact_bwd": ["interact_bwd"],
