@@ -696,7 +696,8 @@ KERNELS_OF_CATEGORY = [      # launch category of dlrm_amd.ops -> substrings of 
     ("linear_bwd_weight", ["gemm3_kernel<false, false", "splitk_reduce_kernel", "smallk_wgrad", "gemv_bwd_weight"]),
     ("linear_bwd_data", ["gemm3_kernel<true, false", "gemv_bwd_data"]),
     ("linear_fwd", ["gemm3_kernel<true, true", "gemv_fwd", "pad_cols_kernel"]),
-    ("emb_interact_fwd", ["interact_fwd_dma_kernel"]), ("emb_interact_bwd", ["interact_bwd_dma_kernel"]),
+    # (fused lookup + interaction: the fused kernel + the predicated two-kernel form that returns at once — ABI 16, three / two launches)
+    ("emb_interact_fwd", ["interact_fwd_dma_kernel", ", true>(EmbArgs"]), ("emb_interact_bwd", ["interact_bwd_dma_kernel"]),
     ("sgd_dense", ["sgd_dense"]), ("bce_loss", ["bce_kernel", "loss_finish_kernel", "scale_kernel"]), ("act_bwd", ["act_bwd_kernel"]),
     ("iota_proof", ["offsets_iota_kernel"])]
 

@@ -28,6 +28,8 @@ CALLS_PER_STEP = {"emb_fwd": 1, "emb_bwd_sgd": 1, "interact_fwd": 1, "interact_b
 def in_cat(cat, pats, kernel):
     """fused lookup + interaction = the <NI, true> instantiations of the LDS-DMA interaction kernels"""
     gather = "_dma_kernel<" in kernel and kernel.split("_dma_kernel<", 1)[1].split(">", 1)[0].replace(" ", "").endswith(",true")
+    if cat == "emb_fwd" and "emb_fwd_kernel<" in kernel and kernel.split("emb_fwd_kernel<", 1)[1].split(">", 1)[0].replace(" ", "").endswith(",true"):
+        return False        # the LOOP = true instantiation is the PREDICATED launch of the fused step (ABI 16): it returns at once there
     if cat.startswith("emb_interact"):
         return gather and any(p in kernel for p in pats)
     if cat.startswith("interact"):
