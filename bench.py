@@ -92,6 +92,12 @@ def parse():
                          "wrote: no device pass, no synchronisation); resident: four batches reused (their proof is cached after warm-up)")
     ap.add_argument("--no-full-size-parity", action="store_true", help="skip the 3-step comparison with the unmodified reference module at the FULL table sizes "
                                                                         "(both models resident on the GPU: 2 x 96 GB)")
+    ap.add_argument("--calibrate", choices=["last", "first"], default="first",
+                    help="where the box calibration (MFMA / copy / gather probes + a rocm-smi subprocess) sits: first (default since the end of round 6) "
+                         "= in front of the W warm-up steps, so that the timed region follows its warm-up steps directly; last (rounds 4-6) = between "
+                         "the warm-up steps and the timed region, + one untimed step — the second of idle queue it puts there cost the headline "
+                         "30-90 us per step (profiles/round6/proof_wait.md)")
+    ap.add_argument("--extra-warmup-step", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--gc", choices=["default", "freeze", "off"], default="default",
                     help="Python garbage collector around the timed region: default = untouched; freeze = gc.collect() + gc.freeze() before the "
                          "warm-up (objects alive then are never scanned again); off = gc.disable() inside the timed region (A/B of host stalls)")
@@ -281,7 +287,7 @@ def merge_box(b0, b1):
         box.setdefault(k, b1[k])
     box["before"] = {k: round(v, 2) for k, v in b0.items() if isinstance(v, float)}
     box["after"] = {k: round(v, 2) for k, v in b1.items() if isinstance(v, float)}
-    box["note"] = ("measured in this run by dlrm_calib_mfma / dlrm_calib_hbm_copy / dlrm_calib_hbm_gather right before and right after the timed "
+    box["note"] = ("measured in this run by dlrm_calib_mfma / dlrm_calib_hbm_copy / dlrm_calib_hbm_gather in front of the warm-up steps and right after the timed "
                    "region (mean); frac_of_measured_peak is priced against the constant-operand MFMA and copy rates, frac against the spec peaks; "
                    "mfma_*_random_tflops = the MFMA probes on random operands (what the chip holds under a GEMM's bit toggling); hbm_gather_gbps = "
                    "512-byte rows at random places of 16 GiB, the embedding kernels' access pattern (reported, not priced against)")
@@ -994,6 +1000,10 @@ def main():
             sys.exit("ERROR: %d ranks share %d GPUs; one process per GPU is required" % (N, len(set(uuids))))
         watchdog(args.hang_timeout, "first training step (RCCL all-to-all + DDP all-reduce for the first time)")
     calls_per_step = None
+    box0 = node0 = None
+    if args.calibrate == "first" and not args.no_box_calibration:
+        box0 = measure_box_or_none(device)
+        node0 = node_state() if (box0 is not None and int(os.environ.get("RANK", "0")) == 0) else None
     for i in range(args.warmup):
         c0_ = ops.CALL_COUNT[0]
         step(i)
@@ -1002,9 +1012,10 @@ def main():
         if i == 0 and N > 1:
             torch.cuda.synchronize()
             watchdog(args.hang_timeout + 20 * (args.warmup + args.steps), "warm-up + timed region")
-    box0 = measure_box_or_none(device) if not args.no_box_calibration else None
-    node0 = node_state() if (box0 is not None and int(os.environ.get("RANK", "0")) == 0) else None
-    if not args.no_box_calibration:      # (every rank, whether or not ITS probes succeeded: the step contains collectives)
+    if args.calibrate != "first":
+        box0 = measure_box_or_none(device) if not args.no_box_calibration else None
+        node0 = node_state() if (box0 is not None and int(os.environ.get("RANK", "0")) == 0) else None
+    if not args.no_box_calibration and (args.calibrate != "first" or args.extra_warmup_step):      # (every rank, whether or not ITS probes succeeded: the step contains collectives)
         step(args.warmup)                # one more untimed step: the timed region starts from the step's own steady state, not the probe's
     if N > 1:
         torch.distributed.barrier()
