@@ -663,19 +663,21 @@ wait_spinning = _wait_event_spinning
 # ---- the verdict left on the DEVICE (ABI 16): no host wait at all ---------------------------------------------------------------------------
 _FLAG_POOL = 1024
 _iota_flag_slots: dict = {}     # device index -> [device int32 pool, pinned int32 pool, next slot]: a slot is used ONCE (zeroed at allocation, never re-armed)
-_iota_unresolved: list = []     # (event, pinned slot, [tensor objects]): proofs whose host-visible verdict has not been looked at yet
+_iota_unresolved: list = []     # (event, pinned slot, [weak references to the tensor objects]): proofs whose host-visible verdict has not been looked at yet
 
 
 def _iota_drain() -> None:
     """remember the verdicts of finished device proofs (event.query(): no wait) — a tensor object that comes back is then known"""
     keep = []
-    for ev, host, srcs in _iota_unresolved:
+    for ev, host, refs in _iota_unresolved:
         if ev.query():
             ok = int(host[0]) == 0
-            for t in srcs:
-                _iota_remember(t, ok)
+            for r in refs:                     # (weak references: the proof keeps no offsets tensor alive; an object that is gone needs no verdict)
+                t = r()
+                if t is not None:
+                    _iota_remember(t, ok)
         else:
-            keep.append((ev, host, srcs))
+            keep.append((ev, host, refs))
     _iota_unresolved[:] = keep[-64:]           # (bounded: a verdict nobody came back for within 64 steps is dropped — the next encounter proves again)
 
 
@@ -723,7 +725,8 @@ def offsets_iota_state(lS_o):
         rc = _lib.load().dlrm_offsets_iota_flags(len(ptrs), srcs[0].size(-1), _lib.ptr_array(ptrs), 64 if srcs[0].dtype == torch.int64 else 32,
                                                  C.c_void_p(flag.data_ptr()), C.c_void_p(host.data_ptr()), _stream(srcs[0]))
     _lib.check(rc, "dlrm_offsets_iota_flags")
-    _iota_unresolved.append((torch.cuda.current_stream(dev).record_event(), host, srcs))
+    import weakref
+    _iota_unresolved.append((torch.cuda.current_stream(dev).record_event(), host, [weakref.ref(t) for t in srcs]))
     IOTA_STATS["device_predicates"] = IOTA_STATS.get("device_predicates", 0) + 1
     IOTA_STATS["host_us"] += (_time.perf_counter() - t0) * 1e6
     del keep
