@@ -699,7 +699,7 @@ def resolve_world(args, argv=None, environ=None):
 KERNELS_OF_CATEGORY = [      # launch category of dlrm_amd.ops -> substrings of the kernels one of its C-ABI calls launches (headline workload)
     ("emb_bwd_sgd", ["expand_kernel", "seg_hist_kernel", "seg_scan_kernel", "seg_colscan_kernel", "seg_groupscan_kernel", "seg_binscan_kernel",
                      "seg_scatter_kernel", "sorted_update_kernel", "emb_bwd_sgd_"]),
-    ("linear_bwd_weight", ["gemm3_kernel<false, false", "splitk_reduce_kernel", "smallk_wgrad", "gemv_bwd_weight"]),
+    ("linear_bwd_weight", ["gemm3_kernel<false, false", "splitk_reduce_kernel", "smallk_wgrad", "gemv_bwd_weight", "gemv_bwd_fused"]),
     ("linear_bwd_data", ["gemm3_kernel<true, false", "gemv_bwd_data"]),
     ("linear_fwd", ["gemm3_kernel<true, true", "gemv_fwd", "pad_cols_kernel"]),
     # (fused lookup + interaction: the fused kernel + the predicated two-kernel form that returns at once — ABI 16, three / two launches)

@@ -77,6 +77,7 @@ SIGNATURES = {
     "dlrm_linear_bwd_data": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "dlrm_linear_bwd_weight_workspace_bytes": (_i64, [_i64, _i32, _i32]),
     "dlrm_linear_bwd_weight": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
+    "dlrm_linear_head_bwd": (_i32, [_i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp]),
     "dlrm_linear_bwd_weight_padded": (_i32, [_i64, _i32, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _i32, _vp]),
     "dlrm_pad_cols": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "dlrm_act_bwd": (_i32, [_i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),

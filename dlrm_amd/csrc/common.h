@@ -143,6 +143,10 @@ int dlrm_gemv_bwd_data(int64_t M, int K, const float* dY, int64_t lddy, const fl
 int dlrm_gemv_bwd_weight(int64_t M, int K, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,
                          float* dbias, int accumulate, void* workspace, int64_t workspace_bytes, hipStream_t st);
 
+int dlrm_gemv_bwd_fused(int64_t M, int K, const float* dY, int64_t lddy, const float* Yout, int64_t ldy, int act_out, const float* X,
+                        int64_t ldx, const float* w, int xact_kind, float* dX, int64_t lddx, float* dW, float* dbias, int accumulate,
+                        void* workspace, int64_t workspace_bytes, hipStream_t st);
+
 // smallk.hip: weight gradient of layers with K <= 16 (the first bottom-MLP layer: 13 dense features padded to 16)
 int64_t dlrm_smallk_bwd_weight_workspace_bytes(int64_t M, int N, int K);
 int dlrm_smallk_bwd_weight(int64_t M, int N, int K, int K_store, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,

@@ -1710,6 +1710,20 @@ static int linear_bwd_weight_impl(int64_t M, int N, int K, int K_store, const fl
     return launch_gemm<false, false>(g, splits, st, arith);
 }
 
+// The backward of an N == 1 layer (the 256 -> 1 head of the top tower, dlrm_s_pytorch.py:208-246 / AddmmBackward + SigmoidBackward :1613) in one
+// pass: dz = dY * act'(Y), dW = dz^T X, db = sum dz, dX = (dz W) * xact'(X).  DLRM_E_MODE: shapes outside csrc/gemv.hip's fast path (the caller
+// runs dlrm_act_bwd + dlrm_linear_bwd_weight + dlrm_linear_bwd_data, whose bits these are).
+extern "C" int dlrm_linear_head_bwd(int64_t M, int K, const float* dY, int64_t lddy, const float* Y, int64_t ldy, int act,
+                                    const float* X, int64_t ldx, const float* W, int xact_kind, float* dX, int64_t lddx,
+                                    float* dW, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (M <= 0 || K <= 0 || !dY || !X || !W || !dW) return DLRM_E_ARG;
+    if (lddy < 1 || ldx < K || (dX && lddx < K) || (Y && ldy < 1)) return DLRM_E_ARG;
+    if (act < DLRM_ACT_NONE || act > DLRM_ACT_SIGMOID || xact_kind < DLRM_ACT_NONE || xact_kind > DLRM_ACT_SIGMOID) return DLRM_E_MODE;
+    const int rc = dlrm_gemv_bwd_fused(M, K, dY, lddy, (Y && act != DLRM_ACT_NONE) ? Y : nullptr, ldy, act, X, ldx, W, xact_kind, dX, lddx, dW,
+                                       dbias, accumulate, workspace, workspace_bytes, (hipStream_t)stream);
+    return rc == DLRM_GEMV_NOT_HANDLED ? DLRM_E_MODE : rc;
+}
+
 extern "C" int dlrm_linear_bwd_weight(int64_t M, int N, int K, const float* dY, int64_t lddy,
                                       const float* X, int64_t ldx, float* dW, int64_t lddw,
                                       float* dbias, int accumulate, void* workspace, int64_t workspace_bytes,

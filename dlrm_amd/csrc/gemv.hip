@@ -137,6 +137,84 @@ __global__ __launch_bounds__(256) void gemv_bwd_weight_partial_kernel(long long 
     }
 }
 
+// The whole backward of the N == 1 layer in ONE pass over X (dlrm_linear_head_bwd, round 6): the step ran act_bwd (dz = dy * act'(y), a launch
+// over 65536 floats), the weight-gradient partials (X read: 67 MB) and the data gradient (X read again for the previous layer's ReLU mask +
+// dX written: 134 MB) as three launches + the finish, 48 us for what one pass moves in ~22.  Same row partition, same accumulation order and the
+// same expressions as gemv_bwd_weight_partial_kernel / gemv_bwd_data_kernel / act_bwd_kernel: partials and dX are BIT-IDENTICAL to theirs.
+__global__ __launch_bounds__(256) void gemv_bwd_fused_partial_kernel(long long M, int K, const float* __restrict__ dY, long long lddy,
+                                                                     const float* __restrict__ Yout, long long ldy, int act_out,
+                                                                     const float* __restrict__ X, long long ldx,
+                                                                     const float* __restrict__ w, int xact_kind,
+                                                                     float* __restrict__ dX, long long lddx,
+                                                                     long long rows_per_block, float* __restrict__ part, int ldp) {
+    __shared__ float4 red[256];
+    __shared__ float redb[256];
+    const int kq = K >> 2;                          // <= 256
+    const int rg = 256 / kq;                        // row groups per pass (>= 1)
+    const int cq = threadIdx.x % kq, g = threadIdx.x / kq;
+    const long long m0 = (long long)blockIdx.x * rows_per_block;
+    const long long m1 = (m0 + rows_per_block < M) ? m0 + rows_per_block : M;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float accb = 0.f;
+    if (g < rg) {
+        const float4 wv = *(const float4*)(w + 4 * cq);
+        constexpr int UR = 8;
+        long long m = m0 + g;
+        for (; m + (long long)(UR - 1) * rg < m1; m += (long long)UR * rg) {
+            float d[UR];
+            float4 x[UR];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const long long r = m + (long long)u * rg;
+                d[u] = dY[r * lddy];
+                if (Yout) d[u] = gv_act_grad(d[u], Yout[r * ldy], act_out);
+                x[u] = *(const float4*)(X + r * ldx + 4 * cq);
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                acc.x = __builtin_fmaf(d[u], x[u].x, acc.x); acc.y = __builtin_fmaf(d[u], x[u].y, acc.y);
+                acc.z = __builtin_fmaf(d[u], x[u].z, acc.z); acc.w = __builtin_fmaf(d[u], x[u].w, acc.w);
+                accb += d[u];
+                if (dX) {
+                    float4 v = make_float4(d[u] * wv.x, d[u] * wv.y, d[u] * wv.z, d[u] * wv.w);
+                    if (xact_kind != DLRM_ACT_NONE) {
+                        v.x = gv_act_grad(v.x, x[u].x, xact_kind); v.y = gv_act_grad(v.y, x[u].y, xact_kind);
+                        v.z = gv_act_grad(v.z, x[u].z, xact_kind); v.w = gv_act_grad(v.w, x[u].w, xact_kind);
+                    }
+                    *(float4*)(dX + (m + (long long)u * rg) * lddx + 4 * cq) = v;
+                }
+            }
+        }
+        for (; m < m1; m += rg) {
+            float d = dY[m * lddy];
+            if (Yout) d = gv_act_grad(d, Yout[m * ldy], act_out);
+            const float4 x = *(const float4*)(X + m * ldx + 4 * cq);
+            acc.x = __builtin_fmaf(d, x.x, acc.x); acc.y = __builtin_fmaf(d, x.y, acc.y);
+            acc.z = __builtin_fmaf(d, x.z, acc.z); acc.w = __builtin_fmaf(d, x.w, acc.w);
+            accb += d;
+            if (dX) {
+                float4 v = make_float4(d * wv.x, d * wv.y, d * wv.z, d * wv.w);
+                if (xact_kind != DLRM_ACT_NONE) {
+                    v.x = gv_act_grad(v.x, x.x, xact_kind); v.y = gv_act_grad(v.y, x.y, xact_kind);
+                    v.z = gv_act_grad(v.z, x.z, xact_kind); v.w = gv_act_grad(v.w, x.w, xact_kind);
+                }
+                *(float4*)(dX + m * lddx + 4 * cq) = v;
+            }
+        }
+    }
+    red[threadIdx.x] = acc; redb[threadIdx.x] = accb;
+    __syncthreads();
+    if (g == 0) {
+        for (int q = 1; q < rg; ++q) {
+            const float4 o = red[q * kq + cq];
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+            accb += redb[q * kq + cq];
+        }
+        *(float4*)(part + (long long)blockIdx.x * ldp + 4 * cq) = acc;
+        if (cq == 0) part[(long long)blockIdx.x * ldp + K] = accb;
+    }
+}
+
 // stage 2: fixed-order sum of the per-workgroup partials (deterministic): a workgroup owns 64 columns, its four
 // thread rows each sum every fourth partial (8 loads in flight), LDS folds the four sums in a fixed order
 __global__ __launch_bounds__(256) void gemv_bwd_weight_finish_kernel(int K, int nblk, const float* __restrict__ part, int ldp,
@@ -231,6 +309,26 @@ int dlrm_gemv_bwd_weight(int64_t M, int K, const float* dY, int64_t lddy, const 
     gemv_wgrad_plan(M, K, &nblk, &rpb, &ldp);
     hipLaunchKernelGGL(gemv_bwd_weight_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (long long)M, K, dY,
                        (long long)lddy, X, (long long)ldx, rpb, (float*)workspace, ldp);
+    DLRM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemv_bwd_weight_finish_kernel, dim3((unsigned)((K + 1 + 63) / 64)), dim3(256), 0, st, K, nblk,
+                       (const float*)workspace, ldp, dW, dbias, accumulate ? 1 : 0);
+    DLRM_LAUNCH_CHECK();
+    return 0;
+}
+
+// dz = dY * act'(Y) (Y == nullptr: dY is dz already), dW = dz^T X, db = sum dz, dX = (dz w) * xact'(X): one pass + the finish.
+// DLRM_GEMV_NOT_HANDLED: the caller runs the three calls.
+int dlrm_gemv_bwd_fused(int64_t M, int K, const float* dY, int64_t lddy, const float* Yout, int64_t ldy, int act_out, const float* X,
+                        int64_t ldx, const float* w, int xact_kind, float* dX, int64_t lddx, float* dW, float* dbias, int accumulate,
+                        void* workspace, int64_t workspace_bytes, hipStream_t st) {
+    if (!gemv_ok(X, ldx, K) || !dlrm_aligned16(w) || K / 4 > 256) return DLRM_GEMV_NOT_HANDLED;
+    if (dX && !gemv_ok(dX, lddx, K)) return DLRM_GEMV_NOT_HANDLED;
+    const int64_t need = dlrm_gemv_bwd_weight_workspace_bytes(M, K);
+    if (!workspace || !dlrm_aligned16(workspace) || workspace_bytes < need) return DLRM_GEMV_NOT_HANDLED;
+    int nblk, ldp; long long rpb;
+    gemv_wgrad_plan(M, K, &nblk, &rpb, &ldp);
+    hipLaunchKernelGGL(gemv_bwd_fused_partial_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (long long)M, K, dY, (long long)lddy, Yout,
+                       (long long)ldy, act_out, X, (long long)ldx, w, xact_kind, dX, (long long)lddx, rpb, (float*)workspace, ldp);
     DLRM_LAUNCH_CHECK();
     hipLaunchKernelGGL(gemv_bwd_weight_finish_kernel, dim3((unsigned)((K + 1 + 63) / 64)), dim3(256), 0, st, K, nblk,
                        (const float*)workspace, ldp, dW, dbias, accumulate ? 1 : 0);

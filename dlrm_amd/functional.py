@@ -57,6 +57,8 @@ MULTI_CAST = os.environ.get("DLRM_BF16_MULTI_CAST", "1") == "1"
 # are the planes form of the bf16-shaped kernel (dlrm_gemm_bf16x6), wherever its shapes hold (DLRM_BF16X6_PLANES=0: every GEMM splits its fp32
 # operands inside its k-loop, the kernels of rounds 1-3; the k-contiguous products are bit-identical either way)
 BF16X6_PLANES = os.environ.get("DLRM_BF16X6_PLANES", "1") == "1"
+# the N == 1 head of a tower (256 -> 1 + sigmoid): its whole backward in one pass over its input (DLRM_HEAD_FUSED=0: the three calls)
+HEAD_FUSED = os.environ.get("DLRM_HEAD_FUSED", "1") == "1"
 _side_streams = {}
 
 
@@ -411,7 +413,22 @@ class MLPFunction(Function):
 
         # last layer: activation backward (its dY comes from outside, e.g. the loss or the interaction)
         N_last = params[2 * (L - 1)].size(0)
-        if ctx.consumer_applies_last_act and _ld(dY) % 4 == 0 and dY.data_ptr() % 16 == 0:
+        first = L - 1                                      # the layer the loop below starts with
+        dZ = None
+        if (HEAD_FUSED and N_last == 1 and L >= 2 and not store16 and not ctx.consumer_applies_last_act and arith == ops.arith_code("f32")
+                and outs[L - 1] is not None and outs[L - 2] is not None and not OVERLAP_WGRAD
+                and not (0 < SMALL_BATCH_OVERLAP and M <= SMALL_BATCH_OVERLAP and torch.cuda.is_current_stream_capturing())):
+            # the 256 -> 1 head of the top tower: act_bwd + weight gradient + data gradient of an N == 1 layer are ONE pass over its input
+            # (dlrm_linear_head_bwd: X read once instead of twice, one launch + the finish instead of four: 48 -> ~29 us at B = 65536; the
+            # bits of the three calls).  Outside its fast path nothing is launched and the three calls below run.
+            dW_h, db_h = _grad_out(params[2 * (L - 1)]), _grad_out(params[2 * (L - 1) + 1])
+            dprev = alloc2d(M, params[2 * (L - 1)].size(1), x)
+            if ops.linear_head_bwd(dY, outs[L - 1], acts[L - 1], outs[L - 2], params[2 * (L - 1)], acts[L - 2], dprev, dW_h, db_h):
+                grads[2 * (L - 1)], grads[2 * (L - 1) + 1] = dW_h, db_h
+                dZ, first = dprev, L - 2
+        if dZ is not None:
+            pass
+        elif ctx.consumer_applies_last_act and _ld(dY) % 4 == 0 and dY.data_ptr() % 16 == 0:
             dZ = dY                                        # already dL/dz of the last layer (see forward)
         else:
             dZ = alloc2d(M, N_last, x)
@@ -432,7 +449,7 @@ class MLPFunction(Function):
                                                           and torch.cuda.is_current_stream_capturing())) else None
         keep = []                                          # tensors the side stream reads stay alive until the join
         dZ16 = None                                        # bf16 copy of dZ when the previous data-gradient GEMM produced one
-        for i in range(L - 1, -1, -1):
+        for i in range(first, -1, -1):
             W = params[2 * i] if not (i == 0 and W0p is not None) else W0p
             X_i = x if i == 0 else outs[i - 1]
             X16_i = ctx.in16[i] if wg16[i] else None

@@ -1156,6 +1156,35 @@ def linear_bwd_weight(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, dbias
     return dW
 
 
+def linear_head_bwd(dY: torch.Tensor, Y: Optional[torch.Tensor], act: int, X: torch.Tensor, W: torch.Tensor, xact_kind: int,
+                    dX: Optional[torch.Tensor], dW: torch.Tensor, dbias: Optional[torch.Tensor], accumulate: bool = False) -> bool:
+    """The whole backward of an N == 1 layer in one pass over X (dlrm_linear_head_bwd): dz = dY * act'(Y), dW [1, K] = dz^T X, dbias [1] = sum dz,
+    dX [M, K] = (dz W) * xact'(X) — the bits of act_bwd + linear_bwd_weight + linear_bwd_data.  False: the shape is outside the fast path and
+    NOTHING was launched (the caller makes the three calls)."""
+    lib = _lib.load()
+    _req(dY, "dY", ndim=2); _req(X, "X", ndim=2); _req(W, "W", ndim=2); _req(dW, "dW", ndim=2)
+    M, K = X.shape
+    if dY.size(0) != M or dY.size(1) != 1 or W.shape != (1, K) or dW.shape != (1, K) or (dX is not None and dX.shape != (M, K)):
+        raise RuntimeError("dlrm_amd: linear_head_bwd shape mismatch")
+    if Y is not None:
+        _req(Y, "Y", ndim=2)
+    if dX is not None:
+        _req(dX, "dX", ndim=2)
+    ws = _wgrad_workspace(lib.dlrm_linear_bwd_weight_workspace_bytes(M, 1, K), dY.device)
+    if ws is None:
+        return False
+    with _timed("linear_bwd_weight"):
+        rc = lib.dlrm_linear_head_bwd(M, K, C.c_void_p(dY.data_ptr()), _ld(dY), C.c_void_p(Y.data_ptr()) if Y is not None else None,
+                                      _ld(Y) if Y is not None else 1, int(act), C.c_void_p(X.data_ptr()), _ld(X), C.c_void_p(W.data_ptr()),
+                                      int(xact_kind), C.c_void_p(dX.data_ptr()) if dX is not None else None, _ld(dX) if dX is not None else K,
+                                      C.c_void_p(dW.data_ptr()), C.c_void_p(dbias.data_ptr()) if dbias is not None else None,
+                                      int(bool(accumulate)), C.c_void_p(ws.data_ptr()), ws.numel(), _stream(dW))
+    if rc == -4:                                     # DLRM_E_MODE: outside the fast path, nothing launched
+        return False
+    _lib.check(rc, "dlrm_linear_head_bwd")
+    return True
+
+
 def linear_bwd_weight_bf16_ok(M: int, N: int, K: int, dZ16: torch.Tensor, X16: torch.Tensor) -> bool:
     """preconditions of dlrm_linear_bwd_weight_bf16 (csrc/gemm_bf16.hip, weight-gradient form)"""
     K = (K + 7) & ~7

@@ -360,6 +360,14 @@ int dlrm_linear_bwd_weight_padded(int64_t M, int N, int K, int K_store,
                            const float* dY, int64_t lddy, const float* X, int64_t ldx,
                            float* dW, int64_t lddw, float* dbias, int accumulate,
                            void* workspace, int64_t workspace_bytes, int arith, void* stream);
+/* The whole backward of an N == 1 layer (the 256 -> 1 head of the top tower) in one pass over X:
+ *   dz = dY * act'(Y) (Y == NULL or act == NONE: dY is dz), dW[K] (+)= dz^T X, dbias[1] (+)= sum dz, dX = (dz W) * xact'(X) (dX == NULL: none).
+ * Bit-identical to dlrm_act_bwd + dlrm_linear_bwd_weight + dlrm_linear_bwd_data with N = 1 (same row partition, order and expressions);
+ * workspace of dlrm_linear_bwd_weight_workspace_bytes(M, 1, K).  DLRM_E_MODE for shapes outside the fast path (K % 4, K > 1024, unaligned
+ * rows): the caller then makes the three calls. */
+int dlrm_linear_head_bwd(int64_t M, int K, const float* dY, int64_t lddy, const float* Y, int64_t ldy, int act,
+                         const float* X, int64_t ldx, const float* W, int xact_kind, float* dX, int64_t lddx,
+                         float* dW, float* dbias, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 /* dst[m, 0:K] = src[m, 0:K], dst[m, K:Kp] = 0   (builds those padded operands: no ATen fill/copy on the hot path) */
 int dlrm_pad_cols(int64_t M, int K, int Kp, const float* src, int64_t ld_src, float* dst, int64_t ld_dst, void* stream);
 

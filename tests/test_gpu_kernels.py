@@ -1700,3 +1700,54 @@ def test_launch_predicates_choose_the_implementation_on_the_device(T, B):
     f3 = ops.offsets_iota_state(lst)
     torch.cuda.synchronize()
     assert int(f3.item()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K", [(65536, 256), (5000, 256), (96, 64), (777, 480), (300, 1024)])
+@pytest.mark.parametrize("act,xact", [(2, 1), (0, 1), (2, 0), (1, 2)])
+def test_head_layer_backward_in_one_pass_is_the_three_calls(M, K, act, xact):
+    """dlrm_linear_head_bwd (the 256 -> 1 head of the top tower: dz = dY * act'(Y), dW, db, dX = (dz W) * xact'(X) in one pass over X)
+    against dlrm_act_bwd + dlrm_linear_bwd_weight + dlrm_linear_bwd_data with N = 1: the SAME bits, plain and accumulating, and directly
+    against numpy in float64; a shape outside the fast path launches nothing and says so.  (activation codes: 0 none, 1 ReLU, 2 sigmoid)"""
+    from dlrm_amd import ops
+    from dlrm_amd import _lib
+    assert (_lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_SIGMOID) == (0, 1, 2)
+    rng = np.random.default_rng(M + K + act)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    if xact == 2:
+        X = (1.0 / (1.0 + np.exp(-X))).astype(np.float32)
+    W = rng.standard_normal((1, K)).astype(np.float32)
+    Y = (1.0 / (1.0 + np.exp(-rng.standard_normal((M, 1))))).astype(np.float32)
+    dY = rng.standard_normal((M, 1)).astype(np.float32)
+    Xd, Wd, Yd, dYd = to_dev(X), to_dev(W), to_dev(Y), to_dev(dY)
+    # the three calls
+    dZ = torch.empty((M, 1), device=dev())
+    ops.act_bwd(dYd, Yd, act, dZ, None)
+    dW0, db0 = torch.empty((1, K), device=dev()), torch.empty((1,), device=dev())
+    ops.linear_bwd_weight(dZ, Xd, dW0, db0)
+    dX0 = torch.empty((M, K), device=dev())
+    ops.linear_bwd_data(dZ, Wd, Xd if xact != 0 else None, xact, dX0, ops.arith_code("f32"))
+    # one pass
+    dW1, db1, dX1 = torch.full((1, K), 7.0, device=dev()), torch.full((1,), 7.0, device=dev()), torch.full((M, K), 7.0, device=dev())
+    assert ops.linear_head_bwd(dYd, Yd, act, Xd, Wd, xact, dX1, dW1, db1) is True
+    torch.cuda.synchronize()
+    assert torch.equal(dW0, dW1) and torch.equal(db0, db1) and torch.equal(dX0, dX1)
+    # accumulate
+    ops.linear_bwd_weight(dZ, Xd, dW0, db0, accumulate=True)
+    assert ops.linear_head_bwd(dYd, Yd, act, Xd, Wd, xact, None, dW1, db1, accumulate=True) is True
+    assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
+    # numpy, float64
+    y64, x64 = Y.astype(np.float64), X.astype(np.float64)
+    dz = dY.astype(np.float64) * ((1 - y64) * y64 if act == 2 else (y64 > 0) if act == 1 else 1.0)
+    dxw = dz * W.astype(np.float64)
+    dxw = dxw * ((x64 > 0) if xact == 1 else ((1 - x64) * x64) if xact == 2 else 1.0)
+    np.testing.assert_allclose(dX1.cpu().numpy(), dxw, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(dW1.cpu().numpy() / 2, dz.T @ x64, rtol=2e-4, atol=2e-4 * np.sqrt(M))
+    np.testing.assert_allclose(db1.cpu().numpy() / 2, dz.sum(0), rtol=2e-4, atol=2e-4 * np.sqrt(M))
+    # outside the fast path: nothing happens
+    if K == 64:
+        Xo = to_dev(rng.standard_normal((M, 62)).astype(np.float32))
+        dWo = torch.full((1, 62), 7.0, device=dev())
+        assert ops.linear_head_bwd(dYd, Yd, act, Xo, to_dev(W[:, :62].copy()), xact, None, dWo, None) is False
+        torch.cuda.synchronize()
+        assert bool((dWo == 7.0).all())
