@@ -549,6 +549,15 @@ def full_size_parity(model, opt, wl, ln_top, batches, lr, device, steps=3):
     return out
 
 
+def sync_device():
+    """torch.cuda.synchronize() at the end of a timed region, reached by POLLING: a thread asleep in hipDeviceSynchronize wakes up whenever the box
+    lets it (30 us ... 1.2 ms measured on this pool, profiles/round6/proof_wait.md), and that latency would be charged to the steps.  The device
+    synchronisation itself still happens (it returns at once)."""
+    from dlrm_amd import ops
+    ops.wait_spinning(torch.cuda.current_stream(), limit_s=30.0)
+    torch.cuda.synchronize()
+
+
 def host_step_intervals(t0, returns, gc_before):
     """Host time between the returns of consecutive timed step() calls (ms).  With --offsets fresh every step ends the host's run-ahead once
     (the proof's verdict), so these intervals ARE the steps as the GPU ran them and a single long one is a host stall the GPU sat out
@@ -1036,7 +1045,7 @@ def main():
             timed_steps += int(ops.timers.enabled)
         loss = step(args.warmup + 1 + i)          # (index args.warmup was the extra untimed step above: every timed step sees a NEW offsets object)
         step_returns.append(time.perf_counter())
-    torch.cuda.synchronize()
+    sync_device()
     if N > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
@@ -1055,7 +1064,7 @@ def main():
         t1 = time.perf_counter()
         for i in range(args.steps):
             step(2 + i)
-        torch.cuda.synchronize()
+        sync_device()
         tagged_ms = (time.perf_counter() - t1) / args.steps * 1e3
         fresh_off = None                               # (every later measurement runs on the resident batches)
         ops.timers = keep_timers

@@ -645,12 +645,12 @@ def offsets_are_iota_start(lS_o):
 SPIN_WAIT_S = 0.0 if os.environ.get("DLRM_SPIN_WAIT", "1") == "0" else 0.05        # DLRM_SPIN_WAIT=0: sleep on the event (A/B)
 
 
-def _wait_event_spinning(ev) -> None:
-    """ev: a torch.cuda.Event or a torch.cuda.Stream (both have query() / synchronize())"""
+def _wait_event_spinning(ev, limit_s: Optional[float] = None) -> None:
+    """ev: a torch.cuda.Event or a torch.cuda.Stream (both have query() / synchronize()); limit_s: how long to poll before sleeping after all"""
     import time as _time
     if ev.query():
         return
-    end = _time.perf_counter() + SPIN_WAIT_S
+    end = _time.perf_counter() + (SPIN_WAIT_S if limit_s is None else (limit_s if SPIN_WAIT_S > 0 else 0.0))
     while not ev.query():
         if _time.perf_counter() > end:
             ev.synchronize()
