@@ -1011,8 +1011,11 @@ def main():
     calls_per_step = None
     box0 = node0 = None
     if args.calibrate == "first" and not args.no_box_calibration:
+        # (the rocm-smi subprocess first — a second of idle queue — then the probes: the warm-up steps start on a busy GPU)
+        node0 = node_state() if int(os.environ.get("RANK", "0")) == 0 else None
         box0 = measure_box_or_none(device)
-        node0 = node_state() if (box0 is not None and int(os.environ.get("RANK", "0")) == 0) else None
+        if box0 is None:
+            node0 = None
     for i in range(args.warmup):
         c0_ = ops.CALL_COUNT[0]
         step(i)
