@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 UPD_ATOMIC, UPD_DETERMINISTIC, UPD_SORTED = 0, 1, 2
 ARITH_F32, ARITH_BF16X6, ARITH_BF16 = 0, 1, 2
-EXPECTED_ABI = 16          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
+EXPECTED_ABI = 17          # dlrm_hip_abi_version() of the library these bindings (SIGNATURES) were written against
 
 _lock = threading.Lock()
 _lib = None
@@ -72,6 +72,10 @@ SIGNATURES = {
     "dlrm_emb_fwd_pred": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pp, _pp, _pi64, _pp, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
     "dlrm_interact_fwd_pred": (_i32, [_i64, _i32, _i32, _pp, _pi64, _pp, _pp, _pi64, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _vp]),
     "dlrm_interact_bwd_pred": (_i32, [_i64, _i32, _i32, _pp, _pi64, _pp, _pp, _pi64, _i32, _i32, _vp, _i64, _pp, _pi64, _vp, _vp, _i32, _vp]),
+    "dlrm_emb_presort": (_i32, [_i32, _i64, _pi64, _pp, _pp, _pi64, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "dlrm_interact_bwd_gather_sgd": (_i32, [_i64, _i32, _i32, _pp, _pi64, _pp, _pp, _pi64, _i32, _i32, _vp, _i64, _pp, _pi64, _vp, _f32, _vp, _vp,
+                                            _vp, _i32, _vp]),
+    "dlrm_emb_bwd_sgd_presorted": (_i32, [_i32, _i64, _i32, _pp, _pi64, _pi64, _vp, _i64, _f32, _vp, _vp, _i64, _i32, _vp, _i32, _vp]),
     "dlrm_relu_bits_bytes": (_i64, [_i64, _i32]),
     "dlrm_linear_fwd": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _i32, _vp]),
     "dlrm_linear_bwd_data": (_i32, [_i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),

@@ -56,21 +56,23 @@ __device__ __forceinline__ void adagrad_apply(float* __restrict__ wrow, float* _
     }
 #pragma unroll
     for (int o = LPB >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-    const float m = *mom_r + sq / (float)D;              // every lane reads the old value before lane 0 stores the new one
+    // (row and accumulator through GLOBAL pointers: sorted_common.h v_gload — generic ones made these flat instructions)
+    const float m = *(const sc_gfloat*)mom_r + sq / (float)D;              // every lane reads the old value before lane 0 stores the new one
     const float denom = sqrtf(m) + eps;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int col = (c * LPB + lig) * VEC;
         if (col < D) {
-            VT w = *(const VT*)(wrow + col);
+            VT w;
+            v_gload(w, wrow + col);
             VT q;
             if constexpr (VEC == 4) q = make_float4(acc[c].x / denom, acc[c].y / denom, acc[c].z / denom, acc[c].w / denom);
             else q = acc[c] / denom;
             if constexpr (VEC == 4) v_step(w, -clr, q); else w = __builtin_fmaf(-clr, q, w);
-            *(VT*)(wrow + col) = w;
+            v_gstore(wrow + col, w);
         }
     }
-    if (lig == 0) *mom_r = m;
+    if (lig == 0) *(sc_gfloat*)mom_r = m;
 }
 
 // Pass 1.  A lookup's gradient row is found through a chain of dependent loads — sorted key, sorted value (= lookup position), bag of

@@ -26,6 +26,8 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // the loads/stores are global_* (not flat_*) instructions
 typedef __attribute__((address_space(1))) float gfloat;
 typedef __attribute__((address_space(1))) floatx4 gfloatx4;
+typedef __attribute__((address_space(1))) char gchar;          // a pointer rebuilt from an integer table is GENERIC unless told otherwise: its stores
+                                                               // would be FLAT instructions, which also count on lgkmcnt — every LDS wait then waits for them
 
 // position of the pair (i, j), j <= i, in the flattened interaction output.  `self` is a mode word: bit 0 = pairs include the
 // diagonal (--arch-interaction-itself), bit 1 = torchrec order — torch.triu_indices(F, F, offset=1), i.e. pair (j, i) of the
@@ -293,7 +295,7 @@ __device__ __forceinline__ void glds16_v(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt_i() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-// wave-uniform runtime count (0..16) -> immediate
+// wave-uniform runtime count (0..40; larger counts wait for more than asked: safe) -> immediate
 __device__ __forceinline__ void wait_vmcnt_rt(int n) {
     switch (n) {
         case 0: wait_vmcnt_i<0>(); break;   case 1: wait_vmcnt_i<1>(); break;   case 2: wait_vmcnt_i<2>(); break;
@@ -302,7 +304,14 @@ __device__ __forceinline__ void wait_vmcnt_rt(int n) {
         case 9: wait_vmcnt_i<9>(); break;   case 10: wait_vmcnt_i<10>(); break; case 11: wait_vmcnt_i<11>(); break;
         case 12: wait_vmcnt_i<12>(); break; case 13: wait_vmcnt_i<13>(); break; case 14: wait_vmcnt_i<14>(); break;
         case 15: wait_vmcnt_i<15>(); break; case 16: wait_vmcnt_i<16>(); break; case 17: wait_vmcnt_i<17>(); break;
-        case 18: wait_vmcnt_i<18>(); break; case 19: wait_vmcnt_i<19>(); break; default: wait_vmcnt_i<20>(); break;
+        case 18: wait_vmcnt_i<18>(); break; case 19: wait_vmcnt_i<19>(); break; case 20: wait_vmcnt_i<20>(); break;
+        case 21: wait_vmcnt_i<21>(); break; case 22: wait_vmcnt_i<22>(); break; case 23: wait_vmcnt_i<23>(); break;
+        case 24: wait_vmcnt_i<24>(); break; case 25: wait_vmcnt_i<25>(); break; case 26: wait_vmcnt_i<26>(); break;
+        case 27: wait_vmcnt_i<27>(); break; case 28: wait_vmcnt_i<28>(); break; case 29: wait_vmcnt_i<29>(); break;
+        case 30: wait_vmcnt_i<30>(); break; case 31: wait_vmcnt_i<31>(); break; case 32: wait_vmcnt_i<32>(); break;
+        case 33: wait_vmcnt_i<33>(); break; case 34: wait_vmcnt_i<34>(); break; case 35: wait_vmcnt_i<35>(); break;
+        case 36: wait_vmcnt_i<36>(); break; case 37: wait_vmcnt_i<37>(); break; case 38: wait_vmcnt_i<38>(); break;
+        case 39: wait_vmcnt_i<39>(); break; default: wait_vmcnt_i<40>(); break;
     }
 }
 
@@ -360,11 +369,14 @@ struct GatherCtx {
     const char* osrc;
     long long rows;              // of feature lane & 31; < 0: plain feature (selector = the sample number) or no feature
     int esz;                     // bytes per index
+    int oesz;                    // bytes per element of this lane's offsets stream (lane 63 may read a uint32 per sample instead: `words`)
 };
+constexpr int GSEL_WORD_OFF = 256 + 4 * 63;      // where lane 63's dword of the second selector load lands inside a slot
 
 template <int NI>
 __device__ __forceinline__ void gather_ctx_init(GatherCtx<NI>& gc, const long long* tp, const long long* tl, const long long* tq,
-                                                const long long* to, const long long* tr, int F, int lane, int idx_bits) {
+                                                const long long* to, const long long* tr, int F, int lane, int idx_bits,
+                                                const unsigned* words = nullptr) {
 #pragma unroll
     for (int c = 0; c < NI; ++c) {
         const int row = 2 * c + (lane >> 5);
@@ -380,13 +392,17 @@ __device__ __forceinline__ void gather_ctx_init(GatherCtx<NI>& gc, const long lo
     gc.osrc = (const char*)to[ff] + hi;
     gc.rows = f < F ? tr[f] : -1;
     gc.esz = idx_bits >> 3;
+    gc.oesz = gc.esz;
+    // one uint32 per sample rides in on the offsets load: lane 63 stands for feature 31, which no gather call has (F <= 27), so its dword of
+    // that load is free — no extra VM operation, no extra LDS (the fused update's single_mask: interact_bwd_dma_kernel<.., UPD>)
+    if (words && lane == 63) { gc.osrc = (const char*)words; gc.oesz = 4; }
 }
 
 // selectors of sample s (any s < B: the caller clamps look-ahead past the end) -> LDS slot; two VM operations
 template <int NI>
 __device__ __forceinline__ void gather_sel_issue(const GatherCtx<NI>& gc, long long s, unsigned slot_lds) {
     glds4_v(gc.qsrc + s * gc.esz, slot_lds);
-    glds4_v(gc.osrc + s * gc.esz, slot_lds + 256);
+    glds4_v(gc.osrc + s * gc.oesz, slot_lds + 256);
 }
 
 // rows of sample s from its (landed) selector slot -> image; NI VM operations.  Verifies the one-lookup-per-bag layout and the
@@ -555,10 +571,17 @@ __global__ __launch_bounds__(320) void interact_fwd_dma_kernel(FeatArgs fa, Gath
 // with float4s of dT rows (16-byte, 256-B-per-row coalesced stores through the {pointer, stride} table).
 constexpr int IDMA_DR_BYTES = 3072;      // dR row image (<= 656 floats for F = 32 with self pairs)
 
-template <int NI, bool GATHER>
+// UPD (dlrm_interact_bwd_gather_sgd, ABI 17): the sparse SGD step of the rows ONE lookup of the batch touches happens here — bit f - 1 of
+// single_mask[b] says that gathered feature f of sample b is such a lookup (dlrm_emb_presort): its table row is staged in this wave's image
+// anyway, so W[idx] = fma(-lr, dT, W[idx]) goes to the TABLE and the gradient row is not written (dlrm_emb_bwd_sgd_presorted skips the same
+// lookups): per single lookup one row write instead of a row write + two row reads + a row write.  No other wave reads or writes that row
+// (that is what single means), and this wave's read of it (the DMA of this sample's image) was retired before its MFMAs started.
+template <int NI, bool GATHER, bool UPD = false>
 __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, FeatArgs da, GatherArgs ga, long long B, int F, int self,
-                                                               const float* __restrict__ dR, long long ldr) {
+                                                               const float* __restrict__ dR, long long ldr,
+                                                               const unsigned* __restrict__ single_mask = nullptr, DlrmStep neg_lr_ = DlrmStep{0.f, nullptr, 0.f}) {
     if (ga.pred.skip()) return;
+    static_assert(!UPD || GATHER, "the fused update exists in gather mode only");
     constexpr int NB = (2 * NI + 15) / 16;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
@@ -590,7 +613,7 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
     if (b >= B) return;
     DmaPlan pl;
     GatherCtx<NI> gc;
-    if constexpr (GATHER) gather_ctx_init<NI>(gc, tp, tl, tq, to, tr, F, lane, ga.idx_bits);
+    if constexpr (GATHER) gather_ctx_init<NI>(gc, tp, tl, tq, to, tr, F, lane, ga.idx_bits, UPD ? single_mask : nullptr);
     else dma_plan_init(pl, tp, tl, F, lane, b, b_stride);
     // dR row: lane covers bytes [1024*c + 16*lane, +16) of the row, c < nr; lanes past the row pitch are masked
     const int nr = __builtin_amdgcn_readfirstlane((int)((ldr * 4 + 1023) / 1024));
@@ -621,20 +644,48 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
             }
             a_off[r][kk] = off * 4; a_scale[r][kk] = sc;
         }
-    // destination rows of this lane: i = 16r + 4g + q
-    char* orow[NB][4];
+    // destination rows of this lane: i = 16r + 4g + q.  GLOBAL pointers: as generic ones (rounds 2-6) their stores were flat_store_dwordx4, which
+    // tick lgkmcnt as well — the next sample's first LDS read then waited for the previous sample's row stores to be acknowledged.
+    // (UPD computes its destinations per sample — table row or gradient row — and keeps only which rows exist: 32 registers fewer)
+    gchar* orow[NB][4];
     long long ostep[NB][4];
+    unsigned rowbits = 0u;
 #pragma unroll
     for (int r = 0; r < NB; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = 16 * r + 4 * g + q;
             const int ii = i < F ? i : 0;
-            orow[r][q] = (i < F) ? (char*)dp[ii] + (b * dl[ii] + 4 * li) * 4 : nullptr;
-            ostep[r][q] = b_stride * dl[ii] * 4;
+            if (i < F) rowbits |= 1u << (4 * r + q);
+            if constexpr (!UPD) {
+                orow[r][q] = (i < F) ? (gchar*)dp[ii] + (b * dl[ii] + 4 * li) * 4 : nullptr;
+                ostep[r][q] = b_stride * dl[ii] * 4;
+            }
         }
+    // how many row-store instructions a sample issues (one exists iff some lane group has the row: g = 0); (UPD) which of this lane's eight
+    // rows are gathered features at all (bit 4 r + q) and the step size
+    unsigned tabbits = 0u;
+    float neg_lr = 0.f;
+    int n_st = 0;
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = 16 * r + 4 * g + q;
+            if (UPD && i >= 1 && i < F && tr[i] >= 0) tabbits |= 1u << (4 * r + q);       // (plain features have rows = -1)
+            n_st += (16 * r + q < F) ? IDMA_D / 64 : 0;
+        }
+    n_st = __builtin_amdgcn_readfirstlane(n_st);
+    if constexpr (UPD) neg_lr = neg_lr_;
+#ifndef DLRM_BWD_STORES_IN_FLIGHT
+#define DLRM_BWD_STORES_IN_FLIGHT 1
+#endif
+#ifndef DLRM_UPD_DIAG
+#define DLRM_UPD_DIAG 0
+#endif
 
     int cur = 0, sl = 0;
+    bool stores_behind = false;        // (UPD) the queue holds a sample's row stores behind the current sample's loads
     if constexpr (GATHER) {
         const long long last = B - 1;
 #pragma unroll
@@ -650,6 +701,29 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
     issue_dr(drow0_lds);
     for (; b < B; b += b_stride) {
         const bool more = b + b_stride < B;
+        // (UPD) which of this lane's rows are single lookups, and where their table rows live: read from this sample's selector slot NOW —
+        // the slot is handed to the selectors three samples ahead a few lines down.  dst = the table row (gathered rows are D floats apart)
+        // or the gradient row; one store per row either way
+        gchar* dst[NB][4];
+        unsigned ones = 0u;
+        if constexpr (UPD) {
+            const char* slot = sel0 + sl * GSEL_SLOT;
+            unsigned um = *(const unsigned*)(slot + GSEL_WORD_OFF);
+            if (DLRM_UPD_DIAG == 1) um = 0u;
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = 16 * r + 4 * g + q;
+                    const unsigned id = *(const unsigned*)(slot + 4 * (i & 31));
+                    const bool one = ((tabbits >> (4 * r + q)) & 1u) && ((um >> ((i - 1) & 31)) & 1u);
+                    gchar* wr = (gchar*)tp[i & 31] + 16 * li + ((unsigned long long)id << 9);
+                    gchar* gr = (gchar*)dp[i & 31] + (b * dl[i & 31] + 4 * li) * 4;
+                    dst[r][q] = (one && DLRM_UPD_DIAG != 2) ? wr : gr;
+                    ones |= one ? 1u << (4 * r + q) : 0u;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         if constexpr (GATHER) {
             // same schedule as the forward kernel: rows + dR row of the next sample and the selectors three samples ahead stay in
             // flight (NI + nr + 2 operations) while this sample is multiplied
@@ -659,13 +733,17 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                 issue_dr(drow0_lds + (cur ^ 1) * DRB);
                 const long long s3 = b + 3 * b_stride;
                 gather_sel_issue<NI>(gc, s3 < B ? s3 : B - 1, sel0_lds + sl * GSEL_SLOT);
-                wait_vmcnt_rt(NI + nr + 2);
+                // (the previous sample's row stores — issued after this sample's loads, before the next one's — may stay in flight too: vmcnt
+                // retires in issue order)
+                if (DLRM_BWD_STORES_IN_FLIGHT && stores_behind) wait_vmcnt_rt(NI + nr + 2 + n_st);
+                else wait_vmcnt_rt(NI + nr + 2);
                 sl = sl1;
             } else wait_vmcnt_i<0>();
         } else if (more) {
             dma_issue<NI>(pl, img0_lds + (cur ^ 1) * IDMA_IMG);
             issue_dr(drow0_lds + (cur ^ 1) * DRB);
-            wait_vmcnt_rt(NI + nr);
+            if (DLRM_BWD_STORES_IN_FLIGHT && stores_behind) wait_vmcnt_rt(NI + nr + n_st);
+            else wait_vmcnt_rt(NI + nr);
         } else wait_vmcnt_i<0>();
         const char* my = img0 + cur * IDMA_IMG;
         const char* dr = drow0 + cur * DRB;
@@ -687,6 +765,17 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
             }
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
+                // (UPD) the table rows this lane may have to step, read HERE — in front of the block's 32 MFMAs, not one LDS round trip per
+                // store behind them (one wave per SIMD: nothing else hides a read's latency; sixteen exposed reads per sample cost 1 us
+                // per sample = 63 us per launch)
+                float4 wv[4];
+                if constexpr (UPD) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = 16 * r + 4 * g + q;          // image row i, this lane's quad, un-swizzled
+                        wv[q] = *(const float4*)(my + i * (IDMA_D * 4) + (((16 * dq + li) ^ (i & 15)) * 16));
+                    }
+                }
                 floatx4 acc[4];
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_) acc[s_] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -699,7 +788,7 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (orow[r][q]) {
+                    if ((rowbits >> (4 * r + q)) & 1u) {
                         float4 v = make_float4(acc[0][q], acc[1][q], acc[2][q], acc[3][q]);
                         if (r == 0 && q == 0 && g == 0) {       // feature 0 also feeds R[:, 0:D]
                             const float4 x = *(const float4*)(dr + (64 * dq + 4 * li) * 4);
@@ -710,7 +799,16 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                                 v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
                             }
                         }
-                        *(float4*)(orow[r][q] + dq * 256) = v;
+                        if constexpr (UPD) {
+                            // a single lookup: the SGD step itself goes to the table row
+                            const float4 w = wv[q];
+                            if ((ones >> (4 * r + q)) & 1u) {
+                                v.x = __builtin_fmaf(neg_lr, v.x, w.x); v.y = __builtin_fmaf(neg_lr, v.y, w.y);
+                                v.z = __builtin_fmaf(neg_lr, v.z, w.z); v.w = __builtin_fmaf(neg_lr, v.w, w.w);
+                            }
+                            *(gfloatx4*)(dst[r][q] + dq * 256) = (floatx4){v.x, v.y, v.z, v.w};
+                        } else
+                            *(gfloatx4*)(orow[r][q] + dq * 256) = (floatx4){v.x, v.y, v.z, v.w};
                     }
                 }
             }
@@ -718,8 +816,9 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
 #pragma unroll
         for (int r = 0; r < NB; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (orow[r][q]) orow[r][q] += ostep[r][q];
+            for (int q = 0; q < 4; ++q) if (!UPD && ((rowbits >> (4 * r + q)) & 1u)) orow[r][q] += ostep[r][q];
         cur ^= 1;
+        stores_behind = true;
     }
 }
 
@@ -911,7 +1010,8 @@ static int interact_fwd_impl(int64_t B, int F, int D, const void* const* feat_ho
 static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
                              const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
                              int self_interaction, const float* dR, int64_t ldr, void* const* dfeat_host,
-                             const int64_t* dfeat_ld_host, int64_t* err, void* stream, DlrmPred pred = DlrmPred{nullptr, 0});
+                             const int64_t* dfeat_ld_host, int64_t* err, void* stream, DlrmPred pred = DlrmPred{nullptr, 0},
+                             const uint32_t* single_mask = nullptr, DlrmStep neg_lr = DlrmStep{0.f, nullptr, 0.f});
 
 extern "C" int dlrm_interact_bwd(int64_t B, int F, int D, const void* const* feat_host,
                                  const int64_t* feat_ld_host, int self_interaction, const float* dR,
@@ -942,10 +1042,27 @@ extern "C" int dlrm_interact_bwd_pred(int64_t B, int F, int D, const void* const
                              ldr, dfeat_host, dfeat_ld_host, err, stream, DlrmPred{(const int*)pred_flag, pred_nonzero});
 }
 
+// ABI 17: dlrm_interact_bwd_pred (gather form) that ALSO takes the sparse SGD step of the single lookups (see interact_bwd_dma_kernel<.., UPD>)
+extern "C" int dlrm_interact_bwd_gather_sgd(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                                            const void* const* index_host, const void* const* offsets_host, const int64_t* rows_host,
+                                            int idx_bits, int self_interaction, const float* dR, int64_t ldr, void* const* dfeat_host,
+                                            const int64_t* dfeat_ld_host, const uint32_t* single_mask, float lr, const float* lr_dev, int64_t* err,
+                                            const int32_t* pred_flag, int pred_nonzero, void* stream) {
+    if (!index_host || !offsets_host || !rows_host || !single_mask) return DLRM_E_ARG;
+    if (idx_bits != 32 && idx_bits != 64) return DLRM_E_MODE;
+    // bit f - 1 of a mask word names feature f: features 1 .. F-1 must all be tables (feature 0 the dense block), rows of D floats
+    if (index_host[0]) return DLRM_E_ARG;
+    for (int f = 1; f < F; ++f) if (!index_host[f] || feat_ld_host[f] != D) return DLRM_E_ARG;
+    return interact_bwd_impl(B, F, D, feat_host, feat_ld_host, index_host, offsets_host, rows_host, idx_bits, self_interaction, dR,
+                             ldr, dfeat_host, dfeat_ld_host, err, stream, DlrmPred{(const int*)pred_flag, pred_nonzero}, single_mask,
+                             dlrm_step_neg(lr, lr_dev));
+}
+
 static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
                              const void* const* gidx, const void* const* goff, const int64_t* grows, int idx_bits,
                              int self_interaction, const float* dR, int64_t ldr, void* const* dfeat_host,
-                             const int64_t* dfeat_ld_host, int64_t* err, void* stream, DlrmPred pred) {
+                             const int64_t* dfeat_ld_host, int64_t* err, void* stream, DlrmPred pred, const uint32_t* single_mask,
+                             DlrmStep neg_lr) {
     if (B <= 0 || F <= 0 || D <= 0 || !feat_host || !feat_ld_host || !dR || !dfeat_host || !dfeat_ld_host)
         return DLRM_E_ARG;
     if (F > DLRM_MAX_FEATURES) return DLRM_E_RANGE;
@@ -971,6 +1088,7 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
         const bool dma_path = (gidx ? (dlrm_interact_gather_ok(F, D) && vec) : interact_dma_ok(F, D, vec)) && dvec && dlrm_aligned16(dR) &&
                               ldr % 4 == 0 && ldr * 4 <= (gidx ? GDR_BYTES : IDMA_DR_BYTES);
         if (gidx && !dma_path) return DLRM_E_MODE;
+        if (single_mask && !gidx) return DLRM_E_ARG;
         if (dma_path) {
             const size_t lds_dma = 7 * DLRM_MAX_FEATURES * sizeof(long long) +
                                    (gidx ? 4 * (2 * (size_t)IDMA_IMG + 2 * (size_t)GDR_BYTES + (size_t)GSEL_WAVE_BYTES)
@@ -979,7 +1097,11 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
             const int ni = (F + 1) / 2;
 #define BWD_DMA(NIV)                                                                                         \
             do {                                                                                             \
-                if (gidx) {                                                                                  \
+                if (gidx && single_mask) {                                                                   \
+                    (void)hipFuncSetAttribute((const void*)interact_bwd_dma_kernel<NIV, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma); \
+                    hipLaunchKernelGGL((interact_bwd_dma_kernel<NIV, true, true>), dim3((unsigned)nb), dim3(256), lds_dma, (hipStream_t)stream, fa, da, ga, \
+                                       (long long)B, F, self_interaction & 7, dR, (long long)ldr, (const unsigned*)single_mask, neg_lr); \
+                } else if (gidx) {                                                                           \
                     (void)hipFuncSetAttribute((const void*)interact_bwd_dma_kernel<NIV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma); \
                     hipLaunchKernelGGL((interact_bwd_dma_kernel<NIV, true>), dim3((unsigned)nb), dim3(256), lds_dma, (hipStream_t)stream, fa, da, ga, \
                                        (long long)B, F, self_interaction & 7, dR, (long long)ldr);       \

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void clamp_bwd_kernel(long long n, const float
 
 }  // namespace
 
-extern "C" int dlrm_hip_abi_version(void) { return 16; }
+extern "C" int dlrm_hip_abi_version(void) { return 17; }
 
 extern "C" const char* dlrm_hip_build_info(void) {
     return "libdlrm_hip gfx950 (CDNA4) " __DATE__ " " __TIME__ " clang " __clang_version__;

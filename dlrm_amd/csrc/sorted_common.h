@@ -27,6 +27,25 @@ __device__ __forceinline__ void v_atomic_add(float* p, const float4& v) {
 }
 __device__ __forceinline__ void v_atomic_add(float* p, const float& v) { atomicAdd(p, v); }
 
+// Table rows through GLOBAL pointers.  A table's address reaches the update kernels as an integer in an LDS table (SortedArgs by value ->
+// shared array), and a pointer rebuilt from an integer is GENERIC: its loads / stores / atomics compile to FLAT instructions, which count on
+// lgkmcnt as well as vmcnt — the next chunk's first LDS read (s_w[t] ...) then waits for the previous chunk's row stores and atomics to be
+// acknowledged by memory.  With an explicit address space they are global_load / global_store / global_atomic_add_f32 (vmcnt only).
+typedef float sc_floatx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) float sc_gfloat;
+typedef __attribute__((address_space(1))) sc_floatx4 sc_gfloatx4;
+__device__ __forceinline__ void v_gload(float4& d, const float* p) { const sc_floatx4 v = *(const sc_gfloatx4*)p; d = make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void v_gload(float& d, const float* p) { d = *(const sc_gfloat*)p; }
+__device__ __forceinline__ void v_gstore(float* p, const float4& v) { *(sc_gfloatx4*)p = (sc_floatx4){v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void v_gstore(float* p, const float& v) { *(sc_gfloat*)p = v; }
+__device__ __forceinline__ void g_atomic_add1(float* p, float v) {
+    (void)__hip_atomic_fetch_add((sc_gfloat*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void v_gatomic_add(float* p, const float4& v) {
+    g_atomic_add1(p + 0, v.x); g_atomic_add1(p + 1, v.y); g_atomic_add1(p + 2, v.z); g_atomic_add1(p + 3, v.w);
+}
+__device__ __forceinline__ void v_gatomic_add(float* p, const float& v) { g_atomic_add1(p, v); }
+
 struct SortedArgs {
     float*       w[DLRM_MAX_TABLES_PER_LAUNCH];
     const float* psw[DLRM_MAX_TABLES_PER_LAUNCH];
@@ -38,7 +57,7 @@ struct SortedArgs {
 template <typename IT, typename KT>
 __global__ __launch_bounds__(256) void expand_kernel(EmbArgs a, SortedArgs sa, long long B, int row_bits,
                                                      KT* __restrict__ keys, unsigned* __restrict__ vals,
-                                                     unsigned* __restrict__ bag_of) {
+                                                     unsigned* __restrict__ bag_of, unsigned* __restrict__ zero_words = nullptr) {
     const int t = blockIdx.y;
     const IT* __restrict__ idx = (const IT*)a.idx[t];
     const IT* __restrict__ off = (const IT*)a.off[t];
@@ -46,6 +65,7 @@ __global__ __launch_bounds__(256) void expand_kernel(EmbArgs a, SortedArgs sa, l
     const long long base = sa.base[t];
     const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
+    if (zero_words && t == 0) zero_words[b] = 0u;        // (dlrm_emb_presort: the per-bag mask single_mask_kernel ORs into after the sort)
     const long long s = (long long)off[b];
     const long long e = (b + 1 < B) ? (long long)off[b + 1] : nnz;
     for (long long i = s; i < e; ++i) {
@@ -102,6 +122,28 @@ __global__ __launch_bounds__(256) void expand_positions_kernel(EmbArgs a, Sorted
         if (vals) vals[pos] = (unsigned)pos;      // (the segmented sorter's first round takes the position itself: vals == nullptr)
         bag_of[pos] = bag;
     }
+}
+
+// A sorted entry is SINGLE when no other lookup of the batch names its (table, row) and the lookup itself is in range — the rows the fused
+// backward (dlrm_interact_bwd_gather_sgd) updates itself and dlrm_emb_bwd_sgd_presorted skips.  ONE rule, used by both sides.
+template <typename KT>
+__device__ __forceinline__ bool sorted_entry_is_single(KT k, bool has_prev, KT prev, bool has_next, KT next, unsigned bag) {
+    return (!has_prev || prev != k) && (!has_next || next != k) && bag != DLRM_DEAD_BAG;
+}
+
+// single_mask[bag] |= 1 << table for every single entry of the sorted list (mask zeroed by expand_kernel; one lookup per bag: a bit names a lookup)
+template <typename KT>
+__global__ __launch_bounds__(256) void single_mask_kernel(long long L, int row_bits, const KT* __restrict__ keys, const unsigned* __restrict__ vals,
+                                                          const unsigned* __restrict__ bag_of, unsigned* __restrict__ mask) {
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= L) return;
+    const KT k = keys[j];
+    const bool hp = j > 0, hn = j + 1 < L;
+    const KT pk = hp ? keys[j - 1] : k, nk = hn ? keys[j + 1] : k;
+    if (pk == k && hp) return;
+    if (nk == k && hn) return;
+    const unsigned bag = bag_of[vals[j]];
+    if (sorted_entry_is_single<KT>(k, hp, pk, hn, nk, bag)) atomicOr(mask + bag, 1u << (unsigned)(k >> row_bits));
 }
 
 static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
@@ -180,7 +222,7 @@ template <typename KT>
 static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight_host, const int64_t* rows_host,
                            const void* const* indices_host, const void* const* offsets_host, const int64_t* nnz_host,
                            const void* const* psw_host, int idx_bits, char* ws, const Layout& lo, size_t L, int row_bits,
-                           int key_bits, hipStream_t st, SortedArgs* sa_out, int64_t* err) {
+                           int key_bits, hipStream_t st, SortedArgs* sa_out, int64_t* err, unsigned* single_mask = nullptr) {
     EmbArgs a;
     a.err = (long long*)err; a.pred.flag = nullptr; a.pred.nonzero = 0;
     SortedArgs& sa = *sa_out;
@@ -199,6 +241,7 @@ static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight
     unsigned* vals_out = (unsigned*)(ws + lo.vals_out);
     unsigned* bag_of = (unsigned*)(ws + lo.bag_of);
     dim3 block(256);
+    if (single_mask && L != (size_t)n * (size_t)B) return DLRM_E_ARG;      // (a mask bit names ONE lookup of a bag)
     if (L > (size_t)2 * (size_t)n * (size_t)B) {
         // multi-hot: one thread per lookup (coalesced stores).  grid.x covers the largest table in one sweep, capped; smaller tables'
         // surplus blocks exit at once
@@ -213,18 +256,26 @@ static int expand_and_sort(int n, const int* ids, int64_t B, void* const* weight
     } else {
         dim3 grid((unsigned)((B + 255) / 256), (unsigned)n, 1);
         if (idx_bits == 64)
-            hipLaunchKernelGGL((expand_kernel<long long, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, lo.own ? nullptr : vals_in, bag_of);
+            hipLaunchKernelGGL((expand_kernel<long long, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, lo.own ? nullptr : vals_in, bag_of, single_mask);
         else
-            hipLaunchKernelGGL((expand_kernel<int, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, lo.own ? nullptr : vals_in, bag_of);
+            hipLaunchKernelGGL((expand_kernel<int, KT>), grid, block, 0, st, a, sa, (long long)B, row_bits, keys_in, lo.own ? nullptr : vals_in, bag_of, single_mask);
     }
     DLRM_LAUNCH_CHECK();
-    if (lo.own)         // table-major segments, per-table digit counts: seg_sort.h (graph-replayable: plain kernels, no memsets)
-        return seg_sort_run<KT>(lo.plan, (const KT*)keys_in, (KT*)(ws + lo.keys_tmp), keys_out, (unsigned*)(ws + lo.vals_tmp), vals_out,
-                                (unsigned*)(ws + lo.hist), (unsigned*)(ws + lo.binbase), (unsigned*)(ws + lo.gtot), (unsigned*)(ws + lo.bsum), st);
-    size_t tb = lo.temp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(ws + lo.temp, tb, (const KT*)keys_in, keys_out, (const unsigned*)vals_in,
-                                             vals_out, L, 0, key_bits, st, false);
-    if (e != hipSuccess) return (int)e;
+    if (lo.own) {       // table-major segments, per-table digit counts: seg_sort.h (graph-replayable: plain kernels, no memsets)
+        const int rc = seg_sort_run<KT>(lo.plan, (const KT*)keys_in, (KT*)(ws + lo.keys_tmp), keys_out, (unsigned*)(ws + lo.vals_tmp), vals_out,
+                                        (unsigned*)(ws + lo.hist), (unsigned*)(ws + lo.binbase), (unsigned*)(ws + lo.gtot), (unsigned*)(ws + lo.bsum), st);
+        if (rc) return rc;
+    } else {
+        size_t tb = lo.temp_bytes;
+        hipError_t e = rocprim::radix_sort_pairs(ws + lo.temp, tb, (const KT*)keys_in, keys_out, (const unsigned*)vals_in,
+                                                 vals_out, L, 0, key_bits, st, false);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (single_mask) {
+        hipLaunchKernelGGL((single_mask_kernel<KT>), dim3((unsigned)((L + 255) / 256)), block, 0, st, (long long)L, row_bits, (const KT*)keys_out,
+                           (const unsigned*)vals_out, (const unsigned*)bag_of, single_mask);
+        DLRM_LAUNCH_CHECK();
+    }
     return 0;
 }
 

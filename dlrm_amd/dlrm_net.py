@@ -133,10 +133,10 @@ class EmbeddingUpdateHook:
     @staticmethod
     def _pre_step(optimizer, args, kwargs):
         for model in list(EmbeddingUpdateHook._models):
+            if (model.overlap_streams or model.update_in_backward) and model._bound_optimizer is None and model._owned_by(optimizer):
+                model._bound_optimizer = weakref.ref(optimizer)      # (what lets the NEXT backward pass launch / take the sparse update itself)
             if model._pending_emb:
                 model.apply_pending_embedding_updates(optimizer)
-            elif model.overlap_streams and model._bound_optimizer is None and model._owned_by(optimizer):
-                model._bound_optimizer = weakref.ref(optimizer)
 
     @staticmethod
     def _post_step(optimizer, args, kwargs):
@@ -223,6 +223,16 @@ class DLRM_Net(nn.Module):
         # a ragged batch with nnz == B — an empty bag next to a two-lookup bag — takes the two kernels like every other multi-hot
         # input).  The kernels still verify the bag starts themselves and report a violation through the index-error block.
         self.fuse_emb_interact = os.environ.get("DLRM_FUSE_EMB_INTERACT", "1") == "1"
+        # True (or env DLRM_UPDATE_IN_BACKWARD=1; opt-in): once the model knows its plain-SGD optimizer (from that optimizer's first step), the
+        # fused backward takes the SGD step of every embedding row that ONE lookup of the batch names — the row is staged in the interaction
+        # kernel's LDS and its gradient is in registers, so the table row is written at once and neither the gradient row nor a second read of
+        # the table row ever touches HBM (ABI 17: dlrm_emb_presort, dlrm_interact_bwd_gather_sgd, dlrm_emb_bwd_sgd_presorted; BASELINE
+        # north_star "fused sparse SGD for the backward embedding update", torchrec's apply_optimizer_in_backward in dlrm_main.py).  Rows named
+        # by several lookups are updated when the optimizer steps, as before.  After backward() + optimizer.step() the tables hold the bits the
+        # step-time update writes (DLRM_UPD_SORTED); what differs is WHEN: single-lookup rows change during backward(), with the learning rate the
+        # optimizer holds then (the reference loop changes it after step(): dlrm_s_pytorch.py:1620-1621).  A loop that calls backward() without
+        # step(), or several times per step, must leave this off — as with overlap_streams, which moves the whole update into backward.
+        self.update_in_backward = os.environ.get("DLRM_UPDATE_IN_BACKWARD", "0") == "1"
         self._bound_optimizer = None        # weakref to the optimizer that owns the tables (learnt at its first step)
         self._side_keep: list = []          # tensors the side stream still reads (released at the join)
         # > 1: the pooled-embedding all-to-all of the distributed forward is pipelined in that many batch chunks (opt-in)
@@ -381,7 +391,35 @@ class DLRM_Net(nn.Module):
             torch.cuda.current_stream(dev).wait_stream(_side_stream(dev))
             self._side_keep = []
 
-    def _stash_embedding_grad(self, weights, bags, dout):
+    def _presort_for_backward(self, weights, bags, pred):
+        """`bags.presort` of the fused lookup + interaction path (GatherInteractFunction.backward): ops.Presorted when this backward pass may
+        take the SGD step of single-lookup rows itself (update_in_backward, a bound plain-SGD optimizer, the sorted update, nothing parked,
+        not inside a distributed forward), else None."""
+        if not (self.update_in_backward and self.fused_emb_update and self.emb_update_mode == ops.UPD_SORTED) or self._pending_emb:
+            return None
+        opt = self._bound_optimizer() if self._bound_optimizer is not None else None
+        if opt is None or not _is_plain_sgd(opt) or not ops.presort_ok(weights, bags):
+            return None
+        plan = _embedding_update_plan(opt, weights)
+        if plan is None or plan[0] != "sgd":
+            return None
+        return ops.emb_presort(weights, bags, plan[1], pred)
+
+    def _stash_embedding_grad(self, weights, bags, dout, presorted=None):
+        if presorted is not None:
+            # the fused backward already applied the single-lookup rows with presorted.lr; the rest follows from the same sorted workspace —
+            # on the side stream now (overlap mode) or when the optimizer steps
+            if self.overlap_streams and self._bound_optimizer is not None and self._bound_optimizer() is not None:
+                cur, side = torch.cuda.current_stream(dout.device), _side_stream(dout.device)
+                if cur != side:
+                    ops.timer_mark()
+                    side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ops.emb_bwd_sgd_presorted(weights, bags, dout, presorted)
+                self._side_keep += [dout, presorted.ws, presorted.mask] + bags.keep
+                return
+            self._pending_emb.append((weights, bags, dout, presorted))
+            return
         if not self.fused_emb_update:
             self._materialize_coo_grads(weights, bags, dout)
             return
@@ -401,7 +439,7 @@ class DLRM_Net(nn.Module):
                     ops.emb_bwd_sgd(weights, bags, dout, plan[1], self.emb_update_mode)
                 self._side_keep += [dout] + bags.keep
                 return
-        self._pending_emb.append((weights, bags, dout))
+        self._pending_emb.append((weights, bags, dout, None))
         if len(self._pending_emb) == 65:
             print("WARNING: dlrm_amd: 65 embedding gradients are parked and no optimizer that owns the tables has stepped; "
                   "every backward() keeps its [B, T*D] gradient buffer alive until then", file=sys.stderr)
@@ -433,13 +471,20 @@ class DLRM_Net(nn.Module):
             ops.timer_mark()
             side.wait_stream(torch.cuda.current_stream(dev))
             self._side_keep += [p_[2] for p_ in pending] + [t for p_ in pending for t in p_[1].keep]
+            self._side_keep += [t for p_ in pending if len(p_) > 3 and p_[3] is not None for t in (p_[3].ws, p_[3].mask)]
             if optimizer is not None and self._bound_optimizer is None and self._owned_by(optimizer):
                 self._bound_optimizer = weakref.ref(optimizer)
         with torch.cuda.stream(side) if side is not None else _NullCtx():
             self._apply_pending(pending, optimizer, lr)
 
     def _apply_pending(self, pending, optimizer, lr):
-        for weights, bags, dout in pending:
+        for entry in pending:
+            weights, bags, dout = entry[:3]
+            pre = entry[3] if len(entry) > 3 else None        # ops.Presorted: the backward pass already took the single-lookup rows
+            if pre is not None:
+                # (the single-lookup rows were updated in backward with pre.lr — the optimizer's lr then; the rest takes the same step size)
+                ops.emb_bwd_sgd_presorted(weights, bags, dout, pre)
+                continue
             if lr is not None:
                 ops.emb_bwd_sgd(weights, bags, dout, lr, self.emb_update_mode)
                 continue
@@ -447,7 +492,7 @@ class DLRM_Net(nn.Module):
             key = tuple(id(w) for w in weights)
             plan = _embedding_update_plan(optimizer, weights, count=sum(1 for p_ in pending if tuple(id(w) for w in p_[0]) == key))
             if plan is None:
-                self._pending_emb.append((weights, bags, dout))   # another optimizer owns these tables
+                self._pending_emb.append((weights, bags, dout, None))   # another optimizer owns these tables
             elif plan[0] == "coo":
                 self._materialize_coo_grads(weights, bags, dout)  # the optimizer's own step consumes .grad right after this hook
             elif plan[0] == "sgd":
@@ -506,6 +551,7 @@ class DLRM_Net(nn.Module):
                         state = ops.offsets_are_iota_finish(proof)
                     if state is not False:
                         bags.iota_flag = state if isinstance(state, torch.Tensor) else None
+                        bags.presort = self._presort_for_backward if self.update_in_backward else None
                         z = GatherInteractFunction.apply(self._stash_embedding_grad, D, self._interaction_mode() | rx, bags, x,
                                                          *self._emb_weights(self.emb_l))
                         return self._clamp(self.apply_mlp(z, self.top_l))

@@ -645,14 +645,21 @@ class GatherInteractFunction(Function):
         B, D, T = x.size(0), ctx.D, len(ctx.weights)
         flat = torch.empty(B * (1 + T) * D, dtype=torch.float32, device=dR.device)
         dx, dE = flat[:B * D].view(B, D), flat[B * D:].view(B, T * D)
-        if ctx.flag is None:
-            ops.interact_bwd_gather(x, ctx.weights, ctx.bags, D, ctx.self_interaction, dR, dx, dE)
-        else:
-            ops.interact_bwd_gather(x, ctx.weights, ctx.bags, D, ctx.self_interaction, dR, dx, dE, pred=(ctx.flag, 0))
-            ops.interact_bwd((x, ctx.saved_tensors[1]), D, ctx.self_interaction, dR, (dx, dE), pred=(ctx.flag, 1))
         if ctx.sink is None:
             raise RuntimeError("dlrm_amd: embedding backward needs a gradient sink (fused update)")
-        ctx.sink(ctx.weights, ctx.bags, dE)
+        # `bags.presort` (DLRM_Net._presort_for_backward; None unless the model was told to update in backward and knows its SGD optimizer): the
+        # sort of the sparse update runs NOW and the fused kernel takes the SGD step of every row a single lookup of the batch names (its table
+        # row is staged in LDS anyway) — ops.Presorted travels to the sink, which applies the rest from the same sorted workspace
+        pred = None if ctx.flag is None else (ctx.flag, 0)
+        presort = getattr(ctx.bags, "presort", None)
+        pre = presort(ctx.weights, ctx.bags, pred) if presort is not None else None
+        ops.interact_bwd_gather(x, ctx.weights, ctx.bags, D, ctx.self_interaction, dR, dx, dE, pred=pred, presorted=pre)
+        if ctx.flag is not None:
+            ops.interact_bwd((x, ctx.saved_tensors[1]), D, ctx.self_interaction, dR, (dx, dE), pred=(ctx.flag, 1))
+        if pre is None:
+            ctx.sink(ctx.weights, ctx.bags, dE)
+        else:
+            ctx.sink(ctx.weights, ctx.bags, dE, presorted=pre)
         return (None, None, None, None, dx) + (None,) * T
 
 

@@ -436,6 +436,57 @@ def emb_bwd_sgd(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Ten
     _lib.check(rc, "dlrm_emb_bwd_sgd")
 
 
+class Presorted:
+    """What dlrm_emb_presort left behind for one backward pass: the workspace holding the lookups sorted by (table, row), the per-sample
+    mask of SINGLE lookups (bit t of mask[b]: lookup (t, b) is the only one of the batch naming its row), the step size both update calls
+    use and the launch predicate the fused backward ran under (None: unconditional)."""
+
+    __slots__ = ("ws", "mask", "lr", "pred")
+
+    def __init__(self, ws, mask, lr, pred):
+        self.ws, self.mask, self.lr, self.pred = ws, mask, lr, pred
+
+
+def presort_ok(weights: Sequence[torch.Tensor], bags: BagBatch) -> bool:
+    """shapes dlrm_emb_presort / dlrm_emb_bwd_sgd_presorted take: one launch group, one lookup per bag position, D = 128, no pooling weights"""
+    return (0 < bags.T <= 32 and len(weights) == bags.T and all(n == bags.B for n in bags.nnz) and bags._psw is None
+            and all(w.size(1) == 128 and w.is_contiguous() and w.data_ptr() % 16 == 0 for w in weights))
+
+
+def emb_presort(weights: Sequence[torch.Tensor], bags: BagBatch, lr: LrLike, pred=None) -> Presorted:
+    """The sort of the sparse update, IN FRONT of the fused backward (dlrm_emb_presort, ABI 17): a fresh workspace (it must survive until
+    emb_bwd_sgd_presorted consumes it, whatever else sorts in between) + the mask of single lookups."""
+    lib = _lib.load()
+    D, wp, rows = _weights_desc(weights)
+    dev = weights[0].device
+    need = lib.dlrm_emb_bwd_workspace_bytes(bags.T, bags._nnz, rows)
+    if need < 0:
+        raise RuntimeError("dlrm_amd: dlrm_emb_bwd_workspace_bytes failed")
+    ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=dev)
+    mask = torch.empty(bags.B, dtype=torch.int32, device=dev)
+    with _timed("emb_bwd_sgd"):
+        rc = lib.dlrm_emb_presort(bags.T, bags.B, rows, bags._idx, bags._off, bags._nnz, bags.idx_bits, C.c_void_p(ws.data_ptr()), ws.numel(),
+                                  C.c_void_p(mask.data_ptr()), None if bags.ignore_oob else C.c_void_p(_err_block(dev).data_ptr()), _stream(mask))
+    _lib.check(rc, "dlrm_emb_presort")
+    return Presorted(ws, mask, lr, pred)
+
+
+def emb_bwd_sgd_presorted(weights: Sequence[torch.Tensor], bags: BagBatch, dout: torch.Tensor, pre: Presorted, skip_singles: bool = True) -> None:
+    """The second half of emb_bwd_sgd(UPD_SORTED) from a Presorted workspace; skip_singles: the lookups the fused backward already applied
+    (interact_bwd_gather(..., presorted=pre)) are left out — when the launch predicate it ran under holds."""
+    lib = _lib.load()
+    D, wp, rows = _weights_desc(weights)
+    _req(dout, "dout", ndim=2)
+    if dout.size(0) != bags.B or dout.size(1) < bags.T * D or len(weights) != bags.T:
+        raise RuntimeError("dlrm_amd: emb_bwd_sgd_presorted shape mismatch")
+    lr_v, lr_p = _lr_args(pre.lr)
+    flag, nz = _pred_args(pre.pred) if pre.pred is not None else (None, 0)
+    with _timed("emb_bwd_sgd"):
+        rc = lib.dlrm_emb_bwd_sgd_presorted(bags.T, bags.B, D, wp, rows, bags._nnz, C.c_void_p(dout.data_ptr()), _ld(dout), lr_v, lr_p,
+                                            C.c_void_p(pre.ws.data_ptr()), pre.ws.numel(), int(bool(skip_singles)), flag, nz, _stream(dout))
+    _lib.check(rc, "dlrm_emb_bwd_sgd_presorted")
+
+
 def emb_bwd_rowwise_adagrad(weights: Sequence[torch.Tensor], states: Sequence[torch.Tensor], bags: BagBatch,
                             dout: torch.Tensor, lr: LrLike, eps: float) -> None:
     """Fused EmbeddingBag backward + row-wise sparse Adagrad (optim/rwsadagrad.py:117-143), in place:
@@ -805,16 +856,25 @@ INTERACT_RELU_X = 4         # DLRM_INTERACT_RELU_X of include/dlrm_hip.h: OR-ed 
 
 
 def interact_bwd_gather(x: torch.Tensor, weights: Sequence[torch.Tensor], bags: BagBatch, D: int, self_interaction: bool,
-                        dR: torch.Tensor, dx: torch.Tensor, dE: torch.Tensor, pred=None) -> None:
+                        dR: torch.Tensor, dx: torch.Tensor, dE: torch.Tensor, pred=None, presorted: Optional["Presorted"] = None) -> None:
     """dx [B, D] = gradient of x; dE [B, T*D] = gradients of the T gathered rows (the dout of the fused embedding update).
-    `self_interaction | INTERACT_RELU_X`: x is a ReLU output and dx comes back multiplied by [x > 0] (see interact_bwd)."""
+    `self_interaction | INTERACT_RELU_X`: x is a ReLU output and dx comes back multiplied by [x > 0] (see interact_bwd).
+    presorted (emb_presort): the sparse SGD step of the single lookups is taken here — their tables rows are UPDATED, their dE rows not
+    written; emb_bwd_sgd_presorted applies the rest (dlrm_interact_bwd_gather_sgd, ABI 17)."""
     lib = _lib.load()
     F, p, ld, gidx, goff, rows = _gather_desc(x, weights, bags, D)
     _req(dR, "dR", ndim=2); _req(dx, "dx", ndim=2); _req(dE, "dE", ndim=2)
     dptrs = [dx.data_ptr()] + [dE.data_ptr() + 4 * k * D for k in range(bags.T)]
     dlds = [_ld(dx)] + [_ld(dE)] * bags.T
     with _timed("emb_interact_bwd"):
-        if pred is None:
+        if presorted is not None:
+            lr_v, lr_p = _lr_args(presorted.lr)
+            flag, nz = _pred_args(pred) if pred is not None else (None, 0)
+            rc = lib.dlrm_interact_bwd_gather_sgd(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(self_interaction),
+                                                  C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
+                                                  C.c_void_p(presorted.mask.data_ptr()), lr_v, lr_p,
+                                                  C.c_void_p(_err_block(dR.device).data_ptr()), flag, nz, _stream(dR))
+        elif pred is None:
             rc = lib.dlrm_interact_bwd_gather(bags.B, F, D, p, ld, gidx, goff, rows, bags.idx_bits, int(self_interaction),
                                               C.c_void_p(dR.data_ptr()), _ld(dR), _lib.ptr_array(dptrs), _lib.i64_array(dlds),
                                               C.c_void_p(_err_block(dR.device).data_ptr()), _stream(dR))

@@ -241,6 +241,36 @@ int dlrm_interact_bwd_pred(int64_t B, int F, int D, const void* const* feat_host
                            void* const* dfeat_host, const int64_t* dfeat_ld_host, int64_t* err,
                            const int32_t* pred_flag, int pred_nonzero, void* stream);
 
+/* ABI 17 — the sparse SGD step of the rows ONE lookup of the batch touches, taken INSIDE the fused backward (BASELINE north_star: "fused
+ * sparse SGD ... for the backward embedding update"; replaces EmbeddingBagBackward + torch.optim.SGD.step, dlrm_s_pytorch.py:1613,1620, for
+ * those rows).  The fused backward (dlrm_interact_bwd_gather) has every gathered table row staged in LDS and computes its gradient row: for a
+ * row that no other lookup of the batch names, W[idx] = fma(-lr, dfeat, W[idx]) can be written to the table at once — the gradient row is
+ * neither written nor read back, the table row not read a second time (per such lookup 1 row of traffic instead of 4; 30 % of the
+ * Criteo-Terabyte batch's lookups, nearly all lookups of its 8 large tables).  Rows named by several lookups keep the sorted update.  Results
+ * are those of dlrm_emb_bwd_sgd(DLRM_UPD_SORTED), bit for bit (a single lookup's update is the same one fma per element).  Three calls:
+ *   dlrm_emb_presort            the first half of dlrm_emb_bwd_sgd(DLRM_UPD_SORTED): lookups expanded and sorted by (table, row) into `workspace`
+ *                               (dlrm_emb_bwd_workspace_bytes), plus single_mask[b] (device uint32[B]): bit t set = lookup (t, b) is in range and the
+ *                               only lookup of the batch that names its row.  One launch group (T <= 32), nnz_host[t] == B for every table.
+ *   dlrm_interact_bwd_gather_sgd  dlrm_interact_bwd_pred (gather form; feature 0 plain, features 1..F-1 = tables 0..F-2 in presort order, rows of
+ *                               D floats) that applies the step for every set bit and writes no dfeat row for it.  The caller must not touch
+ *                               the tables between the presort and this call.  Runs under the launch predicate like dlrm_interact_bwd_pred.
+ *   dlrm_emb_bwd_sgd_presorted  the second half from that workspace: the sorted update with dout = the dfeat rows of the backward; with
+ *                               skip_singles != 0 the single lookups are skipped WHEN the predicate holds ((*pred_flag != 0) == (pred_nonzero != 0),
+ *                               or pred_flag == NULL) — the same predicate dlrm_interact_bwd_gather_sgd ran under; when it does not hold (a ragged
+ *                               batch: the two-kernel backward wrote every dfeat row) all lookups are applied.  D = 128 (else DLRM_E_MODE).
+ * The step size of both update calls must be the same (float lr or device scalar lr_dev, see LEARNING RATES). */
+int dlrm_emb_presort(int T, int64_t B, const int64_t* rows_host, const void* const* indices_host, const void* const* offsets_host,
+                     const int64_t* nnz_host, int idx_bits, void* workspace, int64_t workspace_bytes, uint32_t* single_mask,
+                     int64_t* err, void* stream);
+int dlrm_interact_bwd_gather_sgd(int64_t B, int F, int D, const void* const* feat_host, const int64_t* feat_ld_host,
+                                 const void* const* index_host, const void* const* offsets_host, const int64_t* rows_host,
+                                 int idx_bits, int self_interaction, const float* dR, int64_t ldr, void* const* dfeat_host,
+                                 const int64_t* dfeat_ld_host, const uint32_t* single_mask, float lr, const float* lr_dev, int64_t* err,
+                                 const int32_t* pred_flag, int pred_nonzero, void* stream);
+int dlrm_emb_bwd_sgd_presorted(int T, int64_t B, int D, void* const* weight_host, const int64_t* rows_host, const int64_t* nnz_host,
+                               const float* dout, int64_t dout_ld, float lr, const float* lr_dev, const void* workspace,
+                               int64_t workspace_bytes, int skip_singles, const int32_t* pred_flag, int pred_nonzero, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * K5  MLP layer = nn.Linear + activation  (dlrm_s_pytorch.py:216,238-241,405), fp32 MFMA.
  *   Y[M,N] = act(X[M,K] · W[N,K]^T + bias[N])

@@ -87,7 +87,7 @@ def load(name: str = "terabyte_b65536", verify: bool = True):
     return SimpleNamespace(meta=meta, d=d, init=init, batches=batches, losses=d["losses"])
 
 
-def run_on_gpu(device, arith="f32", mode=None, steps=None, check=True, name="terabyte_b65536", overlap=False, fuse=False):
+def run_on_gpu(device, arith="f32", mode=None, steps=None, check=True, name="terabyte_b65536", overlap=False, fuse=False, update_in_backward=False):
     """Train dlrm_amd.DLRM_Net in bench.py's configuration — stacked [T, B] int64 inputs, UPD_SORTED fused update,
     FusedSGD, and (selected by the shapes) 256-row GEMM tiles and the DMA interaction kernels — on the full-batch golden
     fixture of the live reference.  Returns the per-step relative loss errors; with check=True also asserts predictions
@@ -119,6 +119,8 @@ def run_on_gpu(device, arith="f32", mode=None, steps=None, check=True, name="ter
     model.set_mlp_arith(arith)
     model.fuse_emb_interact = bool(fuse)      # lookups fetched by the interaction kernels (the product default) instead of two kernels
     model.overlap_streams = bool(overlap)     # embedding kernels on a side stream beside the bottom-MLP GEMMs (bench default)
+    # from the second step on (the optimizer is known after its first step) the fused backward takes the SGD step of single-lookup rows (ABI 17)
+    model.update_in_backward = bool(update_in_backward)
     opt = FusedSGD(model.parameters(), lr=meta["lr"])
     rel = []
     close = np.testing.assert_allclose

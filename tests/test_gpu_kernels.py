@@ -1271,6 +1271,115 @@ def test_gather_interaction_is_bit_identical_to_the_two_kernels(T, B, idx_dtype,
     assert not ops.gather_ok(29, 128) and ops.gather_ok(27, 128)      # the dR row of F > 27 (with self pairs) exceeds the gather backward's image
 
 
+@pytest.mark.parametrize("T,B,idx_dtype,itself,lr_on_device,relu_x", [
+    (26, 5000, torch.int64, False, False, True), (26, 4099, torch.int32, False, True, False), (3, 777, torch.int64, True, False, False),
+    (7, 64, torch.int32, True, True, True), (2, 5, torch.int64, False, False, False), (1, 1, torch.int64, False, False, False),
+    (26, 65536, torch.int64, False, True, True)])
+def test_single_lookup_rows_are_updated_inside_the_fused_backward(T, B, idx_dtype, itself, lr_on_device, relu_x):
+    """ABI 17 (dlrm_emb_presort + dlrm_interact_bwd_gather_sgd + dlrm_emb_bwd_sgd_presorted) against dlrm_interact_bwd_gather +
+    dlrm_emb_bwd_sgd(DLRM_UPD_SORTED) — EmbeddingBagBackward + SGD.step of the reference (dlrm_s_pytorch.py:1613,1620): the SAME bits in every
+    table and in dx; the mask of single lookups against numpy's own count of each (table, row); the gradient rows of the single lookups are
+    not written, all others are the plain backward's; under a launch predicate that does NOT hold (a ragged batch) nothing is updated by the
+    backward call and the presorted update applies every lookup; tables mixing rows looked up once, often and never."""
+    from dlrm_amd import ops
+    rng = np.random.default_rng(T * B + 17)
+    D = 128
+    # rows per table from "almost every lookup single" down to "every row hot"
+    rows = [max(1, int(B * f)) for f in rng.choice([40.0, 8.0, 1.5, 0.3, 0.02] if B < 60000 else [6.0, 2.0, 1.0, 0.3, 0.02], size=T)]
+    rows[0] = max(rows[0], 3)
+    gen = torch.Generator(device=dev()); gen.manual_seed(T * B + 18)
+    W0 = [torch.randn((n, D), device=dev(), generator=gen) for n in rows]
+    idx = torch.stack([to_dev(rng.integers(0, n, size=B)) for n in rows]).to(idx_dtype)
+    off = torch.arange(B, device=dev()).repeat(T, 1).to(idx_dtype)
+    x = to_dev(rng.standard_normal((B, D)).astype(np.float32))
+    if relu_x:
+        x = torch.relu(x)
+    bags = ops.BagBatch(off, idx)
+    mode = int(itself) | (ops.INTERACT_RELU_X if relu_x else 0)
+    ldr = (ops.interact_out_width(T + 1, D, itself) + 3) & ~3
+    dR = to_dev(rng.standard_normal((B, ldr)).astype(np.float32))
+    lr = 0.37
+    lr_arg = torch.full((1,), lr, device=dev()) if lr_on_device else lr
+
+    # the two calls of rounds 3-6
+    Wa = [w.clone() for w in W0]
+    dx_a, dE_a = torch.empty((B, D), device=dev()), torch.empty((B, T * D), device=dev())
+    ops.interact_bwd_gather(x, Wa, bags, D, mode, dR, dx_a, dE_a)
+    ops.emb_bwd_sgd(Wa, bags, dE_a, lr_arg, ops.UPD_SORTED)
+
+    # presort -> backward that takes the single rows -> the rest from the sorted workspace
+    Wb = [w.clone() for w in W0]
+    assert ops.presort_ok(Wb, bags)
+    pre = ops.emb_presort(Wb, bags, lr_arg)
+    idx_np = idx.cpu().numpy().astype(np.int64)
+    want_mask = np.zeros(B, dtype=np.uint32)
+    for t in range(T):
+        cnt = np.bincount(idx_np[t], minlength=rows[t])
+        want_mask |= (cnt[idx_np[t]] == 1).astype(np.uint32) << np.uint32(t)
+    got_mask = pre.mask.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got_mask, want_mask)
+    once_or_never = [torch.from_numpy(np.bincount(idx_np[t], minlength=rows[t]) <= 1).to(dev()) for t in range(T)]
+
+    def same_tables(Wx):
+        # rows looked up at most once: the same bits.  Rows looked up several times: the sorted update adds the partial sums of a run that
+        # crosses a 64-entry group boundary with fp32 atomics (DLRM_UPD_SORTED's contract: hot rows are re-associated), in either path
+        for t in range(T):
+            assert torch.equal(Wa[t][once_or_never[t]], Wx[t][once_or_never[t]]), t
+            assert torch.allclose(Wa[t], Wx[t], rtol=1e-5, atol=1e-5), t
+    dx_b = torch.empty((B, D), device=dev())
+    dE_b = torch.full((B, T * D), float("nan"), device=dev())
+    ops.interact_bwd_gather(x, Wb, bags, D, mode, dR, dx_b, dE_b, presorted=pre)
+    single = torch.from_numpy(((want_mask[:, None] >> np.arange(T, dtype=np.uint32)[None, :]) & 1).astype(bool)).to(dev())     # [B, T]
+    dEb3, dEa3 = dE_b.view(B, T, D), dE_a.view(B, T, D)
+    assert torch.isnan(dEb3[single]).all()                               # gradient rows of single lookups: never written
+    assert torch.equal(dEb3[~single], dEa3[~single])
+    assert torch.equal(dx_a, dx_b)
+    # single rows already hold their update, every other row is still untouched
+    for t in range(T):
+        rows_single = idx[t][single[:, t]].long()
+        assert torch.equal(Wb[t][rows_single], Wa[t][rows_single]), t
+        keep = torch.ones(rows[t], dtype=torch.bool, device=dev()); keep[rows_single] = False
+        assert torch.equal(Wb[t][keep], W0[t][keep]), t
+    ops.emb_bwd_sgd_presorted(Wb, bags, dE_b, pre)
+    same_tables(Wb)
+    ops.check_index_errors(sync=True)
+
+    # a launch predicate that does not hold: the fused backward returns at once (the two-kernel form wrote every gradient row) and the
+    # presorted update applies EVERY lookup — with skip_singles asked for
+    flag = torch.ones(1, dtype=torch.int32, device=dev())
+    Wc = [w.clone() for w in W0]
+    pre_c = ops.emb_presort(Wc, bags, lr_arg, pred=(flag, 0))
+    dx_c, dE_c = torch.full((B, D), 3.0, device=dev()), torch.full((B, T * D), 5.0, device=dev())
+    ops.interact_bwd_gather(x, Wc, bags, D, mode, dR, dx_c, dE_c, pred=(flag, 0), presorted=pre_c)
+    assert bool((dx_c == 3.0).all()) and bool((dE_c == 5.0).all())
+    for t in range(T):
+        assert torch.equal(Wc[t], W0[t])
+    ops.emb_bwd_sgd_presorted(Wc, bags, dE_a, pre_c)
+    same_tables(Wc)
+    # ... and one that holds, through the predicated entry
+    flag.zero_()
+    Wd = [w.clone() for w in W0]
+    pre_d = ops.emb_presort(Wd, bags, lr_arg, pred=(flag, 0))
+    dE_d = torch.empty((B, T * D), device=dev())
+    ops.interact_bwd_gather(x, Wd, bags, D, mode, dR, dx_c, dE_d, pred=(flag, 0), presorted=pre_d)
+    ops.emb_bwd_sgd_presorted(Wd, bags, dE_d, pre_d)
+    same_tables(Wd)
+    assert torch.equal(dx_a, dx_c)
+    # skip_singles = False on a plain backward's gradient rows: the second half of the sorted update alone
+    We = [w.clone() for w in W0]
+    ops.emb_bwd_sgd_presorted(We, bags, dE_a, ops.emb_presort(We, bags, lr_arg), skip_singles=False)
+    same_tables(We)
+    # an out-of-range lookup is never a single one: it is skipped by both halves and reported
+    if B >= 5:
+        bad = idx.clone(); bad[0, 3] = rows[0]
+        bb = ops.BagBatch(off, bad)
+        Wf = [w.clone() for w in W0]
+        pre_f = ops.emb_presort(Wf, bb, lr_arg)
+        assert not (int(pre_f.mask[3].item()) & 1)
+        with pytest.raises(IndexError, match="out of range"):
+            ops.check_index_errors(sync=True)
+
+
 @pytest.mark.parametrize("T,B,D,mode", [(26, 4099, 128, 0), (3, 777, 128, 1), (26, 1000, 128, 2), (26, 300, 16, 0), (8, 513, 64, 1), (2, 5, 36, 0)])
 def test_interaction_backward_applies_the_relu_derivative_of_feature_0(T, B, D, mode):
     """`mode | INTERACT_RELU_X`: the backward kernels (LDS-DMA form at D = 128 with and without the fused lookups, the generic form

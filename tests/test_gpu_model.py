@@ -360,21 +360,23 @@ def loss_like_reference(model, Z, T):
     return (loss_ws_ * model.loss_fn(Z, T)).mean()
 
 
-@pytest.mark.parametrize("arith,overlap,fuse", [("f32", False, False), ("f32", True, False), ("bf16x6", True, False), ("f32", True, True)],
-                         ids=["f32-single-stream", "f32-bench-default", "bf16x6-bench-default", "f32-fused-gather-interaction"])
-def test_terabyte_full_batch_matches_reference_golden(arith, overlap, fuse):
+@pytest.mark.parametrize("arith,overlap,fuse,uib", [("f32", False, False, False), ("f32", True, False, False), ("bf16x6", True, False, False),
+                                                    ("f32", True, True, False), ("f32", False, True, True), ("f32", True, True, True)],
+                         ids=["f32-single-stream", "f32-bench-default", "bf16x6-bench-default", "f32-fused-gather-interaction",
+                              "f32-update-in-backward", "f32-update-in-backward-two-streams"])
+def test_terabyte_full_batch_matches_reference_golden(arith, overlap, fuse, uib):
     """BASELINE.json configs[2] — the configuration the headline samples/s is quoted on — against 3 training steps of the
     live reference at the full batch (B = 65536, 26 tables, D = 128, towers 13-512-256-128 / 479-1024-1024-512-256-1, lr 1.0,
     rows capped at 2000): loss within 1e-5 relative at every step (north_star), predictions rtol 2e-5, parameters rtol 1e-4.
     "bench-default" = bench.py's default 2-stream schedule ("fused-gather-interaction" = DLRM_Net.fuse_emb_interact, the default since round 3; the other cases run the two kernels): embedding lookups / fused update on a side HIP stream beside the
     bottom-MLP GEMMs (from the second step on the update is launched during backward) — same kernels, same results."""
     import golden_tb
-    rel = golden_tb.run_on_gpu(torch.device("cuda:0"), arith=arith, overlap=overlap, fuse=fuse)
+    rel = golden_tb.run_on_gpu(torch.device("cuda:0"), arith=arith, overlap=overlap, fuse=fuse, update_in_backward=uib)
     assert len(rel) == 3 and max(rel) <= 1e-5, rel
 
 
-@pytest.mark.parametrize("fuse", [True, False], ids=["fused-lookups", "two-kernels"])
-def test_terabyte_full_batch_hbm_resident_tables_match_reference_golden(fuse):
+@pytest.mark.parametrize("fuse,uib", [(True, False), (False, False), (True, True)], ids=["fused-lookups", "two-kernels", "update-in-backward"])
+def test_terabyte_full_batch_hbm_resident_tables_match_reference_golden(fuse, uib):
     """the same 3 reference training steps at B = 65536 with the seven big tables capped at 4 M rows instead of
     2000 (fixture terabyte_b65536_cap4m: 14.5 GB of tables, 22-bit row keys, rows looked up 0-3 times per batch) — the sorted
     update's long-key / few-duplicates regime and the lookups' HBM-resident regime pinned to the live reference: losses 1e-5,
@@ -383,7 +385,9 @@ def test_terabyte_full_batch_hbm_resident_tables_match_reference_golden(fuse):
     import psutil
     if psutil.virtual_memory().available < 24e9:
         pytest.skip("needs ~16 GB of host RAM to regenerate the reference's initial tables")
-    rel = golden_tb.run_on_gpu(torch.device("cuda:0"), name="terabyte_b65536_cap4m", fuse=fuse)      # fuse = the product default (bench.py)
+    # (update-in-backward: steps 2 and 3 take the SGD step of single-lookup rows inside the fused backward — ABI 17 — in exactly the regime
+    # it is for: 4 M-row tables whose rows are looked up 0-3 times per batch)
+    rel = golden_tb.run_on_gpu(torch.device("cuda:0"), name="terabyte_b65536_cap4m", fuse=fuse, update_in_backward=uib)      # fuse = the product default (bench.py)
     assert max(rel) <= 1e-5, rel
 
 

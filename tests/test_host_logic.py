@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.dlrm_hip_abi_version() == _lib.EXPECTED_ABI == 16
+    assert lib.dlrm_hip_abi_version() == _lib.EXPECTED_ABI == 17
     assert b"gfx950" in lib.dlrm_hip_build_info()
 
 
