@@ -113,6 +113,12 @@ def parse():
                          "alt_two_kernel_lookup")
     ap.add_argument("--fuse", dest="fuse", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-alt-fuse", action="store_true", help="do not also measure the two-kernel lookup + interaction step")
+    ap.add_argument("--update-in-backward", action="store_true",
+                    help="headline WITH DLRM_Net.update_in_backward (opt-in, ABI 17): from the second step on the fused backward takes the sparse SGD "
+                         "step of every embedding row that ONE lookup of the batch names; the rest when the optimizer steps.  Default: off — the "
+                         "headline is the reference loop's schedule (every row updated at optimizer.step()); the opt-in schedule is measured in "
+                         "the same run as alt_update_in_backward")
+    ap.add_argument("--no-alt-update-in-backward", action="store_true", help="do not also measure the update-in-backward step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the pre-run check of this exact configuration against the golden fixture of the live reference")
@@ -707,7 +713,7 @@ def resolve_world(args, argv=None, environ=None):
 
 KERNELS_OF_CATEGORY = [      # launch category of dlrm_amd.ops -> substrings of the kernels one of its C-ABI calls launches (headline workload)
     ("emb_bwd_sgd", ["expand_kernel", "seg_hist_kernel", "seg_scan_kernel", "seg_colscan_kernel", "seg_groupscan_kernel", "seg_binscan_kernel",
-                     "seg_scatter_kernel", "sorted_update_kernel", "emb_bwd_sgd_"]),
+                     "seg_scatter_kernel", "sorted_update_kernel", "emb_bwd_sgd_", "single_mask_kernel"]),
     ("linear_bwd_weight", ["gemm3_kernel<false, false", "splitk_reduce_kernel", "smallk_wgrad", "gemv_bwd_weight", "gemv_bwd_fused"]),
     ("linear_bwd_data", ["gemm3_kernel<true, false", "gemv_bwd_data"]),
     ("linear_fwd", ["gemm3_kernel<true, true", "gemv_fwd", "pad_cols_kernel"]),
@@ -904,6 +910,8 @@ def main():
     model.set_mlp_arith(args.mlp_arith)
     model.overlap_streams = bool(args.overlap) and not args.no_overlap
     model.fuse_emb_interact = bool(args.fuse)
+    if args.update_in_backward:
+        model.update_in_backward = True
     # (what DLRM_Net.sequential_forward checks: dot interaction, one lookup per bag, D = 128, at most 26 tables, single process)
     fused_active = bool(args.fuse) and N == 1 and not hot_cfg and int(D) == 128 and len(rows) + 1 <= 27
     model.a2a_chunks = max(args.a2a_chunks, 1) if (N > 1 and not sharded) else 1
@@ -1258,6 +1266,8 @@ def main():
                    "embedding_update": (args.emb_update if model.emb_update_mode == mode_of[args.emb_update] else
                                         "atomic (the HIP-graph path fell back: a table segment needs the general sorter, which cannot be replayed; dlrm_amd/graph.py)"),
                    "lookup_sort": lookup_sort,
+                   "sparse_update_schedule": ("single-lookup rows inside the fused backward, the rest at optimizer.step() (--update-in-backward, ABI 17)"
+                                              if getattr(model, "update_in_backward", False) else "every row at optimizer.step() (the reference loop's)"),
                    "a2a_chunks": model_a2a_chunks,
                    "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "
                                              "(no pooled-embedding buffer)") if fused_active else "two kernels (dlrm_emb_fwd, dlrm_interact_*)",
@@ -1435,6 +1445,27 @@ def main():
         result["alt_two_kernel_lookup"] = {"value": B / dtu, "unit": "samples/s", "ms_per_step": dtu * 1e3, "final_loss": float(loss_u.detach()),
                                            "note": "--no-fuse: dlrm_emb_fwd + dlrm_interact_fwd / _bwd through the pooled-embedding buffer; bit-identical results"}
         del loss_u
+    if (N == 1 and graphed is None and not hot and fused_active and args.optimizer == "sgd" and args.emb_update == "sorted"
+            and not getattr(model, "update_in_backward", False) and not args.no_alt_update_in_backward):
+        # the same step with the opt-in schedule of ABI 17 (DLRM_Net.update_in_backward): single-lookup rows take their SGD step inside the
+        # fused backward; beside the headline, never instead of it.  Same final tables as the headline's schedule (tests/test_gpu_kernels.py)
+        model.update_in_backward = True
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss_b = step(i)
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - t0) / args.steps
+        model.update_in_backward = False
+        result["alt_update_in_backward"] = {"value": B / dtb, "unit": "samples/s", "ms_per_step": dtb * 1e3, "final_loss": float(loss_b.detach()),
+                                            "note": "opt-in (DLRM_Net.update_in_backward / --update-in-backward; ABI 17: dlrm_emb_presort + "
+                                                    "dlrm_interact_bwd_gather_sgd + dlrm_emb_bwd_sgd_presorted): the rows one lookup of the batch names are "
+                                                    "stepped inside the fused backward, the others at optimizer.step(); the tables after a step hold the "
+                                                    "same values, WHEN single-lookup rows change differs from the reference loop"}
+        del loss_b
+        partial["json"] = json.dumps(result)
     if args.alts and N == 1 and graphed is None and not hot and not (args.overlap and not args.no_overlap) and not args.no_alt_overlap:
         # the same step on two HIP streams (embedding kernels beside the bottom-MLP GEMMs): beside the headline, never instead
         model.overlap_streams = True

@@ -117,6 +117,9 @@ class GraphedTrainStep:
         # the captured step is single-stream: a replayed graph has no launch gaps to hide, and the side-stream overlap
         # of the eager path (DLRM_Net.overlap_streams) would put cross-stream joins into the capture
         model.overlap_streams = False
+        # ... and takes the whole sparse update at its optimizer step (the update-in-backward schedule of ABI 17 allocates its sorted
+        # workspace per backward pass and binds to the optimizer's first EAGER step: not part of a captured step)
+        model.update_in_backward = False
         self.warmup = max(int(warmup), 1)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.stream: Optional[torch.cuda.Stream] = None
