@@ -16,7 +16,7 @@ OUT=gpurun_out/${1:?out tag}; shift
 mkdir -p $OUT
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-QUICK="--no-cpu-baseline --no-parity-check --no-box-calibration --no-rccl-selfcheck --no-high-row-check --no-full-size-parity --no-reference-region"
+QUICK="--no-cpu-baseline --no-parity-check --no-box-calibration --no-rccl-selfcheck --no-high-row-check --no-full-size-parity --no-reference-region --no-alt-update-in-backward"
 n=0
 summ() { python - "$1" <<'PY'
 import json, sys

@@ -27,7 +27,9 @@ CALLS_PER_STEP = {"emb_fwd": 1, "emb_bwd_sgd": 1, "interact_fwd": 1, "interact_b
 
 def in_cat(cat, pats, kernel):
     """fused lookup + interaction = the <NI, true> instantiations of the LDS-DMA interaction kernels"""
-    gather = "_dma_kernel<" in kernel and kernel.split("_dma_kernel<", 1)[1].split(">", 1)[0].replace(" ", "").endswith(",true")
+    # interact_fwd_dma_kernel<NI, GATHER> / interact_bwd_dma_kernel<NI, GATHER, UPD> (UPD since ABI 17): the SECOND template argument
+    targs = kernel.split("_dma_kernel<", 1)[1].split(">", 1)[0].replace(" ", "").split(",") if "_dma_kernel<" in kernel else []
+    gather = len(targs) >= 2 and targs[1] == "true"
     if cat == "emb_fwd" and "emb_fwd_kernel<" in kernel and kernel.split("emb_fwd_kernel<", 1)[1].split(">", 1)[0].replace(" ", "").endswith(",true"):
         return False        # the LOOP = true instantiation is the PREDICATED launch of the fused step (ABI 16): it returns at once there
     if cat.startswith("emb_interact"):
