@@ -517,6 +517,81 @@ def test_ragged_batch_with_one_lookup_per_bag_on_average_takes_the_two_kernels(v
     assert ops.offsets_are_iota(o) is False
 
 
+def test_update_in_backward_follows_the_reference_loop_through_ragged_and_tagged_batches():
+    """ABI 17 at the module level (DLRM_Net.update_in_backward; EmbeddingBagBackward + SGD.step of the reference, dlrm_s_pytorch.py:1613,1620,
+    for single-lookup rows inside the fused backward): six steps of the reference loop against the oracle — step 0 binds the optimizer (step-time
+    update), then fresh untagged offsets (the fused backward + its update run under the DEVICE predicate), a RAGGED batch with nnz == B (the
+    predicate does not hold: the two-kernel backward wrote every gradient row and the presorted update applies every lookup), producer-tagged
+    offsets (no predicate at all), and a learning rate changed between steps (both halves of a step use the lr the optimizer holds at backward).
+    Tables mix rows looked up once, several times and never; losses to 1e-5, predictions, every parameter; and the calls really took the path."""
+    import dlrm_amd
+    from dlrm_amd import ops
+    device = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    D, rows, B = 128, [50, 3000, 7, 40000], 192
+    F = len(rows) + 1
+    ln_bot, ln_top = np.asarray([13, 32, D]), np.asarray([D + F * (F - 1) // 2, 24, 1])
+    np.random.seed(3)
+    model = dlrm_amd.DLRM_Net(D, np.asarray(rows), ln_bot, ln_top, "dot", sigmoid_top=1, loss_function="bce")
+    init = {k: v.numpy().copy() for k, v in model.state_dict().items()}
+    model = model.to(device)
+    model.emb_update_mode = ops.UPD_SORTED
+    model.update_in_backward = True
+    ref = O.OracleDLRM(init, sigmoid_top=1)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    counts = {"presort": 0, "fused_sgd": 0, "presorted": 0, "plain": 0}
+    orig = (ops.emb_presort, ops.interact_bwd_gather, ops.emb_bwd_sgd_presorted, ops.emb_bwd_sgd)
+
+    def w_presort(*a, **k):
+        counts["presort"] += 1
+        return orig[0](*a, **k)
+
+    def w_bwd(*a, **k):
+        counts["fused_sgd"] += 1 if k.get("presorted") is not None else 0
+        return orig[1](*a, **k)
+
+    def w_presorted(*a, **k):
+        counts["presorted"] += 1
+        return orig[2](*a, **k)
+
+    def w_plain(*a, **k):
+        counts["plain"] += 1
+        return orig[3](*a, **k)
+
+    ops.emb_presort, ops.interact_bwd_gather, ops.emb_bwd_sgd_presorted, ops.emb_bwd_sgd = w_presort, w_bwd, w_presorted, w_plain
+    try:
+        for s, kind in enumerate(["bind", "fresh", "ragged", "tagged", "fresh-new-lr", "fresh"]):
+            X = rng.random((B, 13)).astype(np.float32)
+            T = np.round(rng.random((B, 1))).astype(np.float32)
+            lS_i = [rng.integers(0, n, size=B).astype(np.int64) for n in rows]
+            lS_o = [np.arange(B, dtype=np.int64) for _ in rows]
+            if kind == "ragged":
+                lS_o[1] = lS_o[1].copy(); lS_o[1][41] = 42          # bag 40 = two lookups, bag 41 empty, nnz still B
+            if kind == "fresh-new-lr":
+                for g in opt.param_groups:
+                    g["lr"] = 0.03
+            lr = opt.param_groups[0]["lr"]
+            od = [torch.from_numpy(o).to(device) for o in lS_o]
+            idd = [torch.from_numpy(i).to(device) for i in lS_i]
+            if kind == "tagged":
+                od, idd = torch.stack(od), torch.stack(idd)
+                ops.mark_one_lookup_per_bag(od)
+            Z = model(torch.from_numpy(X).to(device), od, idd)
+            E = model.loss_fn(Z, torch.from_numpy(T).to(device))
+            opt.zero_grad(); E.backward(); opt.step()
+            ops.check_index_errors(sync=True)
+            loss, Zr = ref.train_step(X, lS_o, lS_i, T, lr)
+            assert abs(float(E) - loss) <= 1e-5 * abs(loss), (s, kind, float(E), loss)
+            np.testing.assert_allclose(Z.detach().cpu().numpy(), Zr, rtol=2e-5, atol=1e-6, err_msg=kind)
+            for k, v in ref.p.items():
+                np.testing.assert_allclose(model.state_dict()[k].cpu().numpy(), v, rtol=1e-4, atol=2e-6, err_msg="%s after step %d (%s)" % (k, s, kind))
+    finally:
+        ops.emb_presort, ops.interact_bwd_gather, ops.emb_bwd_sgd_presorted, ops.emb_bwd_sgd = orig
+    # step 0: the step-time update (optimizer unknown until its first step); every later step: presort + fused backward + presorted update
+    assert counts == {"presort": 5, "fused_sgd": 5, "presorted": 5, "plain": 1}, counts
+    assert not model._pending_emb
+
+
 def test_producer_tags_and_the_proof_stream():
     """Round 5: (a) tensors whose PRODUCER wrote 0..B-1 carry its proof (dlrm_amd.datagen with one fixed lookup per bag — list and stacked
     forms —, Multihot over all-ones hot sizes): ops.offsets_are_iota answers without a device pass; a versioned in-place write voids the
