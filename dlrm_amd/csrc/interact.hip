@@ -701,12 +701,13 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
     issue_dr(drow0_lds);
     for (; b < B; b += b_stride) {
         const bool more = b + b_stride < B;
-        // (UPD) which of this lane's rows are single lookups, and where their table rows live: read from this sample's selector slot NOW —
-        // the slot is handed to the selectors three samples ahead a few lines down.  dst = the table row (gathered rows are D floats apart)
-        // or the gradient row; one store per row either way
+        // (UPD) which of this lane's rows are single lookups, and where their table rows live: read from this sample's selector slot before
+        // the slot is handed to the selectors three samples ahead — but BEHIND the next sample's row loads (their issue must not wait for these
+        // LDS round trips and the address arithmetic).  dst = the table row (gathered rows are D floats apart) or the gradient row; one store
+        // per row either way
         gchar* dst[NB][4];
         unsigned ones = 0u;
-        if constexpr (UPD) {
+        auto upd_select = [&]() {
             const char* slot = sel0 + sl * GSEL_SLOT;
             unsigned um = *(const unsigned*)(slot + GSEL_WORD_OFF);
             if (DLRM_UPD_DIAG == 1) um = 0u;
@@ -723,7 +724,7 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                     ones |= one ? 1u << (4 * r + q) : 0u;
                 }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+        };
         if constexpr (GATHER) {
             // same schedule as the forward kernel: rows + dR row of the next sample and the selectors three samples ahead stay in
             // flight (NI + nr + 2 operations) while this sample is multiplied
@@ -731,6 +732,7 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                 const int sl1 = sl == 2 ? 0 : sl + 1;
                 gather_rows_issue<NI>(gc, sel0 + sl1 * GSEL_SLOT, b + b_stride, lane, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IDMA_IMG);
                 issue_dr(drow0_lds + (cur ^ 1) * DRB);
+                if constexpr (UPD) upd_select();
                 const long long s3 = b + 3 * b_stride;
                 gather_sel_issue<NI>(gc, s3 < B ? s3 : B - 1, sel0_lds + sl * GSEL_SLOT);
                 // (the previous sample's row stores — issued after this sample's loads, before the next one's — may stay in flight too: vmcnt
@@ -738,7 +740,10 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                 if (DLRM_BWD_STORES_IN_FLIGHT && stores_behind) wait_vmcnt_rt(NI + nr + 2 + n_st);
                 else wait_vmcnt_rt(NI + nr + 2);
                 sl = sl1;
-            } else wait_vmcnt_i<0>();
+            } else {
+                if constexpr (UPD) upd_select();
+                wait_vmcnt_i<0>();
+            }
         } else if (more) {
             dma_issue<NI>(pl, img0_lds + (cur ^ 1) * IDMA_IMG);
             issue_dr(drow0_lds + (cur ^ 1) * DRB);
