@@ -526,10 +526,16 @@ __global__ __launch_bounds__(320) void interact_fwd_dma_kernel(FeatArgs fa, Gath
             for (int s = 0; s < IDMA_D / 16; ++s)
                 fr[r][s] = *(const float4*)(my + (16 * r + li) * (IDMA_D * 4) + (((4 * s + g) ^ li) * 16));      // (row & 15) == li
         // (the scheduler sinks each k-step's two reads to just before its 12 MFMAs — one wave per SIMD, so those LDS round trips are exposed.
-        // Pinning all reads in front of the first MFMA with a scheduling fence was measured: the kernel 195 -> 188 us, the step no faster —
-        // profiles/round5/interact_frags_first_ab.txt; the kernel is bound by its row fetches, 0.85 of the copy rate)
+        // Pinning all reads in front of the first MFMA with a scheduling fence: round 5 measured the kernel 195 -> 188 us and the step no
+        // faster (profiles/round5/interact_frags_first_ab.txt) and left it out; end of round 6: 0.196-0.198 -> 0.194 ms again, adopted below)
         // the tile pairs advance together, one k-substep at a time: consecutive MFMAs are independent, the two accumulators of a
         // pair (even / odd substeps, summed at the end — the summation order of every version of this kernel) are three issues apart
+        // (x = image row 0, for R[:, 0:D]: read with the fragments, not as an exposed LDS round trip behind the MFMAs)
+        const float4 xrow = *(const float4*)(my + (lane & 31) * 16);
+#ifndef DLRM_FWD_PIN
+#define DLRM_FWD_PIN 1
+#endif
+        if (DLRM_FWD_PIN) __builtin_amdgcn_sched_barrier(0);      // all fragment reads in front of the first MFMA (end of round 6: adopted)
         floatx4 acc[NPAIR][2];
 #pragma unroll
         for (int p = 0; p < NPAIR; ++p) { acc[p][0] = (floatx4){0.f, 0.f, 0.f, 0.f}; acc[p][1] = (floatx4){0.f, 0.f, 0.f, 0.f}; }
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(320) void interact_fwd_dma_kernel(FeatArgs fa, Gath
                 if (opos[p][q] >= 0 && !(dbg & 4)) Rb[opos[p][q]] = sum[q];
         }
         // R[:, 0:D] = x (row 0 of the image, un-swizzled: row & 15 == 0), then the alignment padding
-        if (lane < 32) *(float4*)(Rb + 4 * lane) = *(const float4*)(my + lane * 16);
+        if (lane < 32) *(float4*)(Rb + 4 * lane) = xrow;
         for (long long d = IDMA_D + P + lane; d < ldr; d += 64) Rb[d] = 0.f;
         cur ^= 1;
     }
@@ -634,12 +640,15 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
 #pragma unroll
         for (int kk = 0; kk < 4 * NB; ++kk) {
             const int i = 16 * r + li, j = 4 * kk + g;
-            int off = 0; float sc = 0.f;
+            // structural zeros read the LAST word of the dR image: the row's DMA never reaches it (the launcher requires ldr * 4 < DRB) and it was
+            // zeroed with the images — so a fragment is one multiply (x 1, x 2 on the diagonal), not a compare + multiply + select, and a
+            // structural zero stays zero whatever dR holds
+            int off = DRB / 4 - 1; float sc = 1.f;
             if (i < F && j < F) {
                 if (i == j) { if (self & 1) { off = IDMA_D + pair_pos(i, i, F, self); sc = 2.f; } }
                 else {
                     const int hi = i > j ? i : j, lo = i > j ? j : i;
-                    off = IDMA_D + pair_pos(hi, lo, F, self); sc = 1.f;
+                    off = IDMA_D + pair_pos(hi, lo, F, self);
                 }
             }
             a_off[r][kk] = off * 4; a_scale[r][kk] = sc;
@@ -719,7 +728,8 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                     const unsigned id = *(const unsigned*)(slot + 4 * (i & 31));
                     const bool one = ((tabbits >> (4 * r + q)) & 1u) && ((um >> ((i - 1) & 31)) & 1u);
                     gchar* wr = (gchar*)tp[i & 31] + 16 * li + ((unsigned long long)id << 9);
-                    gchar* gr = (gchar*)dp[i & 31] + (b * dl[i & 31] + 4 * li) * 4;
+                    // (32 x 32 -> 64-bit multiply-add: one v_mad_u64_u32; the entry point bounds B and the row pitches)
+                    gchar* gr = (gchar*)dp[i & 31] + 16 * li + (unsigned long long)(unsigned)b * ((unsigned)dl[i & 31] * 4u);
                     dst[r][q] = (one && DLRM_UPD_DIAG != 2) ? wr : gr;
                     ones |= one ? 1u << (4 * r + q) : 0u;
                 }
@@ -758,8 +768,9 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
 #pragma unroll
             for (int kk = 0; kk < 4 * NB; ++kk) {
                 const float v = *(const float*)(dr + a_off[r][kk]);
-                aS[r][kk] = (a_scale[r][kk] != 0.f) ? a_scale[r][kk] * v : 0.f;     // structural zeros stay zero even for non-finite dR
+                aS[r][kk] = a_scale[r][kk] * v;
             }
+        // (B fragments of both 64-column halves read up front: measured, no effect — 0.315-0.322 vs 0.317-0.323 ms)
 #pragma unroll
         for (int dq = 0; dq < IDMA_D / 64; ++dq) {
             float4 bT[4 * NB];
@@ -777,9 +788,19 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                 if constexpr (UPD) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int i = 16 * r + 4 * g + q;          // image row i, this lane's quad, un-swizzled
+                        // image row i, this lane's quad, un-swizzled — or, for a row this lane does not step, the image's zero row 31 (F <= 27:
+                        // rows F..31 are zeroed once and never written): the store below is then ONE fma per element for every row,
+                        // fma(-lr, dT, W) or fma(1, dT, 0) = dT, instead of an fma and a select per element
+                        const int i = ((ones >> (4 * r + q)) & 1u) ? 16 * r + 4 * g + q : 31;
                         wv[q] = *(const float4*)(my + i * (IDMA_D * 4) + (((16 * dq + li) ^ (i & 15)) * 16));
                     }
+                }
+                // feature 0's two extra operands (the x part of dR; x itself for the ReLU derivative), read HERE by every lane: inside the
+                // lane-divergent branch behind the MFMAs each was an exposed LDS round trip (one wave per SIMD)
+                float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), y0 = x0;
+                if (r == 0) {
+                    x0 = *(const float4*)(dr + (64 * dq + 4 * li) * 4);
+                    y0 = *(const float4*)(my + (16 * dq + li) * 16);
                 }
                 floatx4 acc[4];
 #pragma unroll
@@ -796,10 +817,10 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                     if ((rowbits >> (4 * r + q)) & 1u) {
                         float4 v = make_float4(acc[0][q], acc[1][q], acc[2][q], acc[3][q]);
                         if (r == 0 && q == 0 && g == 0) {       // feature 0 also feeds R[:, 0:D]
-                            const float4 x = *(const float4*)(dr + (64 * dq + 4 * li) * 4);
+                            const float4 x = x0;
                             v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
                             if (self & 4) {                     // feature 0 is a ReLU output: its derivative is applied here (image row 0 = x)
-                                const float4 y = *(const float4*)(my + (16 * dq + li) * 16);
+                                const float4 y = y0;
                                 v.x = y.x > 0.f ? v.x : 0.f; v.y = y.y > 0.f ? v.y : 0.f;
                                 v.z = y.z > 0.f ? v.z : 0.f; v.w = y.w > 0.f ? v.w : 0.f;
                             }
@@ -807,10 +828,9 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                         if constexpr (UPD) {
                             // a single lookup: the SGD step itself goes to the table row
                             const float4 w = wv[q];
-                            if ((ones >> (4 * r + q)) & 1u) {
-                                v.x = __builtin_fmaf(neg_lr, v.x, w.x); v.y = __builtin_fmaf(neg_lr, v.y, w.y);
-                                v.z = __builtin_fmaf(neg_lr, v.z, w.z); v.w = __builtin_fmaf(neg_lr, v.w, w.w);
-                            }
+                            const float sc = ((ones >> (4 * r + q)) & 1u) ? neg_lr : 1.f;
+                            v.x = __builtin_fmaf(sc, v.x, w.x); v.y = __builtin_fmaf(sc, v.y, w.y);
+                            v.z = __builtin_fmaf(sc, v.z, w.z); v.w = __builtin_fmaf(sc, v.w, w.w);
                             *(gfloatx4*)(dst[r][q] + dq * 256) = (floatx4){v.x, v.y, v.z, v.w};
                         } else
                             *(gfloatx4*)(orow[r][q] + dq * 256) = (floatx4){v.x, v.y, v.z, v.w};
@@ -1058,6 +1078,8 @@ extern "C" int dlrm_interact_bwd_gather_sgd(int64_t B, int F, int D, const void*
     // bit f - 1 of a mask word names feature f: features 1 .. F-1 must all be tables (feature 0 the dense block), rows of D floats
     if (index_host[0]) return DLRM_E_ARG;
     for (int f = 1; f < F; ++f) if (!index_host[f] || feat_ld_host[f] != D) return DLRM_E_ARG;
+    if (B >= ((int64_t)1 << 32)) return DLRM_E_RANGE;                    // (gradient-row addresses: sample x pitch as a 32 x 32-bit product)
+    for (int f = 0; f < F; ++f) if (dfeat_ld_host && (dfeat_ld_host[f] < 0 || dfeat_ld_host[f] >= ((int64_t)1 << 30))) return DLRM_E_RANGE;
     return interact_bwd_impl(B, F, D, feat_host, feat_ld_host, index_host, offsets_host, rows_host, idx_bits, self_interaction, dR,
                              ldr, dfeat_host, dfeat_ld_host, err, stream, DlrmPred{(const int*)pred_flag, pred_nonzero}, single_mask,
                              dlrm_step_neg(lr, lr_dev));
@@ -1091,7 +1113,7 @@ static int interact_bwd_impl(int64_t B, int F, int D, const void* const* feat_ho
         if (rc) return rc;
         ga.pred = pred;
         const bool dma_path = (gidx ? (dlrm_interact_gather_ok(F, D) && vec) : interact_dma_ok(F, D, vec)) && dvec && dlrm_aligned16(dR) &&
-                              ldr % 4 == 0 && ldr * 4 <= (gidx ? GDR_BYTES : IDMA_DR_BYTES);
+                              ldr % 4 == 0 && ldr * 4 < (gidx ? GDR_BYTES : IDMA_DR_BYTES);      // (strictly: the image's last word stays zero)
         if (gidx && !dma_path) return DLRM_E_MODE;
         if (single_mask && !gidx) return DLRM_E_ARG;
         if (dma_path) {
