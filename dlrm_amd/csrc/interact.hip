@@ -407,12 +407,22 @@ __device__ __forceinline__ void gather_sel_issue(const GatherCtx<NI>& gc, long l
 
 // rows of sample s from its (landed) selector slot -> image; NI VM operations.  Verifies the one-lookup-per-bag layout and the
 // index range in the lane that owns the feature; a violation is reported and row 0 is read instead.
+// (the four selector dwords of a lane: read from a LANDED slot one sample ahead of their use, so that a sample's row loads are issued from
+// registers at the top of the iteration instead of behind an LDS round trip — one wave per SIMD, nothing else hides it)
+struct GatherSel { unsigned lo, hi, olo, ohi; };
+__device__ __forceinline__ GatherSel gather_sel_read(const char* slot, int lane) {
+    const int f = lane & 31;
+    GatherSel g;
+    g.lo = *(const unsigned*)(slot + 4 * f); g.hi = *(const unsigned*)(slot + 128 + 4 * f);
+    g.olo = *(const unsigned*)(slot + 256 + 4 * f); g.ohi = *(const unsigned*)(slot + 384 + 4 * f);
+    return g;
+}
+
 template <int NI>
-__device__ __forceinline__ void gather_rows_issue(const GatherCtx<NI>& gc, const char* slot, long long s, int lane, int idx_bits,
+__device__ __forceinline__ void gather_rows_issue(const GatherCtx<NI>& gc, const GatherSel& gs, long long s, int lane, int idx_bits,
                                                   long long* err, unsigned img_lds) {
     const int f = lane & 31;
-    const unsigned lo = *(const unsigned*)(slot + 4 * f), hi = *(const unsigned*)(slot + 128 + 4 * f);
-    const unsigned olo = *(const unsigned*)(slot + 256 + 4 * f), ohi = *(const unsigned*)(slot + 384 + 4 * f);
+    const unsigned lo = gs.lo, hi = gs.hi, olo = gs.olo, ohi = gs.ohi;
     unsigned idu = (unsigned)s;
     if (gc.rows >= 0) {
         long long id = idx_bits == 64 ? (long long)(((unsigned long long)hi << 32) | lo) : (long long)(int)lo;
@@ -463,6 +473,7 @@ __global__ __launch_bounds__(320) void interact_fwd_dma_kernel(FeatArgs fa, Gath
     const char* sel0 = (const char*)(tr + DLRM_MAX_FEATURES) + (size_t)W * 2 * IMGB + (size_t)wave * GSEL_WAVE_BYTES;
     const unsigned sel0_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)sel0;
     int sl = 0;                                             // slot of the current sample's selectors
+    GatherSel gsn = {0u, 0u, 0u, 0u};                       // selectors of the NEXT sample, in registers
     if constexpr (GATHER) {
         gather_ctx_init<NI>(gc, tp, tl, tq, to, tr, F, lane, ga.idx_bits);
         const long long last = B - 1;
@@ -472,7 +483,8 @@ __global__ __launch_bounds__(320) void interact_fwd_dma_kernel(FeatArgs fa, Gath
             gather_sel_issue<NI>(gc, s < B ? s : last, sel0_lds + k * GSEL_SLOT);
         }
         wait_vmcnt_i<0>();
-        gather_rows_issue<NI>(gc, sel0, b, lane, ga.idx_bits, ga.err, img0_lds);
+        gather_rows_issue<NI>(gc, gather_sel_read(sel0, lane), b, lane, ga.idx_bits, ga.err, img0_lds);
+        gsn = gather_sel_read(sel0 + GSEL_SLOT, lane);          // the next sample's selectors (all three slots have landed)
     } else {
         dma_plan_init(pl, tp, tl, F, lane, b, b_stride);
     }
@@ -504,11 +516,14 @@ __global__ __launch_bounds__(320) void interact_fwd_dma_kernel(FeatArgs fa, Gath
             // now, the selectors three samples ahead take the slot this sample's selectors just left, and the counted wait leaves
             // exactly those NI + 2 operations in flight while this sample is multiplied
             if (more) {
-                const int sl1 = sl == 2 ? 0 : sl + 1;
-                gather_rows_issue<NI>(gc, sel0 + sl1 * GSEL_SLOT, b + b_stride, lane, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IMGB);
+                const int sl1 = sl == 2 ? 0 : sl + 1, sl2 = sl1 == 2 ? 0 : sl1 + 1;
+                gather_rows_issue<NI>(gc, gsn, b + b_stride, lane, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IMGB);
                 const long long s3 = b + 3 * b_stride;
                 gather_sel_issue<NI>(gc, s3 < B ? s3 : B - 1, sel0_lds + sl * GSEL_SLOT);
                 wait_vmcnt_i<NI + 2>();
+                // the selectors two samples ahead are older than everything that wait leaves in flight: into registers now, their LDS round
+                // trip rides with this sample's fragment reads
+                gsn = gather_sel_read(sel0 + sl2 * GSEL_SLOT, lane);
                 sl = sl1;
             } else if (!(dbg & 1)) wait_vmcnt_i<0>();
         } else {
@@ -695,6 +710,7 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
 
     int cur = 0, sl = 0;
     bool stores_behind = false;        // (UPD) the queue holds a sample's row stores behind the current sample's loads
+    GatherSel gsn = {0u, 0u, 0u, 0u};  // selectors of the NEXT sample, in registers (see the forward kernel)
     if constexpr (GATHER) {
         const long long last = B - 1;
 #pragma unroll
@@ -703,7 +719,8 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
             gather_sel_issue<NI>(gc, s < B ? s : last, sel0_lds + k * GSEL_SLOT);
         }
         wait_vmcnt_i<0>();
-        gather_rows_issue<NI>(gc, sel0, b, lane, ga.idx_bits, ga.err, img0_lds);
+        gather_rows_issue<NI>(gc, gather_sel_read(sel0, lane), b, lane, ga.idx_bits, ga.err, img0_lds);
+        gsn = gather_sel_read(sel0 + GSEL_SLOT, lane);
     } else {
         dma_issue<NI>(pl, img0_lds);
     }
@@ -740,7 +757,7 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
             // flight (NI + nr + 2 operations) while this sample is multiplied
             if (more) {
                 const int sl1 = sl == 2 ? 0 : sl + 1;
-                gather_rows_issue<NI>(gc, sel0 + sl1 * GSEL_SLOT, b + b_stride, lane, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IDMA_IMG);
+                gather_rows_issue<NI>(gc, gsn, b + b_stride, lane, ga.idx_bits, ga.err, img0_lds + (cur ^ 1) * IDMA_IMG);
                 issue_dr(drow0_lds + (cur ^ 1) * DRB);
                 if constexpr (UPD) upd_select();
                 const long long s3 = b + 3 * b_stride;
@@ -749,6 +766,7 @@ __global__ __launch_bounds__(256) void interact_bwd_dma_kernel(FeatArgs fa, Feat
                 // retires in issue order)
                 if (DLRM_BWD_STORES_IN_FLIGHT && stores_behind) wait_vmcnt_rt(NI + nr + 2 + n_st);
                 else wait_vmcnt_rt(NI + nr + 2);
+                gsn = gather_sel_read(sel0 + (sl1 == 2 ? 0 : sl1 + 1) * GSEL_SLOT, lane);      // two samples ahead: landed (older than what the wait leaves)
                 sl = sl1;
             } else {
                 if constexpr (UPD) upd_select();
