@@ -1267,7 +1267,7 @@ def main():
                                         "atomic (the HIP-graph path fell back: a table segment needs the general sorter, which cannot be replayed; dlrm_amd/graph.py)"),
                    "lookup_sort": lookup_sort,
                    "sparse_update_schedule": ("single-lookup rows inside the fused backward, the rest at optimizer.step() (--update-in-backward, ABI 17)"
-                                              if getattr(model, "update_in_backward", False) else "every row at optimizer.step() (the reference loop's)"),
+                                              if (getattr(model, "update_in_backward", False) and fused_active) else "every row at optimizer.step() (the reference loop's)"),
                    "a2a_chunks": model_a2a_chunks,
                    "embedding_interaction": ("fused: the interaction kernels gather the one-hot embedding rows themselves "
                                              "(no pooled-embedding buffer)") if fused_active else "two kernels (dlrm_emb_fwd, dlrm_interact_*)",

@@ -400,6 +400,15 @@ def test_bench_two_rank_control_flow(dense_sync):
     assert "linear_fwd" in d["kernels"] and d["roofline"] is not None
 
 
+def test_update_in_backward_is_inert_under_the_distributed_forward():
+    """DLRM_Net.update_in_backward (ABI 17, opt-in) belongs to the single-process fused lookup + interaction path; with table-wise shards the
+    lookups run through dlrm_emb_fwd and the all-to-all (distributed_forward, dlrm_s_pytorch.py:528-585) and the switch changes nothing:
+    the two-rank run trains, and the line names the reference loop's update schedule."""
+    d, _ = _run_bench_n2({"DLRM_UPDATE_IN_BACKWARD": "1"}, ["--steps", "2", "--hang-timeout", "120"], 600)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and np.isfinite(d["final_loss"])
+    assert d["config"]["sparse_update_schedule"].startswith("every row at optimizer.step()")
+
+
 def test_bench_two_rank_self_launch_with_bf16_lean_towers_and_flat_allreduce():
     """`python bench.py --gpus 2` WITHOUT a launcher (VERDICT r3 missing-3): bench.py re-executes itself under torch.distributed.run and the
     line says n_gpus 2.  Run with `--mlp-arith bf16 --dense-sync flat`: the lean bf16 towers (bf16-only hidden activations, weight gradient from
